@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""Headline benchmark: scenes/sec on 80k-point synthetic scans (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one synthetic 80k-voxel scene through the hot path with its inputs already
+resident in HBM.  Scenes are independent, so N ranks run N scenes per step with no data-path
+collective ("scaling": "weak"); value = scenes all ranks processed / max-over-ranks time.
+
+The JSON line also carries
+  roofline     the vote op (zero-fill + accumulate + normalise = every launch of
+               cv_hv_forward_f32) timed with HIP events on its stream inside the timed region,
+               priced with the algorithmic bytes of DESIGN.md / SURVEY.md 8d:
+               B_vote = 40 N + 192 V_in + 68 G
+  cpu_baseline the CPU oracle (oracle/, a port - the reference has no CPU path) on a bounded
+               sample of the same scenes, rank 0 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from canonicalvoting_amd import _lib, decode, hv_cuda  # noqa: E402
+from canonicalvoting_amd.hough import HoughVoting  # noqa: E402
+from canonicalvoting_amd.synth import make_scene, synth_predictions  # noqa: E402
+
+N_POINTS = 80000
+NUM_ROTS = 120
+RES = 0.03
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scenes", type=int, default=4, help="distinct resident scenes per rank")
+    ap.add_argument("--points", type=int, default=N_POINTS)
+    ap.add_argument("--algo", type=int, default=0, help="vote algorithm: 0 auto, 1 direct, 2 tiles")
+    ap.add_argument("--cpu-scenes", type=int, default=6, help="scenes timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--stage", default="auto", choices=["auto", "vote_decode", "full"])
+    return ap.parse_args()
+
+
+class ResidentScene:
+    """One scene with everything the timed region touches already in HBM."""
+
+    def __init__(self, seed, n_points, dev):
+        sc = make_scene(seed, n_points=n_points, res=RES)
+        xyz, scale, prob, cls = synth_predictions(sc)
+        self.host = (sc, xyz, scale, prob, cls)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.coords = t(sc.coords)
+        self.points = (self.coords * RES).float().contiguous()      # eval_joint.py:193
+        self.feats = t(sc.feats)
+        self.xyz, self.scale, self.prob, self.cls = t(xyz), t(scale), t(prob), t(cls)
+        self.corner, _, self.dims = hv_cuda.grid_geometry(self.points, RES)
+        self.v_in = hv_cuda.count_votes(self.points, self.xyz, self.scale, RES, NUM_ROTS, self.corner, self.dims)
+        G = self.dims[0] * self.dims[1] * self.dims[2]
+        self.cells = G
+        self.vote_bytes = 40 * n_points + 192 * self.v_in + 68 * G
+        self.vote_bytes_floor = 40 * n_points + 24 * G                   # compulsory traffic
+
+
+def run_step(hv, s, ev=None):
+    """vote -> decode -> per-class NMS for one resident scene (eval_joint.py:193-280)."""
+    with torch.no_grad():
+        if ev is not None:
+            ev[0].record()
+        grid_obj, grid_rot, grid_scale = hv(s.points, s.xyz, s.scale, s.prob)
+        if ev is not None:
+            ev[1].record()
+    raw = decode.decode_boxes(grid_obj, grid_rot, grid_scale, s.points, s.xyz, s.prob, s.cls, RES,
+                              corner=s.corner)
+    return decode.nms_per_class(raw["boxes"], raw["scores"], raw["classes"]), raw
+
+
+def cpu_baseline(scenes, n):
+    import oracle
+    oracle.lib()
+    t0 = time.perf_counter()
+    boxes = 0
+    for s in scenes[:n]:
+        sc, xyz, scale, prob, cls = s.host
+        pts = sc.points
+        g = oracle.hv_forward(pts, xyz, scale, prob, RES, NUM_ROTS)
+        corner, _, _ = oracle.grid_geometry(pts, RES)
+        d = oracle.decode(g[0], g[1], g[2], corner, RES, pts, xyz, prob, cls)
+        boxes += len(oracle.nms_per_class(d["boxes"], d["scores"], d["classes"]))
+    dt = time.perf_counter() - t0
+    return n / dt, dt, boxes
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    _lib.lib()
+    hv_cuda.set_algorithm(a.algo)
+    hv = HoughVoting(RES, NUM_ROTS)
+
+    # scene i of rank r uses seed r*1000 + i: every rank owns different scenes
+    scenes = [ResidentScene(rank * 1000 + i, a.points, dev) for i in range(a.scenes)]
+    for w in range(a.warmup):
+        run_step(hv, scenes[w % len(scenes)])
+    torch.cuda.synchronize()
+
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(a.steps)]
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    n_det = 0
+    for k in range(a.steps):
+        dets, _ = run_step(hv, scenes[k % len(scenes)], events[k])
+        n_det += len(dets)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    vote_ms = np.array([e0.elapsed_time(e1) for e0, e1 in events])
+    vb = np.array([scenes[k % len(scenes)].vote_bytes for k in range(a.steps)], dtype=np.float64)
+    achieved = float((vb / (vote_ms * 1e-3)).mean() / 1e9)
+    s0 = scenes[0]
+    out = {
+        "metric": "scenes/sec (80k-pt synthetic scans)",
+        "value": a.steps * world / dt,
+        "unit": "scenes/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "single %d-point synthetic scene per GPU-step, eval_joint.py path: "
+                               "vote accumulation + decode + NMS (per-point predictions synthesised; "
+                               "sparse MinkUNet forward not yet on the timed path)" % a.points,
+                   "points": a.points, "num_rots": NUM_ROTS, "res": RES, "grid": s0.dims,
+                   "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}[a.algo],
+                   "parallelism": "scene-parallel x%d, no collective" % world},
+        "roofline": {"bound": "hbm", "kernel": "vote op (all launches of cv_hv_forward_f32)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "avg_ms": float(vote_ms.mean()), "bytes_per_launch": float(vb.mean()),
+                     "compulsory_bytes": float(s0.vote_bytes_floor), "v_in": s0.v_in},
+        "detections_per_scene": n_det / a.steps,
+    }
+    if rank == 0 and world == 1 and a.cpu_scenes > 0:
+        v, secs, _ = cpu_baseline(scenes, min(a.cpu_scenes, len(scenes)))
+        out["cpu_baseline"] = {"value": v, "unit": "scenes/s", "cores": 1, "kind": "port",
+                               "sample": "%d of the same 80k-point scenes, oracle vote+decode+NMS, "
+                                         "%.1f s, 1 thread (build CPU oracle, not reference code)"
+                                         % (min(a.cpu_scenes, len(scenes)), secs)}
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

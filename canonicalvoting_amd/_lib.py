@@ -1,0 +1,79 @@
+"""ctypes loader for the C-ABI library (include/cv_hip.h).
+
+There is no CPU fallback: if the HIP library has not been built the import of any
+op fails loudly with instructions, and every entry point checks its return code.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_C", "libcvhip.so")
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_i32_p = ctypes.POINTER(ctypes.c_int32)
+c_i64_p = ctypes.POINTER(ctypes.c_int64)
+vp = ctypes.c_void_p
+
+
+class CvError(RuntimeError):
+    pass
+
+
+class DecodeParams(ctypes.Structure):
+    """struct cv_decode_params (include/cv_hip.h); defaults = eval_joint.py:18-21,245,252."""
+    _fields_ = [("thresh_high", ctypes.c_float), ("thresh_low", ctypes.c_float),
+                ("valid_ratio", ctypes.c_float), ("elimination", ctypes.c_int),
+                ("prob_thresh", ctypes.c_float), ("elim_hi_plus1", ctypes.c_int),
+                ("max_iters", ctypes.c_int), ("err_thresh", ctypes.c_double)]
+
+
+# symbol -> (restype, argtypes); tests check every symbol of include/cv_hip.h is here and exported
+SIGNATURES = {
+    "cv_abi_version": (ctypes.c_int, []),
+    "cv_last_error": (ctypes.c_char_p, []),
+    "cv_hv_minmax_workspace_bytes": (ctypes.c_size_t, []),
+    "cv_hv_minmax_f32": (ctypes.c_int, [vp, ctypes.c_int64, c_float_p, c_float_p, vp, ctypes.c_size_t, vp]),
+    "cv_hv_grid_dims_f32": (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_float, c_int_p]),
+    "cv_hv_forward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, c_int_p, ctypes.c_int]),
+    "cv_hv_forward_f32": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_int,
+                                         c_float_p, c_int_p, vp, vp, vp, vp, ctypes.c_size_t,
+                                         ctypes.c_int, vp]),
+    "cv_hv_backward_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float,
+                                          ctypes.c_int, c_float_p, c_int_p, vp, vp, vp, vp]),
+    "cv_hv_count_votes_f32": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_int,
+                                             c_float_p, c_int_p, c_i64_p, vp, ctypes.c_size_t, vp]),
+    "cv_decode_workspace_bytes": (ctypes.c_size_t, [c_int_p, ctypes.c_int64, ctypes.c_int]),
+    "cv_decode_f32": (ctypes.c_int, [vp, vp, vp, c_int_p, c_float_p, ctypes.c_float, vp, vp, vp, vp,
+                                     ctypes.c_int64, ctypes.POINTER(DecodeParams), ctypes.c_int, vp,
+                                     ctypes.c_size_t, c_int_p, c_i64_p, c_i32_p, c_int_p, c_float_p,
+                                     c_float_p, c_i32_p, vp]),
+    "cv_iou_obb": (ctypes.c_double, [c_float_p, c_float_p]),
+    "cv_nms_obb": (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_double, c_i32_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded libcvhip.so (raises CvError with build instructions when it is missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CvError(
+                "canonicalvoting_amd: HIP library %s not found. Build it with "
+                "`python -m canonicalvoting_amd.csrc.build` (hipcc, gfx950). There is no CPU "
+                "fallback for this op." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().cv_last_error()
+        raise CvError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))

@@ -1,0 +1,71 @@
+"""Builds canonicalvoting_amd/_C/libcvhip.so with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m canonicalvoting_amd.csrc.build [--force] [--verbose]
+
+The shared object is built in-tree so it travels with the repo snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT_DIR = os.path.join(os.path.dirname(HERE), "_C")
+OBJ_DIR = os.path.join(OUT_DIR, "obj")
+LIB = os.path.join(OUT_DIR, "libcvhip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+          "-I" + HERE, "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+# strict fp32 (no FMA contraction) where results must match the oracle bit for bit
+STRICT = ["-ffp-contract=off"]
+SOURCES = {
+    "cv_host.cpp": STRICT,
+    "hv_vote.hip": STRICT,
+    "hv_decode.hip": STRICT,
+}
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    headers = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
+    headers.append(os.path.join(ROOT, "include", "cv_hip.h"))
+    headers.append(os.path.abspath(__file__))
+    jobs = []
+    objs = []
+    for src, extra in SOURCES.items():
+        s = os.path.join(HERE, src)
+        o = os.path.join(OBJ_DIR, src + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [HIPCC] + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n%s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+        return True
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

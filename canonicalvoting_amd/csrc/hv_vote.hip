@@ -1,0 +1,723 @@
+// Canonical vote accumulation for gfx950 (MI355X).
+//
+// Replaces houghvoting/src/hv_cuda_kernel.cu (forward :12-97, average :100-119,
+// backward :168-261, host shape logic :121-165) behind the C ABI of include/cv_hip.h.
+//
+// Compiled with -ffp-contract=off: the per-vote geometry (offset, grid position,
+// bounds test, floor, trilinear weights) is the strict fp32 operation sequence of
+// the reference source, so cell indices and per-vote contributions are bit-identical
+// to oracle/hv_oracle.c; only the fp32 summation order differs (as it does run to
+// run in the reference, whose accumulation is atomicAdd too).
+//
+// Two forward algorithms:
+//   direct : one lane per (point, rotation), 48 hardware fp32 global atomics per
+//            in-bounds vote, hipMemsetAsync before and a normalise pass after.
+//            This is the reference's algorithm re-parallelised over N*R lanes
+//            instead of N threads (79 blocks at N=80k cannot fill 256 CUs).
+//   tiles  : on-chip accumulation.  Every vote of a point has the same y, so points
+//            are counting-sorted by their vote's y cell (80k keys, not 9.6M).  One
+//            workgroup owns a 32x32 (x,z) tile of ONE y plane in LDS (6 channels,
+//            24 KB), pulls the points of y-bins {y-1, y}, culls them with a
+//            ring-vs-tile test, wave-compacts survivors (ballot + mbcnt), expands
+//            survivors x rotations densely over lanes, wave-compacts the votes that
+//            land in the tile, and drains them with LDS float atomics.  The tile is
+//            then normalised and stored once: no memset, no global atomics, no
+//            second pass over the 63 MB grid.
+#include "cv_common.h"
+
+#include <cmath>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct F3 { float x, y, z; };
+struct I3 { int x, y, z; };
+
+// ---------------------------------------------------------------------------
+// rotation table: (cos, sin)(i * (2*3.141592654f / R)), theta in fp32 exactly as
+// hv_cuda_kernel.cu:35,37, cos/sin correctly rounded (see oracle/hv_oracle.c).
+// Cached per (device, R); built once on the host.
+// ---------------------------------------------------------------------------
+std::mutex g_tab_mu;
+std::unordered_map<uint64_t, float2*> g_tabs;
+
+int get_rot_table(int num_rots, const float2** out) {
+    int dev = 0;
+    CV_HIP_CHECK(hipGetDevice(&dev));
+    const uint64_t key = (uint64_t(uint32_t(dev)) << 32) | uint32_t(num_rots);
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    auto it = g_tabs.find(key);
+    if (it != g_tabs.end()) { *out = it->second; return CV_OK; }
+    std::vector<float2> h(num_rots);
+    const float rot_interval = 2 * 3.141592654f / num_rots;
+    for (int i = 0; i < num_rots; ++i) {
+        const float theta = i * rot_interval;
+        h[i].x = (float)std::cos((double)theta);
+        h[i].y = (float)std::sin((double)theta);
+    }
+    float2* d = nullptr;
+    CV_HIP_CHECK(hipMalloc(&d, sizeof(float2) * num_rots));
+    CV_HIP_CHECK(hipMemcpy(d, h.data(), sizeof(float2) * num_rots, hipMemcpyHostToDevice));
+    g_tabs[key] = d;
+    *out = d;
+    return CV_OK;
+}
+
+// ---------------------------------------------------------------------------
+// shared per-vote geometry (hv_cuda_kernel.cu:38-47)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float grid_pos(float p, float off, float corner, float res) {
+    return ((p + off) - corner) / res;
+}
+
+// ---------------------------------------------------------------------------
+// min / max of points (hv_cuda_kernel.cu:129)
+// ---------------------------------------------------------------------------
+constexpr int MM_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void minmax_partial(const float* __restrict__ pts, int64_t n,
+                                                      float* __restrict__ part) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = pts[i * 3 + k];
+            mn[k] = fminf(mn[k], v);
+            mx[k] = fmaxf(mx[k], v);
+        }
+    }
+    __shared__ float s[6][256];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { s[k][threadIdx.x] = mn[k]; s[3 + k][threadIdx.x] = mx[k]; }
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                s[k][threadIdx.x] = fminf(s[k][threadIdx.x], s[k][threadIdx.x + st]);
+                s[3 + k][threadIdx.x] = fmaxf(s[3 + k][threadIdx.x], s[3 + k][threadIdx.x + st]);
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(256) void minmax_final(const float* __restrict__ part, int nblocks,
+                                                    float* __restrict__ out) {
+    __shared__ float s[6][256];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int b = threadIdx.x; b < nblocks; b += 256)
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = fminf(mn[k], part[b * 6 + k]);
+            mx[k] = fmaxf(mx[k], part[b * 6 + 3 + k]);
+        }
+    for (int k = 0; k < 3; ++k) { s[k][threadIdx.x] = mn[k]; s[3 + k][threadIdx.x] = mx[k]; }
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st)
+            for (int k = 0; k < 3; ++k) {
+                s[k][threadIdx.x] = fminf(s[k][threadIdx.x], s[k][threadIdx.x + st]);
+                s[3 + k][threadIdx.x] = fmaxf(s[3 + k][threadIdx.x], s[3 + k][threadIdx.x + st]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) out[threadIdx.x] = s[threadIdx.x][0];
+}
+
+// ---------------------------------------------------------------------------
+// direct algorithm
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hv_fwd_direct(
+    const float* __restrict__ pts, const float* __restrict__ xyz, const float* __restrict__ scl,
+    const float* __restrict__ obj, int64_t n, int R, float res, F3 corner, I3 dims,
+    const float2* __restrict__ tab, float* __restrict__ g_obj, float* __restrict__ g_rot,
+    float* __restrict__ g_scale) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n * R) return;
+    const int64_t c = t / R;
+    const int i = (int)(t - c * R);
+    const float s0 = scl[c * 3 + 0], s1 = scl[c * 3 + 1], s2 = scl[c * 3 + 2];
+    const float cx = xyz[c * 3 + 0] * s0, cy = xyz[c * 3 + 1] * s1, cz = xyz[c * 3 + 2] * s2;
+    const float2 cs = tab[i];
+    const float ox = (-cs.x) * cx + cs.y * cz;
+    const float oy = -cy;
+    const float oz = (-cs.y) * cx - cs.x * cz;
+    const float gx = grid_pos(pts[c * 3 + 0], ox, corner.x, res);
+    const float gy = grid_pos(pts[c * 3 + 1], oy, corner.y, res);
+    const float gz = grid_pos(pts[c * 3 + 2], oz, corner.z, res);
+    if (gx < 0 || gy < 0 || gz < 0 || gx >= (float)(dims.x - 1) || gy >= (float)(dims.y - 1) ||
+        gz >= (float)(dims.z - 1))
+        return;
+    const int fx = (int)gx, fy = (int)gy, fz = (int)gz;
+    const float rx = gx - floorf(gx), ry = gy - floorf(gy), rz = gz - floorf(gz);
+    const float wx[2] = {1.f - rx, rx}, wy[2] = {1.f - ry, ry}, wz[2] = {1.f - rz, rz};
+    const float ob = obj[c];
+    const int Y = dims.y, Z = dims.z;
+#pragma unroll
+    for (int bx = 0; bx < 2; ++bx)
+#pragma unroll
+        for (int by = 0; by < 2; ++by)
+#pragma unroll
+            for (int bz = 0; bz < 2; ++bz) {
+                const float w = wx[bx] * wy[by] * wz[bz] * ob;
+                const int64_t cell = ((int64_t)(fx + bx) * Y + (fy + by)) * Z + (fz + bz);
+                unsafeAtomicAdd(&g_obj[cell], w);
+                unsafeAtomicAdd(&g_rot[cell * 2 + 0], w * cs.x);
+                unsafeAtomicAdd(&g_rot[cell * 2 + 1], w * cs.y);
+                unsafeAtomicAdd(&g_scale[cell * 3 + 0], w * s0);
+                unsafeAtomicAdd(&g_scale[cell * 3 + 1], w * s1);
+                unsafeAtomicAdd(&g_scale[cell * 3 + 2], w * s2);
+            }
+}
+
+// hv_cuda_kernel.cu:100-119, coalesced along Z (flat cell index).
+__global__ __launch_bounds__(256) void hv_normalise(const float* __restrict__ g_obj,
+                                                    float* __restrict__ g_rot,
+                                                    float* __restrict__ g_scale, int64_t cells) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    const double d = (double)g_obj[i] + 1e-7;
+    float2 r = reinterpret_cast<float2*>(g_rot)[i];
+    r.x = (float)((double)r.x / d);
+    r.y = (float)((double)r.y / d);
+    reinterpret_cast<float2*>(g_rot)[i] = r;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g_scale[i * 3 + j] = (float)((double)g_scale[i * 3 + j] / d);
+}
+
+// ---------------------------------------------------------------------------
+// tiles algorithm
+// ---------------------------------------------------------------------------
+constexpr int TX = 32, TZ = 32, TCELLS = TX * TZ;
+constexpr int TW = 4;        // waves per workgroup
+constexpr int PQ = 64;       // surviving points per wave chunk
+constexpr int VQ = 128;      // vote queue entries per wave
+constexpr int MAX_R_TILES = 256;
+
+// y cell of every vote of a point (theta-independent: offset.y = -corr.y, :38-39).
+__global__ __launch_bounds__(256) void hv_prep_count(const float* __restrict__ pts,
+                                                     const float* __restrict__ xyz,
+                                                     const float* __restrict__ scl, int64_t n,
+                                                     float res, float corner_y, int Y,
+                                                     int* __restrict__ fy_out,
+                                                     int* __restrict__ ycount) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const float cy = xyz[c * 3 + 1] * scl[c * 3 + 1];
+    const float gy = grid_pos(pts[c * 3 + 1], -cy, corner_y, res);
+    int fy = -1;
+    if (gy >= 0 && gy < (float)(Y - 1)) fy = (int)gy;
+    fy_out[c] = fy;
+    if (fy >= 0) atomicAdd(&ycount[fy], 1);
+}
+
+// exclusive scan of ycount[Y] -> ystart[Y+1], cursor[Y] (single workgroup)
+__global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ ycount, int Y,
+                                                     int* __restrict__ ystart,
+                                                     int* __restrict__ cursor) {
+    __shared__ int s[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < Y; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < Y ? ycount[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int incl = s[threadIdx.x] + carry;
+        if (i < Y) { ystart[i] = incl - v; cursor[i] = incl - v; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ystart[Y] = carry;
+}
+
+__global__ __launch_bounds__(256) void hv_prep_scatter(const int* __restrict__ fy_in, int64_t n,
+                                                       int* __restrict__ cursor,
+                                                       int* __restrict__ order) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int fy = fy_in[c];
+    if (fy < 0) return;
+    const int pos = atomicAdd(&cursor[fy], 1);
+    order[pos] = (int)c;
+}
+
+__device__ __forceinline__ int lanes_below(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+__device__ __forceinline__ void lds_add(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+struct TileShared {
+    float acc[6][TCELLS];      // obj, rot.cos, rot.sin, scale.xyz  (SoA: random banks per lane)
+    float pq[TW][9][PQ];       // px, pz, cx, cz, wy, obj, s0, s1, s2 of surviving points
+    uint32_t vq_rec[TW][VQ];   // entry | rot<<6 | (lx+1)<<14 | (lz+1)<<20
+    float vq_rx[TW][VQ];
+    float vq_rz[TW][VQ];
+    float2 tab[MAX_R_TILES];
+};
+
+__device__ __forceinline__ void drain64(TileShared& sh, int wave, int slot, bool active) {
+    if (!active) return;
+    const uint32_t rec = sh.vq_rec[wave][slot];
+    const float rx = sh.vq_rx[wave][slot], rz = sh.vq_rz[wave][slot];
+    const int e = rec & 63, rot = (rec >> 6) & 255;
+    const int lx = (int)((rec >> 14) & 63) - 1, lz = (int)((rec >> 20) & 63) - 1;
+    const float wy = sh.pq[wave][4][e], ob = sh.pq[wave][5][e];
+    const float s0 = sh.pq[wave][6][e], s1 = sh.pq[wave][7][e], s2 = sh.pq[wave][8][e];
+    const float2 cs = sh.tab[rot];
+    const float wx[2] = {1.f - rx, rx}, wz[2] = {1.f - rz, rz};
+#pragma unroll
+    for (int bx = 0; bx < 2; ++bx)
+#pragma unroll
+        for (int bz = 0; bz < 2; ++bz) {
+            const int cxl = lx + bx, czl = lz + bz;
+            if (cxl < 0 || cxl >= TX || czl < 0 || czl >= TZ) continue;
+            // hv_cuda_kernel.cu:52-59 order: ((wx*wy)*wz)*objness
+            const float w = wx[bx] * wy * wz[bz] * ob;
+            const int cell = cxl * TZ + czl;
+            lds_add(&sh.acc[0][cell], w);
+            lds_add(&sh.acc[1][cell], w * cs.x);
+            lds_add(&sh.acc[2][cell], w * cs.y);
+            lds_add(&sh.acc[3][cell], w * s0);
+            lds_add(&sh.acc[4][cell], w * s1);
+            lds_add(&sh.acc[5][cell], w * s2);
+        }
+}
+
+__global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
+    const float* __restrict__ pts, const float* __restrict__ xyz, const float* __restrict__ scl,
+    const float* __restrict__ obj, int R, float res, F3 corner, I3 dims,
+    const float2* __restrict__ tab, const int* __restrict__ ystart, const int* __restrict__ order,
+    int tiles_x, int tiles_z, float* __restrict__ g_obj, float* __restrict__ g_rot,
+    float* __restrict__ g_scale) {
+    __shared__ TileShared sh;
+    const int X = dims.x, Y = dims.y, Z = dims.z;
+    const int tile = blockIdx.x % (tiles_x * tiles_z);
+    const int y = blockIdx.x / (tiles_x * tiles_z);
+    const int x0 = (tile / tiles_z) * TX, z0 = (tile % tiles_z) * TZ;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) (&sh.acc[0][0])[i] = 0.f;
+    for (int i = threadIdx.x; i < R; i += TW * 64) sh.tab[i] = tab[i];
+    __syncthreads();
+
+    // a vote at grid position g touches cells floor(g), floor(g)+1, so it reaches this
+    // tile iff g in [x0-1, x0+TX) x [z0-1, z0+TZ); slack covers fp32 rounding of the test.
+    const float slack = 0.05f;
+    const float xlo = (float)(x0 - 1), xhi = (float)(x0 + TX), zlo = (float)(z0 - 1),
+                zhi = (float)(z0 + TZ);
+    int vq_len = 0;   // wave-uniform
+
+    for (int s = y - 1; s <= y; ++s) {
+        if (s < 0 || s > Y - 2) continue;
+        const int beg = ystart[s], end = ystart[s + 1];
+        for (int base = beg + wave * 64; base < end; base += TW * 64) {
+            const int idx = base + lane;
+            bool keep = false;
+            float px = 0, pz = 0, cx = 0, cz = 0, wy = 0, ob = 0, s0 = 0, s1 = 0, s2 = 0;
+            if (idx < end) {
+                const int64_t c = order[idx];
+                px = pts[c * 3 + 0];
+                const float py = pts[c * 3 + 1];
+                pz = pts[c * 3 + 2];
+                s0 = scl[c * 3 + 0]; s1 = scl[c * 3 + 1]; s2 = scl[c * 3 + 2];
+                cx = xyz[c * 3 + 0] * s0;
+                const float cy = xyz[c * 3 + 1] * s1;
+                cz = xyz[c * 3 + 2] * s2;
+                ob = obj[c];
+                const float gy = grid_pos(py, -cy, corner.y, res);
+                const float ry = gy - floorf(gy);
+                wy = (s == y) ? (1.f - ry) : ry;
+                // conservative ring-vs-rectangle test in grid units
+                const float ux = (px - corner.x) / res, uz = (pz - corner.z) / res;
+                const float r = sqrtf(cx * cx + cz * cz) / res;
+                const float dxn = fmaxf(0.f, fmaxf(xlo - ux, ux - xhi));
+                const float dzn = fmaxf(0.f, fmaxf(zlo - uz, uz - zhi));
+                const float dxf = fmaxf(fabsf(ux - xlo), fabsf(ux - xhi));
+                const float dzf = fmaxf(fabsf(uz - zlo), fabsf(uz - zhi));
+                const float dmin = sqrtf(dxn * dxn + dzn * dzn), dmax = sqrtf(dxf * dxf + dzf * dzf);
+                const float tol = slack + 1e-5f * (r + fabsf(ux) + fabsf(uz));
+                keep = (r >= dmin - tol) && (r <= dmax + tol);
+            }
+            const uint64_t m = __ballot(keep);
+            const int nq = __popcll(m);
+            if (nq == 0) continue;
+            if (keep) {
+                const int p = lanes_below(m);
+                sh.pq[wave][0][p] = px; sh.pq[wave][1][p] = pz; sh.pq[wave][2][p] = cx;
+                sh.pq[wave][3][p] = cz; sh.pq[wave][4][p] = wy; sh.pq[wave][5][p] = ob;
+                sh.pq[wave][6][p] = s0; sh.pq[wave][7][p] = s1; sh.pq[wave][8][p] = s2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            const int items = nq * R;
+            const float inv_nq = 1.0f / (float)nq;
+            for (int ib = 0; ib < items; ib += 64) {
+                const int i = ib + lane;
+                bool isvote = false;
+                uint32_t rec = 0;
+                float rx = 0, rz = 0;
+                if (i < items) {
+                    // rot-major so the 64 lanes of a step are different points at (almost)
+                    // one rotation: distinct cells, few same-address LDS atomic collisions.
+                    const int rot = (int)(((float)i + 0.5f) * inv_nq);
+                    const int e = i - rot * nq;
+                    const float2 cs = sh.tab[rot];
+                    const float ecx = sh.pq[wave][2][e], ecz = sh.pq[wave][3][e];
+                    const float ox = (-cs.x) * ecx + cs.y * ecz;
+                    const float oz = (-cs.y) * ecx - cs.x * ecz;
+                    const float gx = grid_pos(sh.pq[wave][0][e], ox, corner.x, res);
+                    const float gz = grid_pos(sh.pq[wave][1][e], oz, corner.z, res);
+                    if (gx >= 0 && gz >= 0 && gx < (float)(X - 1) && gz < (float)(Z - 1)) {
+                        const int lx = (int)gx - x0, lz = (int)gz - z0;
+                        if (lx >= -1 && lx < TX && lz >= -1 && lz < TZ) {
+                            isvote = true;
+                            rx = gx - floorf(gx);
+                            rz = gz - floorf(gz);
+                            rec = (uint32_t)e | ((uint32_t)rot << 6) | ((uint32_t)(lx + 1) << 14) |
+                                  ((uint32_t)(lz + 1) << 20);
+                        }
+                    }
+                }
+                const uint64_t mv = __ballot(isvote);
+                if (isvote) {
+                    const int p = vq_len + lanes_below(mv);
+                    sh.vq_rec[wave][p] = rec;
+                    sh.vq_rx[wave][p] = rx;
+                    sh.vq_rz[wave][p] = rz;
+                }
+                vq_len += __popcll(mv);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (vq_len >= 64) {
+                    vq_len -= 64;
+                    drain64(sh, wave, vq_len + lane, true);
+                }
+            }
+            // queued votes index this chunk's pq entries: flush before pq is overwritten
+            if (vq_len > 0) {
+                drain64(sh, wave, lane, lane < vq_len);
+                vq_len = 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    __syncthreads();
+
+    // fused normalise (hv_cuda_kernel.cu:112-117) + single store of the tile
+    const int nx = min(TX, X - x0), nz = min(TZ, Z - z0);
+    for (int i = threadIdx.x; i < TCELLS; i += TW * 64) {
+        const int lx = i / TZ, lz = i % TZ;
+        if (lx < nx && lz < nz)
+            g_obj[((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz] = sh.acc[0][i];
+    }
+    for (int i = threadIdx.x; i < TCELLS * 2; i += TW * 64) {
+        const int cell = i >> 1, j = i & 1;
+        const int lx = cell / TZ, lz = cell % TZ;
+        if (lx < nx && lz < nz) {
+            const double d = (double)sh.acc[0][cell] + 1e-7;
+            g_rot[(((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz) * 2 + j] =
+                (float)((double)sh.acc[1 + j][cell] / d);
+        }
+    }
+    for (int i = threadIdx.x; i < TCELLS * 3; i += TW * 64) {
+        const int cell = i / 3, j = i - cell * 3;
+        const int lx = cell / TZ, lz = cell % TZ;
+        if (lx < nx && lz < nz) {
+            const double d = (double)sh.acc[0][cell] + 1e-7;
+            g_scale[(((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz) * 3 + j] =
+                (float)((double)sh.acc[3 + j][cell] / d);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward (hv_cuda_kernel.cu:168-261): one wave per point, lanes over rotations,
+// butterfly reduction (deterministic; no atomics, like the reference).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hv_bwd(
+    const float* __restrict__ grad, const float* __restrict__ pts, const float* __restrict__ xyz,
+    const float* __restrict__ scl, const float* __restrict__ obj, int64_t n, int R, float res,
+    F3 corner, I3 dims, const float2* __restrict__ tab, float* __restrict__ d_xyz,
+    float* __restrict__ d_scl, float* __restrict__ d_obj) {
+    const int lane = threadIdx.x & 63;
+    const int64_t c = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (c >= n) return;
+    const int Y = dims.y, Z = dims.z;
+    const float s0 = scl[c * 3 + 0], s1 = scl[c * 3 + 1], s2 = scl[c * 3 + 2];
+    const float x0 = xyz[c * 3 + 0], x1 = xyz[c * 3 + 1], x2 = xyz[c * 3 + 2];
+    const float cx = x0 * s0, cy = x1 * s1, cz = x2 * s2;
+    const float px = pts[c * 3 + 0], py = pts[c * 3 + 1], pz = pts[c * 3 + 2];
+    const float ob = obj[c];
+    float a_obj = 0, a_x0 = 0, a_x1 = 0, a_x2 = 0, a_s0 = 0, a_s1 = 0, a_s2 = 0;
+    for (int i = lane; i < R; i += 64) {
+        const float2 cs = tab[i];
+        const float ox = (-cs.x) * cx + cs.y * cz;
+        const float oy = -cy;
+        const float oz = (-cs.y) * cx - cs.x * cz;
+        const float gx = grid_pos(px, ox, corner.x, res);
+        const float gy = grid_pos(py, oy, corner.y, res);
+        const float gz = grid_pos(pz, oz, corner.z, res);
+        if (gx < 0 || gy < 0 || gz < 0 || gx >= (float)(dims.x - 1) || gy >= (float)(dims.y - 1) ||
+            gz >= (float)(dims.z - 1))
+            continue;
+        const int fx = (int)gx, fy = (int)gy, fz = (int)gz;
+        const float rx = gx - floorf(gx), ry = gy - floorf(gy), rz = gz - floorf(gz);
+        const float w0x = 1.f - rx, w0y = 1.f - ry, w0z = 1.f - rz, w1x = rx, w1y = ry, w1z = rz;
+        const int64_t b = ((int64_t)fx * Y + fy) * Z + fz;
+        const int64_t sx = (int64_t)Y * Z, sy = Z;
+        const float lll = grad[b], llh = grad[b + 1], lhl = grad[b + sy], lhh = grad[b + sy + 1];
+        const float hll = grad[b + sx], hlh = grad[b + sx + 1], hhl = grad[b + sx + sy],
+                    hhh = grad[b + sx + sy + 1];
+        float dob = lll * w0x * w0y * w0z;
+        dob += llh * w0x * w0y * w1z;
+        dob += lhl * w0x * w1y * w0z;
+        dob += lhh * w0x * w1y * w1z;
+        dob += hll * w1x * w0y * w0z;
+        dob += hlh * w1x * w0y * w1z;
+        dob += hhl * w1x * w1y * w0z;
+        dob += hhh * w1x * w1y * w1z;
+        a_obj += dob;
+        float dx = -lll * w0y * w0z;
+        dx = dx - llh * w0y * w1z; dx = dx - lhl * w1y * w0z; dx = dx - lhh * w1y * w1z;
+        dx = dx + hll * w0y * w0z; dx = dx + hlh * w0y * w1z; dx = dx + hhl * w1y * w0z;
+        dx = dx + hhh * w1y * w1z;
+        float dy = -lll * w0x * w0z;
+        dy = dy - llh * w0x * w1z; dy = dy + lhl * w0x * w0z; dy = dy + lhh * w0x * w1z;
+        dy = dy - hll * w1x * w0z; dy = dy - hlh * w1x * w1z; dy = dy + hhl * w1x * w0z;
+        dy = dy + hhh * w1x * w1z;
+        float dz = -lll * w0x * w0y;
+        dz = dz + llh * w0x * w0y; dz = dz - lhl * w0x * w1y; dz = dz + lhh * w0x * w1y;
+        dz = dz - hll * w1x * w0y; dz = dz + hlh * w1x * w0y; dz = dz - hhl * w1x * w1y;
+        dz = dz + hhh * w1x * w1y;
+        dx *= ob; dy *= ob; dz *= ob;
+        const float dcx = (-cs.x) * dx - cs.y * dz;
+        const float dcy = -dy;
+        const float dcz = cs.y * dx - cs.x * dz;
+        a_x0 += dcx * s0; a_x1 += dcy * s1; a_x2 += dcz * s2;
+        a_s0 += dcx * x0; a_s1 += dcy * x1; a_s2 += dcz * x2;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a_obj += __shfl_xor(a_obj, off);
+        a_x0 += __shfl_xor(a_x0, off); a_x1 += __shfl_xor(a_x1, off); a_x2 += __shfl_xor(a_x2, off);
+        a_s0 += __shfl_xor(a_s0, off); a_s1 += __shfl_xor(a_s1, off); a_s2 += __shfl_xor(a_s2, off);
+    }
+    if (lane == 0) {
+        d_obj[c] = a_obj;
+        d_xyz[c * 3 + 0] = a_x0; d_xyz[c * 3 + 1] = a_x1; d_xyz[c * 3 + 2] = a_x2;
+        d_scl[c * 3 + 0] = a_s0; d_scl[c * 3 + 1] = a_s1; d_scl[c * 3 + 2] = a_s2;
+    }
+}
+
+__global__ __launch_bounds__(256) void hv_count_votes(
+    const float* __restrict__ pts, const float* __restrict__ xyz, const float* __restrict__ scl,
+    int64_t n, int R, float res, F3 corner, I3 dims, const float2* __restrict__ tab,
+    unsigned long long* __restrict__ count) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    bool in = false;
+    if (t < n * R) {
+        const int64_t c = t / R;
+        const int i = (int)(t - c * R);
+        const float cx = xyz[c * 3 + 0] * scl[c * 3 + 0], cy = xyz[c * 3 + 1] * scl[c * 3 + 1],
+                    cz = xyz[c * 3 + 2] * scl[c * 3 + 2];
+        const float2 cs = tab[i];
+        const float ox = (-cs.x) * cx + cs.y * cz, oy = -cy, oz = (-cs.y) * cx - cs.x * cz;
+        const float gx = grid_pos(pts[c * 3 + 0], ox, corner.x, res);
+        const float gy = grid_pos(pts[c * 3 + 1], oy, corner.y, res);
+        const float gz = grid_pos(pts[c * 3 + 2], oz, corner.z, res);
+        in = !(gx < 0 || gy < 0 || gz < 0 || gx >= (float)(dims.x - 1) ||
+               gy >= (float)(dims.y - 1) || gz >= (float)(dims.z - 1));
+    }
+    const uint64_t m = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
+int check_common(const void* a, const void* b, const void* c, int64_t n, float res, int num_rots,
+                 const float* corner, const int* dims) {
+    CV_REQUIRE(a && b && c && corner && dims, CV_EINVAL, "null pointer argument");
+    CV_REQUIRE(n > 0, CV_EINVAL, "n must be positive (got %lld)", (long long)n);
+    CV_REQUIRE(res > 0.f, CV_EINVAL, "res must be positive");
+    CV_REQUIRE(num_rots > 0 && num_rots <= 4096, CV_EINVAL, "num_rots out of range (%d)", num_rots);
+    CV_REQUIRE(dims[0] > 0 && dims[1] > 0 && dims[2] > 0, CV_EINVAL, "bad grid dims");
+    CV_REQUIRE((int64_t)dims[0] * dims[1] * dims[2] < (1ll << 31), CV_EINVAL, "grid too large");
+    CV_REQUIRE(n * (int64_t)num_rots < (1ll << 40), CV_EINVAL, "n*num_rots too large");
+    return CV_OK;
+}
+
+int pick_algo(int algo, int64_t n, int num_rots, const int* dims) {
+    if (algo == 1 || algo == 2) return algo;
+    if (num_rots <= MAX_R_TILES && n < (1ll << 31)) return 2;
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cv_hv_minmax_workspace_bytes(void) { return 256 + sizeof(float) * 6 * (MM_BLOCKS + 1) + 256; }
+
+int cv_hv_minmax_f32(const float* d_points, int64_t n, float* h_min3, float* h_max3, void* d_ws,
+                     size_t ws_bytes, void* stream) {
+    CV_REQUIRE(d_points && h_min3 && h_max3 && d_ws, CV_EINVAL, "null pointer argument");
+    CV_REQUIRE(n > 0, CV_EINVAL, "n must be positive (got %lld)", (long long)n);
+    CV_REQUIRE(ws_bytes >= cv_hv_minmax_workspace_bytes(), CV_ENOMEM, "workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CvCarver cv(d_ws);
+    float* part = cv.take<float>(6 * MM_BLOCKS);
+    float* out = cv.take<float>(6);
+    const int blocks = (int)std::min<int64_t>(MM_BLOCKS, (n + 255) / 256);
+    minmax_partial<<<blocks, 256, 0, st>>>(d_points, n, part);
+    CV_LAUNCH_CHECK();
+    minmax_final<<<1, 256, 0, st>>>(part, blocks, out);
+    CV_LAUNCH_CHECK();
+    float h[6];
+    CV_HIP_CHECK(hipMemcpyAsync(h, out, sizeof h, hipMemcpyDeviceToHost, st));
+    CV_HIP_CHECK(hipStreamSynchronize(st));
+    for (int k = 0; k < 3; ++k) { h_min3[k] = h[k]; h_max3[k] = h[3 + k]; }
+    return CV_OK;
+}
+
+int cv_hv_grid_dims_f32(const float h_min3[3], const float h_max3[3], float res, int dims_out[3]) {
+    CV_REQUIRE(h_min3 && h_max3 && dims_out, CV_EINVAL, "null pointer argument");
+    CV_REQUIRE(res > 0.f, CV_EINVAL, "res must be positive");
+    for (int k = 0; k < 3; ++k) {
+        volatile float d = h_max3[k] - h_min3[k];   // hv_cuda_kernel.cu:131 (fp32 tensor ops)
+        volatile float q = d / res;
+        dims_out[k] = (int)q + 1;                   // :132 .item().to<int>() + 1
+    }
+    return CV_OK;
+}
+
+size_t cv_hv_forward_workspace_bytes(int64_t n, int num_rots, const int dims[3], int algo) {
+    if (!dims || n <= 0) return 0;
+    if (pick_algo(algo, n, num_rots, dims) == 1) return 256;
+    const size_t Y = (size_t)dims[1];
+    return 256 * 6 + sizeof(int) * ((size_t)n * 2 + Y * 3 + 8);
+}
+
+int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_scale,
+                      const float* d_obj, int64_t n, float res, int num_rots,
+                      const float h_corner3[3], const int dims[3], float* d_grid_obj,
+                      float* d_grid_rot, float* d_grid_scale, void* d_ws, size_t ws_bytes, int algo,
+                      void* stream) {
+    int rc = check_common(d_points, d_xyz, d_scale, n, res, num_rots, h_corner3, dims);
+    if (rc) return rc;
+    CV_REQUIRE(d_obj && d_grid_obj && d_grid_rot && d_grid_scale, CV_EINVAL, "null pointer argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float2* tab = nullptr;
+    rc = get_rot_table(num_rots, &tab);
+    if (rc) return rc;
+    const F3 corner{h_corner3[0], h_corner3[1], h_corner3[2]};
+    const I3 d3{dims[0], dims[1], dims[2]};
+    const int64_t cells = (int64_t)dims[0] * dims[1] * dims[2];
+    const int a = pick_algo(algo, n, num_rots, dims);
+    if (a == 2) CV_REQUIRE(num_rots <= MAX_R_TILES, CV_EINVAL, "tiles algorithm needs num_rots <= %d", MAX_R_TILES);
+    if (a == 1) {
+        CV_HIP_CHECK(hipMemsetAsync(d_grid_obj, 0, sizeof(float) * cells, st));
+        CV_HIP_CHECK(hipMemsetAsync(d_grid_rot, 0, sizeof(float) * cells * 2, st));
+        CV_HIP_CHECK(hipMemsetAsync(d_grid_scale, 0, sizeof(float) * cells * 3, st));
+        const int64_t total = n * num_rots;
+        hv_fwd_direct<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+            d_points, d_xyz, d_scale, d_obj, n, num_rots, res, corner, d3, tab, d_grid_obj,
+            d_grid_rot, d_grid_scale);
+        CV_LAUNCH_CHECK();
+        hv_normalise<<<(unsigned)((cells + 255) / 256), 256, 0, st>>>(d_grid_obj, d_grid_rot,
+                                                                     d_grid_scale, cells);
+        CV_LAUNCH_CHECK();
+        return CV_OK;
+    }
+    CV_REQUIRE(d_ws && ws_bytes >= cv_hv_forward_workspace_bytes(n, num_rots, dims, 2), CV_ENOMEM,
+               "workspace too small for the tiles algorithm");
+    const int Y = dims[1];
+    CvCarver cv(d_ws);
+    int* fy = cv.take<int>(n);
+    int* order = cv.take<int>(n);
+    int* ycount = cv.take<int>(Y);
+    int* ystart = cv.take<int>(Y + 1);
+    int* cursor = cv.take<int>(Y);
+    CV_HIP_CHECK(hipMemsetAsync(ycount, 0, sizeof(int) * Y, st));
+    hv_prep_count<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_points, d_xyz, d_scale, n, res,
+                                                              corner.y, Y, fy, ycount);
+    CV_LAUNCH_CHECK();
+    hv_prep_scan<<<1, 1024, 0, st>>>(ycount, Y, ystart, cursor);
+    CV_LAUNCH_CHECK();
+    hv_prep_scatter<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(fy, n, cursor, order);
+    CV_LAUNCH_CHECK();
+    const int tiles_x = (dims[0] + TX - 1) / TX, tiles_z = (dims[2] + TZ - 1) / TZ;
+    const int64_t wgs = (int64_t)tiles_x * tiles_z * Y;
+    CV_REQUIRE(wgs < (1ll << 31), CV_EINVAL, "grid too large");
+    hv_fwd_tiles<<<(unsigned)wgs, TW * 64, 0, st>>>(d_points, d_xyz, d_scale, d_obj, num_rots, res,
+                                                   corner, d3, tab, ystart, order, tiles_x, tiles_z,
+                                                   d_grid_obj, d_grid_rot, d_grid_scale);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+int cv_hv_backward_f32(const float* d_grad_obj, const float* d_points, const float* d_xyz,
+                       const float* d_scale, const float* d_obj, int64_t n, float res, int num_rots,
+                       const float h_corner3[3], const int dims[3], float* d_dxyz, float* d_dscale,
+                       float* d_dobj, void* stream) {
+    int rc = check_common(d_points, d_xyz, d_scale, n, res, num_rots, h_corner3, dims);
+    if (rc) return rc;
+    CV_REQUIRE(d_grad_obj && d_obj && d_dxyz && d_dscale && d_dobj, CV_EINVAL, "null pointer argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float2* tab = nullptr;
+    rc = get_rot_table(num_rots, &tab);
+    if (rc) return rc;
+    const F3 corner{h_corner3[0], h_corner3[1], h_corner3[2]};
+    const I3 d3{dims[0], dims[1], dims[2]};
+    hv_bwd<<<(unsigned)((n + 3) / 4), 256, 0, st>>>(d_grad_obj, d_points, d_xyz, d_scale, d_obj, n,
+                                                   num_rots, res, corner, d3, tab, d_dxyz, d_dscale,
+                                                   d_dobj);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+int cv_hv_count_votes_f32(const float* d_points, const float* d_xyz, const float* d_scale, int64_t n,
+                          float res, int num_rots, const float h_corner3[3], const int dims[3],
+                          int64_t* h_count, void* d_ws, size_t ws_bytes, void* stream) {
+    int rc = check_common(d_points, d_xyz, d_scale, n, res, num_rots, h_corner3, dims);
+    if (rc) return rc;
+    CV_REQUIRE(h_count && d_ws && ws_bytes >= 256, CV_ENOMEM, "workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float2* tab = nullptr;
+    rc = get_rot_table(num_rots, &tab);
+    if (rc) return rc;
+    unsigned long long* cnt = static_cast<unsigned long long*>(d_ws);
+    CV_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(*cnt), st));
+    const F3 corner{h_corner3[0], h_corner3[1], h_corner3[2]};
+    const I3 d3{dims[0], dims[1], dims[2]};
+    const int64_t total = n * num_rots;
+    hv_count_votes<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d_points, d_xyz, d_scale, n,
+                                                                   num_rots, res, corner, d3, tab, cnt);
+    CV_LAUNCH_CHECK();
+    unsigned long long h = 0;
+    CV_HIP_CHECK(hipMemcpyAsync(&h, cnt, sizeof h, hipMemcpyDeviceToHost, st));
+    CV_HIP_CHECK(hipStreamSynchronize(st));
+    *h_count = (int64_t)h;
+    return CV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+"""Drop-in for the reference's pybind module ``hv_cuda`` (houghvoting/src/hv_cuda.cpp:74-77).
+
+    forward(points, xyz_labels, scale_labels, obj_labels, res, num_rots[, corners])
+        -> [grid_obj[X,Y,Z], grid_rot[X,Y,Z,2], grid_scale[X,Y,Z,3]]      (hv_cuda.cpp:30-45)
+    backward(grad_grid, points, xyz_labels, scale_labels, obj_labels, res, num_rots)
+        -> [d_xyz_labels, d_scale_labels, d_obj_labels]                    (hv_cuda.cpp:47-71)
+
+Same argument meaning, same input checks and messages (``"<name> must be a CUDA tensor"``,
+``"<name> must be contiguous"``, hv_cuda.cpp:26-28), same fresh writable outputs on the inputs'
+device.  The optional 7th ``corners[2,3]`` is the SUN RGB-D caller's variant
+(sunrgbd/brnetcanon.py:99).  Under PyTorch-ROCm "cuda" tensors are HIP device memory; the
+work is done by the hand-written gfx950 kernels in libcvhip.so on torch's current stream.
+
+Differences that are improvements, not behaviour changes: kernels run on the current stream
+instead of the legacy default stream, one host sync per forward (the grid shape has to reach
+the host) instead of twelve, zero when ``corners`` is given.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ALGO_AUTO, ALGO_DIRECT, ALGO_TILES = 0, 1, 2
+_algo = ALGO_AUTO
+_scalar_cache = {}
+
+
+def set_algorithm(algo):
+    """0 auto, 1 direct global atomics, 2 LDS tiles (for A/B measurements)."""
+    global _algo
+    _algo = int(algo)
+
+
+def _check_input(x, name):
+    if not x.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor" % name)
+    if not x.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+
+
+def _scalar(t, kind):
+    """Host value of a 0-dim device tensor (res / num_rots).  The reference dereferences these
+    on the device (hv_cuda_kernel.cu:22-23); we need them on the host for the launch geometry,
+    so the value is read once per (storage, version) and cached - no per-call sync."""
+    key = (t.data_ptr(), t._version, t.device.index, kind)
+    v = _scalar_cache.get(key)
+    if v is None:
+        v = float(t.item()) if kind == "f" else int(t.item())
+        if len(_scalar_cache) > 64:
+            _scalar_cache.clear()
+        _scalar_cache[key] = v
+    return v
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _f3(vals):
+    return (ctypes.c_float * 3)(*[float(v) for v in vals])
+
+
+def grid_geometry(points, res):
+    """(corner[3], max[3], dims[3]) as hv_cuda_kernel.cu:129-134 computes them (one host sync)."""
+    L = _lib.lib()
+    ws = torch.empty(L.cv_hv_minmax_workspace_bytes(), dtype=torch.uint8, device=points.device)
+    mn = (ctypes.c_float * 3)()
+    mx = (ctypes.c_float * 3)()
+    with torch.cuda.device(points.device):
+        _lib.check(L.cv_hv_minmax_f32(_ptr(points), points.shape[0], mn, mx, _ptr(ws), ws.numel(),
+                                      _stream(points.device)), "cv_hv_minmax_f32")
+    dims = (ctypes.c_int * 3)()
+    _lib.check(L.cv_hv_grid_dims_f32(mn, mx, ctypes.c_float(res), dims), "cv_hv_grid_dims_f32")
+    return list(mn), list(mx), [int(d) for d in dims]
+
+
+def _checked_inputs(points, xyz_labels, scale_labels, obj_labels, res, num_rots):
+    _check_input(points, "points")
+    _check_input(xyz_labels, "xyz_labels")
+    _check_input(scale_labels, "scale_labels")
+    _check_input(obj_labels, "obj_labels")
+    _check_input(res, "res")
+    _check_input(num_rots, "num_rots")
+    for t, name in ((points, "points"), (xyz_labels, "xyz_labels"), (scale_labels, "scale_labels"),
+                    (obj_labels, "obj_labels")):
+        if t.dtype != torch.float32:
+            raise RuntimeError("%s must be float32 (got %s)" % (name, t.dtype))
+    n = points.shape[0]
+    if points.dim() != 2 or points.shape[1] != 3 or xyz_labels.shape != (n, 3) \
+            or scale_labels.shape != (n, 3) or obj_labels.shape != (n,):
+        raise RuntimeError("expected points/xyz_labels/scale_labels [N,3] and obj_labels [N]")
+    if n == 0:
+        # the reference fails inside torch::min on an empty tensor (hv_cuda_kernel.cu:129)
+        raise RuntimeError("hv_cuda: cannot vote with zero points")
+    return n, _scalar(res, "f"), _scalar(num_rots, "i")
+
+
+def forward(points, xyz_labels, scale_labels, obj_labels, res, num_rots, corners=None):
+    n, res_v, nrot = _checked_inputs(points, xyz_labels, scale_labels, obj_labels, res, num_rots)
+    L = _lib.lib()
+    dev = points.device
+    if corners is None:
+        mn, _, dims = grid_geometry(points, res_v)
+    else:
+        c = corners.detach().to("cpu", torch.float32)
+        mn = [float(v) for v in c[0]]
+        d = (ctypes.c_int * 3)()
+        _lib.check(L.cv_hv_grid_dims_f32(_f3(mn), _f3(c[1]), ctypes.c_float(res_v), d),
+                   "cv_hv_grid_dims_f32")
+        dims = [int(v) for v in d]
+    X, Y, Z = dims
+    grid_obj = torch.empty((X, Y, Z), dtype=torch.float32, device=dev)
+    grid_rot = torch.empty((X, Y, Z, 2), dtype=torch.float32, device=dev)
+    grid_scale = torch.empty((X, Y, Z, 3), dtype=torch.float32, device=dev)
+    cdims = (ctypes.c_int * 3)(*dims)
+    wsb = L.cv_hv_forward_workspace_bytes(n, nrot, cdims, _algo)
+    ws = torch.empty(max(int(wsb), 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.cv_hv_forward_f32(_ptr(points), _ptr(xyz_labels), _ptr(scale_labels),
+                                       _ptr(obj_labels), n, ctypes.c_float(res_v), nrot, _f3(mn),
+                                       cdims, _ptr(grid_obj), _ptr(grid_rot), _ptr(grid_scale),
+                                       _ptr(ws), ws.numel(), _algo, _stream(dev)),
+                   "cv_hv_forward_f32")
+    return [grid_obj, grid_rot, grid_scale]
+
+
+def backward(grad_grid, points, xyz_labels, scale_labels, obj_labels, res, num_rots):
+    _check_input(grad_grid, "grad_grid")
+    n, res_v, nrot = _checked_inputs(points, xyz_labels, scale_labels, obj_labels, res, num_rots)
+    if grad_grid.dtype != torch.float32 or grad_grid.dim() != 3:
+        raise RuntimeError("grad_grid must be a float32 [X,Y,Z] tensor")
+    L = _lib.lib()
+    dev = points.device
+    mn, _, _ = grid_geometry(points, res_v)          # hv_cuda_kernel.cu:274-276
+    cdims = (ctypes.c_int * 3)(*grad_grid.shape)     # :200 sizes come from grad_grid
+    d_xyz = torch.empty_like(xyz_labels)
+    d_scale = torch.empty_like(scale_labels)
+    d_obj = torch.empty_like(obj_labels)
+    with torch.cuda.device(dev):
+        _lib.check(L.cv_hv_backward_f32(_ptr(grad_grid), _ptr(points), _ptr(xyz_labels),
+                                        _ptr(scale_labels), _ptr(obj_labels), n,
+                                        ctypes.c_float(res_v), nrot, _f3(mn), cdims, _ptr(d_xyz),
+                                        _ptr(d_scale), _ptr(d_obj), _stream(dev)),
+                   "cv_hv_backward_f32")
+    return [d_xyz, d_scale, d_obj]
+
+
+def count_votes(points, xyz_labels, scale_labels, res, num_rots, corner, dims):
+    """Number of in-bounds (point, rotation) votes: V_in of the algorithmic byte count."""
+    L = _lib.lib()
+    dev = points.device
+    ws = torch.empty(256, dtype=torch.uint8, device=dev)
+    out = ctypes.c_int64(0)
+    with torch.cuda.device(dev):
+        _lib.check(L.cv_hv_count_votes_f32(_ptr(points), _ptr(xyz_labels), _ptr(scale_labels),
+                                           points.shape[0], ctypes.c_float(res), int(num_rots),
+                                           _f3(corner), (ctypes.c_int * 3)(*dims), ctypes.byref(out),
+                                           _ptr(ws), ws.numel(), _stream(dev)),
+                   "cv_hv_count_votes_f32")
+    return int(out.value)

@@ -1,0 +1,223 @@
+"""CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package.  ``canonicalvoting_amd`` never does; the product
+path fails loudly when its HIP library is missing instead of falling back here.
+
+Contents (each file cites the reference lines it restates):
+  hv_oracle.c      vote forward / average / backward   (hv_cuda_kernel.cu)
+  decode_oracle.c  greedy decode + OBB IoU + NMS        (eval_joint.py, calc_map.py)
+  hv_numpy.py      independent numpy restatement of the vote (cross-check)
+  sparse_oracle.py MinkUNet34C on dense torch convs      (utils/minkunet.py, resnet.py)
+
+PARITY STATUS: parity unpinned (the reference ships no tests/goldens and none of
+its hot path can be built or imported in this image).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libcv_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile the C oracle with gcc (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in ("hv_oracle.c", "decode_oracle.c", "Makefile")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _LIB_PATH
+
+
+class DecodeParams(ctypes.Structure):
+    """Mirrors cv_decode_params; defaults are eval_joint.py:18-21,245,252."""
+    _fields_ = [("thresh_high", ctypes.c_float), ("thresh_low", ctypes.c_float),
+                ("valid_ratio", ctypes.c_float), ("elimination", ctypes.c_int),
+                ("prob_thresh", ctypes.c_float), ("elim_hi_plus1", ctypes.c_int),
+                ("max_iters", ctypes.c_int), ("err_thresh", ctypes.c_double)]
+
+    @classmethod
+    def default(cls, **kw):
+        d = dict(thresh_high=60.0, thresh_low=10.0, valid_ratio=0.2, elimination=2,
+                 prob_thresh=0.3, elim_hi_plus1=1, max_iters=512, err_thresh=0.3)
+        d.update(kw)
+        return cls(**d)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        fp = ctypes.POINTER(ctypes.c_float)
+        ip = ctypes.POINTER(ctypes.c_int)
+        L.hv_oracle_forward.restype = ctypes.c_int64
+        L.hv_oracle_forward.argtypes = [fp, fp, fp, fp, ctypes.c_int64, ctypes.c_float,
+                                        ctypes.c_int, fp, ip, fp, fp, fp]
+        L.hv_oracle_average.restype = None
+        L.hv_oracle_average.argtypes = [fp, fp, fp, ctypes.c_int64]
+        L.hv_oracle_backward.restype = None
+        L.hv_oracle_backward.argtypes = [fp, fp, fp, fp, fp, ctypes.c_int64, ctypes.c_float,
+                                         ctypes.c_int, fp, ip, fp, fp, fp]
+        L.hv_oracle_minmax.restype = None
+        L.hv_oracle_minmax.argtypes = [fp, ctypes.c_int64, fp, fp]
+        L.hv_oracle_grid_dims.restype = None
+        L.hv_oracle_grid_dims.argtypes = [fp, fp, ctypes.c_float, ip]
+        L.hv_oracle_rot_table.restype = None
+        L.hv_oracle_rot_table.argtypes = [ctypes.c_int, fp]
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        L.cv_oracle_decode.restype = ctypes.c_int
+        L.cv_oracle_decode.argtypes = [fp, fp, fp, ip, fp, ctypes.c_float, fp, fp, fp, i32p,
+                                       ctypes.c_int64, ctypes.POINTER(DecodeParams), i64p, i32p,
+                                       fp, fp, i32p, ip]
+        L.cv_oracle_iou_obb.restype = ctypes.c_double
+        L.cv_oracle_iou_obb.argtypes = [fp, fp]
+        L.cv_oracle_nms.restype = ctypes.c_int
+        L.cv_oracle_nms.argtypes = [fp, fp, ctypes.c_int, ctypes.c_double, i32p]
+        _lib = L
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+def grid_geometry(points, res):
+    """(corner[3] f32, dims[3] int) exactly as hv_cuda_kernel.cu:129-134."""
+    L = lib()
+    pts, pp = _f(points)
+    mn_a, mn_p = _f(np.zeros(3, np.float32))
+    mx_a, mx_p = _f(np.zeros(3, np.float32))
+    L.hv_oracle_minmax(pp, pts.shape[0], mn_p, mx_p)
+    dims = (ctypes.c_int * 3)()
+    L.hv_oracle_grid_dims(mn_p, mx_p, ctypes.c_float(res), dims)
+    return mn_a, mx_a, [int(d) for d in dims]
+
+
+def hv_forward(points, xyz, scale, obj, res, num_rots, corners=None, return_vin=False):
+    """Oracle of hv_cuda.forward (hv_cuda.cpp:30-45): -> grid_obj, grid_rot, grid_scale."""
+    L = lib()
+    pts, pp = _f(points)
+    xa, xp = _f(xyz)
+    sa, sp = _f(scale)
+    oa, op = _f(obj)
+    n = pts.shape[0]
+    if corners is None:
+        mn, mx, dims = grid_geometry(pts, res)
+    else:
+        c = np.ascontiguousarray(corners, np.float32)
+        mn, mx = c[0].copy(), c[1].copy()
+        d = (ctypes.c_int * 3)()
+        L.hv_oracle_grid_dims(_f(mn)[1], _f(mx)[1], ctypes.c_float(res), d)
+        dims = [int(v) for v in d]
+    X, Y, Z = dims
+    g_obj = np.zeros((X, Y, Z), np.float32)
+    g_rot = np.zeros((X, Y, Z, 2), np.float32)
+    g_scale = np.zeros((X, Y, Z, 3), np.float32)
+    cdims = (ctypes.c_int * 3)(*dims)
+    mn_a, mn_p = _f(mn)
+    vin = L.hv_oracle_forward(pp, xp, sp, op, n, ctypes.c_float(res), int(num_rots), mn_p, cdims,
+                              _f(g_obj)[1], _f(g_rot)[1], _f(g_scale)[1])
+    L.hv_oracle_average(_f(g_obj)[1], _f(g_rot)[1], _f(g_scale)[1], X * Y * Z)
+    if return_vin:
+        return g_obj, g_rot, g_scale, int(vin)
+    return g_obj, g_rot, g_scale
+
+
+def hv_backward(grad_grid, points, xyz, scale, obj, res, num_rots):
+    """Oracle of hv_cuda.backward (hv_cuda.cpp:47-71): -> d_xyz, d_scale, d_obj."""
+    L = lib()
+    ga, gp = _f(grad_grid)
+    pts, pp = _f(points)
+    xa, xp = _f(xyz)
+    sa, sp = _f(scale)
+    oa, op = _f(obj)
+    n = pts.shape[0]
+    mn, mx, _ = grid_geometry(pts, res)
+    dims = (ctypes.c_int * 3)(*ga.shape)
+    d_xyz = np.zeros((n, 3), np.float32)
+    d_scale = np.zeros((n, 3), np.float32)
+    d_obj = np.zeros((n,), np.float32)
+    L.hv_oracle_backward(gp, pp, xp, sp, op, n, ctypes.c_float(res), int(num_rots), _f(mn)[1],
+                         dims, _f(d_xyz)[1], _f(d_scale)[1], _f(d_obj)[1])
+    return d_xyz, d_scale, d_obj
+
+
+def decode(grid_obj, grid_rot, grid_scale, corner, res, points, xyz_pred, prob_pred, class_pred,
+           params=None):
+    """Oracle of eval_joint.py:195-263.  Mutates a COPY of grid_obj.
+
+    Returns dict(cand_idx, verdict, boxes[K,8,3], scores[K], classes[K], grid_obj_after)."""
+    L = lib()
+    p = params or DecodeParams.default()
+    go = np.array(grid_obj, dtype=np.float32, order="C", copy=True)
+    gr, grp = _f(grid_rot)
+    gs, gsp = _f(grid_scale)
+    pts, pp = _f(points)
+    xa, xp = _f(xyz_pred)
+    pa, prp = _f(prob_pred)
+    ca, cp = _i32(class_pred)
+    dims = (ctypes.c_int * 3)(*go.shape)
+    M = p.max_iters
+    cand = np.zeros(M, np.int64)
+    verdict = np.full(M, -1, np.int32)
+    boxes = np.zeros((M, 8, 3), np.float32)
+    scores = np.zeros(M, np.float32)
+    classes = np.zeros(M, np.int32)
+    nb = ctypes.c_int(0)
+    co, cop = _f(corner)
+    it = L.cv_oracle_decode(go.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), grp, gsp, dims, cop,
+                            ctypes.c_float(res), pp, xp, prp, cp, pts.shape[0], ctypes.byref(p),
+                            cand.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                            verdict.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                            boxes.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                            scores.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                            classes.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.byref(nb))
+    k = nb.value
+    return dict(cand_idx=cand[:it].copy(), verdict=verdict[:it].copy(), boxes=boxes[:k].copy(),
+                scores=scores[:k].copy(), classes=classes[:k].copy(), grid_obj_after=go)
+
+
+def iou_obb(b1, b2):
+    L = lib()
+    return float(L.cv_oracle_iou_obb(_f(b1)[1], _f(b2)[1]))
+
+
+def nms(boxes, scores, thr):
+    """eval_joint.py:75-89 -> list of picked indices (descending score)."""
+    L = lib()
+    ba, bp = _f(boxes)
+    sa, sp = _f(scores)
+    n = int(sa.shape[0])
+    pick = np.zeros(max(n, 1), np.int32)
+    k = L.cv_oracle_nms(bp, sp, n, float(thr), pick.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    return [int(v) for v in pick[:k]]
+
+
+def nms_per_class(boxes, scores, classes, nclasses=9, thr=0.3):
+    """eval_joint.py:270-280 -> list of (class, box[8,3], score) in reference order."""
+    out = []
+    boxes = np.asarray(boxes, np.float32).reshape(-1, 8, 3)
+    scores = np.asarray(scores, np.float32)
+    classes = np.asarray(classes)
+    if len(classes) == 0:
+        return out
+    for i in range(nclasses):
+        sel = classes == i
+        if sel.sum() > 0:
+            b, s = boxes[sel], scores[sel]
+            for j in nms(b, s, thr):
+                out.append((i, b[j], float(s[j])))
+    return out

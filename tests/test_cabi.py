@@ -1,0 +1,105 @@
+"""The C-ABI library builds for gfx950 without a GPU, loads, and exports exactly what
+include/cv_hip.h declares.  Host-only entry points are exercised here; device entry points
+are only checked for presence (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from canonicalvoting_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "cv_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    L = ctypes.CDLL(built_lib)
+    syms = declared_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(L, s), "libcvhip.so does not export %s" % s
+        assert s in _lib.SIGNATURES, "no ctypes signature for %s" % s
+    assert sorted(_lib.SIGNATURES) == syms
+    assert _lib.lib().cv_abi_version() == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.CvError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_grid_dims_host_matches_oracle(built_lib):
+    L = _lib.lib()
+    res = np.float32(0.03)
+    rng = np.random.default_rng(0)
+    for _ in range(500):
+        lo = rng.integers(-200, 200, 3)
+        ext = rng.integers(1, 400, 3)
+        mn = (lo.astype(np.float32) * res).astype(np.float32)
+        mx = ((lo + ext).astype(np.float32) * res).astype(np.float32)
+        d = (ctypes.c_int * 3)()
+        assert L.cv_hv_grid_dims_f32(mn.ctypes.data_as(_lib.c_float_p), mx.ctypes.data_as(_lib.c_float_p),
+                                     ctypes.c_float(res), d) == 0
+        od = (ctypes.c_int * 3)()
+        oracle.lib().hv_oracle_grid_dims(mn.ctypes.data_as(_lib.c_float_p),
+                                         mx.ctypes.data_as(_lib.c_float_p), ctypes.c_float(res), od)
+        assert list(d) == list(od)
+        assert all(dd in (e, e + 1) for dd, e in zip(d, ext))
+    for n in (2, 4, 11, 13, 248, 285):      # SURVEY 8a V1 pitfall vectors
+        mn = np.float32([-150 * res, 0, 0]); mx = np.float32([np.float32(-150 + n) * res, 1, 1])
+        d = (ctypes.c_int * 3)()
+        L.cv_hv_grid_dims_f32(mn.ctypes.data_as(_lib.c_float_p), mx.ctypes.data_as(_lib.c_float_p),
+                              ctypes.c_float(res), d)
+        assert d[0] == n
+
+
+def test_bad_arguments_return_error_codes(built_lib):
+    L = _lib.lib()
+    d = (ctypes.c_int * 3)()
+    assert L.cv_hv_grid_dims_f32(None, None, ctypes.c_float(0.03), d) == -22
+    assert b"null" in L.cv_last_error()
+    assert L.cv_nms_obb(None, None, 3, 0.3, None) == -22
+
+
+def rand_boxes(rng, n):
+    raw = np.array([[1, 1, 1], [1, 1, -1], [-1, 1, -1], [-1, 1, 1], [1, -1, 1], [1, -1, -1],
+                    [-1, -1, -1], [-1, -1, 1]], np.float64)
+    out = []
+    for _ in range(n):
+        t = rng.uniform(0, 2 * np.pi)
+        Rm = np.array([[np.cos(t), 0, -np.sin(t)], [0, 1, 0], [np.sin(t), 0, np.cos(t)]])
+        out.append((raw * rng.uniform(0.2, 0.9, 3)) @ Rm.T + rng.uniform(0, 2.5, 3) * [1, 0.2, 1])
+    return np.array(out, np.float32)
+
+
+def test_host_iou_and_nms_match_oracle(built_lib):
+    from canonicalvoting_amd import decode
+    rng = np.random.default_rng(1)
+    boxes = rand_boxes(rng, 40)
+    nz = 0
+    for i in range(40):
+        for j in range(40):
+            a, b = decode.get_iou_obb(boxes[i], boxes[j]), oracle.iou_obb(boxes[i], boxes[j])
+            assert abs(a - b) < 1e-12
+            nz += a > 0
+    assert nz > 100
+    scores = rng.uniform(0, 1, 40).astype(np.float32)
+    scores[5] = scores[6]
+    for thr in (0.1, 0.3, 0.6):
+        assert decode.nms(boxes, scores, thr) == oracle.nms(boxes, scores, thr)
+    cls = rng.integers(0, 9, 40)
+    a = decode.nms_per_class(boxes, scores, cls)
+    b = oracle.nms_per_class(boxes, scores, cls)
+    assert [(x[0], x[2]) for x in a] == [(x[0], x[2]) for x in b]
+    assert all(np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+    assert decode.nms(boxes[:0], scores[:0], 0.3) == []

@@ -1,0 +1,110 @@
+"""HIP decode (compaction + single-workgroup greedy + parallel back-projection) vs the CPU
+oracle's sequential restatement of eval_joint.py:195-263.  Integer outputs (candidate cells,
+verdicts, box count, classes) must be exact; boxes/scores are bit-identical by construction
+(shared fp32 conventions), asserted to 1e-6."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from canonicalvoting_amd import decode
+from canonicalvoting_amd.hough import HoughVoting
+from canonicalvoting_amd.synth import make_scene, synth_predictions
+
+pytestmark = pytest.mark.gpu
+
+
+def t(cuda, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def compare(cuda, g_obj, g_rot, g_scale, corner, res, pts, xyz, prob, cls, **kw):
+    okw = dict(kw)
+    if "separate_variant" in okw:
+        okw["elim_hi_plus1"] = 0 if okw.pop("separate_variant") else 1
+    ref = oracle.decode(g_obj, g_rot, g_scale, corner, res, pts, xyz, prob, cls,
+                        oracle.DecodeParams.default(**okw))
+    dg = t(cuda, g_obj).clone()
+    hip = decode.decode_boxes(dg, t(cuda, g_rot), t(cuda, g_scale), t(cuda, pts), t(cuda, xyz),
+                              t(cuda, prob), t(cuda, cls), res, corner=corner, mutate_grid=True, **kw)
+    assert list(hip["cand_idx"]) == list(ref["cand_idx"])
+    assert list(hip["verdict"]) == list(ref["verdict"])
+    assert list(hip["classes"]) == list(ref["classes"])
+    assert hip["boxes"].shape == ref["boxes"].shape
+    np.testing.assert_allclose(hip["boxes"], ref["boxes"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(hip["scores"], ref["scores"], rtol=0, atol=0)
+    assert np.array_equal(dg.cpu().numpy(), ref["grid_obj_after"])      # same in-place suppression
+    return ref, hip
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_decode_matches_oracle_on_oracle_grids(cuda, built_lib, seed):
+    sc = make_scene(seed, n_points=8000)
+    xyz, scale, prob, cls = synth_predictions(sc)
+    pts = sc.points
+    g = oracle.hv_forward(pts, xyz, scale, prob, sc.res, 120)
+    corner, _, _ = oracle.grid_geometry(pts, sc.res)
+    thr = float(np.sort(g[0].ravel())[-400])            # a few hundred cells above threshold
+    ref, _ = compare(cuda, g[0], g[1], g[2], corner, sc.res, pts, xyz, prob, cls, thresh_high=thr)
+    assert len(ref["cand_idx"]) >= 3
+    compare(cuda, g[0], g[1], g[2], corner, sc.res, pts, xyz, prob, cls, thresh_high=thr,
+            separate_variant=True)
+
+
+def test_decode_planted_ties_and_rejections(cuda, built_lib):
+    from tests.test_oracle_decode import box_points, planted
+    res = 0.05
+    rng = np.random.default_rng(0)
+    g_obj, g_rot, g_scale = planted()
+    A, B, C, D = (10, 10, 10), (10, 10, 30), (30, 10, 10), (30, 10, 30)
+    g_obj[A] = 100; g_obj[B] = 100; g_obj[C] = 90; g_obj[D] = 80; g_obj[20, 4, 20] = 59.9
+    g_rot[B] = [np.cos(0.7), np.sin(0.7)]
+    half = np.array([0.2, 0.2, 0.2])
+    pa, xa, qa = box_points(np.array(A) * res, half, 0.0, 200, rng)
+    pb, xb, qb = box_points(np.array(B) * res, half, 0.7, 150, rng)
+    pc, xc, qc = box_points(np.array(C) * res, half, 0.0, 100, rng, prob=0.1)
+    pd, xd, qd = box_points(np.array(D) * res, half, 0.0, 100, rng)
+    pts = np.concatenate([pa, pb, pc, pd]); xyz = np.concatenate([xa, xb, xc, -xd])
+    prob = np.concatenate([qa, qb, qc, qd])
+    cls = np.concatenate([np.full(200, 3), np.r_[np.full(70, 5), np.full(80, 2)], np.full(200, 1)]).astype(np.int32)
+    ref, hip = compare(cuda, g_obj, g_rot, g_scale, np.zeros(3, np.float32), res, pts, xyz, prob, cls)
+    assert list(hip["verdict"]) == [0, 0, 1, 2] and list(hip["classes"]) == [3, 2]
+
+
+def test_decode_nothing_above_threshold_and_iteration_cap(cuda, built_lib):
+    from tests.test_oracle_decode import planted
+    g_obj, g_rot, g_scale = planted()
+    pts = np.zeros((4, 3), np.float32)
+    z = np.zeros(3, np.float32)
+    ref, hip = compare(cuda, g_obj, g_rot, g_scale, z, 0.05, pts, pts, np.zeros(4, np.float32),
+                       np.zeros(4, np.int32))
+    assert len(hip["cand_idx"]) == 0 and len(hip["boxes"]) == 0
+    g_scale[...] = 0.001
+    g_obj[::6, ::6, ::6] = 77                          # many isolated peaks, cap at 5 candidates
+    ref, hip = compare(cuda, g_obj, g_rot, g_scale, z, 0.05, pts, pts, np.zeros(4, np.float32),
+                       np.zeros(4, np.int32), max_candidates=5)
+    assert len(hip["cand_idx"]) == 5
+
+
+def test_detect_end_to_end_80k(cuda, built_lib):
+    """vote (HIP) -> decode (HIP) -> NMS vs the oracle chain fed the HIP grids: box count, classes,
+    candidate cells exact (BASELINE.json: bit-exact vote-grid indices / box counts)."""
+    sc = make_scene(0, n_points=80000)
+    xyz, scale, prob, cls = synth_predictions(sc)
+    hv = HoughVoting(sc.res, 120)
+    dets, raw = decode.detect(hv, t(cuda, sc.coords), t(cuda, xyz), t(cuda, scale), t(cuda, prob),
+                              t(cuda, cls), sc.res)
+    pts = sc.points
+    with torch.no_grad():
+        g = [o.cpu().numpy() for o in hv(t(cuda, pts), t(cuda, xyz), t(cuda, scale), t(cuda, prob))]
+    corner, _, _ = oracle.grid_geometry(pts, sc.res)
+    ref = oracle.decode(g[0], g[1], g[2], corner, sc.res, pts, xyz, prob, cls)
+    # the two HIP votes may differ in the last bits (atomic order) but peaks are well separated
+    assert len(raw["boxes"]) == len(ref["boxes"]) >= 6
+    assert list(raw["classes"]) == list(ref["classes"])
+    rd = oracle.nms_per_class(ref["boxes"], ref["scores"], ref["classes"])
+    assert [d[0] for d in dets] == [d[0] for d in rd]
+    # detections recover the planted boxes: every accepted box centre is near a ground-truth centre
+    gt = sc.boxes[:, :3]
+    for b in raw["boxes"]:
+        assert np.min(np.linalg.norm(gt - b.mean(0)[None], axis=1)) < 0.15

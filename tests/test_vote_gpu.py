@@ -1,0 +1,180 @@
+"""HIP vote op vs the CPU oracle, through the hv_cuda drop-in (which calls the C ABI).
+
+Bar (BASELINE.json north_star): grid shape, in-bounds vote count and the set of touched cells
+are exact; accumulated floats agree within 1e-4 relative (fp32 atomic summation order is the
+only difference, as it is run-to-run in the reference itself)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from canonicalvoting_amd import hv_cuda
+from canonicalvoting_amd.hough import HoughVoting
+from canonicalvoting_amd.synth import make_scene, synth_predictions
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-4      # north_star float tolerance
+
+
+def dev_inputs(cuda, pts, xyz, scale, prob):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    return t(pts), t(xyz), t(scale), t(prob)
+
+
+def run_hip(cuda, pts, xyz, scale, prob, res, R, algo):
+    hv_cuda.set_algorithm(algo)
+    try:
+        hv = HoughVoting(res, R)
+        with torch.no_grad():
+            out = hv(*dev_inputs(cuda, pts, xyz, scale, prob))
+        torch.cuda.synchronize()
+        return [o.cpu().numpy() for o in out]
+    finally:
+        hv_cuda.set_algorithm(0)
+
+
+def assert_grids_close(hip, ref, tag=""):
+    g_obj, g_rot, g_scale = hip
+    r_obj, r_rot, r_scale = ref
+    assert g_obj.shape == r_obj.shape and g_rot.shape == r_rot.shape and g_scale.shape == r_scale.shape, tag
+    assert np.array_equal(g_obj == 0, r_obj == 0), tag + ": set of touched cells differs"
+    scale_ = max(1.0, float(np.abs(r_obj).max()))
+    np.testing.assert_allclose(g_obj, r_obj, rtol=RTOL, atol=1e-6 * scale_, err_msg=tag)
+    live = r_obj > 1e-3 * scale_           # quotient grids: cells with non-negligible weight
+    np.testing.assert_allclose(g_rot[live], r_rot[live], rtol=0, atol=RTOL, err_msg=tag)
+    np.testing.assert_allclose(g_scale[live], r_scale[live], rtol=RTOL, atol=RTOL, err_msg=tag)
+    dead = r_obj == 0
+    assert not g_rot[dead].any() and not g_scale[dead].any(), tag
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("seed,n,R", [(0, 600, 24), (1, 2048, 120), (2, 777, 60), (3, 64, 7)])
+def test_forward_matches_oracle_small(cuda, built_lib, algo, seed, n, R):
+    sc = make_scene(seed, n_points=n, res=0.06, room=(1.5, 0.9, 1.5), n_boxes=2, margin=0.5,
+                    box_scale=0.4)
+    xyz, scale, prob, _ = synth_predictions(sc)
+    ref = oracle.hv_forward(sc.points, xyz, scale, prob, sc.res, R, return_vin=True)
+    hip = run_hip(cuda, sc.points, xyz, scale, prob, sc.res, R, algo)
+    assert_grids_close(hip, ref[:3], "algo %d seed %d" % (algo, seed))
+    corner, _, dims = oracle.grid_geometry(sc.points, sc.res)
+    p, x, s, _ = dev_inputs(cuda, sc.points, xyz, scale, prob)
+    assert hv_cuda.count_votes(p, x, s, sc.res, R, corner, dims) == ref[3]
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_forward_matches_oracle_8k_scannet_res(cuda, built_lib, algo):
+    """BASELINE config 1 size (8k points, res 0.03, 120 rotations, shifted origin)."""
+    sc = make_scene(11, n_points=8000)
+    xyz, scale, prob, _ = synth_predictions(sc)
+    ref = oracle.hv_forward(sc.points, xyz, scale, prob, sc.res, 120)
+    hip = run_hip(cuda, sc.points, xyz, scale, prob, sc.res, 120, algo)
+    assert_grids_close(hip, ref, "8k algo %d" % algo)
+
+
+@pytest.mark.parametrize("name", ["vote_512", "vote_2k"])
+def test_forward_backward_match_golden(cuda, built_lib, name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    res, R = float(z["res"]), int(z["num_rots"])
+    pts = (z["coords"].astype(np.float32) * np.float32(res)).astype(np.float32)
+    for algo in (1, 2):
+        g_obj, g_rot, g_scale = run_hip(cuda, pts, z["xyz"], z["scale"], z["prob"], res, R, algo)
+        assert list(g_obj.shape) == list(z["dims"])
+        assert np.array_equal(g_obj == 0, z["grid_obj"] == 0)
+        np.testing.assert_allclose(g_obj, z["grid_obj"], rtol=RTOL, atol=1e-5)
+        np.testing.assert_allclose(g_rot.astype(np.float64).sum((0, 1, 2)), z["rot_sum"], rtol=1e-3, atol=1e-2)
+        np.testing.assert_allclose(g_scale.astype(np.float64).sum((0, 1, 2)), z["scale_sum"], rtol=1e-3, atol=1e-2)
+    p, x, s, o = dev_inputs(cuda, pts, z["xyz"], z["scale"], z["prob"])
+    hv = HoughVoting(res, R)
+    d = hv_cuda.backward(torch.from_numpy(z["grad"]).to(cuda), p, x, s, o, hv.res, hv.num_rots)
+    for got, key in zip(d, ("d_xyz", "d_scale", "d_obj")):
+        ref = z[key]
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=RTOL * max(1.0, np.abs(ref).max()))
+
+
+def test_backward_through_autograd(cuda, built_lib):
+    """HVFunction.backward (eval_joint.py:32-38): only grad_obj is propagated."""
+    sc = make_scene(5, n_points=1500, res=0.06, room=(1.5, 0.9, 1.5), n_boxes=2, margin=0.5, box_scale=0.4)
+    xyz, scale, prob, _ = synth_predictions(sc)
+    p, x, s, o = dev_inputs(cuda, sc.points, xyz, scale, prob)
+    x.requires_grad_(True); s.requires_grad_(True); o.requires_grad_(True)
+    hv = HoughVoting(sc.res, 36)
+    g_obj, g_rot, g_scale = hv(p, x, s, o)
+    rng = np.random.default_rng(0)
+    grad = rng.normal(0, 1, tuple(g_obj.shape)).astype(np.float32)
+    (g_obj * torch.from_numpy(grad).to(cuda)).sum().backward()
+    r_xyz, r_scale, r_obj = oracle.hv_backward(grad, sc.points, xyz, scale, prob, sc.res, 36)
+    for got, ref in ((x.grad, r_xyz), (s.grad, r_scale), (o.grad, r_obj)):
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=RTOL * max(1.0, np.abs(ref).max()))
+    # grad_rot / grad_scale are ignored by the reference's backward
+    x.grad = None
+    g_obj, g_rot, g_scale = hv(p, x, s, o)
+    (g_rot.sum() + g_scale.sum()).backward()
+    assert float(x.grad.abs().max()) == 0.0
+
+
+def test_edge_cases(cuda, built_lib):
+    hv = HoughVoting(0.03, 120)
+    # degenerate cloud: one cell grid, every vote fails `>= size-1` (hv_cuda_kernel.cu:41-44)
+    p = torch.zeros(5, 3, device=cuda); x = torch.zeros(5, 3, device=cuda)
+    s = torch.ones(5, 3, device=cuda); o = torch.ones(5, device=cuda)
+    for algo in (1, 2):
+        hv_cuda.set_algorithm(algo)
+        g = hv(p, x, s, o)
+        assert tuple(g[0].shape) == (1, 1, 1) and float(g[0].sum()) == 0.0
+    hv_cuda.set_algorithm(0)
+    # two points: xyz = 0 votes land on the nodes; the max corner is out of bounds
+    p = torch.tensor([[0, 0, 0], [0.3, 0.3, 0.3]], device=cuda)
+    g = hv(p, torch.zeros(2, 3, device=cuda), torch.ones(2, 3, device=cuda), torch.ones(2, device=cuda))
+    ref = oracle.hv_forward(p.cpu().numpy(), np.zeros((2, 3)), np.ones((2, 3)), np.ones(2), 0.03, 120)
+    assert g[0].shape == ref[0].shape
+    np.testing.assert_allclose(g[0].cpu().numpy(), ref[0], rtol=1e-6)
+    assert float(g[0][0, 0, 0]) == 120.0
+    # outputs are fresh, writable and independent (callers zero grid_obj in place, eval_joint.py:211)
+    g[0][0:1, 0:1, 0:1] = 0
+    assert float(g[0][0, 0, 0]) == 0.0
+
+
+def test_input_checks_match_reference_messages(cuda, built_lib):
+    hv = HoughVoting(0.03, 120)
+    p = torch.rand(10, 3, device=cuda); x = torch.rand(10, 3, device=cuda)
+    s = torch.rand(10, 3, device=cuda); o = torch.rand(10, device=cuda)
+    with pytest.raises(RuntimeError, match="points must be a CUDA tensor"):
+        hv_cuda.forward(p.cpu(), x, s, o, hv.res, hv.num_rots)
+    with pytest.raises(RuntimeError, match="xyz_labels must be contiguous"):
+        hv_cuda.forward(p, torch.rand(3, 10, device=cuda).t(), s, o, hv.res, hv.num_rots)
+    with pytest.raises(RuntimeError, match="res must be a CUDA tensor"):
+        hv_cuda.forward(p, x, s, o, hv.res.cpu(), hv.num_rots)
+    with pytest.raises(RuntimeError, match="grad_grid must be a CUDA tensor"):
+        hv_cuda.backward(torch.zeros(2, 2, 2), p, x, s, o, hv.res, hv.num_rots)
+    with pytest.raises(RuntimeError):
+        hv_cuda.forward(p[:0], x[:0], s[:0], o[:0], hv.res, hv.num_rots)      # N = 0
+
+
+def test_corners_variant(cuda, built_lib):
+    """7-argument forward (sunrgbd/brnetcanon.py:99): grid origin/extent from corners[2,3]."""
+    sc = make_scene(9, n_points=1000, res=0.05, room=(2.0, 1.0, 2.0), n_boxes=2, margin=0.6, box_scale=0.5)
+    xyz, scale, prob, _ = synth_predictions(sc)
+    pts = sc.points
+    corners = np.stack([pts.min(0) - 0.2, pts.max(0) + 0.3]).astype(np.float32)
+    ref = oracle.hv_forward(pts, xyz, scale, prob, 0.05, 60, corners=corners)
+    hv = HoughVoting(0.05, 60)
+    out = hv(*dev_inputs(cuda, pts, xyz, scale, prob), corners=torch.from_numpy(corners).to(cuda))
+    assert_grids_close([o.cpu().numpy() for o in out], ref, "corners")
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_full_size_80k_properties(cuda, built_lib, algo):
+    """BASELINE config 2 size.  Size-independent properties (the oracle takes ~1 s here so it is
+    also compared directly): mass conservation (sum grid_obj = sum over in-bounds votes of obj,
+    because trilinear weights sum to 1) and linearity in obj."""
+    sc = make_scene(0, n_points=80000)
+    xyz, scale, prob, _ = synth_predictions(sc)
+    hip = run_hip(cuda, sc.points, xyz, scale, prob, sc.res, 120, algo)
+    ref = oracle.hv_forward(sc.points, xyz, scale, prob, sc.res, 120)
+    assert_grids_close(hip, ref, "80k algo %d" % algo)
+    hip2 = run_hip(cuda, sc.points, xyz, scale, (prob * 2).astype(np.float32), sc.res, 120, algo)
+    np.testing.assert_allclose(hip2[0], 2 * hip[0], rtol=RTOL, atol=1e-4)
+    np.testing.assert_allclose(hip2[0].sum(dtype=np.float64), 2 * ref[0].sum(dtype=np.float64), rtol=1e-5)
