@@ -165,7 +165,7 @@ def main():
                                "vote accumulation + decode + NMS (per-point predictions synthesised; "
                                "sparse MinkUNet forward not yet on the timed path)" % a.points,
                    "points": a.points, "num_rots": NUM_ROTS, "res": RES, "grid": s0.dims,
-                   "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}[a.algo],
+                   "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}.get(a.algo, "ablation-%d" % a.algo),
                    "parallelism": "scene-parallel x%d, no collective" % world},
         "roofline": {"bound": "hbm", "kernel": "vote op (all launches of cv_hv_forward_f32)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

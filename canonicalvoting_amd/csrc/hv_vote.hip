@@ -193,26 +193,40 @@ __global__ __launch_bounds__(256) void hv_normalise(const float* __restrict__ g_
 // tiles algorithm
 // ---------------------------------------------------------------------------
 constexpr int TX = 32, TZ = 32, TCELLS = TX * TZ;
-constexpr int TW = 4;        // waves per workgroup
+constexpr int TW = 8;        // waves per workgroup
 constexpr int PQ = 64;       // surviving points per wave chunk
 constexpr int VQ = 128;      // vote queue entries per wave
 constexpr int MAX_R_TILES = 256;
 
 // y cell of every vote of a point (theta-independent: offset.y = -corr.y, :38-39).
-__global__ __launch_bounds__(256) void hv_prep_count(const float* __restrict__ pts,
-                                                     const float* __restrict__ xyz,
-                                                     const float* __restrict__ scl, int64_t n,
-                                                     float res, float corner_y, int Y,
-                                                     int* __restrict__ fy_out,
-                                                     int* __restrict__ ycount) {
-    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    const float cy = xyz[c * 3 + 1] * scl[c * 3 + 1];
-    const float gy = grid_pos(pts[c * 3 + 1], -cy, corner_y, res);
-    int fy = -1;
-    if (gy >= 0 && gy < (float)(Y - 1)) fy = (int)gy;
-    fy_out[c] = fy;
-    if (fy >= 0) atomicAdd(&ycount[fy], 1);
+// Global atomics on a few hot addresses serialise at ~11 ns each on MI355X (measured: 80k
+// atomics over 88 counters = 142 us), so bins are aggregated per workgroup in LDS first.
+constexpr int PREP_MAX_Y = 4096;
+constexpr int PREP_THREADS = 1024;
+
+__global__ __launch_bounds__(PREP_THREADS) void hv_prep_count(
+    const float* __restrict__ pts, const float* __restrict__ xyz, const float* __restrict__ scl,
+    int64_t n, float res, float corner_y, int Y, int* __restrict__ fy_out, int* __restrict__ ycount) {
+    __shared__ int lh[PREP_MAX_Y];
+    const bool use_lds = Y <= PREP_MAX_Y;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < Y; i += PREP_THREADS) lh[i] = 0;
+        __syncthreads();
+    }
+    const int64_t c = blockIdx.x * (int64_t)PREP_THREADS + threadIdx.x;
+    if (c < n) {
+        const float cy = xyz[c * 3 + 1] * scl[c * 3 + 1];
+        const float gy = grid_pos(pts[c * 3 + 1], -cy, corner_y, res);
+        int fy = -1;
+        if (gy >= 0 && gy < (float)(Y - 1)) fy = (int)gy;
+        fy_out[c] = fy;
+        if (fy >= 0) atomicAdd(use_lds ? &lh[fy] : &ycount[fy], 1);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < Y; i += PREP_THREADS)
+            if (lh[i]) atomicAdd(&ycount[i], lh[i]);
+    }
 }
 
 // exclusive scan of ycount[Y] -> ystart[Y+1], cursor[Y] (single workgroup)
@@ -243,15 +257,53 @@ __global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ yco
     if (threadIdx.x == 0) ystart[Y] = carry;
 }
 
-__global__ __launch_bounds__(256) void hv_prep_scatter(const int* __restrict__ fy_in, int64_t n,
-                                                       int* __restrict__ cursor,
-                                                       int* __restrict__ order) {
-    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    const int fy = fy_in[c];
-    if (fy < 0) return;
-    const int pos = atomicAdd(&cursor[fy], 1);
-    order[pos] = (int)c;
+// Scatters every point with an in-bounds y into its y-bin and writes a compact SoA record
+// (REC_F floats, bin order) so the tile kernel streams coalesced rows instead of gathering
+// 10 scalars per point through `order[]`:
+//   0 px  1 pz  2 cx  3 cz  4 ry (fractional y)  5 obj  6..8 scale  9 ux  10 uz  11 r
+// (ux,uz) = ring centre and r = ring radius in grid units, used only for culling.
+constexpr int REC_F = 12;
+
+__global__ __launch_bounds__(PREP_THREADS) void hv_prep_scatter(
+    const float* __restrict__ pts, const float* __restrict__ xyz, const float* __restrict__ scl,
+    const float* __restrict__ obj, const int* __restrict__ fy_in, int64_t n, int Y, float res,
+    F3 corner, int* __restrict__ cursor, float* __restrict__ rec, int64_t rec_stride) {
+    __shared__ int lh[PREP_MAX_Y];     // per-workgroup count, then the workgroup's base in the bin
+    const bool use_lds = Y <= PREP_MAX_Y;
+    const int64_t c = blockIdx.x * (int64_t)PREP_THREADS + threadIdx.x;
+    const int fy = c < n ? fy_in[c] : -1;
+    int pos = -1;
+    if (!use_lds) {
+        if (fy >= 0) pos = atomicAdd(&cursor[fy], 1);
+    } else {
+        for (int i = threadIdx.x; i < Y; i += PREP_THREADS) lh[i] = 0;
+        __syncthreads();
+        int rank = 0;
+        if (fy >= 0) rank = atomicAdd(&lh[fy], 1);
+        __syncthreads();
+        for (int i = threadIdx.x; i < Y; i += PREP_THREADS)
+            if (lh[i]) lh[i] = atomicAdd(&cursor[i], lh[i]);
+        __syncthreads();
+        if (fy >= 0) pos = lh[fy] + rank;
+    }
+    if (pos < 0) return;
+    const float px = pts[c * 3 + 0], py = pts[c * 3 + 1], pz = pts[c * 3 + 2];
+    const float s0 = scl[c * 3 + 0], s1 = scl[c * 3 + 1], s2 = scl[c * 3 + 2];
+    const float cx = xyz[c * 3 + 0] * s0, cy = xyz[c * 3 + 1] * s1, cz = xyz[c * 3 + 2] * s2;
+    const float gy = grid_pos(py, -cy, corner.y, res);
+    float* r = rec + pos;
+    r[0 * rec_stride] = px;
+    r[1 * rec_stride] = pz;
+    r[2 * rec_stride] = cx;
+    r[3 * rec_stride] = cz;
+    r[4 * rec_stride] = gy - floorf(gy);
+    r[5 * rec_stride] = obj[c];
+    r[6 * rec_stride] = s0;
+    r[7 * rec_stride] = s1;
+    r[8 * rec_stride] = s2;
+    r[9 * rec_stride] = (px - corner.x) / res;
+    r[10 * rec_stride] = (pz - corner.z) / res;
+    r[11 * rec_stride] = sqrtf(cx * cx + cz * cz) / res;
 }
 
 __device__ __forceinline__ int lanes_below(uint64_t mask) {
@@ -259,12 +311,16 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {
                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
-__device__ __forceinline__ void lds_add(float* p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// LDS fp32 atomic add runs at 0.33 lane-ops/clk/CU on gfx950 (204 G/s chip-wide, measured:
+// profiles/microbench/lds_atomic_rate.hip) while ds_add_f64 sustains 3.1 (1.9 T/s), so the
+// tile accumulates in double.  Side effect: the sums are far more accurate than the
+// reference's fp32 atomics and reproducible run to run after the final rounding to float.
+__device__ __forceinline__ void lds_add(double* p, float v) {
+    __hip_atomic_fetch_add(p, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 struct TileShared {
-    float acc[6][TCELLS];      // obj, rot.cos, rot.sin, scale.xyz  (SoA: random banks per lane)
+    double acc[6][TCELLS];     // obj, rot.cos, rot.sin, scale.xyz  (SoA: random banks per lane)
     float pq[TW][9][PQ];       // px, pz, cx, cz, wy, obj, s0, s1, s2 of surviving points
     uint32_t vq_rec[TW][VQ];   // entry | rot<<6 | (lx+1)<<14 | (lz+1)<<20
     float vq_rx[TW][VQ];
@@ -300,12 +356,18 @@ __device__ __forceinline__ void drain64(TileShared& sh, int wave, int slot, bool
         }
 }
 
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// VARIANT (ablations for profiling only): 0 full, 1 no LDS atomics, 2 no dense phase
+template <int VARIANT>
 __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
-    const float* __restrict__ pts, const float* __restrict__ xyz, const float* __restrict__ scl,
-    const float* __restrict__ obj, int R, float res, F3 corner, I3 dims,
-    const float2* __restrict__ tab, const int* __restrict__ ystart, const int* __restrict__ order,
-    int tiles_x, int tiles_z, float* __restrict__ g_obj, float* __restrict__ g_rot,
-    float* __restrict__ g_scale) {
+    int R, float res, F3 corner, I3 dims, const float2* __restrict__ tab,
+    const int* __restrict__ ystart, const float* __restrict__ rec, int64_t rec_stride, int tiles_x,
+    int tiles_z, float* __restrict__ g_obj, float* __restrict__ g_rot, float* __restrict__ g_scale) {
     __shared__ TileShared sh;
     const int X = dims.x, Y = dims.y, Z = dims.z;
     const int tile = blockIdx.x % (tiles_x * tiles_z);
@@ -313,7 +375,7 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     const int x0 = (tile / tiles_z) * TX, z0 = (tile % tiles_z) * TZ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) (&sh.acc[0][0])[i] = 0.f;
+    for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) (&sh.acc[0][0])[i] = 0.0;
     for (int i = threadIdx.x; i < R; i += TW * 64) sh.tab[i] = tab[i];
     __syncthreads();
 
@@ -330,23 +392,10 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
         for (int base = beg + wave * 64; base < end; base += TW * 64) {
             const int idx = base + lane;
             bool keep = false;
-            float px = 0, pz = 0, cx = 0, cz = 0, wy = 0, ob = 0, s0 = 0, s1 = 0, s2 = 0;
             if (idx < end) {
-                const int64_t c = order[idx];
-                px = pts[c * 3 + 0];
-                const float py = pts[c * 3 + 1];
-                pz = pts[c * 3 + 2];
-                s0 = scl[c * 3 + 0]; s1 = scl[c * 3 + 1]; s2 = scl[c * 3 + 2];
-                cx = xyz[c * 3 + 0] * s0;
-                const float cy = xyz[c * 3 + 1] * s1;
-                cz = xyz[c * 3 + 2] * s2;
-                ob = obj[c];
-                const float gy = grid_pos(py, -cy, corner.y, res);
-                const float ry = gy - floorf(gy);
-                wy = (s == y) ? (1.f - ry) : ry;
+                const float ux = rec[9 * rec_stride + idx], uz = rec[10 * rec_stride + idx],
+                            r = rec[11 * rec_stride + idx];
                 // conservative ring-vs-rectangle test in grid units
-                const float ux = (px - corner.x) / res, uz = (pz - corner.z) / res;
-                const float r = sqrtf(cx * cx + cz * cz) / res;
                 const float dxn = fmaxf(0.f, fmaxf(xlo - ux, ux - xhi));
                 const float dzn = fmaxf(0.f, fmaxf(zlo - uz, uz - zhi));
                 const float dxf = fmaxf(fabsf(ux - xlo), fabsf(ux - xhi));
@@ -354,26 +403,32 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
                 const float dmin = sqrtf(dxn * dxn + dzn * dzn), dmax = sqrtf(dxf * dxf + dzf * dzf);
                 const float tol = slack + 1e-5f * (r + fabsf(ux) + fabsf(uz));
                 keep = (r >= dmin - tol) && (r <= dmax + tol);
+                if (VARIANT == 2) keep = keep && (ux == 1234.5f);
             }
             const uint64_t m = __ballot(keep);
             const int nq = __popcll(m);
             if (nq == 0) continue;
             if (keep) {
                 const int p = lanes_below(m);
-                sh.pq[wave][0][p] = px; sh.pq[wave][1][p] = pz; sh.pq[wave][2][p] = cx;
-                sh.pq[wave][3][p] = cz; sh.pq[wave][4][p] = wy; sh.pq[wave][5][p] = ob;
-                sh.pq[wave][6][p] = s0; sh.pq[wave][7][p] = s1; sh.pq[wave][8][p] = s2;
+                const float ry = rec[4 * rec_stride + idx];
+                sh.pq[wave][0][p] = rec[0 * rec_stride + idx];
+                sh.pq[wave][1][p] = rec[1 * rec_stride + idx];
+                sh.pq[wave][2][p] = rec[2 * rec_stride + idx];
+                sh.pq[wave][3][p] = rec[3 * rec_stride + idx];
+                sh.pq[wave][4][p] = (s == y) ? (1.f - ry) : ry;
+                sh.pq[wave][5][p] = rec[5 * rec_stride + idx];
+                sh.pq[wave][6][p] = rec[6 * rec_stride + idx];
+                sh.pq[wave][7][p] = rec[7 * rec_stride + idx];
+                sh.pq[wave][8][p] = rec[8 * rec_stride + idx];
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            wave_sync_lds();
 
             const int items = nq * R;
             const float inv_nq = 1.0f / (float)nq;
             for (int ib = 0; ib < items; ib += 64) {
                 const int i = ib + lane;
                 bool isvote = false;
-                uint32_t rec = 0;
+                uint32_t vrec = 0;
                 float rx = 0, rz = 0;
                 if (i < items) {
                     // rot-major so the 64 lanes of a step are different points at (almost)
@@ -392,62 +447,61 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
                             isvote = true;
                             rx = gx - floorf(gx);
                             rz = gz - floorf(gz);
-                            rec = (uint32_t)e | ((uint32_t)rot << 6) | ((uint32_t)(lx + 1) << 14) |
-                                  ((uint32_t)(lz + 1) << 20);
+                            vrec = (uint32_t)e | ((uint32_t)rot << 6) | ((uint32_t)(lx + 1) << 14) |
+                                   ((uint32_t)(lz + 1) << 20);
                         }
                     }
                 }
                 const uint64_t mv = __ballot(isvote);
                 if (isvote) {
                     const int p = vq_len + lanes_below(mv);
-                    sh.vq_rec[wave][p] = rec;
+                    sh.vq_rec[wave][p] = vrec;
                     sh.vq_rx[wave][p] = rx;
                     sh.vq_rz[wave][p] = rz;
                 }
                 vq_len += __popcll(mv);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                wave_sync_lds();
                 if (vq_len >= 64) {
                     vq_len -= 64;
-                    drain64(sh, wave, vq_len + lane, true);
+                    if (VARIANT != 1) drain64(sh, wave, vq_len + lane, true);
                 }
             }
             // queued votes index this chunk's pq entries: flush before pq is overwritten
             if (vq_len > 0) {
-                drain64(sh, wave, lane, lane < vq_len);
+                if (VARIANT != 1) drain64(sh, wave, lane, lane < vq_len);
+                else if (lane < vq_len)
+                    sh.acc[0][lane] = sh.vq_rx[wave][lane] + sh.vq_rz[wave][lane] + (float)sh.vq_rec[wave][lane];
                 vq_len = 0;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            wave_sync_lds();
         }
     }
     __syncthreads();
 
-    // fused normalise (hv_cuda_kernel.cu:112-117) + single store of the tile
+    // fused normalise (hv_cuda_kernel.cu:112-117) + single store of the tile.  The weight the
+    // reference divides by is the fp32 grid value, so round the double sum to float first.
     const int nx = min(TX, X - x0), nz = min(TZ, Z - z0);
     for (int i = threadIdx.x; i < TCELLS; i += TW * 64) {
         const int lx = i / TZ, lz = i % TZ;
         if (lx < nx && lz < nz)
-            g_obj[((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz] = sh.acc[0][i];
+            g_obj[((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz] = (float)sh.acc[0][i];
     }
     for (int i = threadIdx.x; i < TCELLS * 2; i += TW * 64) {
         const int cell = i >> 1, j = i & 1;
         const int lx = cell / TZ, lz = cell % TZ;
         if (lx < nx && lz < nz) {
-            const double d = (double)sh.acc[0][cell] + 1e-7;
+            const double d = (double)(float)sh.acc[0][cell] + 1e-7;
             g_rot[(((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz) * 2 + j] =
-                (float)((double)sh.acc[1 + j][cell] / d);
+                (float)((double)(float)sh.acc[1 + j][cell] / d);
         }
     }
     for (int i = threadIdx.x; i < TCELLS * 3; i += TW * 64) {
         const int cell = i / 3, j = i - cell * 3;
         const int lx = cell / TZ, lz = cell % TZ;
         if (lx < nx && lz < nz) {
-            const double d = (double)sh.acc[0][cell] + 1e-7;
+            const double d = (double)(float)sh.acc[0][cell] + 1e-7;
             g_scale[(((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz) * 3 + j] =
-                (float)((double)sh.acc[3 + j][cell] / d);
+                (float)((double)(float)sh.acc[3 + j][cell] / d);
         }
     }
 }
@@ -535,9 +589,8 @@ __global__ __launch_bounds__(256) void hv_count_votes(
     const float* __restrict__ pts, const float* __restrict__ xyz, const float* __restrict__ scl,
     int64_t n, int R, float res, F3 corner, I3 dims, const float2* __restrict__ tab,
     unsigned long long* __restrict__ count) {
-    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    bool in = false;
-    if (t < n * R) {
+    unsigned local = 0;
+    for (int64_t t = blockIdx.x * 256ll + threadIdx.x; t < n * R; t += (int64_t)gridDim.x * 256) {
         const int64_t c = t / R;
         const int i = (int)(t - c * R);
         const float cx = xyz[c * 3 + 0] * scl[c * 3 + 0], cy = xyz[c * 3 + 1] * scl[c * 3 + 1],
@@ -547,11 +600,17 @@ __global__ __launch_bounds__(256) void hv_count_votes(
         const float gx = grid_pos(pts[c * 3 + 0], ox, corner.x, res);
         const float gy = grid_pos(pts[c * 3 + 1], oy, corner.y, res);
         const float gz = grid_pos(pts[c * 3 + 2], oz, corner.z, res);
-        in = !(gx < 0 || gy < 0 || gz < 0 || gx >= (float)(dims.x - 1) ||
-               gy >= (float)(dims.y - 1) || gz >= (float)(dims.z - 1));
+        local += !(gx < 0 || gy < 0 || gz < 0 || gx >= (float)(dims.x - 1) ||
+                   gy >= (float)(dims.y - 1) || gz >= (float)(dims.z - 1));
     }
-    const uint64_t m = __ballot(in);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+    __shared__ unsigned s[256];
+    s[threadIdx.x] = local;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && s[0]) atomicAdd(count, (unsigned long long)s[0]);
 }
 
 int check_common(const void* a, const void* b, const void* c, int64_t n, float res, int num_rots,
@@ -567,6 +626,7 @@ int check_common(const void* a, const void* b, const void* c, int64_t n, float r
 }
 
 int pick_algo(int algo, int64_t n, int num_rots, const int* dims) {
+    if (algo == 21 || algo == 22) return 2;   // profiling ablations of the tiles kernel
     if (algo == 1 || algo == 2) return algo;
     if (num_rots <= MAX_R_TILES && n < (1ll << 31)) return 2;
     return 1;
@@ -614,7 +674,7 @@ size_t cv_hv_forward_workspace_bytes(int64_t n, int num_rots, const int dims[3],
     if (!dims || n <= 0) return 0;
     if (pick_algo(algo, n, num_rots, dims) == 1) return 256;
     const size_t Y = (size_t)dims[1];
-    return 256 * 6 + sizeof(int) * ((size_t)n * 2 + Y * 3 + 8);
+    return 256 * 6 + sizeof(int) * ((size_t)n * (1 + REC_F) + Y * 3 + 8);
 }
 
 int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_scale,
@@ -653,24 +713,30 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
     const int Y = dims[1];
     CvCarver cv(d_ws);
     int* fy = cv.take<int>(n);
-    int* order = cv.take<int>(n);
+    float* rec = cv.take<float>((size_t)n * REC_F);
     int* ycount = cv.take<int>(Y);
     int* ystart = cv.take<int>(Y + 1);
     int* cursor = cv.take<int>(Y);
     CV_HIP_CHECK(hipMemsetAsync(ycount, 0, sizeof(int) * Y, st));
-    hv_prep_count<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_points, d_xyz, d_scale, n, res,
-                                                              corner.y, Y, fy, ycount);
+    hv_prep_count<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
+        d_points, d_xyz, d_scale, n, res, corner.y, Y, fy, ycount);
     CV_LAUNCH_CHECK();
     hv_prep_scan<<<1, 1024, 0, st>>>(ycount, Y, ystart, cursor);
     CV_LAUNCH_CHECK();
-    hv_prep_scatter<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(fy, n, cursor, order);
+    hv_prep_scatter<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
+        d_points, d_xyz, d_scale, d_obj, fy, n, Y, res, corner, cursor, rec, n);
     CV_LAUNCH_CHECK();
     const int tiles_x = (dims[0] + TX - 1) / TX, tiles_z = (dims[2] + TZ - 1) / TZ;
     const int64_t wgs = (int64_t)tiles_x * tiles_z * Y;
     CV_REQUIRE(wgs < (1ll << 31), CV_EINVAL, "grid too large");
-    hv_fwd_tiles<<<(unsigned)wgs, TW * 64, 0, st>>>(d_points, d_xyz, d_scale, d_obj, num_rots, res,
-                                                   corner, d3, tab, ystart, order, tiles_x, tiles_z,
-                                                   d_grid_obj, d_grid_rot, d_grid_scale);
+#define CV_TILES_LAUNCH(V)                                                                      \
+    hv_fwd_tiles<V><<<(unsigned)wgs, TW * 64, 0, st>>>(num_rots, res, corner, d3, tab, ystart, rec, \
+                                                      n, tiles_x, tiles_z, d_grid_obj, d_grid_rot, \
+                                                      d_grid_scale)
+    if (algo == 21) CV_TILES_LAUNCH(1);
+    else if (algo == 22) CV_TILES_LAUNCH(2);
+    else CV_TILES_LAUNCH(0);
+#undef CV_TILES_LAUNCH
     CV_LAUNCH_CHECK();
     return CV_OK;
 }
@@ -710,8 +776,8 @@ int cv_hv_count_votes_f32(const float* d_points, const float* d_xyz, const float
     const F3 corner{h_corner3[0], h_corner3[1], h_corner3[2]};
     const I3 d3{dims[0], dims[1], dims[2]};
     const int64_t total = n * num_rots;
-    hv_count_votes<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(d_points, d_xyz, d_scale, n,
-                                                                   num_rots, res, corner, d3, tab, cnt);
+    hv_count_votes<<<(unsigned)std::min<int64_t>((total + 255) / 256, 2048), 256, 0, st>>>(
+        d_points, d_xyz, d_scale, n, num_rots, res, corner, d3, tab, cnt);
     CV_LAUNCH_CHECK();
     unsigned long long h = 0;
     CV_HIP_CHECK(hipMemcpyAsync(&h, cnt, sizeof h, hipMemcpyDeviceToHost, st));

@@ -53,11 +53,29 @@ def make_scene(seed, n_points=80000, res=0.03, room=(5.2, 2.6, 5.2), n_boxes=12,
     rng = np.random.default_rng(seed)
     W, H, D = room
     # --- objects -------------------------------------------------------------
-    half = np.stack([rng.uniform(0.25, 0.9, n_boxes), rng.uniform(0.3, 0.6, n_boxes),
-                     rng.uniform(0.25, 0.9, n_boxes)], -1) * box_scale
+    # Boxes are placed one at a time without overlap (bounding circles in the xz plane):
+    # overlapping boxes put foreign points inside each other's volume and the reference's
+    # back-projection check (eval_joint.py:249-253) then rejects every candidate, which
+    # would make the decode stage of the benchmark meaningless.  A box that cannot be
+    # placed after 60 tries is shrunk by 0.85 and tried again (keeps K fixed).
+    half = np.zeros((n_boxes, 3))
     yaw = rng.uniform(0, 2 * np.pi, n_boxes)
-    ctr = np.stack([rng.uniform(margin, W - margin, n_boxes), half[:, 1],
-                    rng.uniform(margin, D - margin, n_boxes)], -1)
+    ctr = np.zeros((n_boxes, 3))
+    for b in range(n_boxes):
+        h = np.array([rng.uniform(0.25, 0.9), rng.uniform(0.3, 0.6), rng.uniform(0.25, 0.9)]) * box_scale
+        for attempt in range(2000):
+            if attempt and attempt % 60 == 0:
+                h[[0, 2]] *= 0.85
+            rad = np.hypot(h[0], h[2])
+            m = min(margin, max(rad + 0.05, 0.0))
+            c = np.array([rng.uniform(m, max(W - m, m + 1e-6)), h[1], rng.uniform(m, max(D - m, m + 1e-6))])
+            if b == 0:
+                break
+            prev_rad = np.hypot(half[:b, 0], half[:b, 2])
+            gap = np.hypot(ctr[:b, 0] - c[0], ctr[:b, 2] - c[2]) - prev_rad - rad
+            if np.all(gap > 0.06):
+                break
+        half[b], ctr[b] = h, c
     cls = rng.integers(0, NUM_CLASSES, n_boxes)
     # --- surfaces: (area, sampler) -------------------------------------------
     surfs = []   # (area, origin, u, v, box_id or -1)

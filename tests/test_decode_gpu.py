@@ -22,6 +22,8 @@ def compare(cuda, g_obj, g_rot, g_scale, corner, res, pts, xyz, prob, cls, **kw)
     okw = dict(kw)
     if "separate_variant" in okw:
         okw["elim_hi_plus1"] = 0 if okw.pop("separate_variant") else 1
+    if "max_candidates" in okw:
+        okw["max_iters"] = okw.pop("max_candidates")
     ref = oracle.decode(g_obj, g_rot, g_scale, corner, res, pts, xyz, prob, cls,
                         oracle.DecodeParams.default(**okw))
     dg = t(cuda, g_obj).clone()
