@@ -1,0 +1,1 @@
+from . import resnet_block  # noqa: F401

@@ -48,6 +48,22 @@ SIGNATURES = {
                                      ctypes.c_int64, ctypes.POINTER(DecodeParams), ctypes.c_int, vp,
                                      ctypes.c_size_t, c_int_p, c_i64_p, c_i32_p, c_int_p, c_float_p,
                                      c_float_p, c_i32_p, vp]),
+    "cv_sp_table_capacity": (ctypes.c_longlong, [ctypes.c_longlong]),
+    "cv_sp_levels_workspace_bytes": (ctypes.c_size_t, [ctypes.c_longlong]),
+    "cv_sp_build_levels": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                          ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int, vp,
+                                          c_i32_p, vp, ctypes.c_size_t, vp]),
+    "cv_sp_kernel_map": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp, ctypes.c_longlong, ctypes.c_int,
+                                        ctypes.c_int, vp, vp]),
+    "cv_sp_up_map": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_longlong, vp, vp]),
+    "cv_sp_conv_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int,
+                                      ctypes.c_int, vp, ctypes.c_longlong, vp, vp, vp, ctypes.c_int,
+                                      ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp]),
+    "cv_sp_affine_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp,
+                                        ctypes.c_int, vp, ctypes.c_int, vp]),
+    "cv_sp_bn_fold_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_int, vp, vp, vp]),
+    "cv_head_joint_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         vp, vp, vp, vp, vp]),
     "cv_iou_obb": (ctypes.c_double, [c_float_p, c_float_p]),
     "cv_nms_obb": (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_double, c_i32_p]),
 }

@@ -24,6 +24,8 @@ SOURCES = {
     "cv_host.cpp": STRICT,
     "hv_vote.hip": STRICT,
     "hv_decode.hip": STRICT,
+    "sparse_coords.hip": [],
+    "sparse_conv.hip": [],
 }
 
 

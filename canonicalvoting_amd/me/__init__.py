@@ -1,0 +1,323 @@
+"""MinkowskiEngine-compatible facade over the gfx950 sparse-voxel engine (libcvhip.so).
+
+Only the subset the reference touches: ``SparseTensor`` (``.F``, ``.C``,
+``decomposed_coordinates_and_features``), ``MinkowskiConvolution``,
+``MinkowskiConvolutionTranspose``, ``MinkowskiBatchNorm`` (sub-module ``.bn``),
+``MinkowskiReLU``, ``cat``, ``modules.resnet_block.BasicBlock``,
+``utils.batched_coordinates / sparse_quantize / kaiming_normal_``.
+Call sites: utils/minkunet.py:53-180, utils/resnet.py:109-154, train_joint.py:82,250,
+eval_joint.py:64,169, utils/dataloader.py:197.
+
+Parameter names and shapes follow MinkowskiEngine 0.5.x so reference checkpoints keep their
+keys: conv weight ``kernel`` [K^3, Cin, Cout] ([Cin, Cout] when K = 1), ``bias`` [1, Cout],
+``MinkowskiBatchNorm.bn`` = ``nn.BatchNorm1d``.
+
+Row-order invariant relied on by the reference (train_joint.py:256-272): row i of a
+stride-1 output corresponds to row i of the input coordinates.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from . import utils  # noqa: F401
+
+__version__ = "0.5.3-cvhip"
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class CoordinateManager:
+    """Coordinate sets per tensor stride, their hash tables and the cached kernel maps."""
+
+    NUM_LEVELS = 5
+
+    def __init__(self, coords, num_levels=NUM_LEVELS):
+        assert coords.is_cuda and coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
+        L = _lib.lib()
+        self.device = coords.device
+        n = coords.shape[0]
+        if n == 0:
+            raise RuntimeError("SparseTensor: empty coordinate set")
+        self.cap = int(L.cv_sp_table_capacity(n))
+        self.num_levels = num_levels
+        dev = self.device
+        self._coords_buf = [coords.contiguous()] + [torch.empty((n, 4), dtype=torch.int32, device=dev)
+                                                    for _ in range(num_levels - 1)]
+        self._keys = [torch.empty(self.cap, dtype=torch.int64, device=dev) for _ in range(num_levels)]
+        self._vals = [torch.empty(self.cap, dtype=torch.int32, device=dev) for _ in range(num_levels)]
+        counts_d = torch.empty(8, dtype=torch.int32, device=dev)
+        counts_h = (ctypes.c_int32 * 8)()
+        ws = torch.empty(int(L.cv_sp_levels_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        with torch.cuda.device(dev):
+            _lib.check(L.cv_sp_build_levels(arr(self._coords_buf), arr(self._keys), arr(self._vals), n,
+                                            self.cap, num_levels, _ptr(counts_d), counts_h, _ptr(ws),
+                                            ws.numel(), _stream(dev)), "cv_sp_build_levels")
+        if counts_h[5] != 0:
+            raise RuntimeError("SparseTensor: %d duplicate coordinates (quantise with "
+                               "utils.sparse_quantize first, as utils/dataloader.py:197 does)" % counts_h[5])
+        self.counts = [int(counts_h[i]) for i in range(num_levels)]
+        self.coords = {1 << i: self._coords_buf[i][:self.counts[i]] for i in range(num_levels)}
+        self._level = {1 << i: i for i in range(num_levels)}
+        self._maps = {}
+
+    def num_rows(self, ts):
+        return self.counts[self._level[ts]]
+
+    def kernel_map(self, k, ts_in, stride=1):
+        """int32 [n_out, k^3]: rows of the ts_in set feeding each row of the ts_in*stride set."""
+        key = ("k", k, ts_in, stride)
+        m = self._maps.get(key)
+        if m is None:
+            L = _lib.lib()
+            li = self._level[ts_in]
+            out = self.coords[ts_in * stride]
+            m = torch.empty((out.shape[0], k ** 3), dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(L.cv_sp_kernel_map(_ptr(out), out.shape[0], _ptr(self._keys[li]),
+                                              _ptr(self._vals[li]), self.cap, k, ts_in, _ptr(m),
+                                              _stream(self.device)), "cv_sp_kernel_map")
+            self._maps[key] = m
+        return m
+
+    def up_map(self, ts_coarse):
+        """int32 [n_fine, 8] map of the transposed k2s2 conv ts_coarse -> ts_coarse/2."""
+        key = ("up", ts_coarse)
+        m = self._maps.get(key)
+        if m is None:
+            L = _lib.lib()
+            down = self.kernel_map(2, ts_coarse // 2, 2)
+            n_fine = self.num_rows(ts_coarse // 2)
+            m = torch.empty((n_fine, 8), dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(L.cv_sp_up_map(_ptr(down), down.shape[0], n_fine, _ptr(m), _stream(self.device)),
+                           "cv_sp_up_map")
+            self._maps[key] = m
+        return m
+
+
+class SparseTensor:
+    """``ME.SparseTensor(features, coordinates, device=...)`` (train_joint.py:250)."""
+
+    def __init__(self, features, coordinates=None, device=None, coordinate_manager=None, tensor_stride=1,
+                 **_):
+        if device is None:
+            device = features.device if coordinates is None else (
+                features.device if features.is_cuda else torch.device("cuda"))
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("canonicalvoting_amd SparseTensor runs on the GPU only (no CPU engine); "
+                               "pass device='cuda'")
+        self.F = features.to(device=device, dtype=torch.float32)
+        if coordinate_manager is None:
+            if coordinates is None:
+                raise ValueError("coordinates or coordinate_manager required")
+            c = coordinates
+            if c.is_floating_point():
+                c = torch.floor(c)
+            coordinate_manager = CoordinateManager(c.to(device=device, dtype=torch.int32).contiguous())
+        self.coordinate_manager = coordinate_manager
+        self.tensor_stride = tensor_stride if isinstance(tensor_stride, int) else int(tensor_stride[0])
+        if self.F.shape[0] != coordinate_manager.num_rows(self.tensor_stride):
+            raise RuntimeError("features have %d rows, coordinate set has %d" % (
+                self.F.shape[0], coordinate_manager.num_rows(self.tensor_stride)))
+
+    @property
+    def C(self):
+        return self.coordinate_manager.coords[self.tensor_stride]
+
+    @property
+    def coordinates(self):
+        return self.C
+
+    @property
+    def features(self):
+        return self.F
+
+    @property
+    def device(self):
+        return self.F.device
+
+    @property
+    def shape(self):
+        return self.F.shape
+
+    def __len__(self):
+        return self.F.shape[0]
+
+    @property
+    def decomposed_coordinates_and_features(self):
+        """per-batch (coords[:, 1:], feats) lists (sunrgbd/brnetcanon.py:227)"""
+        C, Fm = self.C, self.F
+        nb = int(C[:, 0].max().item()) + 1
+        cs, fs = [], []
+        for b in range(nb):
+            m = C[:, 0] == b
+            cs.append(C[m][:, 1:])
+            fs.append(Fm[m])
+        return cs, fs
+
+    def _like(self, F, tensor_stride=None):
+        return SparseTensor(F, coordinate_manager=self.coordinate_manager,
+                            tensor_stride=self.tensor_stride if tensor_stride is None else tensor_stride)
+
+
+def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=None, relu=False,
+                 out=None, flavour=0):
+    """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout]."""
+    L = _lib.lib()
+    dev = x_feats.device
+    w = weight if weight.dim() == 3 else weight[None]
+    K, cin, cout = w.shape
+    assert x_feats.shape[1] == cin and x_feats.stride(1) == 1
+    w = w.contiguous()
+    if out is None:
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.cv_sp_conv_f32(_ptr(x_feats), x_feats.shape[0], x_feats.stride(0), cin, _ptr(w), K, cout,
+                                    _ptr(nbr), n_out, _ptr(scale), _ptr(shift), _ptr(residual),
+                                    residual.stride(0) if residual is not None else 0, 1 if relu else 0,
+                                    _ptr(out), out.stride(0), flavour, _stream(dev)), "cv_sp_conv_f32")
+    return out
+
+
+class _ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, kernel, bias, nbr, n_out):
+        shift = bias.reshape(-1).contiguous() if bias is not None else None
+        return conv_forward(feats.contiguous(), kernel, nbr, n_out, shift=shift)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise NotImplementedError("sparse convolution backward (dgrad/wgrad) is not built yet: this round "
+                                  "ships the inference path (BASELINE config 2); see DESIGN.md")
+
+
+class MinkowskiConvolutionBase(nn.Module):
+    TRANSPOSED = False
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, dimension=3, **_):
+        super().__init__()
+        assert dimension == 3, "only D=3 is built"
+        assert dilation == 1, "dilation is not used by the reference network"
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = kernel_size if isinstance(kernel_size, int) else int(kernel_size[0])
+        self.stride = stride if isinstance(stride, int) else int(stride[0])
+        self.dimension = dimension
+        K = self.kernel_size ** 3
+        shape = (in_channels, out_channels) if K == 1 else (K, in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(shape, dtype=torch.float32))
+        self.bias = nn.Parameter(torch.empty((1, out_channels), dtype=torch.float32)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        K = self.kernel_size ** 3
+        n = (self.out_channels if self.TRANSPOSED else self.in_channels) * K
+        stdv = 1.0 / math.sqrt(n)
+        with torch.no_grad():
+            self.kernel.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+    def _map(self, x):
+        cm, ts = x.coordinate_manager, x.tensor_stride
+        if self.TRANSPOSED:
+            assert self.kernel_size == 2 and self.stride == 2, "only k2s2 transposed conv is built"
+            return cm.up_map(ts), ts // 2
+        if self.kernel_size == 1 and self.stride == 1:
+            return None, ts
+        return cm.kernel_map(self.kernel_size, ts, self.stride), ts * self.stride
+
+    def forward(self, x):
+        nbr, ts_out = self._map(x)
+        n_out = x.coordinate_manager.num_rows(ts_out)
+        F = _ConvFn.apply(x.F, self.kernel, self.bias, nbr, n_out)
+        return x._like(F, ts_out)
+
+    def extra_repr(self):
+        return "in=%d, out=%d, kernel_size=%d, stride=%d" % (self.in_channels, self.out_channels,
+                                                             self.kernel_size, self.stride)
+
+
+class MinkowskiConvolution(MinkowskiConvolutionBase):
+    TRANSPOSED = False
+
+
+class MinkowskiConvolutionTranspose(MinkowskiConvolutionBase):
+    TRANSPOSED = True
+
+
+def bn_affine(bn):
+    """(scale, shift) of an eval-mode BatchNorm1d, computed on the device."""
+    L = _lib.lib()
+    c = bn.num_features
+    dev = bn.weight.device
+    out = torch.empty((2, c), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.cv_sp_bn_fold_f32(_ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean),
+                                       _ptr(bn.running_var), _ptr(None), float(bn.eps), c, _ptr(out[0]),
+                                       _ptr(out[1]), _stream(dev)), "cv_sp_bn_fold_f32")
+    return out[0], out[1]
+
+
+def affine_forward(F, scale, shift, relu, out=None):
+    L = _lib.lib()
+    dev = F.device
+    if out is None:
+        out = torch.empty_like(F)
+    with torch.cuda.device(dev):
+        _lib.check(L.cv_sp_affine_f32(_ptr(F), F.shape[0], F.shape[1], F.stride(0), _ptr(scale), _ptr(shift),
+                                      1 if relu else 0, _ptr(out), out.stride(0), _stream(dev)),
+                   "cv_sp_affine_f32")
+    return out
+
+
+class MinkowskiBatchNorm(nn.Module):
+    """``nn.BatchNorm1d`` over the feature rows; sub-module name ``bn`` (utils/resnet.py:115-116)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                 track_running_stats=track_running_stats)
+
+    def forward(self, x):
+        if self.training or torch.is_grad_enabled() and x.F.requires_grad:
+            return x._like(self.bn(x.F))          # batch statistics: torch's own kernel for now
+        scale, shift = bn_affine(self.bn)
+        return x._like(affine_forward(x.F.contiguous(), scale, shift, False))
+
+
+class MinkowskiReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+        self.inplace = inplace
+
+    def forward(self, x):
+        if x.F.requires_grad:
+            return x._like(torch.relu(x.F))
+        F = x.F.contiguous()
+        return x._like(affine_forward(F, None, None, True, out=F if self.inplace else None))
+
+
+def cat(*tensors):
+    """Channel concat of tensors on the same coordinate map (utils/minkunet.py:153)."""
+    if len(tensors) == 1 and isinstance(tensors[0], (list, tuple)):
+        tensors = tuple(tensors[0])
+    t0 = tensors[0]
+    for t in tensors[1:]:
+        assert t.coordinate_manager is t0.coordinate_manager and t.tensor_stride == t0.tensor_stride
+    return t0._like(torch.cat([t.F for t in tensors], dim=1))
+
+
+from . import modules  # noqa: E402,F401

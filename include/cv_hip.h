@@ -117,6 +117,59 @@ double cv_iou_obb(const float* h_box1, const float* h_box2);
 /* eval_joint.py:75-89 (host): greedy NMS, returns the pick count, indices in h_pick. */
 int cv_nms_obb(const float* h_boxes, const float* h_scores, int n, double thr, int32_t* h_pick);
 
+/* ------------------------------------------------------------------------ *
+ * Sparse-voxel engine: replaces the MinkowskiEngine v0.5.3 calls of the network
+ * (external dependency, README.md:53; call sites utils/minkunet.py:53-180,
+ * utils/resnet.py:118-154, train_joint.py:250, eval_joint.py:169-171).
+ * Coordinates are int32 [n][4] = (batch, x, y, z), features fp32 row-major with an
+ * explicit leading dimension, weights are ME's `kernel` layout [K^3][Cin][Cout]
+ * ([Cin][Cout] for 1x1), kernel-offset index with the first spatial axis fastest.
+ * ------------------------------------------------------------------------ */
+
+/* Hash-table slots needed for a coordinate set of n rows (power of two >= 2n). */
+long long cv_sp_table_capacity(long long n);
+size_t cv_sp_levels_workspace_bytes(long long n);
+
+/* Coordinate sets of tensor strides 1,2,4,8,16 (ME coordinate manager: stride-2 sets are
+ * unique(floor(c / 2ts) * 2ts), ordered by first appearance) and one hash table per level.
+ * d_coords[0] is the caller's input (n rows); d_coords[1..], d_keys[L], d_vals[L] are caller
+ * allocated (n rows / `cap` slots each).  h_counts[0..4] = rows per level, h_counts[5] = number
+ * of duplicate input coordinates (must be 0).  Synchronises `stream` once. */
+int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_keys,
+                       int32_t* const* d_vals, long long n, long long cap, int num_levels,
+                       int32_t* d_counts, int32_t* h_counts, void* d_ws, size_t ws_bytes, void* stream);
+
+/* Kernel map of a k^3 kernel (ME "kernel map" / neighbour table): d_nbr[n_out][k^3] = input row of
+ * out_coord + offset*ts or -1.  Odd k centred, even k offsets 0..k-1.  Asynchronous. */
+int cv_sp_kernel_map(const int32_t* d_out_coords, long long n_out, const unsigned long long* d_keys,
+                     const int32_t* d_vals, long long cap, int k, int ts, int32_t* d_nbr, void* stream);
+
+/* Map of MinkowskiConvolutionTranspose(kernel_size=2, stride=2) onto the existing finer set,
+ * derived from the matching strided map: d_up[n_fine][8]. */
+int cv_sp_up_map(const int32_t* d_nbr_down, long long n_coarse, long long n_fine, int32_t* d_up,
+                 void* stream);
+
+/* out[u][:] = relu?( (sum_j W_j^T in[nbr[u][j]]) * scale + shift + residual[u][:] )
+ * = MinkowskiConvolution / ConvolutionTranspose with the eval-mode MinkowskiBatchNorm, bias,
+ * BasicBlock residual and MinkowskiReLU folded into the epilogue (any of scale/shift/residual
+ * may be NULL).  d_nbr may be NULL for K == 1.  flavour: 0 auto, 1 rows, 2 split-K. */
+int cv_sp_conv_f32(const float* d_in, long long n_in, int in_ld, int cin, const float* d_weight, int K,
+                   int cout, const int32_t* d_nbr, long long n_out, const float* d_scale,
+                   const float* d_shift, const float* d_residual, int res_ld, int relu, float* d_out,
+                   int out_ld, int flavour, void* stream);
+
+/* y = relu?(x * scale + shift): MinkowskiBatchNorm (eval) / MinkowskiReLU on feature rows. */
+int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale,
+                     const float* d_shift, int relu, float* d_y, int y_ld, void* stream);
+
+/* scale = gamma / sqrt(var + eps), shift = beta - mean * scale (+ bias * scale). */
+int cv_sp_bn_fold_f32(const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_var,
+                      const float* d_bias, float eps, int c, float* d_scale, float* d_shift, void* stream);
+
+/* Per-point head select of the joint model (eval_joint.py:173-190). */
+int cv_head_joint_f32(const float* d_feats, long long n, int ld, int nclasses, int log_scale, float* d_xyz,
+                      float* d_scale, float* d_prob, int32_t* d_class, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

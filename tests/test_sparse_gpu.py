@@ -1,0 +1,177 @@
+"""gfx950 sparse-voxel engine vs oracle/sparse_oracle.py: coordinate sets and kernel maps exact
+(integer work), convolution / network floats within the north_star tolerance 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_oracle as so
+from canonicalvoting_amd import me as ME
+from canonicalvoting_amd import pipeline
+from canonicalvoting_amd.minkunet import MinkUNet34C
+from canonicalvoting_amd.synth import make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def scene_coords(seed, n, batch=1, small=True):
+    cs, fs = [], []
+    for b in range(batch):
+        if small:
+            sc = make_scene(seed + b, n_points=n, res=0.06, room=(1.5, 0.9, 1.5), n_boxes=2, margin=0.5,
+                            box_scale=0.4)
+        else:
+            sc = make_scene(seed + b, n_points=n)
+        cs.append(np.concatenate([np.full((n, 1), b, np.int64), sc.coords], 1))
+        fs.append(sc.feats * 2 - 1)
+    return np.concatenate(cs), np.concatenate(fs).astype(np.float32)
+
+
+@pytest.mark.parametrize("seed,n,batch", [(0, 700, 1), (1, 3000, 2)])
+def test_coordinate_sets_and_kernel_maps_exact(cuda, built_lib, seed, n, batch):
+    coords, _ = scene_coords(seed, n, batch)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(cuda, torch.int32))
+    ocm = so.CoordinateManager(coords)
+    for ts in (1, 2, 4, 8, 16):
+        assert cm.num_rows(ts) == len(ocm.coords[ts])
+        assert np.array_equal(cm.coords[ts].cpu().numpy(), ocm.coords[ts])       # same order too
+    for k, ts, stride in ((5, 1, 1), (3, 1, 1), (3, 2, 1), (3, 4, 1), (3, 8, 1), (3, 16, 1), (2, 1, 2),
+                          (2, 2, 2), (2, 4, 2), (2, 8, 2)):
+        assert np.array_equal(cm.kernel_map(k, ts, stride).cpu().numpy(), ocm.map(k, ts, stride)), (k, ts, stride)
+    for ts_c in (2, 4, 8, 16):
+        up = cm.up_map(ts_c).cpu().numpy()
+        down = ocm.map(2, ts_c // 2, 2)
+        assert ((up >= 0).sum(1) == 1).all()                      # exactly one parent / octant per fine row
+        f, j = np.nonzero(up >= 0)
+        assert np.array_equal(down[up[f, j], j], f)
+
+
+def test_duplicate_coordinates_rejected(cuda, built_lib):
+    c = torch.tensor([[0, 1, 2, 3], [0, 1, 2, 3], [0, 4, 5, 6]], dtype=torch.int32, device=cuda)
+    with pytest.raises(RuntimeError, match="duplicate"):
+        ME.SparseTensor(torch.zeros(3, 3, device=cuda), c)
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(1e-6, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("cin,cout,k,flavour", [(32, 32, 3, 1), (32, 64, 3, 1), (96, 96, 3, 1), (128, 96, 3, 1),
+                                               (64, 128, 3, 1), (128, 256, 3, 1), (256, 256, 3, 2),
+                                               (64, 64, 3, 2), (32, 32, 3, 2), (3, 32, 5, 1), (6, 32, 5, 1),
+                                               (128, 96, 1, 1), (96, 64, 1, 1), (384, 256, 1, 0)])
+def test_conv_matches_oracle(cuda, built_lib, cin, cout, k, flavour):
+    coords, _ = scene_coords(2, 1500)
+    rng = np.random.default_rng(cin * 1000 + cout)
+    x = rng.normal(0, 1, (len(coords), cin)).astype(np.float32)
+    w = (rng.normal(0, 1, (k ** 3, cin, cout)) / np.sqrt(cin * k ** 3)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.normal(0, 0.2, cout).astype(np.float32)
+    res = rng.normal(0, 1, (len(coords), cout)).astype(np.float32)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(cuda, torch.int32))
+    nbr = cm.kernel_map(k, 1) if k > 1 else None
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    onbr = so.kernel_map(coords, coords, k, 1, 1)
+    ref0 = so.conv(torch.from_numpy(x), torch.from_numpy(w), onbr).numpy()
+    got0 = ME.conv_forward(t(x), t(w), nbr, len(coords), flavour=flavour).cpu().numpy()
+    assert rel_err(got0, ref0) < 1e-5
+    ref1 = np.maximum(ref0 * scale + shift + res, 0)
+    # strided input / output / residual views (the fused network writes into concat buffers)
+    xin = torch.zeros((len(coords), cin + 32), device=cuda); xin[:, 16:16 + cin] = t(x)
+    rbuf = torch.zeros((len(coords), cout + 8), device=cuda); rbuf[:, 4:4 + cout] = t(res)
+    obuf = torch.full((len(coords), cout + 64), -7.0, device=cuda)
+    ME.conv_forward(xin[:, 16:16 + cin], t(w), nbr, len(coords), scale=t(scale), shift=t(shift),
+                    residual=rbuf[:, 4:4 + cout], relu=True, out=obuf[:, 32:32 + cout], flavour=flavour)
+    got1 = obuf[:, 32:32 + cout].cpu().numpy()
+    assert rel_err(got1, ref1) < 1e-5
+    assert float(obuf[:, :32].min()) == -7.0 and float(obuf[:, 32 + cout:].max()) == -7.0   # no stray writes
+
+
+def test_strided_and_transposed_conv_match_oracle(cuda, built_lib):
+    coords, _ = scene_coords(3, 2000)
+    rng = np.random.default_rng(0)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(cuda, torch.int32))
+    ocm = so.CoordinateManager(coords)
+    x = rng.normal(0, 1, (len(coords), 32)).astype(np.float32)
+    w = rng.normal(0, 0.1, (8, 32, 64)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    down = ME.conv_forward(t(x), t(w), cm.kernel_map(2, 1, 2), cm.num_rows(2))
+    rdown = so.conv(torch.from_numpy(x), torch.from_numpy(w), ocm.map(2, 1, 2))
+    assert rel_err(down.cpu().numpy(), rdown.numpy()) < 1e-5
+    wt = rng.normal(0, 0.1, (8, 64, 96)).astype(np.float32)
+    up = ME.conv_forward(down, t(wt), cm.up_map(2), cm.num_rows(1))
+    rup = so.conv_transpose_k2s2(rdown, torch.from_numpy(wt), ocm.map(2, 1, 2))
+    assert rel_err(up.cpu().numpy(), rup.numpy()) < 1e-5
+
+
+def test_modules_match_oracle_and_reference_api(cuda, built_lib):
+    """facade modules one by one (the unfused path the reference takes)"""
+    coords, feats = scene_coords(4, 900)
+    x = ME.SparseTensor(torch.from_numpy(feats), torch.from_numpy(coords).int(), device="cuda")
+    assert x.F.shape == (900, 3) and x.C.shape == (900, 4)
+    conv = ME.MinkowskiConvolution(3, 32, kernel_size=5, dimension=3).cuda()
+    bn = ME.MinkowskiBatchNorm(32).cuda().eval()
+    bn.bn.running_mean.normal_(0, 0.1); bn.bn.running_var.uniform_(0.5, 2)
+    relu = ME.MinkowskiReLU(inplace=True)
+    with torch.no_grad():
+        y = relu(bn(conv(x)))
+    sd = {"c.kernel": conv.kernel.detach().cpu()}
+    sd.update({"b.bn." + k: v.detach().cpu() for k, v in bn.bn.state_dict().items()})
+    ref = torch.relu(so.batch_norm(so.conv(torch.from_numpy(feats), sd["c.kernel"],
+                                           so.kernel_map(coords, coords, 5, 1, 1)), sd, "b"))
+    assert rel_err(y.F.cpu().numpy(), ref.numpy()) < 1e-5
+    z = ME.cat(y, y)
+    assert z.F.shape == (900, 64)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ME.SparseTensor(torch.from_numpy(feats), torch.from_numpy(coords).int(), device="cpu")
+
+
+@pytest.mark.parametrize("n,small", [(800, True), (8000, False)])
+def test_minkunet34c_fused_and_modular_match_oracle(cuda, built_lib, n, small):
+    coords, feats = scene_coords(5, n, small=small)
+    sd = so.make_state_dict(3, 64, seed=1)
+    model = MinkUNet34C(3, 64)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    x = ME.SparseTensor(torch.from_numpy(feats), torch.from_numpy(coords).int(), device="cuda")
+    with torch.no_grad():
+        fused = model(x).F.cpu().numpy()
+        modular = model.modular_forward(x).F.cpu().numpy()
+    ref = so.minkunet34c_forward(sd, coords, feats).numpy()
+    assert fused.shape == ref.shape == (n, 64)
+    # north_star: within 1e-4 on the LCC / scale floats (outputs are O(1))
+    assert np.abs(fused - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    assert np.abs(modular - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    # head split (eval_joint.py:173-190): integer outputs exact, floats 1e-4
+    xyz, scale, prob, cls = pipeline.head_joint(torch.from_numpy(ref).to(cuda))
+    rx, rs, rp, rc = so.head_joint_eval(ref)
+    assert np.array_equal(cls.cpu().numpy(), rc.numpy())
+    np.testing.assert_allclose(xyz.cpu().numpy(), rx.numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(scale.cpu().numpy(), rs.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(prob.cpu().numpy(), rp.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_minkunet_batch_of_scenes_and_row_order(cuda, built_lib):
+    coords, feats = scene_coords(7, 1200, batch=3)
+    sd = so.make_state_dict(3, 8, seed=2)                       # separate-model head (8 channels)
+    model = MinkUNet34C(3, 8)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    perm = np.random.default_rng(0).permutation(len(coords))
+    with torch.no_grad():
+        y = model(ME.SparseTensor(torch.from_numpy(feats[perm]), torch.from_numpy(coords[perm]).int(),
+                                  device="cuda")).F.cpu().numpy()
+    ref = so.minkunet34c_forward(sd, coords, feats).numpy()
+    assert np.abs(y - ref[perm]).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_detect_scene_end_to_end(cuda, built_lib):
+    from canonicalvoting_amd.hough import HoughVoting
+    coords, feats = scene_coords(9, 8000, small=False)
+    model = MinkUNet34C(3, 64)
+    model.load_state_dict(so.make_state_dict(3, 64, seed=3))
+    model = model.cuda().eval()
+    hv = HoughVoting(0.03, 120)
+    dets, raw, y = pipeline.detect_scene(model, hv, torch.from_numpy(coords).int().to(cuda),
+                                         torch.from_numpy(feats).to(cuda), 0.03, thresh_high=5.0)
+    assert y.F.shape == (8000, 64) and torch.isfinite(y.F).all()
+    assert len(raw["verdict"]) == len(raw["cand_idx"])

@@ -1,0 +1,134 @@
+"""Pins oracle/sparse_oracle.py (the [ME-ext] sparse-conv semantics) against dense
+torch.nn.functional ops on densified grids masked to the active set."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import sparse_oracle as so
+
+
+def random_active(rng, size=10, batch=2, frac=0.25, shift=(0, 0, 0)):
+    dense_mask = rng.random((batch, size, size, size)) < frac
+    b, x, y, z = np.nonzero(dense_mask)
+    coords = np.stack([b, x + shift[0], y + shift[1], z + shift[2]], -1).astype(np.int64)
+    perm = rng.permutation(len(coords))
+    return coords[perm], dense_mask
+
+
+def densify(coords, feats, size, batch, shift=(0, 0, 0), div=1):
+    C = feats.shape[1]
+    d = torch.zeros((batch, C, size, size, size))
+    c = np.asarray(coords)
+    d[c[:, 0], :, (c[:, 1] - shift[0]) // div, (c[:, 2] - shift[1]) // div, (c[:, 3] - shift[2]) // div] = feats
+    return d
+
+
+def dense_weight(kernel, k):
+    """[K,Cin,Cout] -> conv3d weight [Cout,Cin,k,k,k] using the oracle's offset table."""
+    offs = so.kernel_offsets(k)
+    lo = offs.min()
+    w = torch.zeros((kernel.shape[2], kernel.shape[1], k, k, k))
+    for j, o in enumerate(offs):
+        w[:, :, o[0] - lo, o[1] - lo, o[2] - lo] = kernel[j].t()
+    return w
+
+
+def test_kernel_offsets_shape_and_centre():
+    o3 = so.kernel_offsets(3)
+    assert o3.shape == (27, 3) and tuple(o3[13]) == (0, 0, 0) and o3.min() == -1 and o3.max() == 1
+    o2 = so.kernel_offsets(2)
+    assert o2.shape == (8, 3) and o2.min() == 0 and o2.max() == 1
+    assert tuple(o3[1] - o3[0]) == (1, 0, 0)          # first spatial axis fastest
+    assert len({tuple(o) for o in so.kernel_offsets(5)}) == 125
+
+
+def test_conv_k3_and_k5_match_dense():
+    rng = np.random.default_rng(0)
+    for k, shift in ((3, (0, 0, 0)), (5, (-7, 3, -20))):
+        coords, mask = random_active(rng, shift=shift)
+        feats = torch.randn(len(coords), 4)
+        kernel = torch.randn(k ** 3, 4, 6)
+        nbr = so.kernel_map(coords, coords, k, 1, 1)
+        out = so.conv(feats, kernel, nbr)
+        dense = F.conv3d(densify(coords, feats, 10, 2, shift), dense_weight(kernel, k), padding=k // 2)
+        c = coords
+        ref = dense[c[:, 0], :, c[:, 1] - shift[0], c[:, 2] - shift[1], c[:, 3] - shift[2]]
+        torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_conv_k3_at_tensor_stride_4():
+    rng = np.random.default_rng(1)
+    coords, _ = random_active(rng, size=8)
+    coords[:, 1:] *= 4                                   # a ts=4 coordinate set
+    feats = torch.randn(len(coords), 3)
+    kernel = torch.randn(27, 3, 5)
+    out = so.conv(feats, kernel, so.kernel_map(coords, coords, 3, 4, 1))
+    dense = F.conv3d(densify(coords, feats, 8, 2, div=4), dense_weight(kernel, 3), padding=1)
+    c = coords
+    torch.testing.assert_close(out, dense[c[:, 0], :, c[:, 1] // 4, c[:, 2] // 4, c[:, 3] // 4],
+                               rtol=1e-4, atol=1e-4)
+
+
+def test_strided_conv_and_transpose_match_dense():
+    rng = np.random.default_rng(2)
+    shift = (-16, 32, -48)                               # multiples of the coarse stride, negative too
+    coords, mask = random_active(rng, size=12, frac=0.2, shift=shift)
+    feats = torch.randn(len(coords), 4)
+    coarse = so.downsample_coords(coords, 1)
+    cmask = F.max_pool3d(torch.from_numpy(mask).float()[:, None], 2)[:, 0] > 0
+    assert len(coarse) == int(cmask.sum())
+    assert np.all(coarse[:, 1:] % 2 == 0)
+    nbr = so.kernel_map(coords, coarse, 2, 1, 2)
+    assert (nbr >= 0).sum() == len(coords)               # every fine voxel has exactly one parent
+    kernel = torch.randn(8, 4, 6)
+    out = so.conv(feats, kernel, nbr)
+    dense = F.conv3d(densify(coords, feats, 12, 2, shift), dense_weight(kernel, 2), stride=2)
+    c = coarse
+    ref = dense[c[:, 0], :, (c[:, 1] - shift[0]) // 2, (c[:, 2] - shift[1]) // 2, (c[:, 3] - shift[2]) // 2]
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+    # transposed conv back onto the fine set
+    kt = torch.randn(8, 6, 3)
+    up = so.conv_transpose_k2s2(out, kt, nbr)
+    wt = torch.zeros((6, 3, 2, 2, 2))
+    for j, o in enumerate(so.kernel_offsets(2)):
+        wt[:, :, o[0], o[1], o[2]] = kt[j]
+    dcoarse = densify(coarse, out, 6, 2, shift, div=2)
+    dup = F.conv_transpose3d(dcoarse, wt, stride=2)
+    c = coords
+    ref = dup[c[:, 0], :, c[:, 1] - shift[0], c[:, 2] - shift[1], c[:, 3] - shift[2]]
+    torch.testing.assert_close(up, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_floor_division_for_negative_coordinates():
+    c = np.array([[0, -1, -2, -3], [0, -4, 0, 1], [0, 3, 2, -5]])
+    d = so.downsample_coords(c, 2)                       # ts=2 -> stride 4
+    assert d.tolist() == [[0, -4, -4, -4], [0, -4, 0, 0], [0, 0, 0, -8]]
+
+
+def test_state_dict_names_and_shapes():
+    sd = so.make_state_dict(3, 64)
+    n_params = sum(v.numel() for k, v in sd.items() if k.endswith(("kernel", "bias", "weight")))
+    assert abs(n_params - 37.86e6) < 0.05e6             # 37.86 M parameters
+    assert sd["conv0p1s1.kernel"].shape == (125, 3, 32)
+    assert sd["block5.0.conv1.kernel"].shape == (27, 384, 256)
+    assert sd["block5.0.downsample.0.kernel"].shape == (384, 256)
+    assert sd["convtr7p2s2.kernel"].shape == (8, 96, 96)
+    assert sd["final.kernel"].shape == (96, 64) and sd["final.bias"].shape == (1, 64)
+    assert "block1.0.downsample.0.kernel" not in sd     # 32 -> 32: no downsample
+    convs = [k for k in sd if k.endswith(".kernel")]
+    bns = [k for k in sd if k.endswith(".bn.weight")]
+    assert len(convs) == 63 and len(bns) == 62          # 63 convs (7 are 1x1 downsamples), 62 BN
+
+
+def test_unet_forward_runs_and_keeps_row_order():
+    from canonicalvoting_amd.synth import make_scene
+    sc = make_scene(1, n_points=600, res=0.06, room=(1.5, 0.9, 1.5), n_boxes=2, margin=0.5, box_scale=0.4)
+    coords = np.concatenate([np.zeros((600, 1), np.int64), sc.coords], 1)
+    sd = so.make_state_dict(3, 64)
+    y = so.minkunet34c_forward(sd, coords, sc.feats * 2 - 1)
+    assert y.shape == (600, 64) and torch.isfinite(y).all()
+    perm = np.random.default_rng(0).permutation(600)
+    y2 = so.minkunet34c_forward(sd, coords[perm], (sc.feats * 2 - 1)[perm])
+    torch.testing.assert_close(y2, y[perm], rtol=1e-3, atol=1e-3)      # output row i <-> input row i
+    xyz, scale, prob, cls = so.head_joint_eval(y)
+    assert xyz.shape == (600, 3) and (scale > 0).all() and cls.max() < 9 and (prob <= 1).all()
