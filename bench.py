@@ -28,8 +28,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from canonicalvoting_amd import _lib, decode, hv_cuda  # noqa: E402
+from canonicalvoting_amd import _lib, decode, hv_cuda, pipeline  # noqa: E402
+from canonicalvoting_amd import me as ME  # noqa: E402
 from canonicalvoting_amd.hough import HoughVoting  # noqa: E402
+from canonicalvoting_amd.minkunet import MinkUNet34C  # noqa: E402
 from canonicalvoting_amd.synth import make_scene, synth_predictions  # noqa: E402
 
 N_POINTS = 80000
@@ -46,8 +48,12 @@ def parse():
     ap.add_argument("--scenes", type=int, default=4, help="distinct resident scenes per rank")
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--algo", type=int, default=0, help="vote algorithm: 0 auto, 1 direct, 2 tiles")
-    ap.add_argument("--cpu-scenes", type=int, default=6, help="scenes timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--stage", default="auto", choices=["auto", "vote_decode", "full"])
+    ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--stage", default="full", choices=["vote_decode", "full"],
+                    help="full = MinkUNet34C forward + head + vote + decode + NMS (eval_joint.py path)")
+    ap.add_argument("--teacher-forced", action="store_true",
+                    help="feed the vote/decode stage with predictions synthesised from the labels "
+                         "(realistic peak counts) instead of the random-weight network's output")
     return ap.parse_args()
 
 
@@ -60,6 +66,8 @@ class ResidentScene:
         self.host = (sc, xyz, scale, prob, cls)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.coords = t(sc.coords)
+        self.coords4 = torch.cat([torch.zeros((n_points, 1), dtype=torch.int32, device=dev), self.coords], 1).contiguous()
+        self.feats_in = (t(sc.feats) * 2.0 - 1.0).contiguous()       # eval_joint.py:167-168
         self.points = (self.coords * RES).float().contiguous()      # eval_joint.py:193
         self.feats = t(sc.feats)
         self.xyz, self.scale, self.prob, self.cls = t(xyz), t(scale), t(prob), t(cls)
@@ -71,27 +79,44 @@ class ResidentScene:
         self.vote_bytes_floor = 40 * n_points + 24 * G                   # compulsory traffic
 
 
-def run_step(hv, s, ev=None):
-    """vote -> decode -> per-class NMS for one resident scene (eval_joint.py:193-280)."""
+def run_step(model, hv, s, ev=None, teacher_forced=False):
+    """One scene through eval_joint.py:163-280: network -> head -> vote -> decode -> per-class NMS."""
+    rec = (lambda i: ev[i].record()) if ev is not None else (lambda i: None)
     with torch.no_grad():
-        if ev is not None:
-            ev[0].record()
-        grid_obj, grid_rot, grid_scale = hv(s.points, s.xyz, s.scale, s.prob)
-        if ev is not None:
-            ev[1].record()
-    raw = decode.decode_boxes(grid_obj, grid_rot, grid_scale, s.points, s.xyz, s.prob, s.cls, RES,
-                              corner=s.corner)
+        rec(0)
+        if model is not None:
+            x = ME.SparseTensor(s.feats_in, s.coords4, device=s.feats_in.device)   # coordinate hash + levels
+            y = model(x)
+            rec(1)
+            xyz, scale, prob, cls = pipeline.head_joint(y.F)
+        else:
+            rec(1)
+        if model is None or teacher_forced:
+            xyz, scale, prob, cls = s.xyz, s.scale, s.prob, s.cls
+        rec(2)
+        grid_obj, grid_rot, grid_scale = hv(s.points, xyz, scale, prob)
+        rec(3)
+    raw = decode.decode_boxes(grid_obj, grid_rot, grid_scale, s.points, xyz, prob, cls, RES, corner=s.corner)
+    rec(4)
     return decode.nms_per_class(raw["boxes"], raw["scores"], raw["classes"]), raw
 
 
-def cpu_baseline(scenes, n):
+def cpu_baseline(scenes, n, model, full):
+    """CPU oracle (a port: the reference has no CPU path for the vote and its sparse engine is an
+    absent external dependency) on n of the same scenes, all host threads torch gives us."""
     import oracle
+    from oracle import sparse_oracle as so
     oracle.lib()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()} if full else None
     t0 = time.perf_counter()
     boxes = 0
     for s in scenes[:n]:
         sc, xyz, scale, prob, cls = s.host
         pts = sc.points
+        if full:
+            c4 = np.concatenate([np.zeros((len(sc.coords), 1), np.int64), sc.coords], 1)
+            y = so.minkunet34c_forward(sd, c4, sc.feats * 2 - 1)
+            xyz, scale, prob, cls = [a.numpy() for a in so.head_joint_eval(y)]
         g = oracle.hv_forward(pts, xyz, scale, prob, RES, NUM_ROTS)
         corner, _, _ = oracle.grid_geometry(pts, RES)
         d = oracle.decode(g[0], g[1], g[2], corner, RES, pts, xyz, prob, cls)
@@ -114,15 +139,19 @@ def main():
     _lib.lib()
     hv_cuda.set_algorithm(a.algo)
     hv = HoughVoting(RES, NUM_ROTS)
+    full = a.stage == "full"
+    model = None
+    if full:
+        torch.manual_seed(0)
+        model = MinkUNet34C(3, 6 * 9 + 9 + 1).cuda().eval()        # eval_joint.py:151, random init
 
     # scene i of rank r uses seed r*1000 + i: every rank owns different scenes
     scenes = [ResidentScene(rank * 1000 + i, a.points, dev) for i in range(a.scenes)]
     for w in range(a.warmup):
-        run_step(hv, scenes[w % len(scenes)])
+        run_step(model, hv, scenes[w % len(scenes)], teacher_forced=a.teacher_forced)
     torch.cuda.synchronize()
 
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-              for _ in range(a.steps)]
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(a.steps)]
 
     def barrier():
         if world > 1:
@@ -134,7 +163,7 @@ def main():
     t0 = time.perf_counter()
     n_det = 0
     for k in range(a.steps):
-        dets, _ = run_step(hv, scenes[k % len(scenes)], events[k])
+        dets, _ = run_step(model, hv, scenes[k % len(scenes)], events[k], a.teacher_forced)
         n_det += len(dets)
     barrier()
     dt = time.perf_counter() - t0
@@ -144,7 +173,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    vote_ms = np.array([e0.elapsed_time(e1) for e0, e1 in events])
+    vote_ms = np.array([e[2].elapsed_time(e[3]) for e in events])
+    stage_ms = {"net": float(np.mean([e[0].elapsed_time(e[1]) for e in events])),
+                "head": float(np.mean([e[1].elapsed_time(e[2]) for e in events])),
+                "vote": float(vote_ms.mean()),
+                "decode": float(np.mean([e[3].elapsed_time(e[4]) for e in events]))}
     vb = np.array([scenes[k % len(scenes)].vote_bytes for k in range(a.steps)], dtype=np.float64)
     achieved = float((vb / (vote_ms * 1e-3)).mean() / 1e9)
     s0 = scenes[0]
@@ -161,9 +194,13 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "single %d-point synthetic scene per GPU-step, eval_joint.py path: "
-                               "vote accumulation + decode + NMS (per-point predictions synthesised; "
-                               "sparse MinkUNet forward not yet on the timed path)" % a.points,
+        "config": {"workload": ("single %d-point synthetic scene per GPU-step, eval_joint.py path: "
+                                "HIP sparse MinkUNet34C forward (fp32, random init) + head + HIP vote "
+                                "accumulation + decode + NMS" % a.points) if full else
+                               ("single %d-point synthetic scene per GPU-step: vote + decode + NMS only "
+                                "(synthesised predictions)" % a.points),
+                   "predictions": "synthesised from labels (teacher-forced)" if (a.teacher_forced or not full)
+                                  else "network output",
                    "points": a.points, "num_rots": NUM_ROTS, "res": RES, "grid": s0.dims,
                    "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}.get(a.algo, "ablation-%d" % a.algo),
                    "parallelism": "scene-parallel x%d, no collective" % world},
@@ -173,13 +210,18 @@ def main():
                      "avg_ms": float(vote_ms.mean()), "bytes_per_launch": float(vb.mean()),
                      "compulsory_bytes": float(s0.vote_bytes_floor), "v_in": s0.v_in},
         "detections_per_scene": n_det / a.steps,
+        "stage_ms": stage_ms,
     }
     if rank == 0 and world == 1 and a.cpu_scenes > 0:
-        v, secs, _ = cpu_baseline(scenes, min(a.cpu_scenes, len(scenes)))
-        out["cpu_baseline"] = {"value": v, "unit": "scenes/s", "cores": 1, "kind": "port",
-                               "sample": "%d of the same 80k-point scenes, oracle vote+decode+NMS, "
-                                         "%.1f s, 1 thread (build CPU oracle, not reference code)"
-                                         % (min(a.cpu_scenes, len(scenes)), secs)}
+        nc = min(a.cpu_scenes, len(scenes))
+        v, secs, _ = cpu_baseline(scenes, nc, model, full)
+        out["cpu_baseline"] = {"value": v, "unit": "scenes/s", "cores": torch.get_num_threads() if full else 1,
+                               "kind": "port",
+                               "sample": "%d of the same %d-point scenes through the CPU oracle (%s), %.1f s; "
+                                         "build CPU oracle, not reference code (the reference has no CPU "
+                                         "vote and MinkowskiEngine is absent)"
+                                         % (nc, a.points, "torch-CPU sparse MinkUNet34C + C vote/decode/NMS"
+                                            if full else "C vote/decode/NMS, 1 thread", secs)}
     else:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -39,11 +39,22 @@ struct ConvArgs {
     const float* res; int res_ld;
     int relu;
     float* out; int out_ld;
+    int splits;          // >1: blockIdx.z handles a contiguous range of kernel offsets and writes raw
+    float* partial;      //     partial sums to partial[split][n_out][cout] (finished by conv_finish)
 };
 
 __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& acc, long long row0,
                                                int col, int lane) {
     if (col >= a.cout) return;
+    if (a.splits > 1) {
+        float* p = a.partial + (long long)blockIdx.z * a.n_out * a.cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < a.n_out) p[row * a.cout + col] = acc[r];
+        }
+        return;
+    }
     const float sc = a.scale ? a.scale[col] : 1.f;
     const float sh = a.shift ? a.shift[col] : 0.f;
 #pragma unroll
@@ -92,7 +103,9 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
         const int a_row = tid >> 3;                      // + 32*i, i = 0..3
         constexpr int B_F4 = KC * NB * 32 / 4;           // float4s in the weight slab
         constexpr int B_PER = (B_F4 + THREADS - 1) / THREADS;
-        for (int j = 0; j < a.K; ++j) {
+        const int j_lo = (int)((long long)a.K * blockIdx.z / a.splits);
+        const int j_hi = (int)((long long)a.K * (blockIdx.z + 1) / a.splits);
+        for (int j = j_lo; j < j_hi; ++j) {
             int my = -1;
             if (tid < TM) {
                 const long long row = row_base + tid;
@@ -100,6 +113,9 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
                 nbr_s[tid] = my;
             }
             if (!__syncthreads_or(my >= 0)) continue;    // nobody in the tile has this neighbour
+            // a wave whose 32 rows all miss this neighbour skips its MFMAs (pays off when rows are
+            // spatially coherent); it still takes part in the staging and the barriers
+            const bool wave_live = __any(nbr_s[wave * 32 + (lane & 31)] >= 0);
             float4 ra[4], rb[B_PER];
             auto load = [&](int kc) {
 #pragma unroll
@@ -147,13 +163,16 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
                 stage();
                 __syncthreads();
                 if (kc + KC < a.cin) load(kc + KC);   // in flight while the matrix cores run
-                compute();
+                if (wave_live) compute();
             }
             __syncthreads();
         }
     } else {
         const int ktot = a.K * a.cin;
-        for (int kc = 0; kc < ktot; kc += KC) {
+        const int nchunks = (ktot + KC - 1) / KC;
+        const int c_lo = (int)((long long)nchunks * blockIdx.z / a.splits);
+        const int c_hi = (int)((long long)nchunks * (blockIdx.z + 1) / a.splits);
+        for (int kc = c_lo * KC; kc < c_hi * KC; kc += KC) {
             __syncthreads();
             for (int e = tid; e < KC * TM; e += THREADS) {
                 const int kk = e / TM, r = e % TM;
@@ -266,6 +285,21 @@ __global__ __launch_bounds__(THREADS) void conv_splitk(ConvArgs a) {
     }
 }
 
+// sums the per-split partial tiles and applies the epilogue (scale/shift/residual/relu)
+__global__ __launch_bounds__(256) void conv_finish(ConvArgs a) {
+    const long long total = a.n_out * (long long)a.cout;
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const long long row = t / a.cout;
+        const int col = (int)(t - row * a.cout);
+        float v = 0.f;
+        for (int sidx = 0; sidx < a.splits; ++sidx) v += a.partial[sidx * total + t];
+        v = v * (a.scale ? a.scale[col] : 1.f) + (a.shift ? a.shift[col] : 0.f);
+        if (a.res) v += a.res[row * a.res_ld + col];
+        if (a.relu) v = fmaxf(v, 0.f);
+        a.out[row * a.out_ld + col] = v;
+    }
+}
+
 // ------------------------------------------------------------------ elementwise helpers
 // y = x*scale + shift (+relu)   (MinkowskiBatchNorm in eval mode, MinkowskiReLU)
 __global__ __launch_bounds__(256) void affine_rows(const float* __restrict__ x, long long n, int c,
@@ -324,11 +358,31 @@ __global__ __launch_bounds__(256) void head_joint(const float* __restrict__ f, l
 
 template <int NB>
 int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
-    dim3 grid((unsigned)((a.n_out + TM - 1) / TM), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)));
+    dim3 grid((unsigned)((a.n_out + TM - 1) / TM), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)),
+              (unsigned)a.splits);
     if (vec) conv_rows<NB, true><<<grid, THREADS, 0, st>>>(a);
     else conv_rows<NB, false><<<grid, THREADS, 0, st>>>(a);
     CV_LAUNCH_CHECK();
+    if (a.splits > 1) {
+        const long long total = a.n_out * (long long)a.cout;
+        conv_finish<<<(unsigned)std::min<long long>((total + 255) / 256, 4096), 256, 0, st>>>(a);
+        CV_LAUNCH_CHECK();
+    }
     return CV_OK;
+}
+
+int nb_for(int cout) { return cout <= 32 ? 1 : cout <= 64 ? 2 : cout <= 96 ? 3 : 4; }
+
+// Enough workgroups to fill 256 CUs about twice; split over kernel offsets (or K chunks).
+int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
+    const int nb = nb_for(cout);
+    const long long tiles = ((n_out + TM - 1) / TM) * ((cout + nb * 32 - 1) / (nb * 32));
+    const int units = vec ? K : (K * cin + KC - 1) / KC;
+    if (tiles >= 384 || units <= 1) return 1;
+    long long s = (512 + tiles - 1) / tiles;
+    if (s > units) s = units;
+    if (s > 27) s = 27;
+    return (int)std::max<long long>(s, 1);
 }
 
 template <int NB>
@@ -343,11 +397,17 @@ int launch_splitk(const ConvArgs& a, hipStream_t st) {
 
 extern "C" {
 
-// flavour: 0 auto, 1 rows, 2 split-K
+size_t cv_sp_conv_workspace_bytes(long long n_out, int cout, int K) {
+    if (n_out <= 0 || cout <= 0 || K <= 0) return 0;
+    return 256 + sizeof(float) * (size_t)27 * (size_t)n_out * (size_t)cout;   // upper bound over split counts
+}
+
+// flavour: 0 auto (rows, split over kernel offsets through the workspace when the grid would not fill
+// the chip), 1 rows without splitting, 2 in-workgroup split-K (32-row tiles)
 int cv_sp_conv_f32(const float* d_in, long long n_in, int in_ld, int cin, const float* d_weight, int K,
                    int cout, const int32_t* d_nbr, long long n_out, const float* d_scale,
                    const float* d_shift, const float* d_residual, int res_ld, int relu, float* d_out,
-                   int out_ld, int flavour, void* stream) {
+                   int out_ld, int flavour, void* d_ws, size_t ws_bytes, void* stream) {
     CV_REQUIRE(d_in && d_weight && d_out, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(n_in > 0 && n_out > 0 && cin > 0 && cout > 0 && K > 0, CV_EINVAL, "bad conv sizes");
     CV_REQUIRE(d_nbr || (K == 1 && n_in == n_out), CV_EINVAL, "a kernel map is required unless K == 1");
@@ -355,21 +415,28 @@ int cv_sp_conv_f32(const float* d_in, long long n_in, int in_ld, int cin, const 
     CV_REQUIRE(d_out != d_in, CV_EINVAL, "conv cannot run in place");
     hipStream_t st = static_cast<hipStream_t>(stream);
     ConvArgs a{d_in, n_in, in_ld, cin, d_weight, K, cout, d_nbr, n_out, d_scale, d_shift, d_residual,
-               res_ld, relu, d_out, out_ld};
+               res_ld, relu, d_out, out_ld, 1, nullptr};
     const bool vec = (cin % KC == 0) && (in_ld % 4 == 0) && (cout % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(d_in) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(d_weight) & 15) == 0);
-    int fl = flavour;
-    if (fl == 0) fl = (vec && n_out <= 16384 && cout >= 64 && K > 1) ? 2 : 1;
-    if (fl == 2 && !vec) fl = 1;
-    if (fl == 2) {
+    if (flavour == 2 && vec) {
         if (cout <= 32) return launch_splitk<1>(a, st);
         return launch_splitk<2>(a, st);
     }
-    if (cout <= 32) return launch_rows<1>(a, vec, st);
-    if (cout <= 64) return launch_rows<2>(a, vec, st);
-    if (cout <= 96) return launch_rows<3>(a, vec, st);
-    return launch_rows<4>(a, vec, st);
+    if (flavour == 0) {
+        const int sp = pick_splits(n_out, cout, K, cin, vec);
+        const size_t need = sizeof(float) * (size_t)sp * (size_t)n_out * (size_t)cout;
+        if (sp > 1 && d_ws && ws_bytes >= need) {
+            a.splits = sp;
+            a.partial = static_cast<float*>(d_ws);
+        }
+    }
+    switch (nb_for(cout)) {
+        case 1: return launch_rows<1>(a, vec, st);
+        case 2: return launch_rows<2>(a, vec, st);
+        case 3: return launch_rows<3>(a, vec, st);
+        default: return launch_rows<4>(a, vec, st);
+    }
 }
 
 int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale,

@@ -172,6 +172,19 @@ class SparseTensor:
                             tensor_stride=self.tensor_stride if tensor_stride is None else tensor_stride)
 
 
+_conv_ws = {}
+
+
+def _workspace(dev, nbytes):
+    """one persistent split-K workspace per device (grown on demand; stream-ordered reuse is safe
+    because every conv is enqueued on the same stream and finishes reading it before the next)."""
+    ws = _conv_ws.get(dev)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _conv_ws[dev] = ws
+    return ws
+
+
 def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=None, relu=False,
                  out=None, flavour=0):
     """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout]."""
@@ -183,11 +196,15 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
     w = w.contiguous()
     if out is None:
         out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    ws = None
+    if flavour == 0 and n_out < 128 * 384:
+        ws = _workspace(dev, min(int(L.cv_sp_conv_workspace_bytes(n_out, cout, K)), 27 * 4 * 128 * 384 * 256 + 256))
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_conv_f32(_ptr(x_feats), x_feats.shape[0], x_feats.stride(0), cin, _ptr(w), K, cout,
                                     _ptr(nbr), n_out, _ptr(scale), _ptr(shift), _ptr(residual),
                                     residual.stride(0) if residual is not None else 0, 1 if relu else 0,
-                                    _ptr(out), out.stride(0), flavour, _stream(dev)), "cv_sp_conv_f32")
+                                    _ptr(out), out.stride(0), flavour, _ptr(ws), ws.numel() if ws is not None else 0,
+                                    _stream(dev)), "cv_sp_conv_f32")
     return out
 
 

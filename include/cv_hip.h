@@ -152,11 +152,14 @@ int cv_sp_up_map(const int32_t* d_nbr_down, long long n_coarse, long long n_fine
 /* out[u][:] = relu?( (sum_j W_j^T in[nbr[u][j]]) * scale + shift + residual[u][:] )
  * = MinkowskiConvolution / ConvolutionTranspose with the eval-mode MinkowskiBatchNorm, bias,
  * BasicBlock residual and MinkowskiReLU folded into the epilogue (any of scale/shift/residual
- * may be NULL).  d_nbr may be NULL for K == 1.  flavour: 0 auto, 1 rows, 2 split-K. */
+ * may be NULL).  d_nbr may be NULL for K == 1.  d_ws (optional, cv_sp_conv_workspace_bytes) lets small
+ * coordinate sets split the kernel offsets over more workgroups.  flavour: 0 auto, 1 no splitting,
+ * 2 in-workgroup split-K. */
+size_t cv_sp_conv_workspace_bytes(long long n_out, int cout, int K);
 int cv_sp_conv_f32(const float* d_in, long long n_in, int in_ld, int cin, const float* d_weight, int K,
                    int cout, const int32_t* d_nbr, long long n_out, const float* d_scale,
                    const float* d_shift, const float* d_residual, int res_ld, int relu, float* d_out,
-                   int out_ld, int flavour, void* stream);
+                   int out_ld, int flavour, void* d_ws, size_t ws_bytes, void* stream);
 
 /* y = relu?(x * scale + shift): MinkowskiBatchNorm (eval) / MinkowskiReLU on feature rows. */
 int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale,
