@@ -28,6 +28,17 @@ class DecodeParams(ctypes.Structure):
                 ("max_iters", ctypes.c_int), ("err_thresh", ctypes.c_double)]
 
 
+class ConvDesc(ctypes.Structure):
+    """struct cv_conv_desc (include/cv_hip.h)"""
+    _fields_ = [("in_", vp), ("n_in", ctypes.c_longlong), ("in_ld", ctypes.c_int), ("cin", ctypes.c_int),
+                ("weight", vp), ("K", ctypes.c_int), ("cout", ctypes.c_int), ("nbr", vp),
+                ("n_out", ctypes.c_longlong), ("scale", vp), ("shift", vp), ("residual", vp),
+                ("res_ld", ctypes.c_int), ("relu", ctypes.c_int), ("out", vp), ("out_ld", ctypes.c_int),
+                ("flavour", ctypes.c_int), ("ws", vp), ("ws_bytes", ctypes.c_size_t), ("row_perm", vp),
+                ("j_begin", ctypes.c_int), ("j_end", ctypes.c_int), ("acc_in", vp), ("acc_ld", ctypes.c_int),
+                ("perm_groups", ctypes.c_int)]
+
+
 # symbol -> (restype, argtypes); tests check every symbol of include/cv_hip.h is here and exported
 SIGNATURES = {
     "cv_abi_version": (ctypes.c_int, []),
@@ -53,13 +64,13 @@ SIGNATURES = {
     "cv_sp_build_levels": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
                                           ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int, vp,
                                           c_i32_p, vp, ctypes.c_size_t, vp]),
+    "cv_sp_morton_keys": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp]),
     "cv_sp_kernel_map": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp, ctypes.c_longlong, ctypes.c_int,
                                         ctypes.c_int, vp, vp]),
     "cv_sp_up_map": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_longlong, vp, vp]),
     "cv_sp_conv_workspace_bytes": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int]),
-    "cv_sp_conv_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int,
-                                      ctypes.c_int, vp, ctypes.c_longlong, vp, vp, vp, ctypes.c_int,
-                                      ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_size_t, vp]),
+    "cv_sp_conv_f32": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp]),
+    "cv_sp_mask_keys": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_affine_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp,
                                         ctypes.c_int, vp, ctypes.c_int, vp]),
     "cv_sp_bn_fold_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_int, vp, vp, vp]),

@@ -18,8 +18,13 @@
 // LDS (next chunk's global loads are issued into registers before the MFMAs of the current
 // one), each wave runs 16 k-steps x NB MFMAs on its 32 rows.  The epilogue applies the folded
 // BatchNorm/bias affine, the residual and ReLU and stores once.
-// Flavour "splitk" (coarse levels: hundreds of rows x 256 channels): one workgroup owns 32 rows
-// x (NB*32) channels and its 4 waves split the kernel offsets, reducing through LDS.
+// Small coordinate sets (coarse levels: hundreds of rows x 256 channels) split the kernel offsets over
+// blockIdx.z into a workspace that conv_finish reduces (+ epilogue).
+// Fine-grained sparsity: only ~23-50 % of (row, offset) pairs exist, but a 32-row MFMA block is live as
+// soon as ONE of its rows has the neighbour.  The caller may therefore pass a processing order
+// (row_perm) that groups rows with equal neighbour bit masks and run the offsets in two halves, each
+// with the order sorted by that half's mask: 32-row blocks then need 29-55 % of the offsets instead of
+// 90 %, and dead waves / tiles skip their MFMAs / staging.
 #include "cv_common.h"
 
 namespace {
@@ -27,7 +32,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KC = 32;            // K chunk (channels per staging step)
-constexpr int TM = 128;           // rows per workgroup, "rows" flavour
+constexpr int TM = 128;           // rows per workgroup
 constexpr int A_LD = TM + 4;      // A staged k-major: A_s[k][row]
 constexpr int THREADS = 256;
 
@@ -39,19 +44,24 @@ struct ConvArgs {
     const float* res; int res_ld;
     int relu;
     float* out; int out_ld;
-    int splits;          // >1: blockIdx.z handles a contiguous range of kernel offsets and writes raw
-    float* partial;      //     partial sums to partial[split][n_out][cout] (finished by conv_finish)
+    int splits;            // >1: blockIdx.z handles a contiguous sub-range of the offsets and writes raw
+    float* partial;        //     partial sums to partial[split][n_out][cout] (finished by conv_finish)
+    const int* row_perm;   // optional processing order: tile row t works on output row row_perm[t]
+    int perm_per_split;    // 1: row_perm is [splits][n_out], one order per offset group (blockIdx.z)
+    int j_begin, j_end;    // kernel offsets handled by this launch
+    const float* acc_in;   // optional [n_out][acc_ld] added to the accumulator before the epilogue
+    int acc_ld;
 };
 
-__device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& acc, long long row0,
+__device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& acc, const int* rows,
                                                int col, int lane) {
     if (col >= a.cout) return;
     if (a.splits > 1) {
         float* p = a.partial + (long long)blockIdx.z * a.n_out * a.cout;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < a.n_out) p[row * a.cout + col] = acc[r];
+            const int row = rows[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+            if (row >= 0) p[(long long)row * a.cout + col] = acc[r];
         }
         return;
     }
@@ -59,25 +69,33 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& 
     const float sh = a.shift ? a.shift[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const long long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= a.n_out) continue;
-        float v = acc[r] * sc + sh;
-        if (a.res) v += a.res[row * a.res_ld + col];
+        const int row = rows[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+        if (row < 0) continue;
+        float v = acc[r];
+        if (a.acc_in) v += a.acc_in[(long long)row * a.acc_ld + col];
+        v = v * sc + sh;
+        if (a.res) v += a.res[(long long)row * a.res_ld + col];
         if (a.relu) v = fmaxf(v, 0.f);
-        a.out[row * a.out_ld + col] = v;
+        a.out[(long long)row * a.out_ld + col] = v;
     }
 }
 
-// ------------------------------------------------------------------ rows flavour
 // VEC: Cin % 32 == 0 (float4 gathers inside one offset).  !VEC: flattened K = K*Cin (stem, Cin=3).
 template <int NB, bool VEC>
 __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
     __shared__ float A_s[KC][A_LD];
     __shared__ float B_s[KC][NB * 32];
     __shared__ int nbr_s[TM];
+    __shared__ int rows_s[TM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long row_base = (long long)blockIdx.x * TM;
     const int n0 = blockIdx.y * (NB * 32);
+
+    if (tid < TM) {
+        const long long t = (long long)blockIdx.x * TM + tid;
+        const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)blockIdx.z * a.n_out : 0) : nullptr;
+        rows_s[tid] = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
+    }
+    __syncthreads();
 
     f32x16 acc[NB];
 #pragma unroll
@@ -97,24 +115,26 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
         }
     };
 
+    const int nj = a.j_end - a.j_begin;
     if (VEC) {
         // thread -> (row = tid/8 + 32*i, 4 channels at (tid%8)*4) : 8 lanes cover one 128 B row chunk
         const int a_col = (tid & 7) * 4;
         const int a_row = tid >> 3;                      // + 32*i, i = 0..3
         constexpr int B_F4 = KC * NB * 32 / 4;           // float4s in the weight slab
         constexpr int B_PER = (B_F4 + THREADS - 1) / THREADS;
-        const int j_lo = (int)((long long)a.K * blockIdx.z / a.splits);
-        const int j_hi = (int)((long long)a.K * (blockIdx.z + 1) / a.splits);
+        const int j_lo = a.j_begin + (int)((long long)nj * blockIdx.z / a.splits);
+        const int j_hi = a.j_begin + (int)((long long)nj * (blockIdx.z + 1) / a.splits);
         for (int j = j_lo; j < j_hi; ++j) {
             int my = -1;
             if (tid < TM) {
-                const long long row = row_base + tid;
-                if (row < a.n_out) my = a.nbr ? a.nbr[row * a.K + j] : (int)row;
+                const int row = rows_s[tid];
+                if (row >= 0) my = a.nbr ? a.nbr[(long long)row * a.K + j] : row;
                 nbr_s[tid] = my;
             }
             if (!__syncthreads_or(my >= 0)) continue;    // nobody in the tile has this neighbour
-            // a wave whose 32 rows all miss this neighbour skips its MFMAs (pays off when rows are
-            // spatially coherent); it still takes part in the staging and the barriers
+            // a wave whose 32 rows all miss this neighbour skips its MFMAs; it still takes part in
+            // the staging and the barriers.  Rows are processed in an order that groups equal
+            // neighbour masks (row_perm), which is what makes whole waves / tiles skippable.
             const bool wave_live = __any(nbr_s[wave * 32 + (lane & 31)] >= 0);
             float4 ra[4], rb[B_PER];
             auto load = [&](int kc) {
@@ -168,20 +188,20 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
             __syncthreads();
         }
     } else {
-        const int ktot = a.K * a.cin;
-        const int nchunks = (ktot + KC - 1) / KC;
+        const int k0 = a.j_begin * a.cin, ktot = a.j_end * a.cin;
+        const int nchunks = (ktot - k0 + KC - 1) / KC;
         const int c_lo = (int)((long long)nchunks * blockIdx.z / a.splits);
         const int c_hi = (int)((long long)nchunks * (blockIdx.z + 1) / a.splits);
-        for (int kc = c_lo * KC; kc < c_hi * KC; kc += KC) {
+        for (int kc = k0 + c_lo * KC; kc < k0 + c_hi * KC; kc += KC) {
             __syncthreads();
             for (int e = tid; e < KC * TM; e += THREADS) {
                 const int kk = e / TM, r = e % TM;
                 const int kf = kc + kk;
                 float v = 0.f;
-                const long long row = row_base + r;
-                if (kf < ktot && row < a.n_out) {
+                const int row = rows_s[r];
+                if (kf < ktot && row >= 0) {
                     const int j = kf / a.cin, c = kf - j * a.cin;
-                    const int src = a.nbr ? a.nbr[row * a.K + j] : (int)row;
+                    const int src = a.nbr ? a.nbr[(long long)row * a.K + j] : row;
                     if (src >= 0) v = a.in[(long long)src * a.in_ld + c];
                 }
                 A_s[kk][r] = v;
@@ -197,92 +217,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
-        epilogue_store(a, acc[nb], row_base + wave * 32, n0 + nb * 32 + (lane & 31), lane);
-}
-
-// ------------------------------------------------------------------ split-K flavour
-// 32 rows x NB*32 channels per workgroup; wave w handles kernel offsets j = w, w+4, ...
-template <int NB>
-__global__ __launch_bounds__(THREADS) void conv_splitk(ConvArgs a) {
-    __shared__ float A_s[4][KC][36];
-    __shared__ float B_s[4][KC][NB * 32];
-    __shared__ float red[3][NB][16][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long row_base = (long long)blockIdx.x * 32;
-    const int n0 = blockIdx.y * (NB * 32);
-    f32x16 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-
-    const int a_col = (lane & 7) * 4, a_row = lane >> 3;        // + 8*i, i = 0..3
-    for (int j = wave; j < a.K; j += 4) {
-        int src[4];
-        bool any = false;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long long row = row_base + a_row + 8 * i;
-            src[i] = -1;
-            if (row < a.n_out) src[i] = a.nbr ? a.nbr[row * a.K + j] : (int)row;
-            any |= src[i] >= 0;
-        }
-        if (!__any(any)) continue;
-        for (int kc = 0; kc < a.cin; kc += KC) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float4 v = src[i] >= 0
-                    ? *reinterpret_cast<const float4*>(a.in + (long long)src[i] * a.in_ld + kc + a_col)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
-                const int r = a_row + 8 * i;
-                A_s[wave][a_col + 0][r] = v.x; A_s[wave][a_col + 1][r] = v.y;
-                A_s[wave][a_col + 2][r] = v.z; A_s[wave][a_col + 3][r] = v.w;
-            }
-            for (int f = lane; f < KC * NB * 8; f += 64) {
-                const int kr = f / (NB * 8), c4 = (f % (NB * 8)) * 4;
-                const int col = n0 + c4;
-                const float* wp = a.w + ((long long)j * a.cin + kc + kr) * a.cout + col;
-                float4 v;
-                if (col + 3 < a.cout) v = *reinterpret_cast<const float4*>(wp);
-                else {
-                    v.x = col < a.cout ? wp[0] : 0.f; v.y = col + 1 < a.cout ? wp[1] : 0.f;
-                    v.z = col + 2 < a.cout ? wp[2] : 0.f; v.w = 0.f;
-                }
-                *reinterpret_cast<float4*>(&B_s[wave][kr][c4]) = v;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int kk = 0; kk < KC; kk += 2) {
-                const float av = A_s[wave][kk + (lane >> 5)][lane & 31];
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const float bv = B_s[wave][kk + (lane >> 5)][nb * 32 + (lane & 31)];
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    }
-    if (wave > 0) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[wave - 1][nb][r][lane] = acc[nb][r];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[nb][r] = ((acc[nb][r] + red[0][nb][r][lane]) + red[1][nb][r][lane]) + red[2][nb][r][lane];
-            epilogue_store(a, acc[nb], row_base, n0 + nb * 32 + (lane & 31), lane);
-        }
-    }
+        epilogue_store(a, acc[nb], rows_s + wave * 32, n0 + nb * 32 + (lane & 31), lane);
 }
 
 // sums the per-split partial tiles and applies the epilogue (scale/shift/residual/relu)
@@ -293,11 +228,23 @@ __global__ __launch_bounds__(256) void conv_finish(ConvArgs a) {
         const int col = (int)(t - row * a.cout);
         float v = 0.f;
         for (int sidx = 0; sidx < a.splits; ++sidx) v += a.partial[sidx * total + t];
+        if (a.acc_in) v += a.acc_in[row * a.acc_ld + col];
         v = v * (a.scale ? a.scale[col] : 1.f) + (a.shift ? a.shift[col] : 0.f);
         if (a.res) v += a.res[row * a.res_ld + col];
         if (a.relu) v = fmaxf(v, 0.f);
         a.out[row * a.out_ld + col] = v;
     }
+}
+
+// sort key of a row = bit mask of its valid neighbours among offsets [j_begin, j_end)
+__global__ __launch_bounds__(256) void mask_keys(const int* __restrict__ nbr, long long n, int K, int j_begin,
+                                                 int j_end, long long* __restrict__ keys) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long m = 0;
+    for (int j = j_begin; j < j_end; ++j)
+        if (nbr[i * K + j] >= 0) m |= 1ull << (j - j_begin);
+    keys[i] = (long long)m;
 }
 
 // ------------------------------------------------------------------ elementwise helpers
@@ -385,14 +332,6 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
     return (int)std::max<long long>(s, 1);
 }
 
-template <int NB>
-int launch_splitk(const ConvArgs& a, hipStream_t st) {
-    dim3 grid((unsigned)((a.n_out + 31) / 32), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)));
-    conv_splitk<NB><<<grid, THREADS, 0, st>>>(a);
-    CV_LAUNCH_CHECK();
-    return CV_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -402,41 +341,58 @@ size_t cv_sp_conv_workspace_bytes(long long n_out, int cout, int K) {
     return 256 + sizeof(float) * (size_t)27 * (size_t)n_out * (size_t)cout;   // upper bound over split counts
 }
 
-// flavour: 0 auto (rows, split over kernel offsets through the workspace when the grid would not fill
-// the chip), 1 rows without splitting, 2 in-workgroup split-K (32-row tiles)
-int cv_sp_conv_f32(const float* d_in, long long n_in, int in_ld, int cin, const float* d_weight, int K,
-                   int cout, const int32_t* d_nbr, long long n_out, const float* d_scale,
-                   const float* d_shift, const float* d_residual, int res_ld, int relu, float* d_out,
-                   int out_ld, int flavour, void* d_ws, size_t ws_bytes, void* stream) {
-    CV_REQUIRE(d_in && d_weight && d_out, CV_EINVAL, "null pointer argument");
-    CV_REQUIRE(n_in > 0 && n_out > 0 && cin > 0 && cout > 0 && K > 0, CV_EINVAL, "bad conv sizes");
-    CV_REQUIRE(d_nbr || (K == 1 && n_in == n_out), CV_EINVAL, "a kernel map is required unless K == 1");
-    CV_REQUIRE(in_ld >= cin && out_ld >= cout && (!d_residual || res_ld >= cout), CV_EINVAL, "bad leading dimension");
-    CV_REQUIRE(d_out != d_in, CV_EINVAL, "conv cannot run in place");
+int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
+    CV_REQUIRE(d, CV_EINVAL, "null descriptor");
+    CV_REQUIRE(d->in && d->weight && d->out, CV_EINVAL, "null pointer argument");
+    CV_REQUIRE(d->n_in > 0 && d->n_out > 0 && d->cin > 0 && d->cout > 0 && d->K > 0, CV_EINVAL, "bad conv sizes");
+    CV_REQUIRE(d->nbr || (d->K == 1 && d->n_in == d->n_out), CV_EINVAL, "a kernel map is required unless K == 1");
+    CV_REQUIRE(d->in_ld >= d->cin && d->out_ld >= d->cout && (!d->residual || d->res_ld >= d->cout) &&
+                   (!d->acc_in || d->acc_ld >= d->cout), CV_EINVAL, "bad leading dimension");
+    CV_REQUIRE(d->out != d->in, CV_EINVAL, "conv cannot run in place");
+    const int jb = d->j_begin, je = d->j_end > 0 ? d->j_end : d->K;
+    CV_REQUIRE(jb >= 0 && jb < je && je <= d->K, CV_EINVAL, "bad kernel offset range");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    ConvArgs a{d_in, n_in, in_ld, cin, d_weight, K, cout, d_nbr, n_out, d_scale, d_shift, d_residual,
-               res_ld, relu, d_out, out_ld, 1, nullptr};
-    const bool vec = (cin % KC == 0) && (in_ld % 4 == 0) && (cout % 4 == 0) &&
-                     ((reinterpret_cast<uintptr_t>(d_in) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(d_weight) & 15) == 0);
-    if (flavour == 2 && vec) {
-        if (cout <= 32) return launch_splitk<1>(a, st);
-        return launch_splitk<2>(a, st);
-    }
-    if (flavour == 0) {
-        const int sp = pick_splits(n_out, cout, K, cin, vec);
-        const size_t need = sizeof(float) * (size_t)sp * (size_t)n_out * (size_t)cout;
-        if (sp > 1 && d_ws && ws_bytes >= need) {
+    ConvArgs a{d->in, d->n_in, d->in_ld, d->cin, d->weight, d->K, d->cout, d->nbr, d->n_out, d->scale,
+               d->shift, d->residual, d->res_ld, d->relu, d->out, d->out_ld, 1, nullptr, d->row_perm, 0, jb, je,
+               d->acc_in, d->acc_ld};
+    const bool vec = (d->cin % KC == 0) && (d->in_ld % 4 == 0) && (d->cout % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(d->in) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(d->weight) & 15) == 0);
+    if (d->perm_groups > 1) {
+        // offsets split into perm_groups contiguous groups, each processed in its own row order, all in
+        // one launch (grid.z); partial tiles are reduced by conv_finish
+        const size_t need = sizeof(float) * (size_t)d->perm_groups * (size_t)d->n_out * (size_t)d->cout;
+        CV_REQUIRE(d->row_perm && vec && d->ws && d->ws_bytes >= need, CV_EINVAL,
+                   "perm_groups needs row_perm[groups][n_out], Cin %% 32 == 0 and a workspace of %zu bytes", need);
+        a.splits = d->perm_groups;
+        a.perm_per_split = 1;
+        a.partial = static_cast<float*>(d->ws);
+    } else if (d->flavour == 0) {
+        const int sp = pick_splits(d->n_out, d->cout, je - jb, d->cin, vec);
+        const size_t need = sizeof(float) * (size_t)sp * (size_t)d->n_out * (size_t)d->cout;
+        if (sp > 1 && d->ws && d->ws_bytes >= need) {
             a.splits = sp;
-            a.partial = static_cast<float*>(d_ws);
+            a.partial = static_cast<float*>(d->ws);
         }
     }
-    switch (nb_for(cout)) {
+    switch (nb_for(d->cout)) {
         case 1: return launch_rows<1>(a, vec, st);
         case 2: return launch_rows<2>(a, vec, st);
         case 3: return launch_rows<3>(a, vec, st);
         default: return launch_rows<4>(a, vec, st);
     }
+}
+
+// d_keys[n] = bit mask of valid neighbours among kernel offsets [j_begin, j_end) of each output row.
+// Sorting rows by this key groups rows that need the same offsets (cv_conv_desc.row_perm).
+int cv_sp_mask_keys(const int32_t* d_nbr, long long n, int K, int j_begin, int j_end, long long* d_keys,
+                    void* stream) {
+    CV_REQUIRE(d_nbr && d_keys && n > 0 && K > 0 && j_begin >= 0 && j_begin < j_end && j_end <= K &&
+                   j_end - j_begin <= 63, CV_EINVAL, "bad mask key arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mask_keys<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_nbr, n, K, j_begin, j_end, d_keys);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
 }
 
 int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale,

@@ -200,6 +200,27 @@ __global__ __launch_bounds__(256) void build_up_map(const int* __restrict__ nbr_
 
 __global__ void set_int(int* p, int v) { *p = v; }
 
+__device__ __forceinline__ unsigned long long spread3(unsigned long long v) {   // 16 bits -> every 3rd bit
+    v &= 0xffffull;
+    v = (v | (v << 32)) & 0x00ff00000000ffffull;     // not needed for 16 bits, kept general to 21
+    v = (v | (v << 16)) & 0x00ff0000ff0000ffull;
+    v = (v | (v << 8)) & 0xf00f00f00f00f00full;
+    v = (v | (v << 4)) & 0x30c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x9249249249249249ull;
+    return v;
+}
+
+// Z-order key (batch in the top bits) so that consecutive rows are spatially compact
+__global__ __launch_bounds__(256) void morton_keys(const int* __restrict__ coords, long long n,
+                                                   long long* __restrict__ keys) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    const unsigned long long m = spread3((unsigned)(c.y + 32768)) | (spread3((unsigned)(c.z + 32768)) << 1) |
+                                 (spread3((unsigned)(c.w + 32768)) << 2);
+    keys[i] = (long long)(((unsigned long long)(c.x & 0x7fff) << 48) | m);
+}
+
 int grid_for(long long n) { return (int)std::min<long long>((n + 255) / 256, 4096); }
 
 }  // namespace
@@ -225,7 +246,7 @@ size_t cv_sp_levels_workspace_bytes(long long n) {
 int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_keys,
                        int32_t* const* d_vals, long long n, long long cap, int num_levels,
                        int32_t* d_counts, int32_t* h_counts, void* d_ws, size_t ws_bytes, void* stream) {
-    CV_REQUIRE(d_coords && d_keys && d_vals && d_counts && h_counts && d_ws, CV_EINVAL, "null pointer argument");
+    CV_REQUIRE(d_coords && d_keys && d_vals && d_counts && d_ws, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(n > 0 && n < (1ll << 30), CV_EINVAL, "bad row count %lld", n);
     CV_REQUIRE(num_levels >= 1 && num_levels <= 5, CV_EINVAL, "num_levels must be 1..5");
     CV_REQUIRE(cap >= 2 * n && (cap & (cap - 1)) == 0, CV_EINVAL, "table capacity must be a power of two >= 2n");
@@ -260,8 +281,20 @@ int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_ke
                                        slot_of_row, d_vals[L], d_coords[L]);
         CV_LAUNCH_CHECK();
     }
-    CV_HIP_CHECK(hipMemcpyAsync(h_counts, d_counts, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
-    CV_HIP_CHECK(hipStreamSynchronize(st));
+    if (h_counts) {
+        CV_HIP_CHECK(hipMemcpyAsync(h_counts, d_counts, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+        CV_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    return CV_OK;
+}
+
+// Z-order sort keys of a coordinate set (the fused network runs on spatially sorted rows so that
+// 32-row wave tiles are compact and whole kernel offsets can be skipped).  Asynchronous.
+int cv_sp_morton_keys(const int32_t* d_coords, long long n, long long* d_keys, void* stream) {
+    CV_REQUIRE(d_coords && d_keys && n > 0, CV_EINVAL, "bad morton arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    morton_keys<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_coords, n, d_keys);
+    CV_LAUNCH_CHECK();
     return CV_OK;
 }
 

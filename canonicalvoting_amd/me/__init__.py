@@ -41,41 +41,120 @@ class CoordinateManager:
 
     NUM_LEVELS = 5
 
-    def __init__(self, coords, num_levels=NUM_LEVELS):
+    def __init__(self, coords, num_levels=NUM_LEVELS, check=True):
+        """check=False with num_levels=1 builds the level-0 hash without any host sync (the
+        duplicate count stays on the device); used for the boundary maps of the fused network."""
         assert coords.is_cuda and coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
-        L = _lib.lib()
         self.device = coords.device
-        n = coords.shape[0]
-        if n == 0:
+        if coords.shape[0] == 0:
             raise RuntimeError("SparseTensor: empty coordinate set")
-        self.cap = int(L.cv_sp_table_capacity(n))
-        self.num_levels = num_levels
+        self.cap = int(_lib.lib().cv_sp_table_capacity(coords.shape[0]))
+        self._input = coords.contiguous()
+        self._fused = None
+        self._build(num_levels, check)
+
+    def _build(self, num_levels, check):
+        L = _lib.lib()
         dev = self.device
-        self._coords_buf = [coords.contiguous()] + [torch.empty((n, 4), dtype=torch.int32, device=dev)
-                                                    for _ in range(num_levels - 1)]
+        n = self._input.shape[0]
+        self.num_levels = num_levels
+        self._coords_buf = [self._input] + [torch.empty((n, 4), dtype=torch.int32, device=dev)
+                                            for _ in range(num_levels - 1)]
         self._keys = [torch.empty(self.cap, dtype=torch.int64, device=dev) for _ in range(num_levels)]
         self._vals = [torch.empty(self.cap, dtype=torch.int32, device=dev) for _ in range(num_levels)]
-        counts_d = torch.empty(8, dtype=torch.int32, device=dev)
+        self._counts_d = torch.empty(8, dtype=torch.int32, device=dev)
         counts_h = (ctypes.c_int32 * 8)()
         ws = torch.empty(int(L.cv_sp_levels_workspace_bytes(n)), dtype=torch.uint8, device=dev)
         arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        sync = check or num_levels > 1
         with torch.cuda.device(dev):
             _lib.check(L.cv_sp_build_levels(arr(self._coords_buf), arr(self._keys), arr(self._vals), n,
-                                            self.cap, num_levels, _ptr(counts_d), counts_h, _ptr(ws),
-                                            ws.numel(), _stream(dev)), "cv_sp_build_levels")
-        if counts_h[5] != 0:
-            raise RuntimeError("SparseTensor: %d duplicate coordinates (quantise with "
-                               "utils.sparse_quantize first, as utils/dataloader.py:197 does)" % counts_h[5])
-        self.counts = [int(counts_h[i]) for i in range(num_levels)]
+                                            self.cap, num_levels, _ptr(self._counts_d),
+                                            counts_h if sync else None, _ptr(ws), ws.numel(), _stream(dev)),
+                       "cv_sp_build_levels")
+        self._verified = sync
+        if sync:
+            self._raise_on_dups(counts_h[5])
+            self.counts = [int(counts_h[i]) for i in range(num_levels)]
+        else:
+            self.counts = [n]
         self.coords = {1 << i: self._coords_buf[i][:self.counts[i]] for i in range(num_levels)}
         self._level = {1 << i: i for i in range(num_levels)}
         self._maps = {}
 
+    @staticmethod
+    def _raise_on_dups(count):
+        if count != 0:
+            raise RuntimeError("SparseTensor: %d duplicate coordinates (quantise with "
+                               "utils.sparse_quantize first, as utils/dataloader.py:197 does)" % count)
+
+    def _verify(self):
+        """deferred duplicate check of a set built without a host sync (first map request pays it)"""
+        if not self._verified:
+            self._raise_on_dups(int(self._counts_d[5].item()))
+            self._verified = True
+
+    def ensure_levels(self, num_levels=NUM_LEVELS):
+        if self.num_levels < num_levels:
+            self._build(num_levels, True)
+
+    def cross_map(self, out_coords, k, ts=1):
+        """kernel map of an arbitrary output set looked up in THIS manager's level-0 table"""
+        L = _lib.lib()
+        m = torch.empty((out_coords.shape[0], k ** 3), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.cv_sp_kernel_map(_ptr(out_coords), out_coords.shape[0], _ptr(self._keys[0]),
+                                          _ptr(self._vals[0]), self.cap, k, ts, _ptr(m), _stream(self.device)),
+                       "cv_sp_kernel_map")
+        return m
+
+    def mask_perms(self, k, ts, groups=2):
+        """int32 [groups, n]: for each contiguous group of the k^3 offsets, the row order sorted by the
+        bit mask of valid neighbours within that group (stride-1 map at tensor stride ts, cached)."""
+        key = ("mp", k, ts, groups)
+        m = self._maps.get(key)
+        if m is None:
+            L = _lib.lib()
+            nbr = self.kernel_map(k, ts)
+            n, K = nbr.shape
+            keys = torch.empty(n, dtype=torch.int64, device=self.device)
+            m = torch.empty((groups, n), dtype=torch.int32, device=self.device)
+            for g in range(groups):
+                jb, je = K * g // groups, K * (g + 1) // groups      # same split as the kernel
+                with torch.cuda.device(self.device):
+                    _lib.check(L.cv_sp_mask_keys(_ptr(nbr), n, K, jb, je, _ptr(keys), _stream(self.device)),
+                               "cv_sp_mask_keys")
+                m[g] = torch.argsort(keys).to(torch.int32)
+            self._maps[key] = m
+        return m
+
+    def fused_plan(self):
+        """Spatially sorted twin of this coordinate set for the fused network:
+        (sorted manager with all levels, stem map sorted<-original rows, final map original<-sorted)."""
+        if self._fused is None:
+            L = _lib.lib()
+            n = self._input.shape[0]
+            keys = torch.empty(n, dtype=torch.int64, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(L.cv_sp_morton_keys(_ptr(self._input), n, _ptr(keys), _stream(self.device)),
+                           "cv_sp_morton_keys")
+            perm = torch.argsort(keys)                      # device radix sort (plumbing, 80k keys)
+            cm_s = CoordinateManager(self._input[perm].contiguous(), CoordinateManager.NUM_LEVELS, True)
+            stem_map = self.cross_map(cm_s.coords[1], 5)    # rows of the ORIGINAL order
+            out_map = cm_s.cross_map(self._input, 1)        # original row i <- sorted row
+            self._fused = (cm_s, stem_map, out_map)
+        return self._fused
+
     def num_rows(self, ts):
+        if ts not in self._level:
+            self.ensure_levels()
         return self.counts[self._level[ts]]
 
     def kernel_map(self, k, ts_in, stride=1):
         """int32 [n_out, k^3]: rows of the ts_in set feeding each row of the ts_in*stride set."""
+        if ts_in * stride not in self._level:
+            self.ensure_levels()
+        self._verify()
         key = ("k", k, ts_in, stride)
         m = self._maps.get(key)
         if m is None:
@@ -125,7 +204,8 @@ class SparseTensor:
             c = coordinates
             if c.is_floating_point():
                 c = torch.floor(c)
-            coordinate_manager = CoordinateManager(c.to(device=device, dtype=torch.int32).contiguous())
+            coordinate_manager = CoordinateManager(c.to(device=device, dtype=torch.int32).contiguous(),
+                                                   num_levels=1, check=False)
         self.coordinate_manager = coordinate_manager
         self.tensor_stride = tensor_stride if isinstance(tensor_stride, int) else int(tensor_stride[0])
         if self.F.shape[0] != coordinate_manager.num_rows(self.tensor_stride):
@@ -134,7 +214,10 @@ class SparseTensor:
 
     @property
     def C(self):
-        return self.coordinate_manager.coords[self.tensor_stride]
+        cm = self.coordinate_manager
+        if self.tensor_stride not in cm.coords:
+            cm.ensure_levels()
+        return cm.coords[self.tensor_stride]
 
     @property
     def coordinates(self):
@@ -186,7 +269,7 @@ def _workspace(dev, nbytes):
 
 
 def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=None, relu=False,
-                 out=None, flavour=0):
+                 out=None, flavour=0, row_perm=None, j_begin=0, j_end=0, acc_in=None, perm_groups=0):
     """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout]."""
     L = _lib.lib()
     dev = x_feats.device
@@ -197,15 +280,26 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
     if out is None:
         out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
     ws = None
-    if flavour == 0 and n_out < 128 * 384:
-        ws = _workspace(dev, min(int(L.cv_sp_conv_workspace_bytes(n_out, cout, K)), 27 * 4 * 128 * 384 * 256 + 256))
+    if perm_groups > 1:
+        ws = _workspace(dev, 4 * perm_groups * n_out * cout + 256)
+    elif flavour == 0 and n_out < 128 * 384:
+        ws = _workspace(dev, int(L.cv_sp_conv_workspace_bytes(n_out, cout, K)))
+    p = lambda t: t.data_ptr() if t is not None else None
+    d = _lib.ConvDesc(p(x_feats), x_feats.shape[0], x_feats.stride(0), cin, p(w), K, cout, p(nbr), n_out,
+                      p(scale), p(shift), p(residual), residual.stride(0) if residual is not None else 0,
+                      1 if relu else 0, p(out), out.stride(0), flavour, p(ws),
+                      ws.numel() if ws is not None else 0, p(row_perm), j_begin, j_end, p(acc_in),
+                      acc_in.stride(0) if acc_in is not None else 0, perm_groups)
     with torch.cuda.device(dev):
-        _lib.check(L.cv_sp_conv_f32(_ptr(x_feats), x_feats.shape[0], x_feats.stride(0), cin, _ptr(w), K, cout,
-                                    _ptr(nbr), n_out, _ptr(scale), _ptr(shift), _ptr(residual),
-                                    residual.stride(0) if residual is not None else 0, 1 if relu else 0,
-                                    _ptr(out), out.stride(0), flavour, _ptr(ws), ws.numel() if ws is not None else 0,
-                                    _stream(dev)), "cv_sp_conv_f32")
+        _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
     return out
+
+
+def conv_forward_masked(x_feats, weight, nbr, perms, n_out, **epilogue):
+    """k^3 conv with the kernel offsets split into G groups, each group processed with the rows in the
+    order sorted by that group's neighbour mask (see sparse_conv.hip); one launch + one reduce.
+    perms: int32 [G, n_out] from CoordinateManager.mask_perms."""
+    return conv_forward(x_feats, weight, nbr, n_out, row_perm=perms, perm_groups=perms.shape[0], **epilogue)
 
 
 class _ConvFn(torch.autograd.Function):

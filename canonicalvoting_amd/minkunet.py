@@ -125,11 +125,19 @@ class MinkUNetBase(ResNetBase):
             cache[id(bn)] = hit
         return hit[1]
 
-    def _run_layer(self, layer, x, nbr, n, out_view):
+    MASKED_MIN_ROWS = 16384     # levels with at least this many rows run the mask-sorted grouped conv
+    MASK_GROUPS = 3
+
+    def _conv3(self, x, kernel, nbr, perms, n, **ep):
+        if perms is not None:
+            return ME.conv_forward_masked(x, kernel, nbr, perms, n, **ep)
+        return ME.conv_forward(x, kernel, nbr, n, **ep)
+
+    def _run_layer(self, layer, x, nbr, n, out_view, perms=None):
         """Sequential of BasicBlocks on features x ([n, C] view); the last block writes out_view."""
         for bi, blk in enumerate(layer):
             s1, b1 = self._fold(blk.norm1)
-            t = ME.conv_forward(x, blk.conv1.kernel, nbr, n, scale=s1, shift=b1, relu=True)
+            t = self._conv3(x, blk.conv1.kernel, nbr, perms, n, scale=s1, shift=b1, relu=True)
             if blk.downsample is not None:
                 sd, bd = self._fold(blk.downsample[1])
                 res = ME.conv_forward(x, blk.downsample[0].kernel, None, n, scale=sd, shift=bd)
@@ -137,22 +145,26 @@ class MinkUNetBase(ResNetBase):
                 res = x
             s2, b2 = self._fold(blk.norm2)
             last = bi == len(layer) - 1
-            x = ME.conv_forward(t, blk.conv2.kernel, nbr, n, scale=s2, shift=b2, residual=res, relu=True,
-                                out=out_view if (last and out_view is not None) else None)
+            x = self._conv3(t, blk.conv2.kernel, nbr, perms, n, scale=s2, shift=b2, residual=res, relu=True,
+                            out=out_view if (last and out_view is not None) else None)
         return x
 
     def fused_forward(self, x):
-        cm = x.coordinate_manager
+        # internal rows are Z-order sorted (compact 32-row wave tiles -> whole kernel offsets are
+        # skipped); the stem reads the caller's rows through stem_map and `final` writes back in the
+        # caller's row order through out_map, so the row-order invariant of the reference holds.
+        cm, stem_map, out_map = x.coordinate_manager.fused_plan()
         dev = x.F.device
         exp = self.BLOCK.expansion
         n = [cm.num_rows(1 << i) for i in range(5)]
+        perms = lambda ts, rows: cm.mask_perms(3, ts, self.MASK_GROUPS) if rows >= self.MASKED_MIN_ROWS else None
         # concat buffers of the decoder: [convtr output | encoder skip]
         up_c = [self.PLANES[4 + i] for i in range(4)]
         skip_c = (self.PLANES[2] * exp, self.PLANES[1] * exp, self.PLANES[0] * exp, self.INIT_DIM)
         cat = [torch.empty((n[3 - i], up_c[i] + skip_c[i]), dtype=torch.float32, device=dev) for i in range(4)]
         skip_view = [cat[i][:, up_c[i]:] for i in range(4)]     # i=3 <- out_p1, 2 <- block1, 1 <- block2, 0 <- block3
         s, b = self._fold(self.bn0)
-        out = ME.conv_forward(x.F.contiguous(), self.conv0p1s1.kernel, cm.kernel_map(5, 1), n[0], scale=s,
+        out = ME.conv_forward(x.F.contiguous(), self.conv0p1s1.kernel, stem_map, n[0], scale=s,
                               shift=b, relu=True, out=skip_view[3])
         for i, (cname, bname) in enumerate(_DOWN):
             ts = 1 << i
@@ -160,7 +172,7 @@ class MinkUNetBase(ResNetBase):
             out = ME.conv_forward(out, getattr(self, cname).kernel, cm.kernel_map(2, ts, 2), n[i + 1],
                                   scale=s, shift=b, relu=True)
             out = self._run_layer(getattr(self, "block%d" % (i + 1)), out, cm.kernel_map(3, 2 * ts), n[i + 1],
-                                  skip_view[2 - i] if i < 3 else None)
+                                  skip_view[2 - i] if i < 3 else None, perms(2 * ts, n[i + 1]))
         for i, (cname, bname) in enumerate(_UP):
             ts_coarse = 16 >> i
             lvl = 3 - i
@@ -168,8 +180,8 @@ class MinkUNetBase(ResNetBase):
             ME.conv_forward(out, getattr(self, cname).kernel, cm.up_map(ts_coarse), n[lvl], scale=s, shift=b,
                             relu=True, out=cat[i][:, :up_c[i]])
             out = self._run_layer(getattr(self, "block%d" % (5 + i)), cat[i], cm.kernel_map(3, ts_coarse // 2),
-                                  n[lvl], None)
-        y = ME.conv_forward(out, self.final.kernel, None, n[0], shift=self.final.bias.reshape(-1))
+                                  n[lvl], None, perms(ts_coarse // 2, n[lvl]))
+        y = ME.conv_forward(out, self.final.kernel, out_map, n[0], shift=self.final.bias.reshape(-1))
         return x._like(y, 1)
 
 

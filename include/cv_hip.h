@@ -134,10 +134,14 @@ size_t cv_sp_levels_workspace_bytes(long long n);
  * unique(floor(c / 2ts) * 2ts), ordered by first appearance) and one hash table per level.
  * d_coords[0] is the caller's input (n rows); d_coords[1..], d_keys[L], d_vals[L] are caller
  * allocated (n rows / `cap` slots each).  h_counts[0..4] = rows per level, h_counts[5] = number
- * of duplicate input coordinates (must be 0).  Synchronises `stream` once. */
+ * of duplicate input coordinates (must be 0).  Synchronises `stream` once, or not at all when
+ * h_counts is NULL (the counts then stay in d_counts only). */
 int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_keys,
                        int32_t* const* d_vals, long long n, long long cap, int num_levels,
                        int32_t* d_counts, int32_t* h_counts, void* d_ws, size_t ws_bytes, void* stream);
+
+/* Z-order (Morton) sort keys, batch index in the top bits: d_keys[n] int64.  Asynchronous. */
+int cv_sp_morton_keys(const int32_t* d_coords, long long n, long long* d_keys, void* stream);
 
 /* Kernel map of a k^3 kernel (ME "kernel map" / neighbour table): d_nbr[n_out][k^3] = input row of
  * out_coord + offset*ts or -1.  Odd k centred, even k offsets 0..k-1.  Asynchronous. */
@@ -149,17 +153,43 @@ int cv_sp_kernel_map(const int32_t* d_out_coords, long long n_out, const unsigne
 int cv_sp_up_map(const int32_t* d_nbr_down, long long n_coarse, long long n_fine, int32_t* d_up,
                  void* stream);
 
-/* out[u][:] = relu?( (sum_j W_j^T in[nbr[u][j]]) * scale + shift + residual[u][:] )
+/* out[u][:] = relu?( (acc_in[u][:] + sum_{j in [j_begin,j_end)} W_j^T in[nbr[u][j]]) * scale + shift
+ *                    + residual[u][:] )
  * = MinkowskiConvolution / ConvolutionTranspose with the eval-mode MinkowskiBatchNorm, bias,
- * BasicBlock residual and MinkowskiReLU folded into the epilogue (any of scale/shift/residual
- * may be NULL).  d_nbr may be NULL for K == 1.  d_ws (optional, cv_sp_conv_workspace_bytes) lets small
- * coordinate sets split the kernel offsets over more workgroups.  flavour: 0 auto, 1 no splitting,
- * 2 in-workgroup split-K. */
+ * BasicBlock residual and MinkowskiReLU folded into the epilogue.  Optional members may be NULL / 0. */
+typedef struct cv_conv_desc {
+    const float* in;        /* [n_in][in_ld] input features */
+    long long n_in;
+    int in_ld, cin;
+    const float* weight;    /* [K][cin][cout] (ME `kernel`) */
+    int K, cout;
+    const int32_t* nbr;     /* [n_out][K] kernel map; NULL for K == 1 on the same coordinate set */
+    long long n_out;
+    const float* scale;     /* [cout] or NULL */
+    const float* shift;     /* [cout] or NULL */
+    const float* residual;  /* [n_out][res_ld] or NULL */
+    int res_ld;
+    int relu;
+    float* out;             /* [n_out][out_ld] */
+    int out_ld;
+    int flavour;            /* 0 auto (may split offsets over workgroups through ws), 1 never split */
+    void* ws;               /* optional workspace, cv_sp_conv_workspace_bytes */
+    size_t ws_bytes;
+    const int32_t* row_perm;/* optional [n_out] processing order (rows with equal neighbour masks adjacent) */
+    int j_begin, j_end;     /* kernel offsets to accumulate; j_end == 0 means K */
+    const float* acc_in;    /* optional [n_out][acc_ld] partial sums from a previous launch */
+    int acc_ld;
+    int perm_groups;        /* >1: row_perm is [perm_groups][n_out]; the offsets are split into that many
+                               contiguous groups, each run in its own order in ONE launch (needs ws) */
+} cv_conv_desc;
+
 size_t cv_sp_conv_workspace_bytes(long long n_out, int cout, int K);
-int cv_sp_conv_f32(const float* d_in, long long n_in, int in_ld, int cin, const float* d_weight, int K,
-                   int cout, const int32_t* d_nbr, long long n_out, const float* d_scale,
-                   const float* d_shift, const float* d_residual, int res_ld, int relu, float* d_out,
-                   int out_ld, int flavour, void* d_ws, size_t ws_bytes, void* stream);
+int cv_sp_conv_f32(const cv_conv_desc* desc, void* stream);
+
+/* d_keys[n] (int64) = bit mask of the valid neighbours among offsets [j_begin, j_end) of every row of a
+ * kernel map; argsort of it is a row_perm for cv_conv_desc.  Asynchronous. */
+int cv_sp_mask_keys(const int32_t* d_nbr, long long n, int K, int j_begin, int j_end, long long* d_keys,
+                    void* stream);
 
 /* y = relu?(x * scale + shift): MinkowskiBatchNorm (eval) / MinkowskiReLU on feature rows. */
 int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale,

@@ -47,8 +47,11 @@ def test_coordinate_sets_and_kernel_maps_exact(cuda, built_lib, seed, n, batch):
 
 def test_duplicate_coordinates_rejected(cuda, built_lib):
     c = torch.tensor([[0, 1, 2, 3], [0, 1, 2, 3], [0, 4, 5, 6]], dtype=torch.int32, device=cuda)
-    with pytest.raises(RuntimeError, match="duplicate"):
-        ME.SparseTensor(torch.zeros(3, 3, device=cuda), c)
+    with pytest.raises(RuntimeError, match="duplicate"):      # reported at the first map request
+        ME.MinkowskiConvolution(3, 8, kernel_size=3, dimension=3).cuda()(ME.SparseTensor(torch.zeros(3, 3, device=cuda), c))
+    model = MinkUNet34C(3, 8).cuda().eval()
+    with pytest.raises(RuntimeError, match="duplicate"), torch.no_grad():
+        model(ME.SparseTensor(torch.zeros(3, 3, device=cuda), c))
 
 
 def rel_err(a, b):
@@ -56,8 +59,8 @@ def rel_err(a, b):
 
 
 @pytest.mark.parametrize("cin,cout,k,flavour", [(32, 32, 3, 1), (32, 64, 3, 1), (96, 96, 3, 1), (128, 96, 3, 1),
-                                               (64, 128, 3, 1), (128, 256, 3, 1), (256, 256, 3, 2),
-                                               (64, 64, 3, 2), (32, 32, 3, 2), (3, 32, 5, 1), (6, 32, 5, 1),
+                                               (64, 128, 3, 1), (128, 256, 3, 1), (256, 256, 3, 0),
+                                               (64, 64, 3, 0), (32, 32, 3, 0), (3, 32, 5, 1), (6, 32, 5, 1),
                                                (128, 96, 1, 1), (96, 64, 1, 1), (384, 256, 1, 0)])
 def test_conv_matches_oracle(cuda, built_lib, cin, cout, k, flavour):
     coords, _ = scene_coords(2, 1500)
@@ -84,6 +87,34 @@ def test_conv_matches_oracle(cuda, built_lib, cin, cout, k, flavour):
     got1 = obuf[:, 32:32 + cout].cpu().numpy()
     assert rel_err(got1, ref1) < 1e-5
     assert float(obuf[:, :32].min()) == -7.0 and float(obuf[:, 32 + cout:].max()) == -7.0   # no stray writes
+
+
+def test_masked_two_pass_conv_matches_oracle(cuda, built_lib):
+    """mask-sorted processing order + offset halves + acc_in give the same conv"""
+    coords, _ = scene_coords(6, 5000, small=False)
+    rng = np.random.default_rng(3)
+    x = rng.normal(0, 1, (len(coords), 64)).astype(np.float32)
+    w = (rng.normal(0, 1, (27, 64, 96)) / 40).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, 96).astype(np.float32)
+    shift = rng.normal(0, 0.2, 96).astype(np.float32)
+    res = rng.normal(0, 1, (len(coords), 96)).astype(np.float32)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(cuda, torch.int32))
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    ref = so.conv(torch.from_numpy(x), torch.from_numpy(w), so.kernel_map(coords, coords, 3, 1, 1)).numpy()
+    ref = np.maximum(ref * scale + shift + res, 0)
+    for groups in (2, 3, 4):
+        perms = cm.mask_perms(3, 1, groups)
+        for p in perms:
+            assert sorted(p.cpu().tolist()) == list(range(len(coords)))
+        got = ME.conv_forward_masked(t(x), t(w), cm.kernel_map(3, 1), perms, len(coords), scale=t(scale),
+                                     shift=t(shift), residual=t(res), relu=True).cpu().numpy()
+        assert rel_err(got, ref) < 1e-5
+    # explicit two-launch form: offset halves chained through acc_in
+    perms = cm.mask_perms(3, 1, 2)
+    part = ME.conv_forward(t(x), t(w), cm.kernel_map(3, 1), len(coords), flavour=1, row_perm=perms[0], j_begin=0, j_end=13)
+    got = ME.conv_forward(t(x), t(w), cm.kernel_map(3, 1), len(coords), flavour=1, row_perm=perms[1], j_begin=13,
+                          j_end=27, acc_in=part, scale=t(scale), shift=t(shift), residual=t(res), relu=True).cpu().numpy()
+    assert rel_err(got, ref) < 1e-5
 
 
 def test_strided_and_transposed_conv_match_oracle(cuda, built_lib):
