@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--scenes", type=int, default=4, help="distinct resident scenes per rank")
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--algo", type=int, default=0, help="vote algorithm: 0 auto, 1 direct, 2 tiles")
-    ap.add_argument("--cpu-scenes", type=int, default=2, help="scenes timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-scenes", type=int, default=1, help="scenes timed on the CPU oracle (0 = skip)")
     ap.add_argument("--stage", default="full", choices=["vote_decode", "full"],
                     help="full = MinkUNet34C forward + head + vote + decode + NMS (eval_joint.py path)")
     ap.add_argument("--teacher-forced", action="store_true",

@@ -23,7 +23,6 @@ from . import _lib
 
 ALGO_AUTO, ALGO_DIRECT, ALGO_TILES = 0, 1, 2
 _algo = ALGO_AUTO
-_scalar_cache = {}
 
 
 def set_algorithm(algo):
@@ -42,15 +41,16 @@ def _check_input(x, name):
 def _scalar(t, kind):
     """Host value of a 0-dim device tensor (res / num_rots).  The reference dereferences these
     on the device (hv_cuda_kernel.cu:22-23); we need them on the host for the launch geometry,
-    so the value is read once per (storage, version) and cached - no per-call sync."""
-    key = (t.data_ptr(), t._version, t.device.index, kind)
-    v = _scalar_cache.get(key)
-    if v is None:
-        v = float(t.item()) if kind == "f" else int(t.item())
-        if len(_scalar_cache) > 64:
-            _scalar_cache.clear()
-        _scalar_cache[key] = v
-    return v
+    so the value is read once per tensor OBJECT and version and kept on the object itself
+    (a cache keyed by address would hand a recycled allocation the previous tensor's value)."""
+    hit = getattr(t, "_cv_host_value", None)
+    if hit is None or hit[0] != t._version:
+        hit = (t._version, float(t.item()) if kind == "f" else int(t.item()))
+        try:
+            t._cv_host_value = hit
+        except AttributeError:      # exotic tensor subclass without a __dict__: just re-read every call
+            pass
+    return hit[1]
 
 
 def _ptr(t):
