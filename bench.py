@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from canonicalvoting_amd import _lib, decode, hv_cuda, pipeline  # noqa: E402
+from canonicalvoting_amd import dist as cvd  # noqa: E402
 from canonicalvoting_amd import me as ME  # noqa: E402
 from canonicalvoting_amd.hough import HoughVoting  # noqa: E402
 from canonicalvoting_amd.minkunet import MinkUNet34C  # noqa: E402
@@ -127,15 +128,11 @@ def cpu_baseline(scenes, n, model, full):
 
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local = cvd.world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    cvd.init("nccl", dev)
     _lib.lib()
     hv_cuda.set_algorithm(a.algo)
     hv = HoughVoting(RES, NUM_ROTS)
@@ -146,19 +143,14 @@ def main():
         model = MinkUNet34C(3, 6 * 9 + 9 + 1).cuda().eval()        # eval_joint.py:151, random init
 
     # scene i of rank r uses seed r*1000 + i: every rank owns different scenes
-    scenes = [ResidentScene(rank * 1000 + i, a.points, dev) for i in range(a.scenes)]
+    scenes = [ResidentScene(seed, a.points, dev) for seed in cvd.scene_seeds(rank, a.scenes)]
     for w in range(a.warmup):
         run_step(model, hv, scenes[w % len(scenes)], teacher_forced=a.teacher_forced)
     torch.cuda.synchronize()
 
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(a.steps)]
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    barrier = lambda: cvd.barrier(dev)
     barrier()
     t0 = time.perf_counter()
     n_det = 0
@@ -167,11 +159,7 @@ def main():
         n_det += len(dets)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = cvd.reduce_scalar(dt, "max", dev)
 
     vote_ms = np.array([e[2].elapsed_time(e[3]) for e in events])
     stage_ms = {"net": float(np.mean([e[0].elapsed_time(e[1]) for e in events])),
@@ -183,7 +171,7 @@ def main():
     s0 = scenes[0]
     out = {
         "metric": "scenes/sec (80k-pt synthetic scans)",
-        "value": a.steps * world / dt,
+        "value": cvd.throughput(a.steps, world, dt),
         "unit": "scenes/s",
         "n_gpus": world,
         "steps": a.steps,
@@ -226,9 +214,7 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    cvd.finalize()
 
 
 if __name__ == "__main__":
