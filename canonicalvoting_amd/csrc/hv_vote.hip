@@ -230,9 +230,16 @@ __global__ __launch_bounds__(PREP_THREADS) void hv_prep_count(
 }
 
 // exclusive scan of ycount[Y] -> ystart[Y+1], cursor[Y] (single workgroup)
+// Hough peaks concentrate votes: the hottest (tile, plane) of an 80k scene receives ~27x the mean and
+// would take 0.3 ms on one CU.  Planes whose two y-bins hold many points are therefore split into
+// up to MAX_PARTS workgroups per tile (disjoint record chunks), merged by the last arriver.
+constexpr int PART_RECORDS = 4096;
+constexpr int MAX_PARTS = 8;
+
 __global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ ycount, int Y,
                                                      int* __restrict__ ystart,
-                                                     int* __restrict__ cursor) {
+                                                     int* __restrict__ cursor,
+                                                     int* __restrict__ part_start) {
     __shared__ int s[1024];
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
@@ -254,15 +261,40 @@ __global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ yco
         if (threadIdx.x == 1023) carry = incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) ystart[Y] = carry;
+    if (threadIdx.x == 0) { ystart[Y] = carry; carry = 0; }
+    __syncthreads();
+    // part_start[y] = exclusive scan of the number of workgroups per tile of plane y
+    for (int base = 0; base < Y; base += 1024) {
+        const int i = base + threadIdx.x;
+        int v = 0;
+        if (i < Y) {
+            const int n2 = (i >= 1 ? ycount[i - 1] : 0) + (i <= Y - 2 ? ycount[i] : 0);
+            v = min(max((n2 + PART_RECORDS - 1) / PART_RECORDS, 1), MAX_PARTS);
+        }
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int incl = s[threadIdx.x] + carry;
+        if (i < Y) part_start[i] = incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part_start[Y] = carry;
 }
 
 // Scatters every point with an in-bounds y into its y-bin and writes a compact SoA record
 // (REC_F floats, bin order) so the tile kernel streams coalesced rows instead of gathering
 // 10 scalars per point through `order[]`:
-//   0 px  1 pz  2 cx  3 cz  4 ry (fractional y)  5 obj  6..8 scale  9 ux  10 uz  11 r
-// (ux,uz) = ring centre and r = ring radius in grid units, used only for culling.
-constexpr int REC_F = 12;
+//   0 px  1 pz  2 cx  3 cz  4 ry (fractional y)  5 obj  6..8 scale  9 ux  10 uz  11 r  12 a0
+// (ux,uz) = ring centre, r = ring radius in grid units and a0 = angle (seen from the ring centre)
+// of the vote at rotation 0; used only for culling.
+constexpr int REC_F = 13;
 
 __global__ __launch_bounds__(PREP_THREADS) void hv_prep_scatter(
     const float* __restrict__ pts, const float* __restrict__ xyz, const float* __restrict__ scl,
@@ -304,6 +336,8 @@ __global__ __launch_bounds__(PREP_THREADS) void hv_prep_scatter(
     r[9 * rec_stride] = (px - corner.x) / res;
     r[10 * rec_stride] = (pz - corner.z) / res;
     r[11 * rec_stride] = sqrtf(cx * cx + cz * cz) / res;
+    // vote(theta) = u - r (cos(theta + phi), sin(theta + phi)) with (cx, cz) = r (cos phi, sin phi)
+    r[12 * rec_stride] = atan2f(cz, cx) + 3.14159265f;
 }
 
 __device__ __forceinline__ int lanes_below(uint64_t mask) {
@@ -322,6 +356,8 @@ __device__ __forceinline__ void lds_add(double* p, float v) {
 struct TileShared {
     double acc[6][TCELLS];     // obj, rot.cos, rot.sin, scale.xyz  (SoA: random banks per lane)
     float pq[TW][9][PQ];       // px, pz, cx, cz, wy, obj, s0, s1, s2 of surviving points
+    int arc_start[TW][PQ];     // first rotation whose vote can reach the tile
+    int arc_cum[TW][PQ];       // inclusive prefix sum of the arc lengths
     uint32_t vq_rec[TW][VQ];   // entry | rot<<6 | (lx+1)<<14 | (lz+1)<<20
     float vq_rx[TW][VQ];
     float vq_rz[TW][VQ];
@@ -366,12 +402,27 @@ __device__ __forceinline__ void wave_sync_lds() {
 template <int VARIANT>
 __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     int R, float res, F3 corner, I3 dims, const float2* __restrict__ tab,
-    const int* __restrict__ ystart, const float* __restrict__ rec, int64_t rec_stride, int tiles_x,
-    int tiles_z, float* __restrict__ g_obj, float* __restrict__ g_rot, float* __restrict__ g_scale) {
+    const int* __restrict__ ystart, const int* __restrict__ part_start, const float* __restrict__ rec,
+    int64_t rec_stride, int tiles_x, int tiles_z, float* __restrict__ partials,
+    int* __restrict__ arrivals, float* __restrict__ g_obj, float* __restrict__ g_rot,
+    float* __restrict__ g_scale) {
     __shared__ TileShared sh;
+    __shared__ int last_flag;
     const int X = dims.x, Y = dims.y, Z = dims.z;
-    const int tile = blockIdx.x % (tiles_x * tiles_z);
-    const int y = blockIdx.x / (tiles_x * tiles_z);
+    const int ntiles = tiles_x * tiles_z;
+    const int tile = blockIdx.x % ntiles;
+    const int q = blockIdx.x / ntiles;               // (plane, part) slot
+    if (q >= part_start[Y]) return;
+    int y;
+    {
+        int lo = 0, hi = Y - 1;                      // largest y with part_start[y] <= q
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (part_start[mid] <= q) lo = mid; else hi = mid - 1;
+        }
+        y = lo;
+    }
+    const int part = q - part_start[y], nparts = part_start[y + 1] - part_start[y];
     const int x0 = (tile / tiles_z) * TX, z0 = (tile % tiles_z) * TZ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -389,9 +440,10 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     for (int s = y - 1; s <= y; ++s) {
         if (s < 0 || s > Y - 2) continue;
         const int beg = ystart[s], end = ystart[s + 1];
-        for (int base = beg + wave * 64; base < end; base += TW * 64) {
+        for (int base = beg + (wave * nparts + part) * 64; base < end; base += TW * nparts * 64) {
             const int idx = base + lane;
             bool keep = false;
+            int a_start = 0, a_len = 0;
             if (idx < end) {
                 const float ux = rec[9 * rec_stride + idx], uz = rec[10 * rec_stride + idx],
                             r = rec[11 * rec_stride + idx];
@@ -404,10 +456,41 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
                 const float tol = slack + 1e-5f * (r + fabsf(ux) + fabsf(uz));
                 keep = (r >= dmin - tol) && (r <= dmax + tol);
                 if (VARIANT == 2) keep = keep && (ux == 1234.5f);
+                if (keep) {
+                    // rotations whose vote can fall in the rectangle: the rectangle subtends an arc
+                    // [b0+lo, b0+hi] seen from the ring centre unless the centre is (nearly) inside it
+                    a_len = R;
+                    if (dxn + dzn > 0.5f) {
+                        const float b0 = atan2f(0.5f * (zlo + zhi) - uz, 0.5f * (xlo + xhi) - ux);
+                        float lo = 0.f, hi = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float d = atan2f(((k & 2) ? zhi : zlo) - uz, ((k & 1) ? xhi : xlo) - ux) - b0;
+                            d -= 6.28318531f * rintf(d * 0.159154943f);
+                            lo = fminf(lo, d);
+                            hi = fmaxf(hi, d);
+                        }
+                        const float a0 = rec[12 * rec_stride + idx];
+                        const float inv_step = (float)R * 0.159154943f;          // 1 / rot_interval
+                        float first = (b0 + lo - a0) * inv_step - 2.f;           // 2 steps of slack per side
+                        const int len = (int)((hi - lo) * inv_step) + 6;
+                        first -= (float)R * floorf(first / (float)R);
+                        a_start = min(max((int)first, 0), R - 1);
+                        a_len = min(len, R);
+                    }
+                }
             }
             const uint64_t m = __ballot(keep);
             const int nq = __popcll(m);
             if (nq == 0) continue;
+            // inclusive scan of the arc lengths in compacted (lane) order
+            int cum = keep ? a_len : 0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(cum, off);
+                if (lane >= off) cum += t;
+            }
+            const int items = __shfl(cum, 63);
             if (keep) {
                 const int p = lanes_below(m);
                 const float ry = rec[4 * rec_stride + idx];
@@ -420,21 +503,43 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
                 sh.pq[wave][6][p] = rec[6 * rec_stride + idx];
                 sh.pq[wave][7][p] = rec[7 * rec_stride + idx];
                 sh.pq[wave][8][p] = rec[8 * rec_stride + idx];
+                sh.arc_start[wave][p] = a_start;
+                sh.arc_cum[wave][p] = cum;
             }
             wave_sync_lds();
 
-            const int items = nq * R;
-            const float inv_nq = 1.0f / (float)nq;
-            for (int ib = 0; ib < items; ib += 64) {
-                const int i = ib + lane;
+            // lane l walks items [l*S, (l+1)*S): at any step the 64 lanes sit on 64 different arcs
+            // (different cells -> few same-address LDS atomic collisions), and a lane only advances
+            // along its arc, so the (entry, step) pair is found by ONE binary search per chunk.
+            const int S = (items + 63) >> 6;
+            int it0 = lane * S;
+            const int it1 = min(it0 + S, items);
+            int e = 0;
+            {
+                int lo = 0, hi = nq - 1;                     // smallest e with cum[e] > it0
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sh.arc_cum[wave][mid] > it0) hi = mid; else lo = mid + 1;
+                }
+                e = lo;
+            }
+            int e_end = it0 < items ? sh.arc_cum[wave][e] : 0;          // first item of the next entry
+            int rot = 0;
+            if (it0 < items) {
+                const int e_beg = e > 0 ? sh.arc_cum[wave][e - 1] : 0;
+                rot = sh.arc_start[wave][e] + (it0 - e_beg);
+                if (rot >= R) rot -= R;
+            }
+            for (int step = 0; step < S; ++step, ++it0) {
                 bool isvote = false;
                 uint32_t vrec = 0;
                 float rx = 0, rz = 0;
-                if (i < items) {
-                    // rot-major so the 64 lanes of a step are different points at (almost)
-                    // one rotation: distinct cells, few same-address LDS atomic collisions.
-                    const int rot = (int)(((float)i + 0.5f) * inv_nq);
-                    const int e = i - rot * nq;
+                if (it0 < it1) {
+                    if (it0 == e_end) {                      // next arc
+                        ++e;
+                        e_end = sh.arc_cum[wave][e];
+                        rot = sh.arc_start[wave][e];
+                    }
                     const float2 cs = sh.tab[rot];
                     const float ecx = sh.pq[wave][2][e], ecz = sh.pq[wave][3][e];
                     const float ox = (-cs.x) * ecx + cs.y * ecz;
@@ -451,6 +556,7 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
                                    ((uint32_t)(lz + 1) << 20);
                         }
                     }
+                    if (++rot == R) rot = 0;
                 }
                 const uint64_t mv = __ballot(isvote);
                 if (isvote) {
@@ -477,6 +583,32 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
         }
     }
     __syncthreads();
+
+    if (nparts > 1) {
+        // publish this part's tile, the last arriver sums the parts in part order (deterministic):
+        // plain stores -> per-wave vmcnt(0) -> barrier -> one-lane agent release -> ticket.
+        float* mine = partials + ((int64_t)q * ntiles + tile) * (6 * TCELLS);
+        for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) mine[i] = (float)(&sh.acc[0][0])[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int old = __hip_atomic_fetch_add(&arrivals[y * ntiles + tile], 1, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = old == nparts - 1;
+            if (last_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        const float* base = partials + ((int64_t)part_start[y] * ntiles + tile) * (6 * TCELLS);
+        for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) {
+            double sum = 0.0;
+            for (int p2 = 0; p2 < nparts; ++p2) sum += (double)base[(int64_t)p2 * ntiles * (6 * TCELLS) + i];
+            (&sh.acc[0][0])[i] = sum;
+        }
+        __syncthreads();
+    }
 
     // fused normalise (hv_cuda_kernel.cu:112-117) + single store of the tile.  The weight the
     // reference divides by is the fp32 grid value, so round the double sum to float first.
@@ -625,6 +757,9 @@ int check_common(const void* a, const void* b, const void* c, int64_t n, float r
     return CV_OK;
 }
 
+// sum over planes of parts per tile: sum_y ceil(n2_y / PART_RECORDS) <= Y + 2n / PART_RECORDS
+int64_t tiles_q_bound(int64_t n, int Y) { return (int64_t)Y + (2 * n + PART_RECORDS - 1) / PART_RECORDS; }
+
 int pick_algo(int algo, int64_t n, int num_rots, const int* dims) {
     if (algo == 21 || algo == 22) return 2;   // profiling ablations of the tiles kernel
     if (algo == 1 || algo == 2) return algo;
@@ -674,7 +809,9 @@ size_t cv_hv_forward_workspace_bytes(int64_t n, int num_rots, const int dims[3],
     if (!dims || n <= 0) return 0;
     if (pick_algo(algo, n, num_rots, dims) == 1) return 256;
     const size_t Y = (size_t)dims[1];
-    return 256 * 6 + sizeof(int) * ((size_t)n * (1 + REC_F) + Y * 3 + 8);
+    const size_t ntiles = (size_t)((dims[0] + TX - 1) / TX) * (size_t)((dims[2] + TZ - 1) / TZ);
+    return 256 * 9 + sizeof(int) * ((size_t)n * (1 + REC_F) + Y * 4 + 16 + Y * ntiles) +
+           sizeof(float) * (size_t)tiles_q_bound(n, (int)Y) * ntiles * 6 * TCELLS;
 }
 
 int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_scale,
@@ -717,22 +854,28 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
     int* ycount = cv.take<int>(Y);
     int* ystart = cv.take<int>(Y + 1);
     int* cursor = cv.take<int>(Y);
+    int* part_start = cv.take<int>(Y + 1);
+    const int tiles_x = (dims[0] + TX - 1) / TX, tiles_z = (dims[2] + TZ - 1) / TZ;
+    const int ntiles = tiles_x * tiles_z;
+    const int64_t max_q = tiles_q_bound(n, Y);
+    int* arrivals = cv.take<int>((size_t)Y * ntiles);
+    float* partials = cv.take<float>((size_t)max_q * ntiles * 6 * TCELLS);
     CV_HIP_CHECK(hipMemsetAsync(ycount, 0, sizeof(int) * Y, st));
+    CV_HIP_CHECK(hipMemsetAsync(arrivals, 0, sizeof(int) * (size_t)Y * ntiles, st));
     hv_prep_count<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, n, res, corner.y, Y, fy, ycount);
     CV_LAUNCH_CHECK();
-    hv_prep_scan<<<1, 1024, 0, st>>>(ycount, Y, ystart, cursor);
+    hv_prep_scan<<<1, 1024, 0, st>>>(ycount, Y, ystart, cursor, part_start);
     CV_LAUNCH_CHECK();
     hv_prep_scatter<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, d_obj, fy, n, Y, res, corner, cursor, rec, n);
     CV_LAUNCH_CHECK();
-    const int tiles_x = (dims[0] + TX - 1) / TX, tiles_z = (dims[2] + TZ - 1) / TZ;
-    const int64_t wgs = (int64_t)tiles_x * tiles_z * Y;
+    const int64_t wgs = max_q * ntiles;
     CV_REQUIRE(wgs < (1ll << 31), CV_EINVAL, "grid too large");
-#define CV_TILES_LAUNCH(V)                                                                      \
-    hv_fwd_tiles<V><<<(unsigned)wgs, TW * 64, 0, st>>>(num_rots, res, corner, d3, tab, ystart, rec, \
-                                                      n, tiles_x, tiles_z, d_grid_obj, d_grid_rot, \
-                                                      d_grid_scale)
+#define CV_TILES_LAUNCH(V)                                                                          \
+    hv_fwd_tiles<V><<<(unsigned)wgs, TW * 64, 0, st>>>(num_rots, res, corner, d3, tab, ystart, part_start, \
+                                                      rec, n, tiles_x, tiles_z, partials, arrivals,    \
+                                                      d_grid_obj, d_grid_rot, d_grid_scale)
     if (algo == 21) CV_TILES_LAUNCH(1);
     else if (algo == 22) CV_TILES_LAUNCH(2);
     else CV_TILES_LAUNCH(0);
