@@ -122,9 +122,21 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
         const int a_row = tid >> 3;                      // + 32*i, i = 0..3
         constexpr int B_F4 = KC * NB * 32 / 4;           // float4s in the weight slab
         constexpr int B_PER = (B_F4 + THREADS - 1) / THREADS;
-        const int j_lo = a.j_begin + (int)((long long)nj * blockIdx.z / a.splits);
-        const int j_hi = a.j_begin + (int)((long long)nj * (blockIdx.z + 1) / a.splits);
-        for (int j = j_lo; j < j_hi; ++j) {
+        // work units = (kernel offset, 32-channel chunk); a split owns a contiguous range of units,
+        // or a whole offset group when every group has its own row order
+        const int nch = a.cin / KC;
+        int u_lo, u_hi;
+        if (a.perm_per_split) {
+            u_lo = (int)((long long)nj * blockIdx.z / a.splits) * nch;
+            u_hi = (int)((long long)nj * (blockIdx.z + 1) / a.splits) * nch;
+        } else {
+            u_lo = (int)((long long)nj * nch * blockIdx.z / a.splits);
+            u_hi = (int)((long long)nj * nch * (blockIdx.z + 1) / a.splits);
+        }
+        const int j_first = a.j_begin + u_lo / nch, j_last = a.j_begin + (u_hi - 1) / nch;
+        for (int j = j_first; j <= j_last && u_hi > u_lo; ++j) {
+            const int kc_begin = (j == j_first ? u_lo % nch : 0) * KC;
+            const int kc_end = (j == j_last ? (u_hi - 1) % nch + 1 : nch) * KC;
             int my = -1;
             if (tid < TM) {
                 const int row = rows_s[tid];
@@ -177,12 +189,12 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
                     }
                 }
             };
-            load(0);
-            for (int kc = 0; kc < a.cin; kc += KC) {
+            load(kc_begin);
+            for (int kc = kc_begin; kc < kc_end; kc += KC) {
                 __syncthreads();                 // previous chunk's MFMAs are done with the LDS tiles
                 stage();
                 __syncthreads();
-                if (kc + KC < a.cin) load(kc + KC);   // in flight while the matrix cores run
+                if (kc + KC < kc_end) load(kc + KC);  // in flight while the matrix cores run
                 if (wave_live) compute();
             }
             __syncthreads();
@@ -245,6 +257,68 @@ __global__ __launch_bounds__(256) void mask_keys(const int* __restrict__ nbr, lo
     for (int j = j_begin; j < j_end; ++j)
         if (nbr[i * K + j] >= 0) m |= 1ull << (j - j_begin);
     keys[i] = (long long)m;
+}
+
+// ---- row orders per offset group by counting sort on the group's neighbour bit mask (<= 10 bits).
+// Three launches for all groups (blockIdx.y = group); LDS-aggregated histograms because global
+// atomics on a few hundred hot counters serialise (~11 ns each on MI355X).
+constexpr int MP_BINS = 1024;
+constexpr int MP_THREADS = 1024;
+
+__device__ __forceinline__ int group_mask(const int* __restrict__ nbr, long long row, int K, int jb, int je) {
+    int m = 0;
+    for (int j = jb; j < je; ++j)
+        if (nbr[row * K + j] >= 0) m |= 1 << (j - jb);
+    return m;
+}
+
+__global__ __launch_bounds__(MP_THREADS) void mp_hist(const int* __restrict__ nbr, long long n, int K, int groups,
+                                                      int* __restrict__ hist /*[groups][MP_BINS]*/) {
+    __shared__ int lh[MP_BINS];
+    const int g = blockIdx.y;
+    const int jb = K * g / groups, je = K * (g + 1) / groups;
+    for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS) lh[i] = 0;
+    __syncthreads();
+    const long long row = blockIdx.x * (long long)MP_THREADS + threadIdx.x;
+    if (row < n) atomicAdd(&lh[group_mask(nbr, row, K, jb, je)], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS)
+        if (lh[i]) atomicAdd(&hist[g * MP_BINS + i], lh[i]);
+}
+
+__global__ __launch_bounds__(MP_BINS) void mp_scan(int* __restrict__ hist) {   // exclusive, in place, per group
+    __shared__ int s[MP_BINS];
+    int* h = hist + blockIdx.x * MP_BINS;
+    const int v = h[threadIdx.x];
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < MP_BINS; off <<= 1) {
+        const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    h[threadIdx.x] = s[threadIdx.x] - v;
+}
+
+__global__ __launch_bounds__(MP_THREADS) void mp_scatter(const int* __restrict__ nbr, long long n, int K, int groups,
+                                                         int* __restrict__ cursor, int* __restrict__ perm) {
+    __shared__ int lh[MP_BINS];
+    const int g = blockIdx.y;
+    const int jb = K * g / groups, je = K * (g + 1) / groups;
+    for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS) lh[i] = 0;
+    __syncthreads();
+    const long long row = blockIdx.x * (long long)MP_THREADS + threadIdx.x;
+    int key = 0, rank = 0;
+    if (row < n) {
+        key = group_mask(nbr, row, K, jb, je);
+        rank = atomicAdd(&lh[key], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS)
+        if (lh[i]) lh[i] = atomicAdd(&cursor[g * MP_BINS + i], lh[i]);
+    __syncthreads();
+    if (row < n) perm[(long long)g * n + lh[key] + rank] = (int)row;
 }
 
 // ------------------------------------------------------------------ elementwise helpers
@@ -320,15 +394,18 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
 
 int nb_for(int cout) { return cout <= 32 ? 1 : cout <= 64 ? 2 : cout <= 96 ? 3 : 4; }
 
-// Enough workgroups to fill 256 CUs about twice; split over kernel offsets (or K chunks).
+// Enough workgroups to fill 256 CUs a few times with short dependent chains: split the (offset,
+// chunk) units over blockIdx.z; the partial tiles cost 8 bytes of traffic per output element per split.
 int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
     const int nb = nb_for(cout);
     const long long tiles = ((n_out + TM - 1) / TM) * ((cout + nb * 32 - 1) / (nb * 32));
-    const int units = vec ? K : (K * cin + KC - 1) / KC;
+    const long long units = vec ? (long long)K * (cin / KC) : ((long long)K * cin + KC - 1) / KC;
     if (tiles >= 384 || units <= 1) return 1;
-    long long s = (512 + tiles - 1) / tiles;
-    if (s > units) s = units;
-    if (s > 27) s = 27;
+    long long s = (1024 + tiles - 1) / tiles;
+    s = std::min(s, units);
+    const long long by_traffic = (48ll << 20) / std::max<long long>(1, n_out * cout * 4);   // <= 48 MB of partials
+    s = std::min(s, std::max<long long>(by_traffic, 2));
+    s = std::min<long long>(s, 64);
     return (int)std::max<long long>(s, 1);
 }
 
@@ -338,7 +415,8 @@ extern "C" {
 
 size_t cv_sp_conv_workspace_bytes(long long n_out, int cout, int K) {
     if (n_out <= 0 || cout <= 0 || K <= 0) return 0;
-    return 256 + sizeof(float) * (size_t)27 * (size_t)n_out * (size_t)cout;   // upper bound over split counts
+    const size_t one = sizeof(float) * (size_t)n_out * (size_t)cout;
+    return 256 + std::min<size_t>(64 * one, std::max<size_t>((size_t)48 << 20, 2 * one));   // see pick_splits
 }
 
 int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
@@ -391,6 +469,27 @@ int cv_sp_mask_keys(const int32_t* d_nbr, long long n, int K, int j_begin, int j
                    j_end - j_begin <= 63, CV_EINVAL, "bad mask key arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     mask_keys<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_nbr, n, K, j_begin, j_end, d_keys);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+// d_perm[groups][n] = rows ordered by the neighbour bit mask of each contiguous group of the K offsets
+// (ceil(K/groups) <= 10).  d_ws: groups*1024 ints of scratch.  Asynchronous, three launches.
+int cv_sp_mask_perms(const int32_t* d_nbr, long long n, int K, int groups, int32_t* d_perm, void* d_ws,
+                     size_t ws_bytes, void* stream) {
+    CV_REQUIRE(d_nbr && d_perm && d_ws && n > 0 && K > 0 && groups >= 1 && groups <= K, CV_EINVAL,
+               "bad mask perm arguments");
+    CV_REQUIRE((K + groups - 1) / groups <= 10, CV_EINVAL, "at most 10 kernel offsets per group");
+    CV_REQUIRE(ws_bytes >= sizeof(int) * (size_t)groups * MP_BINS, CV_ENOMEM, "workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int* hist = static_cast<int*>(d_ws);
+    CV_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * (size_t)groups * MP_BINS, st));
+    dim3 grid((unsigned)((n + MP_THREADS - 1) / MP_THREADS), (unsigned)groups);
+    mp_hist<<<grid, MP_THREADS, 0, st>>>(d_nbr, n, K, groups, hist);
+    CV_LAUNCH_CHECK();
+    mp_scan<<<groups, MP_BINS, 0, st>>>(hist);
+    CV_LAUNCH_CHECK();
+    mp_scatter<<<grid, MP_THREADS, 0, st>>>(d_nbr, n, K, groups, hist, d_perm);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

@@ -110,43 +110,61 @@ __global__ __launch_bounds__(256) void flag_first(const int* n_ptr, const int* v
         flag[i] = vals[slot_of_row[i]] == i ? 1 : 0;
 }
 
-// single-workgroup exclusive scan (n up to a few million is fine: ~1 us per 16k elements)
-__global__ __launch_bounds__(1024) void scan_flags(const int* __restrict__ flag, const int* n_ptr,
-                                                   int* __restrict__ rank, int* total_out) {
-    __shared__ int s[1024];
-    __shared__ int carry;
-    const int n = *n_ptr;
-    if (threadIdx.x == 0) carry = 0;
+// exclusive scan of the 0/1 flags in three short launches (a single-workgroup scan of 80k flags took
+// 37 us): per-block sums -> scan of the block sums -> per-block scan + offset.
+constexpr int SCAN_PER = 8, SCAN_BLOCK = 1024 * SCAN_PER;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* s /*[1024]*/) {
+    s[threadIdx.x] = v;
     __syncthreads();
-    constexpr int PER = 8;
-    for (int base = 0; base < n; base += 1024 * PER) {
-        int v[PER];
-        int sum = 0;
-        const int b0 = base + threadIdx.x * PER;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            v[j] = (b0 + j < n) ? flag[b0 + j] : 0;
-            sum += v[j];
-        }
-        s[threadIdx.x] = sum;
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
         __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        int run = s[threadIdx.x] - sum + carry;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            if (b0 + j < n) rank[b0 + j] = run;
-            run += v[j];
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += s[1023];
+        s[threadIdx.x] += t;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total_out = carry;
+    return s[threadIdx.x] - v;
+}
+
+__global__ __launch_bounds__(1024) void scan_block_sums(const int* __restrict__ flag, const int* n_ptr,
+                                                        int* __restrict__ bsum) {
+    __shared__ int s[1024];
+    const int n = *n_ptr;
+    const int b0 = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER;
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; ++j) sum += (b0 + j < n) ? flag[b0 + j] : 0;
+    s[threadIdx.x] = sum;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if (threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(1024) void scan_block_offsets(int* __restrict__ bsum, int nblocks, int* total_out) {
+    __shared__ int s[1024];
+    const int v = threadIdx.x < nblocks ? bsum[threadIdx.x] : 0;
+    const int ex = block_exclusive_scan(v, s);
+    if (threadIdx.x < nblocks) bsum[threadIdx.x] = ex;
+    if (threadIdx.x == 1023) *total_out = ex + v;
+}
+
+__global__ __launch_bounds__(1024) void scan_apply(const int* __restrict__ flag, const int* n_ptr,
+                                                   const int* __restrict__ boff, int* __restrict__ rank) {
+    __shared__ int s[1024];
+    const int n = *n_ptr;
+    const int b0 = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER;
+    int v[SCAN_PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; ++j) { v[j] = (b0 + j < n) ? flag[b0 + j] : 0; sum += v[j]; }
+    int run = block_exclusive_scan(sum, s) + boff[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; ++j) {
+        if (b0 + j < n) rank[b0 + j] = run;
+        run += v[j];
+    }
 }
 
 __global__ __launch_bounds__(256) void emit_coarse(const int* __restrict__ coords, const int* n_ptr,
@@ -235,7 +253,7 @@ long long cv_sp_table_capacity(long long n) {
 
 size_t cv_sp_levels_workspace_bytes(long long n) {
     // slot_of_row (8n) + flag (4n) + rank (4n) + counters
-    return cv_align_up((size_t)n * 8, 256) + 2 * cv_align_up((size_t)n * 4, 256) + 1024;
+    return cv_align_up((size_t)n * 8, 256) + 2 * cv_align_up((size_t)n * 4, 256) + 4096 + 1024;
 }
 
 // Builds the coordinate sets of tensor strides 1,2,4,8,16 and their hash tables.
@@ -256,6 +274,9 @@ int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_ke
     long long* slot_of_row = cv.take<long long>(n);
     int* flag = cv.take<int>(n);
     int* rank = cv.take<int>(n);
+    int* bsum = cv.take<int>(1024);
+    const int nsb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    CV_REQUIRE(nsb <= 1024, CV_EINVAL, "coordinate set too large for the scan (%lld rows)", n);
     const int g = grid_for(n);
     CV_HIP_CHECK(hipMemsetAsync(d_counts, 0, sizeof(int) * 8, st));
     set_int<<<1, 1, 0, st>>>(d_counts, (int)n);
@@ -275,7 +296,11 @@ int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_ke
         CV_LAUNCH_CHECK();
         flag_first<<<g, 256, 0, st>>>(d_counts + L - 1, d_vals[L], slot_of_row, flag);
         CV_LAUNCH_CHECK();
-        scan_flags<<<1, 1024, 0, st>>>(flag, d_counts + L - 1, rank, d_counts + L);
+        scan_block_sums<<<nsb, 1024, 0, st>>>(flag, d_counts + L - 1, bsum);
+        CV_LAUNCH_CHECK();
+        scan_block_offsets<<<1, 1024, 0, st>>>(bsum, nsb, d_counts + L);
+        CV_LAUNCH_CHECK();
+        scan_apply<<<nsb, 1024, 0, st>>>(flag, d_counts + L - 1, bsum, rank);
         CV_LAUNCH_CHECK();
         emit_coarse<<<g, 256, 0, st>>>(d_coords[L - 1], d_counts + L - 1, stride2, flag, rank,
                                        slot_of_row, d_vals[L], d_coords[L]);

@@ -117,14 +117,20 @@ class CoordinateManager:
             L = _lib.lib()
             nbr = self.kernel_map(k, ts)
             n, K = nbr.shape
-            keys = torch.empty(n, dtype=torch.int64, device=self.device)
             m = torch.empty((groups, n), dtype=torch.int32, device=self.device)
-            for g in range(groups):
-                jb, je = K * g // groups, K * (g + 1) // groups      # same split as the kernel
+            if (K + groups - 1) // groups <= 10:
+                ws = torch.empty(groups * 4096, dtype=torch.uint8, device=self.device)
                 with torch.cuda.device(self.device):
-                    _lib.check(L.cv_sp_mask_keys(_ptr(nbr), n, K, jb, je, _ptr(keys), _stream(self.device)),
-                               "cv_sp_mask_keys")
-                m[g] = torch.argsort(keys).to(torch.int32)
+                    _lib.check(L.cv_sp_mask_perms(_ptr(nbr), n, K, groups, _ptr(m), _ptr(ws), ws.numel(),
+                                                  _stream(self.device)), "cv_sp_mask_perms")
+            else:       # wide groups: generic key + device sort
+                keys = torch.empty(n, dtype=torch.int64, device=self.device)
+                for g in range(groups):
+                    jb, je = K * g // groups, K * (g + 1) // groups      # same split as the kernel
+                    with torch.cuda.device(self.device):
+                        _lib.check(L.cv_sp_mask_keys(_ptr(nbr), n, K, jb, je, _ptr(keys), _stream(self.device)),
+                                   "cv_sp_mask_keys")
+                    m[g] = torch.argsort(keys).to(torch.int32)
             self._maps[key] = m
         return m
 

@@ -191,6 +191,12 @@ int cv_sp_conv_f32(const cv_conv_desc* desc, void* stream);
 int cv_sp_mask_keys(const int32_t* d_nbr, long long n, int K, int j_begin, int j_end, long long* d_keys,
                     void* stream);
 
+/* d_perm[groups][n]: for each contiguous group of the K kernel offsets, the rows ordered by the bit
+ * mask of their valid neighbours in that group (counting sort; at most 10 offsets per group).
+ * d_ws: groups * 4096 bytes.  Asynchronous. */
+int cv_sp_mask_perms(const int32_t* d_nbr, long long n, int K, int groups, int32_t* d_perm, void* d_ws,
+                     size_t ws_bytes, void* stream);
+
 /* y = relu?(x * scale + shift): MinkowskiBatchNorm (eval) / MinkowskiReLU on feature rows. */
 int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale,
                      const float* d_shift, int relu, float* d_y, int y_ld, void* stream);
