@@ -232,6 +232,128 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
         epilogue_store(a, acc[nb], rows_s + wave * 32, n0 + nb * 32 + (lane & 31), lane);
 }
 
+// ------------------------------------------------------------------ wave-independent flavour
+// For the big fine levels.  One wave owns 32 output rows (taken in mask-sorted order) and walks ONLY the
+// kernel offsets that at least one of its rows needs: no workgroup barriers, no LDS staging, no
+// waiting for neighbours' dead offsets.  MFMA operands come straight from L2 into registers:
+//   A: lane l holds row (l&31), channels 8q + 4(l>>5) + {0..3} as one float4 per 8-channel sub-step;
+//      sub-step (q, t) multiplies k = 8q + t (lanes 0-31) and k = 8q + 4 + t (lanes 32-63) - the
+//      k pairing inside a 32x32x2 MFMA is free as long as B uses the same rows;
+//   B: lane l loads NB consecutive floats of weight row k at columns NB*(l&31).. (one dwordxNB load),
+//      so MFMA block nb computes the output columns == nb (mod NB); the epilogue un-permutes.
+template <int NB>
+struct BVec;
+template <> struct BVec<1> { typedef float type; };
+template <> struct BVec<2> { typedef float2 type; };
+template <> struct BVec<3> { typedef float3 type; };
+template <> struct BVec<4> { typedef float4 type; };
+
+template <int NB>
+__device__ __forceinline__ float bcomp(const typename BVec<NB>::type& v, int i);
+template <> __device__ __forceinline__ float bcomp<1>(const float& v, int) { return v; }
+template <> __device__ __forceinline__ float bcomp<2>(const float2& v, int i) { return i ? v.y : v.x; }
+template <> __device__ __forceinline__ float bcomp<3>(const float3& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+template <> __device__ __forceinline__ float bcomp<4>(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+template <int NB>
+__global__ __launch_bounds__(THREADS) void conv_wave(ConvArgs a) {
+    typedef typename BVec<NB>::type bvec;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long blk = (long long)blockIdx.x * 4 + wave;            // 32-row block in processing order
+    if (blk * 32 >= a.n_out) return;
+    const int g = blockIdx.z;
+    const int n0 = blockIdx.y * (NB * 32);
+    const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)g * a.n_out : 0) : nullptr;
+    const long long t = blk * 32 + (lane & 31);
+    const int row = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
+    const int nj = a.j_end - a.j_begin;
+    const int j_lo = a.j_begin + (int)((long long)nj * g / a.splits);
+    const int j_hi = a.j_begin + (int)((long long)nj * (g + 1) / a.splits);
+    const int half = lane >> 5;
+    const int colb = n0 + NB * (lane & 31);                            // first of this lane's NB columns
+    const bool col_ok = colb + NB <= a.cout;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    // software pipeline over the live (offset, chunk) steps: the loads of step s+1 are in flight while
+    // the 16*NB MFMAs of step s run (operands are double-buffered in registers)
+    struct Operands { float4 av[4]; bvec bv[4][4]; };
+    auto next_live = [&](int j, int& src) {          // first offset >= j that some row of the block needs
+        for (; j < j_hi; ++j) {
+            src = row >= 0 ? (a.nbr ? a.nbr[(long long)row * a.K + j] : row) : -1;
+            if (__any(src >= 0)) break;
+        }
+        return j;
+    };
+    auto load = [&](Operands& o, int j, int src, int kc) {
+        const float* arow = a.in + (long long)(src >= 0 ? src : 0) * a.in_ld + half * 4 + kc;
+        const float* wrow = a.w + ((long long)j * a.cin + half * 4 + kc) * a.cout + colb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            o.av[q] = src >= 0 ? *reinterpret_cast<const float4*>(arow + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                if (col_ok) o.bv[q][tt] = *reinterpret_cast<const bvec*>(wrow + (long long)(8 * q + tt) * a.cout);
+                else {
+                    float tmp[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int i = 0; i < NB; ++i)
+                        if (colb + i < a.cout) tmp[i] = wrow[(long long)(8 * q + tt) * a.cout + i];
+                    o.bv[q][tt] = *reinterpret_cast<const bvec*>(tmp);
+                }
+            }
+    };
+    int src = -1;
+    int j = next_live(j_lo, src);
+    int kc = 0;
+    Operands cur, nxt;
+    if (j < j_hi) load(cur, j, src, 0);
+    while (j < j_hi) {
+        int j2 = j, src2 = src, kc2 = kc + KC;
+        if (kc2 >= a.cin) { kc2 = 0; j2 = next_live(j + 1, src2); }
+        if (j2 < j_hi) load(nxt, j2, src2, kc2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float ak[4] = {cur.av[q].x, cur.av[q].y, cur.av[q].z, cur.av[q].w};
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[tt], bcomp<NB>(cur.bv[q][tt], nb), acc[nb], 0, 0, 0);
+        }
+        cur = nxt;
+        j = j2; src = src2; kc = kc2;
+    }
+    // epilogue: accumulator register r of lane l is output row (r&3) + 8(r>>2) + 4(l>>5) of the block,
+    // MFMA block nb / lane column (l&31) is output column colb + nb
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int orow = __shfl(row, rr);
+        if (orow < 0) continue;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = colb + nb;
+            if (col >= a.cout) continue;
+            float v = acc[nb][r];
+            if (a.splits > 1) {
+                a.partial[((long long)g * a.n_out + orow) * a.cout + col] = v;
+            } else {
+                if (a.acc_in) v += a.acc_in[(long long)orow * a.acc_ld + col];
+                v = v * (a.scale ? a.scale[col] : 1.f) + (a.shift ? a.shift[col] : 0.f);
+                if (a.res) v += a.res[(long long)orow * a.res_ld + col];
+                if (a.relu) v = fmaxf(v, 0.f);
+                a.out[(long long)orow * a.out_ld + col] = v;
+            }
+        }
+    }
+}
+
 // sums the per-split partial tiles and applies the epilogue (scale/shift/residual/relu)
 __global__ __launch_bounds__(256) void conv_finish(ConvArgs a) {
     const long long total = a.n_out * (long long)a.cout;
@@ -392,6 +514,19 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
     return CV_OK;
 }
 
+template <int NB>
+int launch_wave(const ConvArgs& a, hipStream_t st) {
+    dim3 grid((unsigned)((a.n_out + 127) / 128), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)), (unsigned)a.splits);
+    conv_wave<NB><<<grid, THREADS, 0, st>>>(a);
+    CV_LAUNCH_CHECK();
+    if (a.splits > 1) {
+        const long long total = a.n_out * (long long)a.cout;
+        conv_finish<<<(unsigned)std::min<long long>((total + 255) / 256, 4096), 256, 0, st>>>(a);
+        CV_LAUNCH_CHECK();
+    }
+    return CV_OK;
+}
+
 int nb_for(int cout) { return cout <= 32 ? 1 : cout <= 64 ? 2 : cout <= 96 ? 3 : 4; }
 
 // Enough workgroups to fill 256 CUs a few times with short dependent chains: split the (offset,
@@ -445,6 +580,15 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         a.splits = d->perm_groups;
         a.perm_per_split = 1;
         a.partial = static_cast<float*>(d->ws);
+        if (d->flavour == 3 && d->in_ld % 4 == 0 && d->cout % nb_for(d->cout) == 0 &&
+            (reinterpret_cast<uintptr_t>(d->weight) & 15) == 0) {
+            switch (nb_for(d->cout)) {
+                case 1: return launch_wave<1>(a, st);
+                case 2: return launch_wave<2>(a, st);
+                case 3: return launch_wave<3>(a, st);
+                default: return launch_wave<4>(a, st);
+            }
+        }
     } else if (d->flavour == 0) {
         const int sp = pick_splits(d->n_out, d->cout, je - jb, d->cin, vec);
         const size_t need = sizeof(float) * (size_t)sp * (size_t)d->n_out * (size_t)d->cout;

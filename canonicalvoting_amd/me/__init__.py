@@ -301,11 +301,15 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
     return out
 
 
+MASKED_FLAVOUR = 0      # 0: workgroup-tiled kernel (default, slightly faster here), 3: wave-independent kernel
+
+
 def conv_forward_masked(x_feats, weight, nbr, perms, n_out, **epilogue):
     """k^3 conv with the kernel offsets split into G groups, each group processed with the rows in the
     order sorted by that group's neighbour mask (see sparse_conv.hip); one launch + one reduce.
     perms: int32 [G, n_out] from CoordinateManager.mask_perms."""
-    return conv_forward(x_feats, weight, nbr, n_out, row_perm=perms, perm_groups=perms.shape[0], **epilogue)
+    return conv_forward(x_feats, weight, nbr, n_out, row_perm=perms, perm_groups=perms.shape[0],
+                        flavour=epilogue.pop("flavour", MASKED_FLAVOUR), **epilogue)
 
 
 class _ConvFn(torch.autograd.Function):

@@ -172,7 +172,8 @@ typedef struct cv_conv_desc {
     int relu;
     float* out;             /* [n_out][out_ld] */
     int out_ld;
-    int flavour;            /* 0 auto (may split offsets over workgroups through ws), 1 never split */
+    int flavour;            /* 0 auto (may split offsets over workgroups through ws), 1 never split,
+                               3 wave-independent kernel (with perm_groups; big fine levels) */
     void* ws;               /* optional workspace, cv_sp_conv_workspace_bytes */
     size_t ws_bytes;
     const int32_t* row_perm;/* optional [n_out] processing order (rows with equal neighbour masks adjacent) */

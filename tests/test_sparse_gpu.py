@@ -106,9 +106,16 @@ def test_masked_two_pass_conv_matches_oracle(cuda, built_lib):
         perms = cm.mask_perms(3, 1, groups)
         for p in perms:
             assert sorted(p.cpu().tolist()) == list(range(len(coords)))
-        got = ME.conv_forward_masked(t(x), t(w), cm.kernel_map(3, 1), perms, len(coords), scale=t(scale),
-                                     shift=t(shift), residual=t(res), relu=True).cpu().numpy()
-        assert rel_err(got, ref) < 1e-5
+        for flavour in (0, 3):
+            got = ME.conv_forward_masked(t(x), t(w), cm.kernel_map(3, 1), perms, len(coords), scale=t(scale),
+                                         shift=t(shift), residual=t(res), relu=True, flavour=flavour).cpu().numpy()
+            assert rel_err(got, ref) < 1e-5, (groups, flavour)
+    for cout in (32, 64, 128, 256):            # every B-vector width of the wave kernel
+        w2 = (rng.normal(0, 1, (27, 64, cout)) / 40).astype(np.float32)
+        ref2 = so.conv(torch.from_numpy(x), torch.from_numpy(w2), so.kernel_map(coords, coords, 3, 1, 1)).numpy()
+        got2 = ME.conv_forward_masked(t(x), t(w2), cm.kernel_map(3, 1), cm.mask_perms(3, 1, 3), len(coords),
+                                      flavour=3).cpu().numpy()
+        assert rel_err(got2, ref2) < 1e-5, cout
     # explicit two-launch form: offset halves chained through acc_in
     perms = cm.mask_perms(3, 1, 2)
     part = ME.conv_forward(t(x), t(w), cm.kernel_map(3, 1), len(coords), flavour=1, row_perm=perms[0], j_begin=0, j_end=13)
