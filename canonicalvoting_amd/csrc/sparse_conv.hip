@@ -354,6 +354,115 @@ __global__ __launch_bounds__(THREADS) void conv_wave(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ backward: weight gradient
+// dW[j][ci][co] = sum_u x[nbr[u][j]][ci] * dy[u][co]   (the reduction runs over the output rows).
+// One wave owns (offset j, 32 input channels, NB*32 output channels, a contiguous range of rows) and
+// accumulates a 32 x NB*32 tile on the fp32 matrix cores: per MFMA step two rows u0,u1 are consumed -
+// A operand lane l = x[nbr[u_{l>>5}][j]][ci0 + (l&31)], B operand lane l = dy[u_{l>>5}][co0 + nb*32 + (l&31)],
+// both coalesced 128-byte row segments straight from L2.  Steps whose two rows both miss the neighbour
+// are skipped (wave-uniform branch).  Partial tiles go to ws[split][K][cin][cout]; wgrad_reduce sums them.
+template <int NB>
+__global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ x, int x_ld, int cin,
+                                                      const float* __restrict__ dy, int dy_ld, int cout,
+                                                      const int* __restrict__ nbr, int K, long long n_out,
+                                                      int row_splits, float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ci_blocks = cin / 32, co_blocks = (cout + NB * 32 - 1) / (NB * 32);
+    long long task = (long long)blockIdx.x * 4 + wave;
+    const long long ntasks = (long long)K * ci_blocks * co_blocks * row_splits;
+    if (task >= ntasks) return;
+    const int split = (int)(task % row_splits); task /= row_splits;
+    const int cob = (int)(task % co_blocks); task /= co_blocks;
+    const int cib = (int)(task % ci_blocks);
+    const int j = (int)(task / ci_blocks);
+    const long long r_lo = n_out * split / row_splits, r_hi = n_out * (split + 1) / row_splits;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int ci0 = cib * 32, co0 = cob * NB * 32;
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    for (long long u = r_lo; u < r_hi; u += 2) {
+        const long long mu = u + half;
+        int src = -1;
+        if (mu < r_hi) src = nbr ? nbr[mu * K + j] : (int)mu;
+        if (!__any(src >= 0)) continue;
+        const float av = src >= 0 ? x[(long long)src * x_ld + ci0 + l31] : 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = co0 + nb * 32 + l31;
+            const float bv = (src >= 0 && col < cout) ? dy[mu * dy_ld + col] : 0.f;
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
+        }
+    }
+    float* p = partial + ((long long)split * K + j) * cin * cout;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int col = co0 + nb * 32 + l31;
+        if (col >= cout) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            p[(long long)ci * cout + col] = acc[nb][r];
+        }
+    }
+}
+
+// generic (any Cin, e.g. the 3-channel stem): one thread per (j, ci, co), serial over rows of a split
+__global__ __launch_bounds__(256) void conv_wgrad_small(const float* __restrict__ x, int x_ld, int cin,
+                                                        const float* __restrict__ dy, int dy_ld, int cout,
+                                                        const int* __restrict__ nbr, int K, long long n_out,
+                                                        int row_splits, float* __restrict__ partial) {
+    const long long e = blockIdx.x * 256ll + threadIdx.x;
+    const long long per = (long long)K * cin * cout;
+    if (e >= per) return;
+    const int split = blockIdx.y;
+    const int co = (int)(e % cout), ci = (int)((e / cout) % cin), j = (int)(e / ((long long)cout * cin));
+    const long long r_lo = n_out * split / row_splits, r_hi = n_out * (split + 1) / row_splits;
+    float s = 0.f;
+    for (long long u = r_lo; u < r_hi; ++u) {
+        const int src = nbr ? nbr[u * K + j] : (int)u;
+        if (src >= 0) s += x[(long long)src * x_ld + ci] * dy[u * dy_ld + co];
+    }
+    partial[split * per + e] = s;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ partial, long long per, int splits,
+                                                    float* __restrict__ dw) {
+    const long long e = blockIdx.x * 256ll + threadIdx.x;
+    if (e >= per) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += partial[k * per + e];
+    dw[e] = s;
+}
+
+// transposed kernel map: nbr_t[i][j] = u with nbr[u][j] == i  (per offset the map is injective)
+__global__ __launch_bounds__(256) void transpose_map(const int* __restrict__ nbr, long long n_out, int K,
+                                                     int* __restrict__ nbr_t) {
+    const long long t = blockIdx.x * 256ll + threadIdx.x;
+    if (t >= n_out * K) return;
+    const int i = nbr[t];
+    if (i >= 0) nbr_t[(long long)i * K + (t % K)] = (int)(t / K);
+}
+
+// column sums (bias gradient): one block per 32 columns
+__global__ __launch_bounds__(256) void col_sum(const float* __restrict__ x, long long n, int c, int ld,
+                                               float* __restrict__ out) {
+    __shared__ float s[8][32];
+    const int col = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
+    float acc = 0.f;
+    if (col < c)
+        for (long long r = ry; r < n; r += 8) acc += x[r * ld + col];
+    s[ry][threadIdx.x & 31] = acc;
+    __syncthreads();
+    if (ry == 0 && col < c) {
+        float t = 0.f;
+        for (int k = 0; k < 8; ++k) t += s[k][threadIdx.x & 31];
+        out[col] = t;
+    }
+}
+
 // sums the per-split partial tiles and applies the epilogue (scale/shift/residual/relu)
 __global__ __launch_bounds__(256) void conv_finish(ConvArgs a) {
     const long long total = a.n_out * (long long)a.cout;
@@ -634,6 +743,62 @@ int cv_sp_mask_perms(const int32_t* d_nbr, long long n, int K, int groups, int32
     mp_scan<<<groups, MP_BINS, 0, st>>>(hist);
     CV_LAUNCH_CHECK();
     mp_scatter<<<grid, MP_THREADS, 0, st>>>(d_nbr, n, K, groups, hist, d_perm);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+// ---- training support -------------------------------------------------------------------------
+int cv_sp_transpose_map(const int32_t* d_nbr, long long n_out, int K, long long n_in, int32_t* d_nbr_t, void* stream) {
+    CV_REQUIRE(d_nbr && d_nbr_t && n_out > 0 && n_in > 0 && K > 0, CV_EINVAL, "bad transpose_map arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CV_HIP_CHECK(hipMemsetAsync(d_nbr_t, 0xff, sizeof(int) * (size_t)n_in * K, st));
+    transpose_map<<<(unsigned)((n_out * K + 255) / 256), 256, 0, st>>>(d_nbr, n_out, K, d_nbr_t);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+static int wgrad_splits(long long n_out) { return (int)std::min<long long>(64, std::max<long long>(1, n_out / 2048)); }
+
+size_t cv_sp_wgrad_workspace_bytes(long long n_out, int cin, int cout, int K) {
+    if (n_out <= 0 || cin <= 0 || cout <= 0 || K <= 0) return 0;
+    return 256 + sizeof(float) * (size_t)wgrad_splits(n_out) * (size_t)K * cin * cout;
+}
+
+int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy, int dy_ld, int cout,
+                         const int32_t* d_nbr, int K, long long n_out, float* d_dw, void* d_ws, size_t ws_bytes,
+                         void* stream) {
+    CV_REQUIRE(d_x && d_dy && d_dw && d_ws, CV_EINVAL, "null pointer argument");
+    CV_REQUIRE(n_out > 0 && cin > 0 && cout > 0 && K > 0 && x_ld >= cin && dy_ld >= cout, CV_EINVAL, "bad wgrad sizes");
+    CV_REQUIRE(d_nbr || K == 1, CV_EINVAL, "a kernel map is required unless K == 1");
+    CV_REQUIRE(ws_bytes >= cv_sp_wgrad_workspace_bytes(n_out, cin, cout, K), CV_ENOMEM, "workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int splits = wgrad_splits(n_out);
+    const long long per = (long long)K * cin * cout;
+    float* partial = static_cast<float*>(d_ws);
+    if (cin % 32 == 0) {
+        const int nb = nb_for(cout);
+        const long long tasks = (long long)K * (cin / 32) * ((cout + nb * 32 - 1) / (nb * 32)) * splits;
+        const unsigned grid = (unsigned)((tasks + 3) / 4);
+        switch (nb) {
+            case 1: conv_wgrad<1><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, splits, partial); break;
+            case 2: conv_wgrad<2><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, splits, partial); break;
+            case 3: conv_wgrad<3><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, splits, partial); break;
+            default: conv_wgrad<4><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, splits, partial); break;
+        }
+    } else {
+        dim3 grid((unsigned)((per + 255) / 256), (unsigned)splits);
+        conv_wgrad_small<<<grid, 256, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, splits, partial);
+    }
+    CV_LAUNCH_CHECK();
+    wgrad_reduce<<<(unsigned)((per + 255) / 256), 256, 0, st>>>(partial, per, splits, d_dw);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+int cv_sp_col_sum_f32(const float* d_x, long long n, int c, int ld, float* d_out, void* stream) {
+    CV_REQUIRE(d_x && d_out && n > 0 && c > 0 && ld >= c, CV_EINVAL, "bad col_sum arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    col_sum<<<(c + 31) / 32, 256, 0, st>>>(d_x, n, c, ld, d_out);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

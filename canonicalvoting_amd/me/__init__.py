@@ -312,16 +312,71 @@ def conv_forward_masked(x_feats, weight, nbr, perms, n_out, **epilogue):
                         flavour=epilogue.pop("flavour", MASKED_FLAVOUR), **epilogue)
 
 
+def transposed_map(nbr, n_in):
+    """nbr_t [n_in, K] with nbr_t[i][j] = u iff nbr[u][j] == i (cached on the map tensor)."""
+    hit = getattr(nbr, "_cv_transposed", None)
+    if hit is None or hit.shape[0] != n_in:
+        L = _lib.lib()
+        hit = torch.empty((n_in, nbr.shape[1]), dtype=torch.int32, device=nbr.device)
+        with torch.cuda.device(nbr.device):
+            _lib.check(L.cv_sp_transpose_map(_ptr(nbr), nbr.shape[0], nbr.shape[1], n_in, _ptr(hit),
+                                             _stream(nbr.device)), "cv_sp_transpose_map")
+        nbr._cv_transposed = hit
+    return hit
+
+
+def conv_wgrad(x_feats, grad_out, nbr, K):
+    """dW [K, Cin, Cout] = sum_u x[nbr[u][j]]^T dy[u]  (cv_sp_conv_wgrad_f32)."""
+    L = _lib.lib()
+    dev = x_feats.device
+    cin, cout, n_out = x_feats.shape[1], grad_out.shape[1], grad_out.shape[0]
+    dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
+    ws = _workspace(dev, int(L.cv_sp_wgrad_workspace_bytes(n_out, cin, cout, K)))
+    with torch.cuda.device(dev):
+        _lib.check(L.cv_sp_conv_wgrad_f32(_ptr(x_feats), x_feats.stride(0), cin, _ptr(grad_out), grad_out.stride(0),
+                                          cout, _ptr(nbr), K, n_out, _ptr(dw), _ptr(ws), ws.numel(), _stream(dev)),
+                   "cv_sp_conv_wgrad_f32")
+    return dw
+
+
+def col_sum(x):
+    L = _lib.lib()
+    out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(L.cv_sp_col_sum_f32(_ptr(x), x.shape[0], x.shape[1], x.stride(0), _ptr(out), _stream(x.device)),
+                   "cv_sp_col_sum_f32")
+    return out
+
+
 class _ConvFn(torch.autograd.Function):
+    """Sparse convolution with HIP forward, input-gradient (the same kernel on the transposed map with
+    transposed weights) and weight-gradient kernels."""
+
     @staticmethod
     def forward(ctx, feats, kernel, bias, nbr, n_out):
+        feats = feats.contiguous()
+        ctx.save_for_backward(feats, kernel, nbr if nbr is not None else torch.empty(0))
+        ctx.has_nbr = nbr is not None
+        ctx.has_bias = bias is not None
         shift = bias.reshape(-1).contiguous() if bias is not None else None
-        return conv_forward(feats.contiguous(), kernel, nbr, n_out, shift=shift)
+        return conv_forward(feats, kernel, nbr, n_out, shift=shift)
 
     @staticmethod
     def backward(ctx, grad):
-        raise NotImplementedError("sparse convolution backward (dgrad/wgrad) is not built yet: this round "
-                                  "ships the inference path (BASELINE config 2); see DESIGN.md")
+        feats, kernel, nbr = ctx.saved_tensors
+        nbr = nbr if ctx.has_nbr else None
+        grad = grad.contiguous()
+        k3 = kernel if kernel.dim() == 3 else kernel[None]
+        d_feats = d_kernel = d_bias = None
+        if ctx.needs_input_grad[0]:
+            w_t = k3.detach().permute(0, 2, 1).contiguous()
+            nbr_t = transposed_map(nbr, feats.shape[0]) if nbr is not None else None
+            d_feats = conv_forward(grad, w_t, nbr_t, feats.shape[0])
+        if ctx.needs_input_grad[1]:
+            d_kernel = conv_wgrad(feats, grad, nbr, k3.shape[0]).reshape(kernel.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            d_bias = col_sum(grad).reshape(1, -1)
+        return d_feats, d_kernel, d_bias, None, None
 
 
 class MinkowskiConvolutionBase(nn.Module):

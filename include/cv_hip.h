@@ -198,6 +198,18 @@ int cv_sp_mask_keys(const int32_t* d_nbr, long long n, int K, int j_begin, int j
 int cv_sp_mask_perms(const int32_t* d_nbr, long long n, int K, int groups, int32_t* d_perm, void* d_ws,
                      size_t ws_bytes, void* stream);
 
+/* Training support (train_joint.py:283 `loss.backward()` through the sparse convolutions).
+ * Input gradient = cv_sp_conv_f32 on the transposed map with the transposed weights:
+ *   d_nbr_t[n_in][K], nbr_t[i][j] = u iff nbr[u][j] == i.
+ * Weight gradient dW[j][ci][co] = sum_u x[nbr[u][j]][ci] * dy[u][co] (fp32 matrix cores, split over rows). */
+int cv_sp_transpose_map(const int32_t* d_nbr, long long n_out, int K, long long n_in, int32_t* d_nbr_t, void* stream);
+size_t cv_sp_wgrad_workspace_bytes(long long n_out, int cin, int cout, int K);
+int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy, int dy_ld, int cout,
+                         const int32_t* d_nbr, int K, long long n_out, float* d_dw, void* d_ws, size_t ws_bytes,
+                         void* stream);
+/* out[c] = sum over rows of x[:, c] (bias gradient). */
+int cv_sp_col_sum_f32(const float* d_x, long long n, int c, int ld, float* d_out, void* stream);
+
 /* y = relu?(x * scale + shift): MinkowskiBatchNorm (eval) / MinkowskiReLU on feature rows. */
 int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale,
                      const float* d_shift, int relu, float* d_y, int y_ld, void* stream);

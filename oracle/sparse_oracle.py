@@ -156,7 +156,9 @@ def _layer(x, sd, name, n, cm, ts, training):
 
 def minkunet34c_forward(sd, coords, feats, training=False, return_intermediates=False):
     """utils/minkunet.py:122-180 on (coords [N,4] int (b,x,y,z), feats [N,Cin]) -> [N, Cout]."""
-    sd = {k: (v.detach().to(torch.float32).cpu() if torch.is_tensor(v) else v) for k, v in sd.items()}
+    # tensors that require grad are used as they are so torch autograd can differentiate the oracle
+    sd = {k: (v if (torch.is_tensor(v) and v.requires_grad) else
+              (v.detach().to(torch.float32).cpu().clone() if torch.is_tensor(v) else v)) for k, v in sd.items()}
     cm = CoordinateManager(coords)
     x = torch.as_tensor(feats, dtype=torch.float32)
     inter = {}
