@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--cpu-scenes", type=int, default=1, help="scenes timed on the CPU oracle (0 = skip)")
     ap.add_argument("--stage", default="full", choices=["vote_decode", "full"],
                     help="full = MinkUNet34C forward + head + vote + decode + NMS (eval_joint.py path)")
+    ap.add_argument("--large", action="store_true",
+                    help="BASELINE config 5 shaped scenes: 9x3x9 m room, 40 boxes (use with --points 300000)")
     ap.add_argument("--teacher-forced", action="store_true",
                     help="feed the vote/decode stage with predictions synthesised from the labels "
                          "(realistic peak counts) instead of the random-weight network's output")
@@ -61,8 +63,9 @@ def parse():
 class ResidentScene:
     """One scene with everything the timed region touches already in HBM."""
 
-    def __init__(self, seed, n_points, dev):
-        sc = make_scene(seed, n_points=n_points, res=RES)
+    def __init__(self, seed, n_points, dev, large=False):
+        kw = dict(room=(9.0, 3.0, 9.0), n_boxes=40) if large else {}
+        sc = make_scene(seed, n_points=n_points, res=RES, **kw)
         xyz, scale, prob, cls = synth_predictions(sc)
         self.host = (sc, xyz, scale, prob, cls)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -143,7 +146,7 @@ def main():
         model = MinkUNet34C(3, 6 * 9 + 9 + 1).cuda().eval()        # eval_joint.py:151, random init
 
     # scene i of rank r uses seed r*1000 + i: every rank owns different scenes
-    scenes = [ResidentScene(seed, a.points, dev) for seed in cvd.scene_seeds(rank, a.scenes)]
+    scenes = [ResidentScene(seed, a.points, dev, a.large) for seed in cvd.scene_seeds(rank, a.scenes)]
     for w in range(a.warmup):
         run_step(model, hv, scenes[w % len(scenes)], teacher_forced=a.teacher_forced)
     torch.cuda.synchronize()
@@ -169,6 +172,12 @@ def main():
     vb = np.array([scenes[k % len(scenes)].vote_bytes for k in range(a.steps)], dtype=np.float64)
     achieved = float((vb / (vote_ms * 1e-3)).mean() / 1e9)
     s0 = scenes[0]
+    # HBM bytes of the vote kernel from the PMC counters are collected offline (rocprofv3 --pmc in its
+    # own passes, profiles/r1/vote_hbm_traffic.json) for the default 80k workload; null otherwise
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "r1", "vote_hbm_traffic.json")
+    if os.path.exists(tj) and a.points == N_POINTS and not a.large and a.algo in (0, 2):
+        traffic = json.load(open(tj))["hbm_bytes_per_launch"]
     out = {
         "metric": "scenes/sec (80k-pt synthetic scans)",
         "value": cvd.throughput(a.steps, world, dt),
@@ -194,7 +203,7 @@ def main():
                    "parallelism": "scene-parallel x%d, no collective" % world},
         "roofline": {"bound": "hbm", "kernel": "vote op (all launches of cv_hv_forward_f32)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_ms": float(vote_ms.mean()), "bytes_per_launch": float(vb.mean()),
                      "compulsory_bytes": float(s0.vote_bytes_floor), "v_in": s0.v_in},
         "detections_per_scene": n_det / a.steps,
