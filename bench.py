@@ -147,6 +147,11 @@ def main():
 
     # scene i of rank r uses seed r*1000 + i: every rank owns different scenes
     scenes = [ResidentScene(seed, a.points, dev, a.large) for seed in cvd.scene_seeds(rank, a.scenes)]
+    net_flops = None
+    if full:
+        with torch.no_grad():
+            x0 = ME.SparseTensor(scenes[0].feats_in, scenes[0].coords4, device=dev)
+            net_flops = model.forward_flops(x0)       # (pairs-based, dense-equivalent), untimed
     for w in range(a.warmup):
         run_step(model, hv, scenes[w % len(scenes)], teacher_forced=a.teacher_forced)
     torch.cuda.synchronize()
@@ -206,6 +211,13 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_ms": float(vote_ms.mean()), "bytes_per_launch": float(vb.mean()),
                      "compulsory_bytes": float(s0.vote_bytes_floor), "v_in": s0.v_in},
+        "roofline_conv": None if not full else {
+            "bound": "mfma", "kernel": "sparse MinkUNet34C forward (all conv launches + coordinate manager)",
+            "achieved": net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+            "frac": net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12 / 157.3,
+            "flops_per_forward": net_flops[0], "dense_equivalent_flops": net_flops[1],
+            "note": "fp32 matrix cores (v_mfma_f32_32x32x2_f32); achieved counts only existing "
+                    "(input,output) pairs, sum 2*P*Cin*Cout over the 63 conv layers"},
         "detections_per_scene": n_det / a.steps,
         "stage_ms": stage_ms,
     }

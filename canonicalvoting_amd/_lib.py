@@ -82,6 +82,7 @@ SIGNATURES = {
     "cv_sp_bn_fold_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_int, vp, vp, vp]),
     "cv_head_joint_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          vp, vp, vp, vp, vp]),
+    "cv_head_separate_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
     "cv_iou_obb": (ctypes.c_double, [c_float_p, c_float_p]),
     "cv_nms_obb": (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_double, c_i32_p]),
 }

@@ -608,6 +608,23 @@ __global__ __launch_bounds__(256) void head_joint(const float* __restrict__ f, l
     cls[i] = ao;
 }
 
+// eval_separate.py:170-181 / train_separate.py:247-249,362: 8-channel head of a per-category model:
+// xyz = f[0:3], scale = exp(f[3:6]), prob = softmax(f[6:8])[1]
+__global__ __launch_bounds__(256) void head_separate(const float* __restrict__ f, long long n, int ld,
+                                                     int log_scale, float* __restrict__ xyz,
+                                                     float* __restrict__ scale, float* __restrict__ prob) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= n) return;
+    const float* row = f + i * ld;
+    for (int d = 0; d < 3; ++d) {
+        xyz[i * 3 + d] = row[d];
+        scale[i * 3 + d] = log_scale ? expf(row[3 + d]) : row[3 + d];
+    }
+    const float mx = fmaxf(row[6], row[7]);
+    const float e0 = expf(row[6] - mx), e1 = expf(row[7] - mx);
+    prob[i] = e1 / (e0 + e1);
+}
+
 template <int NB>
 int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
     dim3 grid((unsigned)((a.n_out + TM - 1) / TM), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)),
@@ -829,6 +846,15 @@ int cv_head_joint_f32(const float* d_feats, long long n, int ld, int nclasses, i
     hipStream_t st = static_cast<hipStream_t>(stream);
     head_joint<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_feats, n, ld, nclasses, log_scale, d_xyz,
                                                            d_scale, d_prob, d_class);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+int cv_head_separate_f32(const float* d_feats, long long n, int ld, int log_scale, float* d_xyz, float* d_scale,
+                         float* d_prob, void* stream) {
+    CV_REQUIRE(d_feats && d_xyz && d_scale && d_prob && n > 0 && ld >= 8, CV_EINVAL, "bad head arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    head_separate<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_feats, n, ld, log_scale, d_xyz, d_scale, d_prob);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

@@ -134,6 +134,23 @@ class CoordinateManager:
             self._maps[key] = m
         return m
 
+    def up_perm(self, ts_coarse):
+        """row order of the fine set sorted by octant (the 8-bit mask of the transposed-conv map): tiles of
+        128 rows then share one kernel offset and the other seven are skipped."""
+        key = ("upperm", ts_coarse)
+        m = self._maps.get(key)
+        if m is None:
+            L = _lib.lib()
+            up = self.up_map(ts_coarse)
+            m = torch.empty((1, up.shape[0]), dtype=torch.int32, device=self.device)
+            ws = torch.empty(4096, dtype=torch.uint8, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(L.cv_sp_mask_perms(_ptr(up), up.shape[0], 8, 1, _ptr(m), _ptr(ws), ws.numel(),
+                                              _stream(self.device)), "cv_sp_mask_perms")
+            m = m[0]
+            self._maps[key] = m
+        return m
+
     def fused_plan(self):
         """Spatially sorted twin of this coordinate set for the fused network:
         (sorted manager with all levels, stem map sorted<-original rows, final map original<-sorted)."""

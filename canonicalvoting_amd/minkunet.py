@@ -126,7 +126,7 @@ class MinkUNetBase(ResNetBase):
         return hit[1]
 
     MASKED_MIN_ROWS = 16384     # levels with at least this many rows run the mask-sorted grouped conv
-    MASK_GROUPS = 3
+    MASK_GROUPS = 4
 
     def _conv3(self, x, kernel, nbr, perms, n, **ep):
         if perms is not None:
@@ -178,11 +178,50 @@ class MinkUNetBase(ResNetBase):
             lvl = 3 - i
             s, b = self._fold(getattr(self, bname))
             ME.conv_forward(out, getattr(self, cname).kernel, cm.up_map(ts_coarse), n[lvl], scale=s, shift=b,
-                            relu=True, out=cat[i][:, :up_c[i]])
+                            relu=True, out=cat[i][:, :up_c[i]], row_perm=cm.up_perm(ts_coarse))
             out = self._run_layer(getattr(self, "block%d" % (5 + i)), cat[i], cm.kernel_map(3, ts_coarse // 2),
                                   n[lvl], None, perms(ts_coarse // 2, n[lvl]))
         y = ME.conv_forward(out, self.final.kernel, out_map, n[0], shift=self.final.bias.reshape(-1))
         return x._like(y, 1)
+
+
+    def forward_flops(self, x):
+        """Algorithmic flops of one forward on x's coordinate set:
+        sum over conv layers of 2 * P * Cin * Cout with P = existing (input, output) pairs of the
+        layer's kernel map, counted exactly from the maps.  Also returns the dense-equivalent count
+        (every kernel offset present)."""
+        cm = x.coordinate_manager.fused_plan()[0]
+        n = [cm.num_rows(1 << i) for i in range(5)]
+        pairs = lambda m: int((m >= 0).sum().item())
+        p5, p3 = pairs(x.coordinate_manager.fused_plan()[1]), {1 << i: pairs(cm.kernel_map(3, 1 << i)) for i in range(5)}
+        pd = {1 << i: pairs(cm.kernel_map(2, 1 << i, 2)) for i in range(4)}
+        sparse = dense = 0
+
+        def add(p, full, cin, cout):
+            nonlocal sparse, dense
+            sparse += 2 * p * cin * cout
+            dense += 2 * full * cin * cout
+
+        def layer(seq, ts, lvl):
+            for blk in seq:
+                cin, cout = blk.conv1.in_channels, blk.conv1.out_channels
+                add(p3[ts], n[lvl] * 27, cin, cout)
+                add(p3[ts], n[lvl] * 27, cout, cout)
+                if blk.downsample is not None:
+                    add(n[lvl], n[lvl], cin, cout)
+
+        add(p5, n[0] * 125, self.conv0p1s1.in_channels, self.conv0p1s1.out_channels)
+        for i, (cname, _) in enumerate(_DOWN):
+            c = getattr(self, cname)
+            add(pd[1 << i], n[i + 1] * 8, c.in_channels, c.out_channels)
+            layer(getattr(self, "block%d" % (i + 1)), 2 << i, i + 1)
+        for i, (cname, _) in enumerate(_UP):
+            c = getattr(self, cname)
+            lvl = 3 - i
+            add(n[lvl], n[lvl], c.in_channels, c.out_channels)          # one parent per fine voxel
+            layer(getattr(self, "block%d" % (5 + i)), 8 >> i, lvl)
+        add(n[0], n[0], self.final.in_channels, self.final.out_channels)
+        return sparse, dense
 
 
 class MinkUNet14(MinkUNetBase):

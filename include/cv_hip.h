@@ -222,6 +222,10 @@ int cv_sp_bn_fold_f32(const float* d_gamma, const float* d_beta, const float* d_
 int cv_head_joint_f32(const float* d_feats, long long n, int ld, int nclasses, int log_scale, float* d_xyz,
                       float* d_scale, float* d_prob, int32_t* d_class, void* stream);
 
+/* 8-channel head of a per-category model (eval_separate.py:170-181): xyz, exp(scale), softmax(obj)[1]. */
+int cv_head_separate_f32(const float* d_feats, long long n, int ld, int log_scale, float* d_xyz, float* d_scale,
+                         float* d_prob, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -216,6 +216,13 @@ def head_joint_eval(out, nclasses=9, log_scale=True):
     return xyz, scale, prob, cls
 
 
+def head_separate_eval(out, log_scale=True):
+    """eval_separate.py:170-181"""
+    out = torch.as_tensor(out)
+    scale = torch.exp(out[:, 3:6]) if log_scale else out[:, 3:6]
+    return out[:, :3], scale, torch.softmax(out[:, 6:8], dim=-1)[:, 1]
+
+
 def make_state_dict(in_channels=3, out_channels=64, seed=0):
     """Random MinkUNet34C parameters with the reference's names and init
     (utils/resnet.py:109-116: kaiming-normal fan_out/relu on conv kernels, BN gamma 1 beta 0;

@@ -16,6 +16,6 @@ def run(n=8):
         torch.cuda.synchronize(); t=time.perf_counter()
         for _ in range(n): y=m(ME.SparseTensor(f,c4,device=dev))
         torch.cuda.synchronize(); return (time.perf_counter()-t)/n*1e3
-for groups,minrows in ((2,16384),(3,16384),(4,16384),(2,4096),(3,4096),(2,10**9)):
+for groups,minrows in ((3,16384),(3,4096),(3,2048),(4,16384),(3,10**9)):
     MinkUNetBase.MASK_GROUPS=groups; MinkUNetBase.MASKED_MIN_ROWS=minrows
     print('groups',groups,'minrows',minrows,'net ms %.3f'%run())

@@ -213,3 +213,31 @@ def test_detect_scene_end_to_end(cuda, built_lib):
                                          torch.from_numpy(feats).to(cuda), 0.03, thresh_high=5.0)
     assert y.F.shape == (8000, 64) and torch.isfinite(y.F).all()
     assert len(raw["verdict"]) == len(raw["cand_idx"])
+
+
+def test_separate_models_share_one_coordinate_manager(cuda, built_lib):
+    """eval_separate.py path: several 8-channel models on one SparseTensor; head vs oracle, maps built once"""
+    from canonicalvoting_amd.hough import HoughVoting
+    coords, feats = scene_coords(15, 3000, small=False)
+    sds = {c: so.make_state_dict(3, 8, seed=30 + i) for i, c in enumerate(("chair", "table"))}
+    models = {}
+    for c, sd in sds.items():
+        m = MinkUNet34C(3, 8)
+        m.load_state_dict(sd)
+        models[c] = m.cuda().eval()
+    x = ME.SparseTensor(torch.from_numpy(feats), torch.from_numpy(coords).int(), device="cuda")
+    with torch.no_grad():
+        y = {c: m(x).F for c, m in models.items()}
+    plan = x.coordinate_manager.fused_plan()
+    assert x.coordinate_manager.fused_plan() is plan                      # cached: built once for all models
+    for c in models:
+        ref = so.minkunet34c_forward(sds[c], coords, feats)
+        assert np.abs(y[c].cpu().numpy() - ref.numpy()).max() < 1e-4 * max(1.0, float(ref.abs().max()))
+        xyz, scale, prob = pipeline.head_separate(y[c])
+        rx, rs, rp = so.head_separate_eval(y[c].cpu())
+        np.testing.assert_allclose(xyz.cpu().numpy(), rx.numpy(), rtol=0, atol=0)
+        np.testing.assert_allclose(scale.cpu().numpy(), rs.numpy(), rtol=1e-5)
+        np.testing.assert_allclose(prob.cpu().numpy(), rp.numpy(), rtol=1e-5, atol=1e-6)
+    dets = pipeline.detect_scene_separate(models, HoughVoting(0.03, 120), torch.from_numpy(coords).int().to(cuda),
+                                          torch.from_numpy(feats).to(cuda), 0.03, thresh_high=3.0)
+    assert all(d[0] in models for d in dets)
