@@ -99,6 +99,12 @@ def lib():
                 "canonicalvoting_amd: HIP library %s not found. Build it with "
                 "`python -m canonicalvoting_amd.csrc.build` (hipcc, gfx950). There is no CPU "
                 "fallback for this op." % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP runtime; it has to be the one already resident when
+        # libcvhip.so resolves libamdhip64, otherwise two runtimes end up in the process and ours
+        # sees no device ("no ROCm-capable device is detected").
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
