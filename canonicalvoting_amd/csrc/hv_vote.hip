@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void hv_normalise(const float* __restrict__ g_
 // tiles algorithm
 // ---------------------------------------------------------------------------
 constexpr int TX = 32, TZ = 32, TCELLS = TX * TZ;
-constexpr int TW = 8;        // waves per workgroup
+constexpr int TW = 16;       // waves per workgroup
 constexpr int PQ = 64;       // surviving points per wave chunk
 constexpr int VQ = 128;      // vote queue entries per wave
 constexpr int MAX_R_TILES = 256;
