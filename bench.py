@@ -100,7 +100,7 @@ def run_step(model, hv, s, ev=None, teacher_forced=False):
         rec(2)
         grid_obj, grid_rot, grid_scale = hv(s.points, xyz, scale, prob)
         rec(3)
-    raw = decode.decode_boxes(grid_obj, grid_rot, grid_scale, s.points, xyz, prob, cls, RES, corner=s.corner)
+    raw = decode.decode_boxes(grid_obj, grid_rot, grid_scale, s.points, xyz, prob, cls, RES)
     rec(4)
     return decode.nms_per_class(raw["boxes"], raw["scores"], raw["classes"]), raw
 
@@ -152,6 +152,14 @@ def main():
         with torch.no_grad():
             x0 = ME.SparseTensor(scenes[0].feats_in, scenes[0].coords4, device=dev)
             net_flops = model.forward_flops(x0)       # (pairs-based, dense-equivalent), untimed
+            if not a.teacher_forced:
+                # the votes that are timed come from the network's predictions: count THEIR in-bounds
+                # votes for the algorithmic byte count (untimed)
+                for s in scenes:
+                    y = model(ME.SparseTensor(s.feats_in, s.coords4, device=dev))
+                    xyz, scale, prob, cls = pipeline.head_joint(y.F)
+                    s.v_in = hv_cuda.count_votes(s.points, xyz, scale, RES, NUM_ROTS, s.corner, s.dims)
+                    s.vote_bytes = 40 * a.points + 192 * s.v_in + 68 * s.cells
     for w in range(a.warmup):
         run_step(model, hv, scenes[w % len(scenes)], teacher_forced=a.teacher_forced)
     torch.cuda.synchronize()

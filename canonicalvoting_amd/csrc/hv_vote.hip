@@ -398,7 +398,7 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// VARIANT (ablations for profiling only): 0 full, 1 no LDS atomics, 2 no dense phase
+// VARIANT (ablations for profiling only): 0 full, 1 no LDS atomics, 2 no dense phase, 3 no record streaming
 template <int VARIANT>
 __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     int R, float res, F3 corner, I3 dims, const float2* __restrict__ tab,
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     int vq_len = 0;   // wave-uniform
 
     for (int s = y - 1; s <= y; ++s) {
-        if (s < 0 || s > Y - 2) continue;
+        if (s < 0 || s > Y - 2 || VARIANT == 3) continue;
         const int beg = ystart[s], end = ystart[s + 1];
         for (int base = beg + (wave * nparts + part) * 64; base < end; base += TW * nparts * 64) {
             const int idx = base + lane;
@@ -761,7 +761,7 @@ int check_common(const void* a, const void* b, const void* c, int64_t n, float r
 int64_t tiles_q_bound(int64_t n, int Y) { return (int64_t)Y + (2 * n + PART_RECORDS - 1) / PART_RECORDS; }
 
 int pick_algo(int algo, int64_t n, int num_rots, const int* dims) {
-    if (algo == 21 || algo == 22) return 2;   // profiling ablations of the tiles kernel
+    if (algo >= 21 && algo <= 23) return 2;   // profiling ablations of the tiles kernel
     if (algo == 1 || algo == 2) return algo;
     if (num_rots <= MAX_R_TILES && n < (1ll << 31)) return 2;
     return 1;
@@ -878,6 +878,7 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
                                                       d_grid_obj, d_grid_rot, d_grid_scale)
     if (algo == 21) CV_TILES_LAUNCH(1);
     else if (algo == 22) CV_TILES_LAUNCH(2);
+    else if (algo == 23) CV_TILES_LAUNCH(3);
     else CV_TILES_LAUNCH(0);
 #undef CV_TILES_LAUNCH
     CV_LAUNCH_CHECK();

@@ -43,6 +43,8 @@ def decode_boxes(grid_obj, grid_rot, grid_scale, scan_points, xyz_pred, prob_pre
     cls = class_pred.to(torch.int32).contiguous()
     n = scan_points.shape[0]
     if corner is None:
+        corner = hv_cuda.recent_corner(grid_obj)            # set by hv_cuda.forward (same points)
+    if corner is None:
         corner, _, _ = hv_cuda.grid_geometry(scan_points, float(res))
     dims = (ctypes.c_int * 3)(*grid_obj.shape)
     p = _lib.DecodeParams(float(thresh_high), float(thresh_low), float(valid_ratio),

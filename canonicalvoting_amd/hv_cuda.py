@@ -31,6 +31,20 @@ def set_algorithm(algo):
     _algo = int(algo)
 
 
+_recent_corners = {}
+
+
+def _remember_corner(grid_obj, mn):
+    if len(_recent_corners) > 16:
+        _recent_corners.clear()
+    _recent_corners[(grid_obj.data_ptr(), tuple(grid_obj.shape))] = [float(v) for v in mn]
+
+
+def recent_corner(grid_obj):
+    """grid origin of a grid_obj returned by forward() (None if it is not one of the last few)"""
+    return _recent_corners.get((grid_obj.data_ptr(), tuple(grid_obj.shape)))
+
+
 def _check_input(x, name):
     if not x.is_cuda:
         raise RuntimeError("%s must be a CUDA tensor" % name)
@@ -126,6 +140,8 @@ def forward(points, xyz_labels, scale_labels, obj_labels, res, num_rots, corners
                                        cdims, _ptr(grid_obj), _ptr(grid_rot), _ptr(grid_scale),
                                        _ptr(ws), ws.numel(), _algo, _stream(dev)),
                    "cv_hv_forward_f32")
+    # remember the grid origin of this grid so the decode that follows does not reduce the points again
+    _remember_corner(grid_obj, mn)
     return [grid_obj, grid_rot, grid_scale]
 
 
