@@ -383,17 +383,49 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    for (long long u = r_lo; u < r_hi; u += 2) {
-        const long long mu = u + half;
-        int src = -1;
-        if (mu < r_hi) src = nbr ? nbr[mu * K + j] : (int)mu;
-        if (!__any(src >= 0)) continue;
-        const float av = src >= 0 ? x[(long long)src * x_ld + ci0 + l31] : 0.f;
+    // 64 output rows per batch: every lane fetches one neighbour index (one coalesced-ish load instead
+    // of a dependent load per MFMA step), the rows that HAVE the neighbour are taken two at a time from
+    // the ballot mask (work proportional to the existing pairs), and the operand loads of up to STEPS
+    // MFMA steps are issued back to back before the matrix cores consume them.
+    constexpr int STEPS = 8;
+    for (long long u0 = r_lo; u0 < r_hi; u0 += 64) {
+        const long long mu = u0 + lane;
+        const int src_l = mu < r_hi ? (nbr ? nbr[mu * K + j] : (int)mu) : -1;
+        unsigned long long m = __ballot(src_l >= 0);
+        while (m) {
+            float av[STEPS], bv[STEPS][NB];
+            int nsteps = 0;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int col = co0 + nb * 32 + l31;
-            const float bv = (src >= 0 && col < cout) ? dy[mu * dy_ld + col] : 0.f;
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
+            for (int t = 0; t < STEPS; ++t) {
+                av[t] = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bv[t][nb] = 0.f;
+                if (m) {                                                   // wave-uniform
+                    const int ra = __ffsll((unsigned long long)m) - 1;
+                    m &= m - 1;
+                    int rb = -1;
+                    if (m) { rb = __ffsll((unsigned long long)m) - 1; m &= m - 1; }
+                    const int r = half ? rb : ra;                          // this half-wave's row of the pair
+                    // shuffle with ALL lanes active: ds_bpermute returns 0 for an inactive source lane
+                    const int got = __shfl(src_l, r >= 0 ? r : 0);
+                    const int src = r >= 0 ? got : -1;
+                    if (src >= 0) {
+                        av[t] = x[(long long)src * x_ld + ci0 + l31];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const int col = co0 + nb * 32 + l31;
+                            if (col < cout) bv[t][nb] = dy[(u0 + r) * dy_ld + col];
+                        }
+                    }
+                    nsteps = t + 1;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < STEPS; ++t)
+                if (t < nsteps)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t][nb], acc[nb], 0, 0, 0);
         }
     }
     float* p = partial + ((long long)split * K + j) * cin * cout;
@@ -446,20 +478,22 @@ __global__ __launch_bounds__(256) void transpose_map(const int* __restrict__ nbr
     if (i >= 0) nbr_t[(long long)i * K + (t % K)] = (int)(t / K);
 }
 
-// column sums (bias gradient): one block per 32 columns
+// column sums (bias gradient): blocks over (32 columns, row chunk); partial sums meet through fp32
+// atomics on the c output words (out is pre-zeroed)
 __global__ __launch_bounds__(256) void col_sum(const float* __restrict__ x, long long n, int c, int ld,
                                                float* __restrict__ out) {
     __shared__ float s[8][32];
     const int col = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
+    const long long r_lo = n * blockIdx.y / gridDim.y, r_hi = n * (blockIdx.y + 1) / gridDim.y;
     float acc = 0.f;
     if (col < c)
-        for (long long r = ry; r < n; r += 8) acc += x[r * ld + col];
+        for (long long r = r_lo + ry; r < r_hi; r += 8) acc += x[r * ld + col];
     s[ry][threadIdx.x & 31] = acc;
     __syncthreads();
     if (ry == 0 && col < c) {
         float t = 0.f;
         for (int k = 0; k < 8; ++k) t += s[k][threadIdx.x & 31];
-        out[col] = t;
+        unsafeAtomicAdd(&out[col], t);
     }
 }
 
@@ -861,7 +895,9 @@ int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy,
 int cv_sp_col_sum_f32(const float* d_x, long long n, int c, int ld, float* d_out, void* stream) {
     CV_REQUIRE(d_x && d_out && n > 0 && c > 0 && ld >= c, CV_EINVAL, "bad col_sum arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    col_sum<<<(c + 31) / 32, 256, 0, st>>>(d_x, n, c, ld, d_out);
+    CV_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(float) * c, st));
+    dim3 grid((unsigned)((c + 31) / 32), (unsigned)std::min<long long>(256, (n + 1023) / 1024));
+    col_sum<<<grid, 256, 0, st>>>(d_x, n, c, ld, d_out);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

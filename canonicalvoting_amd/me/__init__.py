@@ -302,6 +302,12 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
     w = w.contiguous()
     if out is None:
         out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    if (AUTO_MASK_GROUPS > 1 and row_perm is None and perm_groups == 0 and flavour == 0 and nbr is not None
+            and K == 27 and n_out >= AUTO_MASK_MIN_ROWS and cin % 32 == 0 and j_begin == 0 and j_end == 0
+            and acc_in is None):
+        # generic (module-by-module / training) path: mask-sorted offset groups, orders cached on the map
+        row_perm = map_mask_perms(nbr, AUTO_MASK_GROUPS)
+        perm_groups = AUTO_MASK_GROUPS
     ws = None
     if perm_groups > 1:
         ws = _workspace(dev, 4 * perm_groups * n_out * cout + 256)
@@ -316,6 +322,25 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
     return out
+
+
+AUTO_MASK_GROUPS = 4        # conv_forward applies mask-sorted groups to big 3x3x3 maps on its own (0 = off)
+AUTO_MASK_MIN_ROWS = 16384
+
+
+def map_mask_perms(nbr, groups):
+    """[groups, n] processing orders of a kernel map (see CoordinateManager.mask_perms), cached on the map."""
+    hit = getattr(nbr, "_cv_mask_perms", None)
+    if hit is None or hit.shape[0] != groups:
+        L = _lib.lib()
+        n, K = nbr.shape
+        hit = torch.empty((groups, n), dtype=torch.int32, device=nbr.device)
+        ws = torch.empty(groups * 4096, dtype=torch.uint8, device=nbr.device)
+        with torch.cuda.device(nbr.device):
+            _lib.check(L.cv_sp_mask_perms(_ptr(nbr), n, K, groups, _ptr(hit), _ptr(ws), ws.numel(),
+                                          _stream(nbr.device)), "cv_sp_mask_perms")
+        nbr._cv_mask_perms = hit
+    return hit
 
 
 MASKED_FLAVOUR = 0      # 0: workgroup-tiled kernel (default, slightly faster here), 3: wave-independent kernel
