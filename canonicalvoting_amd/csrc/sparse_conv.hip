@@ -367,7 +367,7 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
                                                       const int* __restrict__ nbr, int K, long long n_out,
                                                       int row_splits, float* __restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ci_blocks = cin / 32, co_blocks = (cout + NB * 32 - 1) / (NB * 32);
+    const int ci_blocks = (cin + 31) / 32, co_blocks = (cout + NB * 32 - 1) / (NB * 32);
     long long task = (long long)blockIdx.x * 4 + wave;
     const long long ntasks = (long long)K * ci_blocks * co_blocks * row_splits;
     if (task >= ntasks) return;
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
                     const int got = __shfl(src_l, r >= 0 ? r : 0);
                     const int src = r >= 0 ? got : -1;
                     if (src >= 0) {
-                        av[t] = x[(long long)src * x_ld + ci0 + l31];
+                        if (ci0 + l31 < cin) av[t] = x[(long long)src * x_ld + ci0 + l31];
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
                             const int col = co0 + nb * 32 + l31;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            p[(long long)ci * cout + col] = acc[nb][r];
+            if (ci < cin) p[(long long)ci * cout + col] = acc[nb][r];
         }
     }
 }
@@ -872,9 +872,9 @@ int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy,
     const int splits = wgrad_splits(n_out);
     const long long per = (long long)K * cin * cout;
     float* partial = static_cast<float*>(d_ws);
-    if (cin % 32 == 0) {
+    if (true) {     // any Cin: channels beyond Cin are zero lanes of the 32-wide A operand (stem: Cin = 3)
         const int nb = nb_for(cout);
-        const long long tasks = (long long)K * (cin / 32) * ((cout + nb * 32 - 1) / (nb * 32)) * splits;
+        const long long tasks = (long long)K * ((cin + 31) / 32) * ((cout + nb * 32 - 1) / (nb * 32)) * splits;
         const unsigned grid = (unsigned)((tasks + 3) / 4);
         switch (nb) {
             case 1: conv_wgrad<1><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, splits, partial); break;
