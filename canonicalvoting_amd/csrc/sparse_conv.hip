@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int KC = 32;            // K chunk (channels per staging step)
 constexpr int TM = 128;           // rows per workgroup
-constexpr int A_LD = TM + 4;      // A staged k-major: A_s[k][row]
+constexpr int A_LD = TM + 2;      // A staged k-major: A_s[k][row]; +2 makes the 4-row-strided staging stores 2-way (free) instead of 4-way conflicted
 constexpr int THREADS = 256;
 
 struct ConvArgs {
