@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""train_joint.py counterpart (reference train_joint.py:191-291) on synthetic scans: Adam, step LR decay,
+batch of 3 scenes, masked MSE(xyz) + MSE(log scale) + CE(class); one process per GPU with DDP when launched
+through torch.distributed.run (the reference is single-GPU).
+
+    python scripts/train_joint.py [--epochs 2] [--scenes 6] [--points 20000] [--batch 3]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from canonicalvoting_amd import dist as cvd  # noqa: E402
+from canonicalvoting_amd import train  # noqa: E402
+from canonicalvoting_amd.data import SyntheticScanDataset, collate_fn  # noqa: E402
+from canonicalvoting_amd.minkunet import MinkUNet34C  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--epochs", type=int, default=2)
+    ap.add_argument("--scenes", type=int, default=6)
+    ap.add_argument("--points", type=int, default=20000)
+    ap.add_argument("--batch", type=int, default=3)
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--save", default=None)
+    a = ap.parse_args()
+    world, rank, local = cvd.world()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cvd.init("nccl", dev)
+    torch.manual_seed(0)
+    model = MinkUNet34C(3, 6 * 9 + 9 + 1).to(dev)
+    net = train.make_ddp(model, dev) if world > 1 else model
+    opt = train.make_optimizer(model, lr=a.lr)
+    ds = SyntheticScanDataset(a.scenes, a.points, seed0=1000 * rank)          # every rank owns its scenes
+    loader = torch.utils.data.DataLoader(ds, batch_size=a.batch, shuffle=True, collate_fn=collate_fn, drop_last=True)
+    for epoch in range(a.epochs):
+        train.adjust_learning_rate(opt, epoch, a.lr)
+        net.train()
+        t0, tot, n = time.perf_counter(), 0.0, 0
+        for _, coords, feats, xyz, scale, cls in loader:
+            loss, _ = train.train_step(net, opt, coords.to(dev), feats.to(dev) * 2.0 - 1.0, xyz.to(dev),
+                                       scale.to(dev), cls.to(dev))
+            tot += float(loss)
+            n += 1
+        if rank == 0:
+            print("epoch %d  loss %.4f  %.1f s" % (epoch, tot / max(n, 1), time.perf_counter() - t0), flush=True)
+    if a.save and rank == 0:
+        torch.save(model.state_dict(), a.save)                                # train_joint.py:290-291
+    cvd.finalize()
+
+
+if __name__ == "__main__":
+    main()

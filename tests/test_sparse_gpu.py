@@ -241,3 +241,25 @@ def test_separate_models_share_one_coordinate_manager(cuda, built_lib):
     dets = pipeline.detect_scene_separate(models, HoughVoting(0.03, 120), torch.from_numpy(coords).int().to(cuda),
                                           torch.from_numpy(feats).to(cuda), 0.03, thresh_high=3.0)
     assert all(d[0] in models for d in dets)
+
+
+def test_eval_script_pipeline_recovers_planted_boxes(cuda, built_lib):
+    """eval_joint.py-shaped loop on synthetic scans with teacher-forced predictions: network forward runs,
+    vote + decode + NMS recover the planted boxes and the mAP evaluator scores them (end-to-end sanity of
+    vote -> decode -> NMS -> calc_map against ground truth that none of those stages has seen)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "cv_eval_joint", os.path.join(os.path.dirname(os.path.dirname(__file__)), "scripts", "eval_joint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from canonicalvoting_amd.data import SyntheticScanDataset, collate_fn
+    ds = SyntheticScanDataset(2, 40000, seed0=200)
+    batch = collate_fn([ds[0], ds[1]])
+    assert batch[1].shape == (80000, 4) and batch[1].dtype == torch.int32 and int(batch[1][:, 0].max()) == 1
+    assert batch[5].dtype == torch.int64 and len(ds.gt_lines(0)) == 12
+    torch.manual_seed(0)
+    model = MinkUNet34C(3, 64).cuda().eval()
+    res = mod.evaluate(model, ds, teacher=True)
+    assert res[0.25]["mAP"] > 0.85 and res[0.25]["AR"] > 0.85, res
+    assert res[0.5]["mAP"] > 0.5, res
