@@ -265,3 +265,35 @@ class MinkUNet34B(MinkUNet34):
 
 class MinkUNet34C(MinkUNet34):
     PLANES = (32, 64, 128, 256, 256, 128, 96, 96)
+
+
+# ----------------------------------------------------------------------------------------------- checkpoints
+def convert_kernel_offset_order(state_dict, from_order="z_fastest", to_order="x_fastest"):
+    """Checkpoint interchange.  Parameter names and shapes are MinkowskiEngine's, so the
+    authors' ``joint.pth`` / ``separate/*.pth`` load with ``load_state_dict`` as they are.  The one thing that
+    cannot be verified without a real checkpoint is the order in which ME enumerates the K^3 kernel offsets
+    along dim 0 of every ``kernel``; this engine runs the first spatial axis fastest (``x_fastest``).  If ME's
+    order turns out to be the last axis fastest, this permutes every [K^3, Cin, Cout] kernel accordingly
+    (k = round(K^(1/3)); 1x1 kernels are untouched).  Returns a new dict."""
+    if from_order == to_order:
+        return dict(state_dict)
+    out = {}
+    for name, w in state_dict.items():
+        if name.endswith(".kernel") and w.dim() == 3:
+            K = w.shape[0]
+            k = int(round(K ** (1.0 / 3.0)))
+            assert k ** 3 == K, name
+            # index j = a + k*(b + k*c) with (a,b,c) = (x,y,z) for x_fastest and (z,y,x) for z_fastest
+            w = w.reshape(k, k, k, *w.shape[1:]).permute(2, 1, 0, 3, 4).reshape(K, *w.shape[1:]).contiguous()
+        out[name] = w
+    return out
+
+
+def load_reference_checkpoint(model, path, offset_order="x_fastest", key=None):
+    """torch.load + (optional) kernel-offset permutation + load_state_dict.  ``key`` selects a sub-dict such
+    as ``model_state_dict`` of the SUN RGB-D checkpoint (sunrgbd/brnetcanon.py:167)."""
+    sd = torch.load(path, map_location="cpu")
+    if key is not None:
+        sd = sd[key]
+    model.load_state_dict(convert_kernel_offset_order(sd, offset_order, "x_fastest"))
+    return model

@@ -132,3 +132,24 @@ def test_unet_forward_runs_and_keeps_row_order():
     torch.testing.assert_close(y2, y[perm], rtol=1e-3, atol=1e-3)      # output row i <-> input row i
     xyz, scale, prob, cls = so.head_joint_eval(y)
     assert xyz.shape == (600, 3) and (scale > 0).all() and cls.max() < 9 and (prob <= 1).all()
+
+
+def test_kernel_offset_order_conversion_is_the_axis_swap():
+    """convert_kernel_offset_order(z_fastest -> x_fastest): conv with converted weights under the x-fastest
+    offset table == conv with the original weights under a z-fastest table; applying it twice is identity."""
+    from canonicalvoting_amd.minkunet import convert_kernel_offset_order
+    rng = np.random.default_rng(0)
+    coords, _ = random_active(rng)
+    x = torch.randn(len(coords), 4)
+    w = torch.randn(27, 4, 5)
+    sd = {"a.kernel": w, "b.kernel": torch.randn(4, 5), "c.bn.weight": torch.ones(3)}
+    conv = convert_kernel_offset_order(sd)
+    assert torch.equal(convert_kernel_offset_order(conv)["a.kernel"], w) and torch.equal(conv["b.kernel"], sd["b.kernel"])
+    y_x = so.conv(x, conv["a.kernel"], so.kernel_map(coords, coords, 3, 1, 1))
+    old = so.KERNEL_OFFSET_ORDER
+    try:
+        so.KERNEL_OFFSET_ORDER = "z_fastest"
+        y_z = so.conv(x, w, so.kernel_map(coords, coords, 3, 1, 1))
+    finally:
+        so.KERNEL_OFFSET_ORDER = old
+    torch.testing.assert_close(y_x, y_z, rtol=1e-5, atol=1e-5)
