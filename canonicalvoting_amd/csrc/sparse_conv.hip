@@ -91,7 +91,10 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
     const int n0 = blockIdx.y * (NB * 32);
 
     if (tid < TM) {
-        const long long t = (long long)blockIdx.x * TM + tid;
+        // mask-sorted orders end with the rows that need the most offsets: start those tiles FIRST so the
+        // light tiles fill the tail of the launch (longest-processing-time-first)
+        const long long tile_id = a.row_perm ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
+        const long long t = tile_id * TM + tid;
         const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)blockIdx.z * a.n_out : 0) : nullptr;
         rows_s[tid] = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
     }
@@ -588,6 +591,9 @@ __device__ __forceinline__ int group_mask(const int* __restrict__ nbr, long long
     int m = 0;
     for (int j = jb; j < je; ++j)
         if (nbr[row * K + j] >= 0) m |= 1 << (j - jb);
+    // sort key: rows with equal masks adjacent, and (when it fits the 1024 bins) ordered by the NUMBER of
+    // offsets they need, so the tiles at the end of the order are the most expensive ones
+    if (je - jb <= 7) m |= __popc(m) << 7;
     return m;
 }
 
