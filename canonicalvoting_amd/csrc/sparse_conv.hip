@@ -672,6 +672,94 @@ __global__ void bn_fold(const float* gamma, const float* beta, const float* mean
     shift[k] = beta[k] - mean[k] * s + (bias ? bias[k] * s : 0.f);
 }
 
+// ------------------------------------------------------------------ BatchNorm in training mode
+// MinkowskiBatchNorm = nn.BatchNorm1d over the [N, C] feature rows (utils/minkunet.py:56): batch mean and
+// biased variance per channel.  Two-level column reduction: blocks of (32 channels x 8 row lanes) over row
+// chunks accumulate in double, a second tiny kernel combines the chunks.
+constexpr int BN_CHUNKS = 256;
+
+template <int MODE>   // 0: sum x, sum x^2      1: sum dy', sum dy'*xhat   (dy' = dy masked by y > 0 if y given)
+__global__ __launch_bounds__(256) void bn_col_reduce(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     const float* __restrict__ y, long long n, int c, int ld,
+                                                     const float* __restrict__ mean, const float* __restrict__ var,
+                                                     float eps, double* __restrict__ partial) {
+    __shared__ double s0[8][32], s1[8][32];
+    const int col = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
+    const long long r_lo = n * blockIdx.y / gridDim.y, r_hi = n * (blockIdx.y + 1) / gridDim.y;
+    double a0 = 0.0, a1 = 0.0;
+    if (col < c) {
+        float mu = 0.f, istd = 0.f;
+        if (MODE == 1) { mu = mean[col]; istd = 1.0f / sqrtf(var[col] + eps); }
+        for (long long r = r_lo + ry; r < r_hi; r += 8) {
+            const float xv = x[r * ld + col];
+            if (MODE == 0) { a0 += (double)xv; a1 += (double)xv * (double)xv; }
+            else {
+                float g = dy[r * ld + col];
+                if (y && !(y[r * ld + col] > 0.f)) g = 0.f;
+                a0 += (double)g;
+                a1 += (double)(g * ((xv - mu) * istd));
+            }
+        }
+    }
+    s0[ry][threadIdx.x & 31] = a0; s1[ry][threadIdx.x & 31] = a1;
+    __syncthreads();
+    if (ry == 0 && col < c) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int k = 0; k < 8; ++k) { t0 += s0[k][threadIdx.x & 31]; t1 += s1[k][threadIdx.x & 31]; }
+        partial[((long long)blockIdx.y * c + col) * 2 + 0] = t0;
+        partial[((long long)blockIdx.y * c + col) * 2 + 1] = t1;
+    }
+}
+
+// MODE 0: mean/var from the partials, running statistics update (momentum, unbiased variance), folded
+// scale/shift for the apply pass.  MODE 1: out0 = sum dy' (d beta), out1 = sum dy'*xhat (d gamma).
+template <int MODE>
+__global__ void bn_col_finish(const double* __restrict__ partial, int chunks, long long n, int c, float* out0,
+                              float* out1, float* running_mean, float* running_var, float momentum,
+                              const float* gamma, const float* beta, float eps, float* scale, float* shift) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= c) return;
+    double t0 = 0.0, t1 = 0.0;
+    for (int q = 0; q < chunks; ++q) { t0 += partial[((long long)q * c + k) * 2]; t1 += partial[((long long)q * c + k) * 2 + 1]; }
+    if (MODE == 0) {
+        const double mu = t0 / (double)n;
+        double v = t1 / (double)n - mu * mu;
+        if (v < 0.0) v = 0.0;
+        out0[k] = (float)mu;
+        out1[k] = (float)v;
+        if (running_mean) {
+            const double unb = n > 1 ? v * (double)n / (double)(n - 1) : v;
+            running_mean[k] = (1.f - momentum) * running_mean[k] + momentum * (float)mu;
+            running_var[k] = (1.f - momentum) * running_var[k] + momentum * (float)unb;
+        }
+        const float sc = gamma[k] / sqrtf((float)v + eps);
+        scale[k] = sc;
+        shift[k] = beta[k] - (float)mu * sc;
+    } else {
+        out0[k] = (float)t0;
+        out1[k] = (float)t1;
+    }
+}
+
+// dx = gamma*istd * (dy' - sum_dy/n - xhat * sum_dy_xhat/n)
+__global__ __launch_bounds__(256) void bn_backward_apply(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ y, long long n, int c, int ld,
+                                                         const float* __restrict__ mean, const float* __restrict__ var,
+                                                         float eps, const float* __restrict__ gamma,
+                                                         const float* __restrict__ sum_dy,
+                                                         const float* __restrict__ sum_dy_xhat, float* __restrict__ dx) {
+    const float inv_n = 1.0f / (float)n;
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < n * c; t += (long long)gridDim.x * 256) {
+        const long long r = t / c;
+        const int k = (int)(t - r * c);
+        const float istd = 1.0f / sqrtf(var[k] + eps);
+        const float xh = (x[r * ld + k] - mean[k]) * istd;
+        float g = dy[r * ld + k];
+        if (y && !(y[r * ld + k] > 0.f)) g = 0.f;
+        dx[r * ld + k] = gamma[k] * istd * (g - sum_dy[k] * inv_n - xh * sum_dy_xhat[k] * inv_n);
+    }
+}
+
 // eval_joint.py:173-190: per point, head select by argmax class (class 9 -> head 0), exp(scale),
 // prob = max softmax over the 9 object classes, class = argmax over the 9 object logits.
 __global__ __launch_bounds__(256) void head_joint(const float* __restrict__ f, long long n, int ld,
@@ -923,6 +1011,53 @@ int cv_sp_bn_fold_f32(const float* d_gamma, const float* d_beta, const float* d_
     CV_REQUIRE(d_gamma && d_beta && d_mean && d_var && d_scale && d_shift && c > 0, CV_EINVAL, "bad bn_fold arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     bn_fold<<<(c + 127) / 128, 128, 0, st>>>(d_gamma, d_beta, d_mean, d_var, d_bias, eps, c, d_scale, d_shift);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+size_t cv_sp_bn_workspace_bytes(int c) { return c > 0 ? 256 + sizeof(double) * 2 * (size_t)BN_CHUNKS * c : 0; }
+
+static int bn_chunks(long long n) { return (int)std::min<long long>(BN_CHUNKS, std::max<long long>(1, n / 512)); }
+
+// Training-mode BatchNorm statistics of x[n][c]: d_mean, d_var (biased), running statistics updated in place
+// (may be NULL), and the folded d_scale/d_shift for cv_sp_affine_f32 (y = x*scale + shift).
+int cv_sp_bn_stats_f32(const float* d_x, long long n, int c, int ld, const float* d_gamma, const float* d_beta,
+                       float eps, float momentum, float* d_running_mean, float* d_running_var, float* d_mean,
+                       float* d_var, float* d_scale, float* d_shift, void* d_ws, size_t ws_bytes, void* stream) {
+    CV_REQUIRE(d_x && d_gamma && d_beta && d_mean && d_var && d_scale && d_shift && d_ws, CV_EINVAL, "null pointer argument");
+    CV_REQUIRE(n > 0 && c > 0 && ld >= c, CV_EINVAL, "bad bn sizes");
+    CV_REQUIRE(ws_bytes >= cv_sp_bn_workspace_bytes(c), CV_ENOMEM, "workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* partial = static_cast<double*>(d_ws);
+    const int chunks = bn_chunks(n);
+    dim3 grid((unsigned)((c + 31) / 32), (unsigned)chunks);
+    bn_col_reduce<0><<<grid, 256, 0, st>>>(d_x, nullptr, nullptr, n, c, ld, nullptr, nullptr, eps, partial);
+    CV_LAUNCH_CHECK();
+    bn_col_finish<0><<<(c + 127) / 128, 128, 0, st>>>(partial, chunks, n, c, d_mean, d_var, d_running_mean,
+                                                     d_running_var, momentum, d_gamma, d_beta, eps, d_scale, d_shift);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+// Backward of training-mode BatchNorm (optionally with the ReLU that follows it: pass its output d_y, else NULL):
+// d_dgamma, d_dbeta, d_dx.
+int cv_sp_bn_backward_f32(const float* d_x, const float* d_dy, const float* d_y, long long n, int c, int ld,
+                          const float* d_mean, const float* d_var, float eps, const float* d_gamma, float* d_dgamma,
+                          float* d_dbeta, float* d_dx, void* d_ws, size_t ws_bytes, void* stream) {
+    CV_REQUIRE(d_x && d_dy && d_mean && d_var && d_gamma && d_dgamma && d_dbeta && d_dx && d_ws, CV_EINVAL, "null pointer argument");
+    CV_REQUIRE(n > 0 && c > 0 && ld >= c, CV_EINVAL, "bad bn sizes");
+    CV_REQUIRE(ws_bytes >= cv_sp_bn_workspace_bytes(c), CV_ENOMEM, "workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* partial = static_cast<double*>(d_ws);
+    const int chunks = bn_chunks(n);
+    dim3 grid((unsigned)((c + 31) / 32), (unsigned)chunks);
+    bn_col_reduce<1><<<grid, 256, 0, st>>>(d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, partial);
+    CV_LAUNCH_CHECK();
+    bn_col_finish<1><<<(c + 127) / 128, 128, 0, st>>>(partial, chunks, n, c, d_dbeta, d_dgamma, nullptr, nullptr, 0.f,
+                                                     nullptr, nullptr, eps, nullptr, nullptr);
+    CV_LAUNCH_CHECK();
+    bn_backward_apply<<<(unsigned)std::min<long long>((n * c + 255) / 256, 8192), 256, 0, st>>>(
+        d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dbeta, d_dgamma, d_dx);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

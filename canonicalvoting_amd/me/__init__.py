@@ -501,6 +501,44 @@ def affine_forward(F, scale, shift, relu, out=None):
     return out
 
 
+class _BNTrainFn(torch.autograd.Function):
+    """Training-mode BatchNorm1d over feature rows on the HIP kernels (statistics, apply, backward)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps):
+        L = _lib.lib()
+        x = x.contiguous()
+        n, c = x.shape
+        dev = x.device
+        stats = torch.empty((4, c), dtype=torch.float32, device=dev)          # mean, var, scale, shift
+        ws = torch.empty(int(L.cv_sp_bn_workspace_bytes(c)), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.cv_sp_bn_stats_f32(_ptr(x), n, c, x.stride(0), _ptr(gamma), _ptr(beta), float(eps),
+                                            float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(stats[0]),
+                                            _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(ws), ws.numel(),
+                                            _stream(dev)), "cv_sp_bn_stats_f32")
+        y = affine_forward(x, stats[2], stats[3], False)
+        ctx.save_for_backward(x, gamma, stats)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, gamma, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c = x.shape
+        dev = x.device
+        dx = torch.empty_like(x)
+        dg = torch.empty((2, c), dtype=torch.float32, device=dev)
+        ws = torch.empty(int(L.cv_sp_bn_workspace_bytes(c)), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.cv_sp_bn_backward_f32(_ptr(x), _ptr(dy), None, n, c, x.stride(0), _ptr(stats[0]), _ptr(stats[1]),
+                                               ctx.eps, _ptr(gamma), _ptr(dg[0]), _ptr(dg[1]), _ptr(dx), _ptr(ws),
+                                               ws.numel(), _stream(dev)), "cv_sp_bn_backward_f32")
+        return dx, dg[0], dg[1], None, None, None, None
+
+
 class MinkowskiBatchNorm(nn.Module):
     """``nn.BatchNorm1d`` over the feature rows; sub-module name ``bn`` (utils/resnet.py:115-116)."""
 
@@ -510,8 +548,14 @@ class MinkowskiBatchNorm(nn.Module):
                                  track_running_stats=track_running_stats)
 
     def forward(self, x):
+        bn = self.bn
+        if self.training and bn.affine and bn.track_running_stats and bn.momentum is not None and x.F.shape[0] > 1:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+            return x._like(_BNTrainFn.apply(x.F, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                            bn.momentum, bn.eps))
         if self.training or torch.is_grad_enabled() and x.F.requires_grad:
-            return x._like(self.bn(x.F))          # batch statistics: torch's own kernel for now
+            return x._like(self.bn(x.F))          # unusual configurations / eval with autograd: torch's kernel
         scale, shift = bn_affine(self.bn)
         return x._like(affine_forward(x.F.contiguous(), scale, shift, False))
 

@@ -126,3 +126,36 @@ def test_train_step_reduces_loss_and_matches_reference_loss(cuda, built_lib):
     hist = [float(train.train_step(model, opt, coords, feats, xyz, scale, cls)[0]) for _ in range(6)]
     assert all(np.isfinite(hist)) and hist[-1] < hist[0]
     assert train.adjust_learning_rate(opt, 85) == pytest.approx(1e-4) and opt.param_groups[0]["lr"] == pytest.approx(1e-4)
+
+
+def test_batchnorm_training_kernels_match_torch(cuda, built_lib):
+    """MinkowskiBatchNorm in train mode (HIP statistics / apply / backward) vs torch.nn.BatchNorm1d on the CPU,
+    including the running-statistics update and a strided feature view."""
+    rng = np.random.default_rng(0)
+    for n, c in ((5000, 96), (333, 32), (20000, 256)):
+        x = (rng.normal(0.3, 2.0, (n, c)) * rng.uniform(0.5, 2, c)).astype(np.float32)
+        gy = rng.normal(0, 1, (n, c)).astype(np.float32)
+        ref = torch.nn.BatchNorm1d(c)
+        with torch.no_grad():
+            ref.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)))
+            ref.bias.copy_(torch.from_numpy(rng.normal(0, 0.2, c).astype(np.float32)))
+        mine = ME.MinkowskiBatchNorm(c)
+        mine.bn.load_state_dict(ref.state_dict())
+        mine = mine.cuda().train()
+        ref.train()
+        xr = torch.from_numpy(x).requires_grad_(True)
+        yr = ref(xr)
+        (yr * torch.from_numpy(gy)).sum().backward()
+        xd = torch.from_numpy(x).to(cuda).requires_grad_(True)
+        coords = torch.cat([torch.zeros((n, 1), dtype=torch.int32), torch.arange(n, dtype=torch.int32)[:, None],
+                            torch.zeros((n, 2), dtype=torch.int32)], 1)
+        st = ME.SparseTensor(xd, coords, device="cuda")
+        yd = mine(st).F
+        (yd * torch.from_numpy(gy).to(cuda)).sum().backward()
+        assert rel_err(yd.detach().cpu().numpy(), yr.detach().numpy()) < 1e-5
+        assert rel_err(xd.grad.cpu().numpy(), xr.grad.numpy()) < 1e-4
+        assert rel_err(mine.bn.weight.grad.cpu().numpy(), ref.weight.grad.numpy()) < 1e-4
+        assert rel_err(mine.bn.bias.grad.cpu().numpy(), ref.bias.grad.numpy()) < 1e-4
+        assert rel_err(mine.bn.running_mean.cpu().numpy(), ref.running_mean.numpy()) < 1e-5
+        assert rel_err(mine.bn.running_var.cpu().numpy(), ref.running_var.numpy()) < 1e-5
+        assert int(mine.bn.num_batches_tracked) == 1
