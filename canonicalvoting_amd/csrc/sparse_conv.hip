@@ -364,20 +364,33 @@ __global__ __launch_bounds__(THREADS) void conv_wave(ConvArgs a) {
 // A operand lane l = x[nbr[u_{l>>5}][j]][ci0 + (l&31)], B operand lane l = dy[u_{l>>5}][co0 + nb*32 + (l&31)],
 // both coalesced 128-byte row segments straight from L2.  Steps whose two rows both miss the neighbour
 // are skipped (wave-uniform branch).  Partial tiles go to ws[split][K][cin][cout]; wgrad_reduce sums them.
+// Launch plan of one weight-gradient call: offsets in heavy-first order (the centre offset pairs every row, face
+// neighbours most, corners few - longest tasks are dispatched first) and a per-offset number of row splits so the
+// tasks carry comparable numbers of pairs.  Partial tile of (offset j, split s) = slot first[j] + s.
+constexpr int WG_MAX_K = 128;
+struct WgradPlan {
+    short order[WG_MAX_K];        // rank -> offset
+    short nsplit[WG_MAX_K];       // by offset
+    int first[WG_MAX_K];          // by offset: first partial slot
+    int task_end[WG_MAX_K];       // by rank: cumulative (splits x ci blocks x co blocks)
+};
+
 template <int NB>
 __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ x, int x_ld, int cin,
                                                       const float* __restrict__ dy, int dy_ld, int cout,
                                                       const int* __restrict__ nbr, int K, long long n_out,
-                                                      int row_splits, float* __restrict__ partial) {
+                                                      WgradPlan plan, float* __restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ci_blocks = (cin + 31) / 32, co_blocks = (cout + NB * 32 - 1) / (NB * 32);
-    long long task = (long long)blockIdx.x * 4 + wave;
-    const long long ntasks = (long long)K * ci_blocks * co_blocks * row_splits;
-    if (task >= ntasks) return;
-    const int split = (int)(task % row_splits); task /= row_splits;
-    const int cob = (int)(task % co_blocks); task /= co_blocks;
-    const int cib = (int)(task % ci_blocks);
-    const int j = (int)(task / ci_blocks);
+    int task = blockIdx.x * 4 + wave;
+    if (task >= plan.task_end[K - 1]) return;
+    int rank = 0;
+    while (task >= plan.task_end[rank]) ++rank;                            // wave-uniform, K <= 128 entries
+    if (rank) task -= plan.task_end[rank - 1];
+    const int j = plan.order[rank], row_splits = plan.nsplit[j];
+    const int split = task % row_splits; task /= row_splits;
+    const int cob = task % co_blocks;
+    const int cib = task / co_blocks;
     const long long r_lo = n_out * split / row_splits, r_hi = n_out * (split + 1) / row_splits;
     const int half = lane >> 5, l31 = lane & 31;
     const int ci0 = cib * 32, co0 = cob * NB * 32;
@@ -386,14 +399,19 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    // 64 output rows per batch: every lane fetches one neighbour index (one coalesced-ish load instead
-    // of a dependent load per MFMA step), the rows that HAVE the neighbour are taken two at a time from
-    // the ballot mask (work proportional to the existing pairs), and the operand loads of up to STEPS
-    // MFMA steps are issued back to back before the matrix cores consume them.
+    // 64 output rows per batch: every lane fetches one neighbour index (the next batch's is already in
+    // flight), the rows that HAVE the neighbour are taken two at a time from the ballot mask (work
+    // proportional to the existing pairs), and the operand loads of up to STEPS MFMA steps are issued back
+    // to back before the matrix cores consume them.
     constexpr int STEPS = 8;
-    for (long long u0 = r_lo; u0 < r_hi; u0 += 64) {
+    auto fetch = [&](long long u0) -> int {
         const long long mu = u0 + lane;
-        const int src_l = mu < r_hi ? (nbr ? nbr[mu * K + j] : (int)mu) : -1;
+        return mu < r_hi ? (nbr ? nbr[mu * K + j] : (int)mu) : -1;
+    };
+    int src_next = fetch(r_lo);
+    for (long long u0 = r_lo; u0 < r_hi; u0 += 64) {
+        const int src_l = src_next;
+        src_next = fetch(u0 + 64);
         unsigned long long m = __ballot(src_l >= 0);
         while (m) {
             float av[STEPS], bv[STEPS][NB];
@@ -431,7 +449,7 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
                         acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t][nb], acc[nb], 0, 0, 0);
         }
     }
-    float* p = partial + ((long long)split * K + j) * cin * cout;
+    float* p = partial + (long long)(plan.first[j] + split) * cin * cout;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int col = co0 + nb * 32 + l31;
@@ -444,31 +462,16 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
     }
 }
 
-// generic (any Cin, e.g. the 3-channel stem): one thread per (j, ci, co), serial over rows of a split
-__global__ __launch_bounds__(256) void conv_wgrad_small(const float* __restrict__ x, int x_ld, int cin,
-                                                        const float* __restrict__ dy, int dy_ld, int cout,
-                                                        const int* __restrict__ nbr, int K, long long n_out,
-                                                        int row_splits, float* __restrict__ partial) {
-    const long long e = blockIdx.x * 256ll + threadIdx.x;
-    const long long per = (long long)K * cin * cout;
-    if (e >= per) return;
-    const int split = blockIdx.y;
-    const int co = (int)(e % cout), ci = (int)((e / cout) % cin), j = (int)(e / ((long long)cout * cin));
-    const long long r_lo = n_out * split / row_splits, r_hi = n_out * (split + 1) / row_splits;
-    float s = 0.f;
-    for (long long u = r_lo; u < r_hi; ++u) {
-        const int src = nbr ? nbr[u * K + j] : (int)u;
-        if (src >= 0) s += x[(long long)src * x_ld + ci] * dy[u * dy_ld + co];
-    }
-    partial[split * per + e] = s;
-}
-
-__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ partial, long long per, int splits,
+// dW[j] = sum of offset j's partial tiles, in slot order (deterministic)
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ partial, int cc, int K, WgradPlan plan,
                                                     float* __restrict__ dw) {
     const long long e = blockIdx.x * 256ll + threadIdx.x;
-    if (e >= per) return;
+    if (e >= (long long)cc * K) return;
+    const int j = (int)(e / cc);
+    const int w = (int)(e - (long long)j * cc);
+    const float* p = partial + (long long)plan.first[j] * cc + w;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += partial[k * per + e];
+    for (int k = 0; k < plan.nsplit[j]; ++k) s += p[(long long)k * cc];
     dw[e] = s;
 }
 
@@ -650,13 +653,15 @@ __global__ __launch_bounds__(MP_THREADS) void mp_scatter(const int* __restrict__
 // y = x*scale + shift (+relu)   (MinkowskiBatchNorm in eval mode, MinkowskiReLU)
 __global__ __launch_bounds__(256) void affine_rows(const float* __restrict__ x, long long n, int c,
                                                    int x_ld, const float* __restrict__ scale,
-                                                   const float* __restrict__ shift, int relu,
+                                                   const float* __restrict__ shift,
+                                                   const float* __restrict__ residual, int res_ld, int relu,
                                                    float* __restrict__ y, int y_ld) {
     for (long long t = blockIdx.x * 256ll + threadIdx.x; t < n * c; t += (long long)gridDim.x * 256) {
         const long long r = t / c;
         const int k = (int)(t - r * c);
         float v = x[r * x_ld + k];
         if (scale) v = v * scale[k] + (shift ? shift[k] : 0.f);
+        if (residual) v += residual[r * res_ld + k];
         if (relu) v = fmaxf(v, 0.f);
         y[r * y_ld + k] = v;
     }
@@ -747,7 +752,8 @@ __global__ __launch_bounds__(256) void bn_backward_apply(const float* __restrict
                                                          const float* __restrict__ mean, const float* __restrict__ var,
                                                          float eps, const float* __restrict__ gamma,
                                                          const float* __restrict__ sum_dy,
-                                                         const float* __restrict__ sum_dy_xhat, float* __restrict__ dx) {
+                                                         const float* __restrict__ sum_dy_xhat, float* __restrict__ dx,
+                                                         float* __restrict__ dres) {
     const float inv_n = 1.0f / (float)n;
     for (long long t = blockIdx.x * 256ll + threadIdx.x; t < n * c; t += (long long)gridDim.x * 256) {
         const long long r = t / c;
@@ -757,6 +763,7 @@ __global__ __launch_bounds__(256) void bn_backward_apply(const float* __restrict
         float g = dy[r * ld + k];
         if (y && !(y[r * ld + k] > 0.f)) g = 0.f;
         dx[r * ld + k] = gamma[k] * istd * (g - sum_dy[k] * inv_n - xh * sum_dy_xhat[k] * inv_n);
+        if (dres) dres[r * ld + k] = g;
     }
 }
 
@@ -938,6 +945,8 @@ int cv_sp_mask_perms(const int32_t* d_nbr, long long n, int K, int groups, int32
     return CV_OK;
 }
 
+constexpr long long WGRAD_TARGET_TASKS = 8192;
+
 // ---- training support -------------------------------------------------------------------------
 int cv_sp_transpose_map(const int32_t* d_nbr, long long n_out, int K, long long n_in, int32_t* d_nbr_t, void* stream) {
     CV_REQUIRE(d_nbr && d_nbr_t && n_out > 0 && n_in > 0 && K > 0, CV_EINVAL, "bad transpose_map arguments");
@@ -948,11 +957,52 @@ int cv_sp_transpose_map(const int32_t* d_nbr, long long n_out, int K, long long 
     return CV_OK;
 }
 
-static int wgrad_splits(long long n_out) { return (int)std::min<long long>(64, std::max<long long>(1, n_out / 2048)); }
+// Row splits of the weight-gradient reduction: enough (offset, ci block, co block, split) wave tasks to fill
+// 256 CUs x 4 SIMDs a few times over even on the coarse levels (a few thousand rows), at least 128 rows each;
+// the centre offset of an odd cubic kernel and its face neighbours hold the most pairs: they go first and get
+// twice the splits (measured: profiles/wgrad_micro.py).
+static long long wgrad_plan(long long n_out, int cin, int cout, int K, WgradPlan* plan) {
+    const int nb = nb_for(cout);
+    const int tiles = ((cin + 31) / 32) * ((cout + nb * 32 - 1) / (nb * 32));
+    int ks = 1;
+    while (ks * ks * ks < K) ++ks;
+    const bool cubic = ks * ks * ks == K && (ks & 1) && ks > 1;
+    int mult[WG_MAX_K], cls[WG_MAX_K], msum = 0;
+    for (int j = 0; j < K; ++j) {
+        int d1 = 3;
+        if (cubic) {
+            const int h = ks / 2;
+            d1 = std::abs(j % ks - h) + std::abs(j / ks % ks - h) + std::abs(j / (ks * ks) - h);
+        }
+        mult[j] = cubic && d1 <= 1 ? 2 : 1;
+        cls[j] = !cubic ? 2 : d1 == 0 ? 0 : d1 == 1 ? 1 : 2;
+        msum += mult[j];
+    }
+    const long long want = (WGRAD_TARGET_TASKS + (long long)msum * tiles - 1) / ((long long)msum * tiles);
+    const long long ws_cap = (256ll << 20) / ((long long)msum * cin * cout * 4);      // partial tiles <= 256 MB
+    const long long base = std::max<long long>(1, std::min({64ll, want, n_out / 256, ws_cap}));
+    long long slots = 0;
+    int rank = 0, tasks = 0;
+    for (int pass = 0; pass < 3; ++pass)
+        for (int j = 0; j < K; ++j) {
+            if (cls[j] != pass) continue;
+            const int sp = (int)std::max<long long>(1, std::min<long long>(base * mult[j], n_out / 128));
+            if (plan) {
+                plan->order[rank] = (short)j;
+                plan->nsplit[j] = (short)sp;
+                plan->first[j] = (int)slots;
+                tasks += sp * tiles;
+                plan->task_end[rank] = tasks;
+            }
+            slots += sp;
+            ++rank;
+        }
+    return slots;
+}
 
 size_t cv_sp_wgrad_workspace_bytes(long long n_out, int cin, int cout, int K) {
-    if (n_out <= 0 || cin <= 0 || cout <= 0 || K <= 0) return 0;
-    return 256 + sizeof(float) * (size_t)wgrad_splits(n_out) * (size_t)K * cin * cout;
+    if (n_out <= 0 || cin <= 0 || cout <= 0 || K <= 0 || K > WG_MAX_K) return 0;
+    return 256 + sizeof(float) * (size_t)wgrad_plan(n_out, cin, cout, K, nullptr) * (size_t)cin * cout;
 }
 
 int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy, int dy_ld, int cout,
@@ -960,28 +1010,24 @@ int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy,
                          void* stream) {
     CV_REQUIRE(d_x && d_dy && d_dw && d_ws, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(n_out > 0 && cin > 0 && cout > 0 && K > 0 && x_ld >= cin && dy_ld >= cout, CV_EINVAL, "bad wgrad sizes");
+    CV_REQUIRE(K <= WG_MAX_K, CV_EINVAL, "kernel volume above 128 is not supported");
     CV_REQUIRE(d_nbr || K == 1, CV_EINVAL, "a kernel map is required unless K == 1");
     CV_REQUIRE(ws_bytes >= cv_sp_wgrad_workspace_bytes(n_out, cin, cout, K), CV_ENOMEM, "workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int splits = wgrad_splits(n_out);
-    const long long per = (long long)K * cin * cout;
+    WgradPlan plan = {};
+    wgrad_plan(n_out, cin, cout, K, &plan);
     float* partial = static_cast<float*>(d_ws);
-    if (true) {     // any Cin: channels beyond Cin are zero lanes of the 32-wide A operand (stem: Cin = 3)
-        const int nb = nb_for(cout);
-        const long long tasks = (long long)K * ((cin + 31) / 32) * ((cout + nb * 32 - 1) / (nb * 32)) * splits;
-        const unsigned grid = (unsigned)((tasks + 3) / 4);
-        switch (nb) {
-            case 1: conv_wgrad<1><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, splits, partial); break;
-            case 2: conv_wgrad<2><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, splits, partial); break;
-            case 3: conv_wgrad<3><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, splits, partial); break;
-            default: conv_wgrad<4><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, splits, partial); break;
-        }
-    } else {
-        dim3 grid((unsigned)((per + 255) / 256), (unsigned)splits);
-        conv_wgrad_small<<<grid, 256, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, splits, partial);
+    // any Cin: channels beyond Cin are zero lanes of the 32-wide A operand (stem: Cin = 3)
+    const unsigned grid = (unsigned)((plan.task_end[K - 1] + 3) / 4);
+    switch (nb_for(cout)) {
+        case 1: conv_wgrad<1><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); break;
+        case 2: conv_wgrad<2><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); break;
+        case 3: conv_wgrad<3><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); break;
+        default: conv_wgrad<4><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); break;
     }
     CV_LAUNCH_CHECK();
-    wgrad_reduce<<<(unsigned)((per + 255) / 256), 256, 0, st>>>(partial, per, splits, d_dw);
+    const long long per = (long long)K * cin * cout;
+    wgrad_reduce<<<(unsigned)((per + 255) / 256), 256, 0, st>>>(partial, cin * cout, K, plan, d_dw);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }
@@ -997,11 +1043,13 @@ int cv_sp_col_sum_f32(const float* d_x, long long n, int c, int ld, float* d_out
 }
 
 int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale,
-                     const float* d_shift, int relu, float* d_y, int y_ld, void* stream) {
+                     const float* d_shift, const float* d_residual, int res_ld, int relu, float* d_y, int y_ld,
+                     void* stream) {
     CV_REQUIRE(d_x && d_y && n > 0 && c > 0 && x_ld >= c && y_ld >= c, CV_EINVAL, "bad affine arguments");
+    CV_REQUIRE(!d_residual || res_ld >= c, CV_EINVAL, "bad residual stride");
     hipStream_t st = static_cast<hipStream_t>(stream);
     affine_rows<<<(unsigned)std::min<long long>((n * c + 255) / 256, 8192), 256, 0, st>>>(
-        d_x, n, c, x_ld, d_scale, d_shift, relu, d_y, y_ld);
+        d_x, n, c, x_ld, d_scale, d_shift, d_residual, res_ld, relu, d_y, y_ld);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }
@@ -1040,10 +1088,11 @@ int cv_sp_bn_stats_f32(const float* d_x, long long n, int c, int ld, const float
 }
 
 // Backward of training-mode BatchNorm (optionally with the ReLU that follows it: pass its output d_y, else NULL):
-// d_dgamma, d_dbeta, d_dx.
+// d_dgamma, d_dbeta, d_dx, and optionally d_dres = the ReLU-masked incoming gradient (gradient of a residual
+// that was added between the normalisation and the ReLU).
 int cv_sp_bn_backward_f32(const float* d_x, const float* d_dy, const float* d_y, long long n, int c, int ld,
                           const float* d_mean, const float* d_var, float eps, const float* d_gamma, float* d_dgamma,
-                          float* d_dbeta, float* d_dx, void* d_ws, size_t ws_bytes, void* stream) {
+                          float* d_dbeta, float* d_dx, float* d_dres, void* d_ws, size_t ws_bytes, void* stream) {
     CV_REQUIRE(d_x && d_dy && d_mean && d_var && d_gamma && d_dgamma && d_dbeta && d_dx && d_ws, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(n > 0 && c > 0 && ld >= c, CV_EINVAL, "bad bn sizes");
     CV_REQUIRE(ws_bytes >= cv_sp_bn_workspace_bytes(c), CV_ENOMEM, "workspace too small");
@@ -1057,7 +1106,7 @@ int cv_sp_bn_backward_f32(const float* d_x, const float* d_dy, const float* d_y,
                                                      nullptr, nullptr, eps, nullptr, nullptr);
     CV_LAUNCH_CHECK();
     bn_backward_apply<<<(unsigned)std::min<long long>((n * c + 255) / 256, 8192), 256, 0, st>>>(
-        d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dbeta, d_dgamma, d_dx);
+        d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dbeta, d_dgamma, d_dx, d_dres);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

@@ -489,23 +489,25 @@ def bn_affine(bn):
     return out[0], out[1]
 
 
-def affine_forward(F, scale, shift, relu, out=None):
+def affine_forward(F, scale, shift, relu, out=None, residual=None):
     L = _lib.lib()
     dev = F.device
     if out is None:
         out = torch.empty_like(F)
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_affine_f32(_ptr(F), F.shape[0], F.shape[1], F.stride(0), _ptr(scale), _ptr(shift),
+                                      _ptr(residual), residual.stride(0) if residual is not None else 0,
                                       1 if relu else 0, _ptr(out), out.stride(0), _stream(dev)),
                    "cv_sp_affine_f32")
     return out
 
 
 class _BNTrainFn(torch.autograd.Function):
-    """Training-mode BatchNorm1d over feature rows on the HIP kernels (statistics, apply, backward)."""
+    """Training-mode BatchNorm1d over feature rows on the HIP kernels (statistics, apply, backward), with the
+    residual add and ReLU that follow it in BasicBlock folded into the same passes."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu):
         L = _lib.lib()
         x = x.contiguous()
         n, c = x.shape
@@ -517,26 +519,33 @@ class _BNTrainFn(torch.autograd.Function):
                                             float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(stats[0]),
                                             _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(ws), ws.numel(),
                                             _stream(dev)), "cv_sp_bn_stats_f32")
-        y = affine_forward(x, stats[2], stats[3], False)
-        ctx.save_for_backward(x, gamma, stats)
+        if residual is not None and residual.stride(1) != 1:
+            residual = residual.contiguous()
+        y = affine_forward(x, stats[2], stats[3], relu, residual=residual)
+        ctx.save_for_backward(x, gamma, stats, y if relu else None)
         ctx.eps = float(eps)
+        ctx.has_res = residual is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
         L = _lib.lib()
-        x, gamma, stats = ctx.saved_tensors
+        x, gamma, stats, y = ctx.saved_tensors
         dy = dy.contiguous()
         n, c = x.shape
         dev = x.device
         dx = torch.empty_like(x)
         dg = torch.empty((2, c), dtype=torch.float32, device=dev)
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[7]:
+            dres = torch.empty_like(x) if y is not None else dy
         ws = torch.empty(int(L.cv_sp_bn_workspace_bytes(c)), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(L.cv_sp_bn_backward_f32(_ptr(x), _ptr(dy), None, n, c, x.stride(0), _ptr(stats[0]), _ptr(stats[1]),
-                                               ctx.eps, _ptr(gamma), _ptr(dg[0]), _ptr(dg[1]), _ptr(dx), _ptr(ws),
-                                               ws.numel(), _stream(dev)), "cv_sp_bn_backward_f32")
-        return dx, dg[0], dg[1], None, None, None, None
+            _lib.check(L.cv_sp_bn_backward_f32(_ptr(x), _ptr(dy), _ptr(y), n, c, x.stride(0), _ptr(stats[0]),
+                                               _ptr(stats[1]), ctx.eps, _ptr(gamma), _ptr(dg[0]), _ptr(dg[1]),
+                                               _ptr(dx), _ptr(dres) if y is not None else None, _ptr(ws), ws.numel(),
+                                               _stream(dev)), "cv_sp_bn_backward_f32")
+        return dx, dg[0], dg[1], None, None, None, None, dres, None
 
 
 class MinkowskiBatchNorm(nn.Module):
@@ -548,16 +557,24 @@ class MinkowskiBatchNorm(nn.Module):
                                  track_running_stats=track_running_stats)
 
     def forward(self, x):
+        return self.forward_fused(x)
+
+    def forward_fused(self, x, residual=None, relu=False):
+        """relu?(bn(x) + residual) in one pass (BasicBlock's tail, resnet_block.py forward)."""
         bn = self.bn
         if self.training and bn.affine and bn.track_running_stats and bn.momentum is not None and x.F.shape[0] > 1:
             with torch.no_grad():
                 bn.num_batches_tracked += 1
             return x._like(_BNTrainFn.apply(x.F, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                            bn.momentum, bn.eps))
-        if self.training or torch.is_grad_enabled() and x.F.requires_grad:
-            return x._like(self.bn(x.F))          # unusual configurations / eval with autograd: torch's kernel
+                                            bn.momentum, bn.eps, residual, bool(relu)))
+        if self.training or torch.is_grad_enabled() and (x.F.requires_grad or residual is not None and
+                                                         residual.requires_grad):
+            y = self.bn(x.F)                      # unusual configurations / eval with autograd: torch's kernels
+            if residual is not None:
+                y = y + residual
+            return x._like(torch.relu(y) if relu else y)
         scale, shift = bn_affine(self.bn)
-        return x._like(affine_forward(x.F.contiguous(), scale, shift, False))
+        return x._like(affine_forward(x.F.contiguous(), scale, shift, relu, residual=residual))
 
 
 class MinkowskiReLU(nn.Module):

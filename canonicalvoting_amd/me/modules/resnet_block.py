@@ -22,9 +22,7 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         residual = x
-        out = self.relu(self.norm1(self.conv1(x)))
-        out = self.norm2(self.conv2(out))
+        out = self.norm1.forward_fused(self.conv1(x), relu=True)
         if self.downsample is not None:
             residual = self.downsample(x)
-        out = out._like(out.F + residual.F)
-        return self.relu(out)
+        return self.norm2.forward_fused(self.conv2(out), residual=residual.F, relu=True)

@@ -99,16 +99,16 @@ class MinkUNetBase(ResNetBase):
         return self.modular_forward(x)
 
     def modular_forward(self, x):
-        out_p1 = self.relu(self.bn0(self.conv0p1s1(x)))
+        out_p1 = self.bn0.forward_fused(self.conv0p1s1(x), relu=True)
         skips = [out_p1]
         out = out_p1
         for i, (cname, bname) in enumerate(_DOWN):
-            out = self.relu(getattr(self, bname)(getattr(self, cname)(out)))
+            out = getattr(self, bname).forward_fused(getattr(self, cname)(out), relu=True)
             out = getattr(self, "block%d" % (i + 1))(out)
             skips.append(out)
         skips.pop()                                             # block4 output is not a skip
         for i, (cname, bname) in enumerate(_UP):
-            out = self.relu(getattr(self, bname)(getattr(self, cname)(out)))
+            out = getattr(self, bname).forward_fused(getattr(self, cname)(out), relu=True)
             out = ME.cat(out, skips.pop())
             out = getattr(self, "block%d" % (5 + i))(out)
         return self.final(out)

@@ -212,18 +212,21 @@ int cv_sp_col_sum_f32(const float* d_x, long long n, int c, int ld, float* d_out
 
 /* Training-mode MinkowskiBatchNorm (= nn.BatchNorm1d over the feature rows, utils/minkunet.py:56):
  * batch mean / biased variance per channel, running statistics updated in place (NULL to skip), folded
- * scale/shift for cv_sp_affine_f32; and its backward (d_y = output of the ReLU that follows, or NULL). */
+ * scale/shift for cv_sp_affine_f32; and its backward (d_y = output of the ReLU that follows, or NULL;
+ * d_dres = optional ReLU-masked gradient for a residual added before that ReLU, resnet_block forward). */
 size_t cv_sp_bn_workspace_bytes(int c);
 int cv_sp_bn_stats_f32(const float* d_x, long long n, int c, int ld, const float* d_gamma, const float* d_beta,
                        float eps, float momentum, float* d_running_mean, float* d_running_var, float* d_mean,
                        float* d_var, float* d_scale, float* d_shift, void* d_ws, size_t ws_bytes, void* stream);
 int cv_sp_bn_backward_f32(const float* d_x, const float* d_dy, const float* d_y, long long n, int c, int ld,
                           const float* d_mean, const float* d_var, float eps, const float* d_gamma, float* d_dgamma,
-                          float* d_dbeta, float* d_dx, void* d_ws, size_t ws_bytes, void* stream);
+                          float* d_dbeta, float* d_dx, float* d_dres, void* d_ws, size_t ws_bytes, void* stream);
 
-/* y = relu?(x * scale + shift): MinkowskiBatchNorm (eval) / MinkowskiReLU on feature rows. */
+/* y = relu?(x * scale + shift + residual): MinkowskiBatchNorm (eval) / MinkowskiReLU / the residual add of
+ * BasicBlock on feature rows; scale, shift and residual may each be NULL. */
 int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale,
-                     const float* d_shift, int relu, float* d_y, int y_ld, void* stream);
+                     const float* d_shift, const float* d_residual, int res_ld, int relu, float* d_y, int y_ld,
+                     void* stream);
 
 /* scale = gamma / sqrt(var + eps), shift = beta - mean * scale (+ bias * scale). */
 int cv_sp_bn_fold_f32(const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_var,

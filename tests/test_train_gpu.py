@@ -159,3 +159,20 @@ def test_batchnorm_training_kernels_match_torch(cuda, built_lib):
         assert rel_err(mine.bn.running_mean.cpu().numpy(), ref.running_mean.numpy()) < 1e-5
         assert rel_err(mine.bn.running_var.cpu().numpy(), ref.running_var.numpy()) < 1e-5
         assert int(mine.bn.num_batches_tracked) == 1
+
+        # BasicBlock's tail in one pass: relu(bn(x) + residual)
+        res = rng.normal(0, 1, (n, c)).astype(np.float32)
+        ref.zero_grad(); mine.zero_grad()
+        xr = torch.from_numpy(x).requires_grad_(True)
+        rr = torch.from_numpy(res).requires_grad_(True)
+        yr = torch.relu(ref(xr) + rr)
+        (yr * torch.from_numpy(gy)).sum().backward()
+        xd = torch.from_numpy(x).to(cuda).requires_grad_(True)
+        rd = torch.from_numpy(res).to(cuda).requires_grad_(True)
+        yd = mine.forward_fused(ME.SparseTensor(xd, coords, device="cuda"), residual=rd, relu=True).F
+        (yd * torch.from_numpy(gy).to(cuda)).sum().backward()
+        assert rel_err(yd.detach().cpu().numpy(), yr.detach().numpy()) < 1e-5
+        assert rel_err(xd.grad.cpu().numpy(), xr.grad.numpy()) < 1e-4
+        assert rel_err(rd.grad.cpu().numpy(), rr.grad.numpy()) < 1e-5
+        assert rel_err(mine.bn.weight.grad.cpu().numpy(), ref.weight.grad.numpy()) < 1e-4
+        assert rel_err(mine.bn.bias.grad.cpu().numpy(), ref.bias.grad.numpy()) < 1e-4
