@@ -36,7 +36,8 @@ class ConvDesc(ctypes.Structure):
                 ("res_ld", ctypes.c_int), ("relu", ctypes.c_int), ("out", vp), ("out_ld", ctypes.c_int),
                 ("flavour", ctypes.c_int), ("ws", vp), ("ws_bytes", ctypes.c_size_t), ("row_perm", vp),
                 ("j_begin", ctypes.c_int), ("j_end", ctypes.c_int), ("acc_in", vp), ("acc_ld", ctypes.c_int),
-                ("perm_groups", ctypes.c_int)]
+                ("perm_groups", ctypes.c_int), ("plan_ent", vp), ("plan_cnt", vp),
+                ("weight_packed", vp)]
 
 
 # symbol -> (restype, argtypes); tests check every symbol of include/cv_hip.h is here and exported
@@ -70,6 +71,10 @@ SIGNATURES = {
     "cv_sp_up_map": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_longlong, vp, vp]),
     "cv_sp_conv_workspace_bytes": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int]),
     "cv_sp_conv_f32": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp]),
+    "cv_sp_tile_plan_ints": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
+    "cv_sp_tile_plan": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, vp, vp, vp]),
+    "cv_sp_tile_kw": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "cv_sp_pack_weights_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_mask_keys": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_mask_perms": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t, vp]),
     "cv_sp_transpose_map": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, vp, vp]),

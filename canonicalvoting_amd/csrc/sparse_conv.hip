@@ -51,6 +51,9 @@ struct ConvArgs {
     int j_begin, j_end;    // kernel offsets handled by this launch
     const float* acc_in;   // optional [n_out][acc_ld] added to the accumulator before the epilogue
     int acc_ld;
+    const int* plan_ent;   // tile flavour: compacted (input row, tile row) lists per (tile, offset), see tile_plan
+    const int* plan_cnt;
+    const float4* wp;      // tile flavour: weights in MFMA operand order, see pack_weights
 };
 
 __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& acc, const int* rows,
@@ -354,6 +357,274 @@ __global__ __launch_bounds__(THREADS) void conv_wave(ConvArgs a) {
                 a.out[(long long)orow * a.out_ld + col] = v;
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------ pair-compacted tile flavour
+// The matrix cores only ever see (input, output) pairs that exist.  A plan kernel (tile_plan, once per kernel
+// map, shared by every convolution on that map) cuts the output rows into tiles of TT = 128 consecutive rows
+// (Z-order: neighbours are nearby rows) and compacts, per tile and kernel offset, the rows that HAVE that
+// neighbour into a list of (input row, tile row) entries.  One workgroup of CS waves owns a tile x CS*32 output
+// channels whose fp32 accumulators live in LDS.  It walks the lists in steps of 32 entries (two 16-row MFMA
+// units; a step with <= 16 entries issues half the MFMAs): the 32 gathered input rows of a KW-channel chunk are
+// staged row-major in LDS with 16-byte stores (double buffered: the next step's gathers are in flight during
+// the MFMAs, entry lists are fetched two steps ahead), wave w multiplies them with columns [32w, 32w+32) of W_j
+// on v_mfma_f32_16x16x4_f32, the accumulator tiles being read from and written back to the LDS rows the entries
+// belong to - waves own disjoint column slices and the rows of one list are distinct, so no atomics are needed.
+// k order: MFMA k-slot q of step s multiplies channel q*KW/4 + s of the chunk, so a lane's A operands of four
+// consecutive steps are one ds_read_b128; the weights are pre-packed (pack_weights, once per weight tensor) in
+// exactly the per-lane order of the B operand: one fully coalesced dwordx4 load per four steps, kept in registers
+// while (offset, chunk) stays the same and prefetched one step before it changes.
+// MFMA work = pairs padded to 16 per (tile, offset): 79 % (ts1) - 90 % (coarse levels) useful, against 25 - 55 %
+// for output-stationary 32-row blocks.  The epilogue (BatchNorm affine, residual, ReLU) streams the finished
+// tile out as full coalesced rows.  Small coordinate sets split the offsets over blockIdx.z into partial tiles
+// reduced by conv_finish.
+constexpr int TT = 128;
+constexpr int T_MAXK = 27;
+constexpr int PAD_ENT = -128;          // list padding: negative (no gather) and (e & 255) == TT (scratch row)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// one wave per tile: ent[(tile*K + j)*TT + p] = (input row << 8) | tile row of the p-th row of the tile that has
+// neighbour j, cnt[tile*32 + j] = number of such rows
+__global__ __launch_bounds__(256) void tile_plan(const int* __restrict__ nbr, long long n_out, int K,
+                                                 const int* __restrict__ row_perm, int* __restrict__ ent,
+                                                 int* __restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const long long tile = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (tile * TT >= n_out) return;
+    const long long t0 = tile * TT + lane, t1 = t0 + 64;
+    const long long g0 = t0 < n_out ? (row_perm ? row_perm[t0] : t0) : -1;
+    const long long g1 = t1 < n_out ? (row_perm ? row_perm[t1] : t1) : -1;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int j = 0; j < K; ++j) {
+        const int v0 = g0 >= 0 ? nbr[g0 * K + j] : -1, v1 = g1 >= 0 ? nbr[g1 * K + j] : -1;
+        const unsigned long long m0 = __ballot(v0 >= 0), m1 = __ballot(v1 >= 0);
+        const int n0v = __popcll(m0);
+        int* e = ent + (tile * K + j) * TT;
+        if (v0 >= 0) e[__popcll(m0 & below)] = (v0 << 8) | lane;
+        if (v1 >= 0) e[n0v + __popcll(m1 & below)] = (v1 << 8) | (lane + 64);
+        if (lane == 0) cnt[tile * 32 + j] = n0v + __popcll(m1);
+    }
+}
+
+// wp float4 index ((((j*NC + c)*NW + w)*NG + g)*2 + t)*64 + lane holds, for lane = 16*q + n,
+// W[j][c*KW + q*KW/4 + 4g + {0,1,2,3}][32w + 16t + n]      (NC = cin/KW, NW = cout/32, NG = KW/16)
+__global__ __launch_bounds__(256) void pack_weights(const float* __restrict__ w, int K, int cin, int cout, int KW,
+                                                    float4* __restrict__ wp) {
+    const long long total = (long long)K * cin * cout / 4;
+    const int NC = cin / KW, NW = cout / 32, NG = KW / 16;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long r = i;
+        const int lane = (int)(r % 64); r /= 64;
+        const int t = (int)(r % 2); r /= 2;
+        const int g = (int)(r % NG); r /= NG;
+        const int ws = (int)(r % NW); r /= NW;
+        const int c = (int)(r % NC); r /= NC;
+        const int j = (int)r;
+        const int q = lane >> 4, n = lane & 15;
+        const float* p = w + ((long long)j * cin + c * KW + q * (KW / 4) + 4 * g) * cout + 32 * ws + 16 * t + n;
+        wp[i] = make_float4(p[0], p[cout], p[2 * (long long)cout], p[3 * (long long)cout]);
+    }
+}
+
+template <int CS, int KW>
+__global__ __launch_bounds__(64 * CS) void conv_tile(ConvArgs a) {
+    constexpr int NT = 64 * CS, CW = 32 * CS;
+    constexpr int ROW_F4 = KW / 4;                    // float4s per gathered row chunk
+    constexpr int A_F4 = 32 * ROW_F4;
+    constexpr int A_PER = (A_F4 + NT - 1) / NT;
+    constexpr int NG = KW / 16;                       // groups of four MFMA k-steps
+    constexpr int A_LD = KW + 4;                      // floats per staged row (16-byte aligned, odd multiple of 4 banks)
+    __shared__ float out_s[TT + 1][CW];               // row TT: scratch row of the list padding
+    __shared__ __attribute__((aligned(16))) float A_s[2][32][A_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = lane >> 4, l15 = lane & 15, l31 = lane & 31;
+    const int n0 = blockIdx.y * CW;
+    const int K = a.K;
+    const int nj = a.j_end - a.j_begin;
+    const int j_lo = a.j_begin + (int)((long long)nj * blockIdx.z / a.splits);
+    const int j_hi = a.j_begin + (int)((long long)nj * (blockIdx.z + 1) / a.splits);
+    const long long tile = blockIdx.x;
+    const int tile_rows = (int)min((long long)TT, a.n_out - tile * TT);
+    const int NC = a.cin / KW, NW = a.cout / 32;
+
+    // lane j holds the list length of offset j
+    int cntv = 0;
+    if (lane >= j_lo && lane < j_hi) cntv = a.plan_cnt ? a.plan_cnt[tile * 32 + lane] : tile_rows;
+    const unsigned long long live = __ballot(cntv > 0);
+    for (int e = tid; e < TT * CW / 4; e += NT) reinterpret_cast<float4*>(&out_s[0][0])[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto first_live = [&](int from) {        // first offset >= from with a non-empty list, 64 if none
+        const unsigned long long m = from < 64 ? (live >> from) << from : 0ull;
+        return m ? (int)__ffsll((long long)m) - 1 : 64;
+    };
+    struct Step { int j, c, b, cnt; };       // offset, K chunk, block of 32 list entries, list length
+    auto advance = [&](Step s) {             // b runs fastest so the weights stay in registers
+        ++s.b;
+        if (32 * s.b >= s.cnt) {
+            s.b = 0;
+            if (++s.c >= NC) {
+                s.c = 0;
+                s.j = first_live(s.j + 1);
+                s.cnt = s.j < 64 ? __builtin_amdgcn_readlane(cntv, s.j) : 0;
+            }
+        }
+        return s;
+    };
+    // entry of list slot 32*b + l31 (one per lane, lanes 32-63 mirror 0-31)
+    auto load_ent = [&](const Step& s) {
+        const int p = 32 * s.b + l31;
+        if (s.j >= 64 || p >= s.cnt) return PAD_ENT;
+        if (a.plan_ent) return a.plan_ent[(tile * K + s.j) * TT + p];
+        const long long g = tile * TT + p;                                   // K == 1 on the same coordinate set
+        return (int)(((a.row_perm ? a.row_perm[g] : (int)g) << 8) | p);
+    };
+    // gather mapping of this thread: float4 i covers list slot a_slot[i], channels 4*a_c4[i]..+3 of the chunk
+    int a_slot[A_PER], a_c4[A_PER];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int idx = tid + i * NT;
+        a_slot[i] = idx < A_F4 ? idx / ROW_F4 : -1;
+        a_c4[i] = idx - (idx / ROW_F4) * ROW_F4;
+    }
+    auto load_a = [&](int ent, int c, float4* ra) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int e = __shfl(ent, a_slot[i] & 31);
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_slot[i] >= 0 && e >= 0)
+                ra[i] = *reinterpret_cast<const float4*>(a.in + (long long)(e >> 8) * a.in_ld + c * KW + 4 * a_c4[i]);
+        }
+    };
+    auto store_a = [&](int buf, const float4* ra) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i)
+            if (a_slot[i] >= 0) *reinterpret_cast<float4*>(&A_s[buf][a_slot[i]][4 * a_c4[i]]) = ra[i];
+    };
+    const float4* wlane = a.wp + wave * (NG * 2 * 64) + lane;
+    auto load_b = [&](const Step& s, float4 (*bv)[2]) {
+        const float4* p = wlane + ((long long)(s.j * NC + s.c) * NW + blockIdx.y * CS) * (NG * 2 * 64);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { bv[g][0] = p[(g * 2) * 64]; bv[g][1] = p[(g * 2 + 1) * 64]; }
+    };
+
+    Step s0, s1, s2;
+    s0.j = first_live(j_lo); s0.c = 0; s0.b = 0;
+    s0.cnt = s0.j < 64 ? __builtin_amdgcn_readlane(cntv, s0.j) : 0;
+    s1 = s0.j < 64 ? advance(s0) : s0;
+    s2 = s1.j < 64 ? advance(s1) : s1;
+    int e0 = load_ent(s0), e1 = load_ent(s1), e2 = load_ent(s2);
+    float4 bc[NG][2], bn[NG][2];
+    float4 ra[A_PER];
+    int cur = 0;
+    if (s0.j < 64) {
+        load_a(e0, s0.c, ra);
+        load_b(s0, bc);
+        store_a(0, ra);
+        if (s1.j < 64) load_a(e1, s1.c, ra);
+    }
+    __syncthreads();
+    const int col0 = wave * 32 + l15;
+    while (s0.j < 64) {
+        // entries of step u+3 and weights of step u+1 go out before the MFMAs of step u; gathers of u+1 are in ra
+        const Step s3 = s2.j < 64 ? advance(s2) : s2;
+        const int e3 = load_ent(s3);
+        const bool more = s1.j < 64;
+        const bool new_b = more && (s1.j != s0.j || s1.c != s0.c);
+        if (new_b) load_b(s1, bn);
+        const bool two = s0.cnt - 32 * s0.b > 16;
+        // accumulator tiles come from / go back to the LDS rows of the entries: D row 4*kq + i, col l15
+        int r0[4], r1[4];
+        f32x4 c00, c01, c10, c11;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r0[i] = __shfl(e0, 4 * kq + i) & 255;
+            c00[i] = out_s[r0[i]][col0];
+            c01[i] = out_s[r0[i]][col0 + 16];
+        }
+        if (two) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r1[i] = __shfl(e0, 16 + 4 * kq + i) & 255;
+                c10[i] = out_s[r1[i]][col0];
+                c11[i] = out_s[r1[i]][col0 + 16];
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const float4 a0 = *reinterpret_cast<const float4*>(&A_s[cur][l15][kq * (KW / 4) + 4 * g]);
+                const float4 a1 = *reinterpret_cast<const float4*>(&A_s[cur][16 + l15][kq * (KW / 4) + 4 * g]);
+                const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+                const float b0v[4] = {bc[g][0].x, bc[g][0].y, bc[g][0].z, bc[g][0].w};
+                const float b1v[4] = {bc[g][1].x, bc[g][1].y, bc[g][1].z, bc[g][1].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[q], b0v[q], c00, 0, 0, 0);
+                    c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[q], b1v[q], c01, 0, 0, 0);
+                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[q], b0v[q], c10, 0, 0, 0);
+                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[q], b1v[q], c11, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { out_s[r1[i]][col0] = c10[i]; out_s[r1[i]][col0 + 16] = c11[i]; }
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const float4 a0 = *reinterpret_cast<const float4*>(&A_s[cur][l15][kq * (KW / 4) + 4 * g]);
+                const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
+                const float b0v[4] = {bc[g][0].x, bc[g][0].y, bc[g][0].z, bc[g][0].w};
+                const float b1v[4] = {bc[g][1].x, bc[g][1].y, bc[g][1].z, bc[g][1].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[q], b0v[q], c00, 0, 0, 0);
+                    c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[q], b1v[q], c01, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { out_s[r0[i]][col0] = c00[i]; out_s[r0[i]][col0 + 16] = c01[i]; }
+        if (more) store_a(cur ^ 1, ra);
+        if (new_b) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { bc[g][0] = bn[g][0]; bc[g][1] = bn[g][1]; }
+        }
+        if (s2.j < 64) load_a(e2, s2.c, ra);      // gathers of step u+2: in flight across the barrier and step u+1
+        __syncthreads();
+        cur ^= 1;
+        s0 = s1; s1 = s2; s2 = s3;
+        e0 = e1; e1 = e2; e2 = e3;
+    }
+
+    // epilogue: full rows, float4 per lane
+    constexpr int C4 = CS * 8;
+    for (int e = tid; e < TT * C4; e += NT) {
+        const int t = e / C4, q = e - t * C4;
+        if (t >= tile_rows) break;
+        const long long g = tile * TT + t;
+        const int row = a.row_perm ? a.row_perm[g] : (int)g;
+        const int col = n0 + 4 * q;
+        float4 v = *reinterpret_cast<const float4*>(&out_s[t][4 * q]);
+        if (a.splits > 1) {
+            *reinterpret_cast<float4*>(a.partial + ((long long)blockIdx.z * a.n_out + row) * a.cout + col) = v;
+            continue;
+        }
+        if (a.acc_in) {
+            const float4 p = *reinterpret_cast<const float4*>(a.acc_in + (long long)row * a.acc_ld + col);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        if (a.scale) {
+            const float4 s = *reinterpret_cast<const float4*>(a.scale + col);
+            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+        }
+        if (a.shift) {
+            const float4 s = *reinterpret_cast<const float4*>(a.shift + col);
+            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        }
+        if (a.res) {
+            const float4 p = *reinterpret_cast<const float4*>(a.res + (long long)row * a.res_ld + col);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(a.out + (long long)row * a.out_ld + col) = v;
     }
 }
 
@@ -836,6 +1107,60 @@ int launch_wave(const ConvArgs& a, hipStream_t st) {
 
 int nb_for(int cout) { return cout <= 32 ? 1 : cout <= 64 ? 2 : cout <= 96 ? 3 : 4; }
 
+// ---- tile flavour dispatch: CS = waves (32-column slices) per workgroup, KW = K chunk width
+int tile_cs(int cout) {
+    const int s = cout / 32;
+    return s % 2 == 0 ? 2 : s % 3 == 0 ? 3 : 1;
+}
+int tile_kw(int cin, int cout) {
+    if (cin % 32 || cout % 32) return 0;
+    const int cap = tile_cs(cout) == 3 ? 96 : 128;      // LDS: tile + double-buffered staging <= 80 KB (2 per CU)
+    for (int kw : {128, 96, 64, 32})
+        if (kw <= cap && cin % kw == 0) return kw;
+    return 0;
+}
+bool tile_ok(const ConvArgs& a, bool vec) {
+    return vec && a.K <= T_MAXK && tile_kw(a.cin, a.cout) > 0 && a.n_in < (1ll << 23) && a.out_ld % 4 == 0 && a.wp &&
+           (a.plan_ent || !a.nbr) && (!a.res || a.res_ld % 4 == 0) && (!a.acc_in || a.acc_ld % 4 == 0) &&
+           ((reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(a.res) |
+             reinterpret_cast<uintptr_t>(a.acc_in) | reinterpret_cast<uintptr_t>(a.scale) |
+             reinterpret_cast<uintptr_t>(a.shift) | reinterpret_cast<uintptr_t>(a.wp)) & 15) == 0;
+}
+// offsets are split over blockIdx.z only while the launch still fits the chip in one round (2 workgroups per CU)
+int tile_splits(long long n_out, int cout, int nj) {
+    const long long wgs = ((n_out + TT - 1) / TT) * (cout / (tile_cs(cout) * 32));
+    if (wgs >= 256) return 1;
+    long long s = std::min<long long>(512 / wgs, nj);
+    const long long by_traffic = (32ll << 20) / std::max<long long>(1, n_out * cout * 4);
+    s = std::min(s, std::max<long long>(by_traffic, 2));
+    return (int)std::max<long long>(s, 1);
+}
+
+template <int CS, int KW>
+int launch_tile_k(const ConvArgs& a, hipStream_t st) {
+    dim3 grid((unsigned)((a.n_out + TT - 1) / TT), (unsigned)(a.cout / (CS * 32)), (unsigned)a.splits);
+    conv_tile<CS, KW><<<grid, 64 * CS, 0, st>>>(a);
+    CV_LAUNCH_CHECK();
+    if (a.splits > 1) return launch_finish(a, st);
+    return CV_OK;
+}
+template <int CS>
+int launch_tile_cs(const ConvArgs& a, hipStream_t st) {
+    switch (tile_kw(a.cin, a.cout)) {
+        case 128: if (CS < 3) return launch_tile_k<CS < 3 ? CS : 1, 128>(a, st);
+        case 96: return launch_tile_k<CS, 96>(a, st);
+        case 64: return launch_tile_k<CS, 64>(a, st);
+        default: return launch_tile_k<CS, 32>(a, st);
+    }
+}
+int launch_tile(const ConvArgs& a, hipStream_t st) {
+    switch (tile_cs(a.cout)) {
+        case 3: return launch_tile_cs<3>(a, st);
+        case 2: return launch_tile_cs<2>(a, st);
+        default: return launch_tile_cs<1>(a, st);
+    }
+}
+
 // Enough workgroups to fill 256 CUs a few times with short dependent chains: split the (offset,
 // chunk) units over blockIdx.z; the partial tiles cost 8 bytes of traffic per output element per split.
 int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
@@ -874,7 +1199,9 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     ConvArgs a{d->in, d->n_in, d->in_ld, d->cin, d->weight, d->K, d->cout, d->nbr, d->n_out, d->scale,
                d->shift, d->residual, d->res_ld, d->relu, d->out, d->out_ld, 1, nullptr, d->row_perm, 0, jb, je,
-               d->acc_in, d->acc_ld};
+               d->acc_in, d->acc_ld, d->plan_ent, d->plan_cnt,
+               reinterpret_cast<const float4*>(d->weight_packed)};
+    CV_REQUIRE(!d->plan_ent == !d->plan_cnt, CV_EINVAL, "plan_ent and plan_cnt go together");
     const bool vec = (d->cin % KC == 0) && (d->in_ld % 4 == 0) && (d->cout % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(d->in) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(d->weight) & 15) == 0);
@@ -896,6 +1223,18 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
                 default: return launch_wave<4>(a, st);
             }
         }
+    } else if (d->flavour == 4 && !tile_ok(a, vec)) {
+        CV_REQUIRE(false, CV_EINVAL, "flavour 4 needs Cin %% 32 == 0, Cout %% 32 == 0, K <= 27, 16-byte aligned "
+                                     "operands, packed weights (cv_sp_pack_weights_f32) and a tile plan "
+                                     "(cv_sp_tile_plan) for the kernel map");
+    } else if ((d->flavour == 0 || d->flavour == 4) && tile_ok(a, vec)) {
+        const int sp = tile_splits(d->n_out, d->cout, je - jb);
+        const size_t need = sizeof(float) * (size_t)sp * (size_t)d->n_out * (size_t)d->cout;
+        if (sp > 1 && d->ws && d->ws_bytes >= need) {
+            a.splits = sp;
+            a.partial = static_cast<float*>(d->ws);
+        }
+        return launch_tile(a, st);
     } else if (d->flavour == 0) {
         const int sp = pick_splits(d->n_out, d->cout, je - jb, d->cin, vec);
         const size_t need = sizeof(float) * (size_t)sp * (size_t)d->n_out * (size_t)d->cout;
@@ -941,6 +1280,46 @@ int cv_sp_mask_perms(const int32_t* d_nbr, long long n, int K, int groups, int32
     mp_scan<<<groups, MP_BINS, 0, st>>>(hist);
     CV_LAUNCH_CHECK();
     mp_scatter<<<grid, MP_THREADS, 0, st>>>(d_nbr, n, K, groups, hist, d_perm);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+size_t cv_sp_tile_plan_ints(long long n_out, int K, size_t* cnt_offset) {
+    if (n_out <= 0 || K <= 0) return 0;
+    const size_t tiles = (size_t)((n_out + TT - 1) / TT);
+    const size_t ent = cv_align_up(tiles * (size_t)K * TT, 64);
+    if (cnt_offset) *cnt_offset = ent;
+    return ent + tiles * 32;
+}
+
+// Pair lists of the tile flavour for one kernel map (and one processing order): d_plan is
+// cv_sp_tile_plan_ints(n_out, K, &cnt_offset) int32 words; plan_ent = d_plan, plan_cnt = d_plan + cnt_offset.
+int cv_sp_tile_plan(const int32_t* d_nbr, long long n_out, int K, const int32_t* d_row_perm, int32_t* d_plan,
+                    void* stream) {
+    CV_REQUIRE(d_nbr && d_plan && n_out > 0 && K > 0 && K <= T_MAXK, CV_EINVAL, "bad tile plan arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    size_t off = 0;
+    cv_sp_tile_plan_ints(n_out, K, &off);
+    const long long tiles = (n_out + TT - 1) / TT;
+    tile_plan<<<(unsigned)((tiles + 3) / 4), 256, 0, st>>>(d_nbr, n_out, K, d_row_perm, d_plan, d_plan + off);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+// K chunk width the tile kernel uses for a Cin x Cout convolution (the packing of its weights depends on it);
+// 0 when the tile kernel does not take the shape.
+int cv_sp_tile_kw(int cin, int cout) { return tile_kw(cin, cout); }
+
+// d_wp[K*cin*cout] = d_w[K][cin][cout] re-ordered into the per-lane B operand order of the tile kernel.
+int cv_sp_pack_weights_f32(const float* d_w, int K, int cin, int cout, float* d_wp, void* stream) {
+    CV_REQUIRE(d_w && d_wp && K > 0, CV_EINVAL, "bad pack_weights arguments");
+    const int kw = tile_kw(cin, cout);
+    CV_REQUIRE(kw > 0, CV_EINVAL, "the tile kernel does not take Cin = %d, Cout = %d", cin, cout);
+    CV_REQUIRE((reinterpret_cast<uintptr_t>(d_wp) & 15) == 0, CV_EINVAL, "d_wp must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long total = (long long)K * cin * cout / 4;
+    pack_weights<<<(unsigned)std::min<long long>((total + 255) / 256, 4096), 256, 0, st>>>(
+        d_w, K, cin, cout, kw, reinterpret_cast<float4*>(d_wp));
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

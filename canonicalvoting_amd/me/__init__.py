@@ -17,6 +17,7 @@ stride-1 output corresponds to row i of the input coordinates.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -308,23 +309,31 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
         # generic (module-by-module / training) path: mask-sorted offset groups, orders cached on the map
         row_perm = map_mask_perms(nbr, AUTO_MASK_GROUPS)
         perm_groups = AUTO_MASK_GROUPS
+    plan = wp = None
+    if ((flavour == 4 or (TILE_KERNEL and flavour == 0)) and perm_groups == 0 and K <= 27 and cin % 32 == 0
+            and cout % 32 == 0 and L.cv_sp_tile_kw(cin, cout) > 0):
+        plan = tile_plan(nbr, row_perm) if nbr is not None else None
+        wp = packed_weights(weight, w)
     ws = None
     if perm_groups > 1:
         ws = _workspace(dev, 4 * perm_groups * n_out * cout + 256)
-    elif flavour == 0 and n_out < 128 * 384:
+    elif flavour in (0, 4) and n_out < 128 * 384:
         ws = _workspace(dev, int(L.cv_sp_conv_workspace_bytes(n_out, cout, K)))
     p = lambda t: t.data_ptr() if t is not None else None
     d = _lib.ConvDesc(p(x_feats), x_feats.shape[0], x_feats.stride(0), cin, p(w), K, cout, p(nbr), n_out,
                       p(scale), p(shift), p(residual), residual.stride(0) if residual is not None else 0,
                       1 if relu else 0, p(out), out.stride(0), flavour, p(ws),
                       ws.numel() if ws is not None else 0, p(row_perm), j_begin, j_end, p(acc_in),
-                      acc_in.stride(0) if acc_in is not None else 0, perm_groups)
+                      acc_in.stride(0) if acc_in is not None else 0, perm_groups,
+                      plan[0].data_ptr() if plan is not None else None,
+                      plan[0].data_ptr() + 4 * plan[1] if plan is not None else None, p(wp))
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
     return out
 
 
-AUTO_MASK_GROUPS = 4        # conv_forward applies mask-sorted groups to big 3x3x3 maps on its own (0 = off)
+# conv_forward applies mask-sorted offset groups to big 3x3x3 maps on its own (0 = off)
+AUTO_MASK_GROUPS = int(os.environ.get("CV_MASK_GROUPS", "4"))
 AUTO_MASK_MIN_ROWS = 16384
 
 
@@ -340,6 +349,57 @@ def map_mask_perms(nbr, groups):
             _lib.check(L.cv_sp_mask_perms(_ptr(nbr), n, K, groups, _ptr(hit), _ptr(ws), ws.numel(),
                                           _stream(nbr.device)), "cv_sp_mask_perms")
         nbr._cv_mask_perms = hit
+    return hit
+
+
+# 1: flavour 0 (auto) runs the pair-compacted tile kernel wherever it applies.  Off by default: measured on MI355X
+# (profiles/tile_ablate.py) it ties the output-stationary kernel on the coarse levels and loses on the fine ones.
+TILE_KERNEL = os.environ.get("CV_TILE_KERNEL", "0") != "0"
+
+
+_packed = {}
+
+
+def packed_weights(weight, w3):
+    """weights in the tile kernel's MFMA operand order (cv_sp_pack_weights_f32), cached per parameter tensor and
+    re-packed when it is modified in place (optimizer step, load_state_dict) or re-allocated."""
+    key = id(weight)
+    ver = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _packed.get(key)
+    if hit is None or hit[0] != ver or hit[2]() is not weight:
+        import weakref
+        L = _lib.lib()
+        K, cin, cout = w3.shape
+        wp = torch.empty(w3.numel(), dtype=torch.float32, device=w3.device)
+        with torch.cuda.device(w3.device):
+            _lib.check(L.cv_sp_pack_weights_f32(_ptr(w3), K, cin, cout, _ptr(wp), _stream(w3.device)),
+                       "cv_sp_pack_weights_f32")
+        try:
+            ref = weakref.ref(weight, lambda _r, k=key: _packed.pop(k, None))
+        except TypeError:
+            ref = lambda: weight
+        hit = _packed[key] = (ver, wp, ref)
+    return hit[1]
+
+
+def tile_plan(nbr, row_perm=None):
+    """(int32 plan words, offset of the counts) of the pair-compacted tile kernel for a kernel map and a
+    processing order (cv_sp_tile_plan); cached on the map tensor, shared by every conv that uses the map."""
+    cache = getattr(nbr, "_cv_tile_plans", None)
+    if cache is None:
+        cache = nbr._cv_tile_plans = {}
+    key = row_perm.data_ptr() if row_perm is not None else 0
+    hit = cache.get(key)
+    if hit is None:
+        L = _lib.lib()
+        n, K = nbr.shape
+        off = ctypes.c_size_t(0)
+        words = int(L.cv_sp_tile_plan_ints(n, K, ctypes.byref(off)))
+        buf = torch.empty(words, dtype=torch.int32, device=nbr.device)
+        with torch.cuda.device(nbr.device):
+            _lib.check(L.cv_sp_tile_plan(_ptr(nbr), n, K, _ptr(row_perm), _ptr(buf), _stream(nbr.device)),
+                       "cv_sp_tile_plan")
+        hit = cache[key] = (buf, int(off.value), row_perm)     # keeps the order tensor alive with the plan
     return hit
 
 

@@ -11,6 +11,8 @@ Two forwards with identical results:
     its epilogue, skip connections are written straight into the concat buffers
     (no ``cat`` copy): 63 launches for the whole network.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -125,7 +127,8 @@ class MinkUNetBase(ResNetBase):
             cache[id(bn)] = hit
         return hit[1]
 
-    MASKED_MIN_ROWS = 16384     # levels with at least this many rows run the mask-sorted grouped conv
+    # levels with at least this many rows run the mask-sorted grouped conv
+    MASKED_MIN_ROWS = int(os.environ.get("CV_MASKED_MIN_ROWS", "16384"))
     MASK_GROUPS = 4
 
     def _conv3(self, x, kernel, nbr, perms, n, **ep):

@@ -61,7 +61,13 @@ def rel_err(a, b):
 @pytest.mark.parametrize("cin,cout,k,flavour", [(32, 32, 3, 1), (32, 64, 3, 1), (96, 96, 3, 1), (128, 96, 3, 1),
                                                (64, 128, 3, 1), (128, 256, 3, 1), (256, 256, 3, 0),
                                                (64, 64, 3, 0), (32, 32, 3, 0), (3, 32, 5, 1), (6, 32, 5, 1),
-                                               (128, 96, 1, 1), (96, 64, 1, 1), (384, 256, 1, 0)])
+                                               (128, 96, 1, 1), (96, 64, 1, 1), (384, 256, 1, 0),
+                                               # flavour 4 = pair-compacted tile kernel (every CS / KW instance)
+                                               (32, 32, 3, 4), (64, 32, 3, 4), (96, 32, 3, 4), (32, 64, 3, 4),
+                                               (64, 64, 3, 4), (96, 96, 3, 4), (128, 96, 3, 4), (32, 96, 3, 4),
+                                               (64, 128, 3, 4), (128, 256, 3, 4), (256, 256, 3, 4),
+                                               (192, 128, 3, 4), (384, 256, 3, 4), (160, 64, 3, 4),
+                                               (128, 96, 1, 4), (96, 64, 1, 4)])
 def test_conv_matches_oracle(cuda, built_lib, cin, cout, k, flavour):
     coords, _ = scene_coords(2, 1500)
     rng = np.random.default_rng(cin * 1000 + cout)
@@ -87,6 +93,33 @@ def test_conv_matches_oracle(cuda, built_lib, cin, cout, k, flavour):
     got1 = obuf[:, 32:32 + cout].cpu().numpy()
     assert rel_err(got1, ref1) < 1e-5
     assert float(obuf[:, :32].min()) == -7.0 and float(obuf[:, 32 + cout:].max()) == -7.0   # no stray writes
+
+
+def test_tile_conv_single_launch_and_row_perm(cuda, built_lib):
+    """pair-compacted tile kernel on a coordinate set large enough to run without offset splits, in natural and
+    permuted processing order, with the fused epilogue"""
+    coords, _ = scene_coords(11, 40000, small=False)
+    rng = np.random.default_rng(5)
+    n = len(coords)
+    x = rng.normal(0, 1, (n, 32)).astype(np.float32)
+    w = (rng.normal(0, 1, (27, 32, 96)) / 30).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, 96).astype(np.float32)
+    shift = rng.normal(0, 0.2, 96).astype(np.float32)
+    res = rng.normal(0, 1, (n, 96)).astype(np.float32)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(cuda, torch.int32))
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    ref = so.conv(torch.from_numpy(x), torch.from_numpy(w), so.kernel_map(coords, coords, 3, 1, 1)).numpy()
+    ref = np.maximum(ref * scale + shift + res, 0)
+    perm = torch.from_numpy(rng.permutation(n).astype(np.int32)).to(cuda)
+    for rp in (None, perm):
+        got = ME.conv_forward(t(x), t(w), cm.kernel_map(3, 1), n, scale=t(scale), shift=t(shift), residual=t(res),
+                              relu=True, flavour=4, row_perm=rp).cpu().numpy()
+        assert rel_err(got, ref) < 1e-5
+    # offset sub-range chained through acc_in
+    part = ME.conv_forward(t(x), t(w), cm.kernel_map(3, 1), n, flavour=4, j_begin=0, j_end=10)
+    got = ME.conv_forward(t(x), t(w), cm.kernel_map(3, 1), n, flavour=4, j_begin=10, j_end=27, acc_in=part,
+                          scale=t(scale), shift=t(shift), residual=t(res), relu=True).cpu().numpy()
+    assert rel_err(got, ref) < 1e-5
 
 
 def test_masked_two_pass_conv_matches_oracle(cuda, built_lib):
