@@ -46,6 +46,7 @@ SIGNATURES = {
     "cv_last_error": (ctypes.c_char_p, []),
     "cv_hv_minmax_workspace_bytes": (ctypes.c_size_t, []),
     "cv_hv_minmax_f32": (ctypes.c_int, [vp, ctypes.c_int64, c_float_p, c_float_p, vp, ctypes.c_size_t, vp]),
+    "cv_hv_minmax_async_f32": (ctypes.c_int, [vp, ctypes.c_int64, vp, vp, ctypes.c_size_t, vp]),
     "cv_hv_grid_dims_f32": (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_float, c_int_p]),
     "cv_hv_forward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, c_int_p, ctypes.c_int]),
     "cv_hv_forward_f32": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_int,

@@ -794,6 +794,27 @@ int cv_hv_minmax_f32(const float* d_points, int64_t n, float* h_min3, float* h_m
     return CV_OK;
 }
 
+// Same reduction without the host wait: h_minmax6 (PINNED host memory: min xyz, max xyz) is valid once the
+// work enqueued on `stream` up to this call has completed (record an event after it).  Lets a pipeline start
+// the bounds reduction of a scene before its network forward instead of stalling in front of the vote.
+int cv_hv_minmax_async_f32(const float* d_points, int64_t n, float* h_minmax6, void* d_ws, size_t ws_bytes,
+                           void* stream) {
+    CV_REQUIRE(d_points && h_minmax6 && d_ws, CV_EINVAL, "null pointer argument");
+    CV_REQUIRE(n > 0, CV_EINVAL, "n must be positive (got %lld)", (long long)n);
+    CV_REQUIRE(ws_bytes >= cv_hv_minmax_workspace_bytes(), CV_ENOMEM, "workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CvCarver cv(d_ws);
+    float* part = cv.take<float>(6 * MM_BLOCKS);
+    float* out = cv.take<float>(6);
+    const int blocks = (int)std::min<int64_t>(MM_BLOCKS, (n + 255) / 256);
+    minmax_partial<<<blocks, 256, 0, st>>>(d_points, n, part);
+    CV_LAUNCH_CHECK();
+    minmax_final<<<1, 256, 0, st>>>(part, blocks, out);
+    CV_LAUNCH_CHECK();
+    CV_HIP_CHECK(hipMemcpyAsync(h_minmax6, out, 6 * sizeof(float), hipMemcpyDeviceToHost, st));
+    return CV_OK;
+}
+
 int cv_hv_grid_dims_f32(const float h_min3[3], const float h_max3[3], float res, int dims_out[3]) {
     CV_REQUIRE(h_min3 && h_max3 && dims_out, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(res > 0.f, CV_EINVAL, "res must be positive");

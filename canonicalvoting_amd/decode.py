@@ -108,13 +108,14 @@ def nms_per_class(boxes, scores, classes, nclasses=9, overlap_threshold=0.3):
     return out
 
 
-def detect(hv, coords_int, xyz_pred, scale_pred, prob_pred, class_pred, res, nclasses=9, **kw):
+def detect(hv, coords_int, xyz_pred, scale_pred, prob_pred, class_pred, res, nclasses=9, scan_points=None, **kw):
     """eval_joint.py:193-280 after the network: vote, decode, per-class NMS.
 
     ``hv`` is a HoughVoting module, ``coords_int`` the [N,3] integer voxel coordinates
     (``scan_points[:, 1:]``).  Returns (detections, raw) where detections is the
     ``map_scene`` list of (class, box, score)."""
-    scan_points = (coords_int.to(xyz_pred.device) * res).float().contiguous()    # :193,:200
+    if scan_points is None:
+        scan_points = (coords_int.to(xyz_pred.device) * res).float().contiguous()    # :193,:200
     with torch.no_grad():
         grid_obj, grid_rot, grid_scale = hv(scan_points, xyz_pred.contiguous(),
                                             scale_pred.contiguous(), prob_pred.contiguous())

@@ -79,9 +79,47 @@ def _f3(vals):
     return (ctypes.c_float * 3)(*[float(v) for v in vals])
 
 
-def grid_geometry(points, res):
-    """(corner[3], max[3], dims[3]) as hv_cuda_kernel.cu:129-134 computes them (one host sync)."""
+_prefetched = {}
+
+
+def prefetch_geometry(points):
+    """Start the bounds reduction of `points` now, without waiting for it: a later forward()/grid_geometry() on
+    the same (unmodified) tensor picks the result up instead of reducing and stalling in front of the vote.
+    Call it before the network forward of the scene (pipeline.detect_scene does)."""
     L = _lib.lib()
+    dev = points.device
+    ws = torch.empty(L.cv_hv_minmax_workspace_bytes(), dtype=torch.uint8, device=dev)
+    host = torch.empty(6, dtype=torch.float32).pin_memory()
+    with torch.cuda.device(dev):
+        _lib.check(L.cv_hv_minmax_async_f32(_ptr(points), points.shape[0], ctypes.c_void_p(host.data_ptr()),
+                                            _ptr(ws), ws.numel(), _stream(dev)), "cv_hv_minmax_async_f32")
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    if len(_prefetched) > 8:
+        _prefetched.clear()
+    # the entry keeps `points` (and the workspace) alive, so the address cannot be recycled while it is cached
+    _prefetched[points.data_ptr()] = (points, points._version, host, ev, ws)
+
+
+def _take_prefetched(points):
+    hit = _prefetched.pop(points.data_ptr(), None)
+    if hit is None or hit[0] is not points or hit[1] != points._version:
+        return None
+    hit[3].synchronize()
+    h = hit[2].tolist()
+    return h[:3], h[3:]
+
+
+def grid_geometry(points, res):
+    """(corner[3], max[3], dims[3]) as hv_cuda_kernel.cu:129-134 computes them (one host sync, or none when
+    prefetch_geometry(points) ran earlier)."""
+    L = _lib.lib()
+    pre = _take_prefetched(points)
+    if pre is not None:
+        mn, mx = _f3(pre[0]), _f3(pre[1])
+        dims = (ctypes.c_int * 3)()
+        _lib.check(L.cv_hv_grid_dims_f32(mn, mx, ctypes.c_float(res), dims), "cv_hv_grid_dims_f32")
+        return list(mn), list(mx), [int(d) for d in dims]
     ws = torch.empty(L.cv_hv_minmax_workspace_bytes(), dtype=torch.uint8, device=points.device)
     mn = (ctypes.c_float * 3)()
     mx = (ctypes.c_float * 3)()

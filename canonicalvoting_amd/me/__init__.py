@@ -283,12 +283,13 @@ _conv_ws = {}
 
 
 def _workspace(dev, nbytes):
-    """one persistent split-K workspace per device (grown on demand; stream-ordered reuse is safe
-    because every conv is enqueued on the same stream and finishes reading it before the next)."""
-    ws = _conv_ws.get(dev)
+    """one persistent split-K workspace per (device, stream), grown on demand; stream-ordered reuse is safe
+    because every conv of a stream finishes reading it before the next one starts."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _conv_ws.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-        _conv_ws[dev] = ws
+        _conv_ws[key] = ws
     return ws
 
 

@@ -5,7 +5,7 @@ import ctypes
 
 import torch
 
-from . import _lib, decode
+from . import _lib, decode, hv_cuda
 from . import me as ME
 
 
@@ -30,10 +30,14 @@ def detect_scene(model, hv, coords4, feats, res, nclasses=9, log_scale=True, **d
     """coords4 [N,4] int (batch 0), feats [N,C] already recentred (eval_joint.py:167-168).
     Returns (detections [(class, box[8,3], score)], raw decode dict, network output)."""
     with torch.no_grad():
+        # eval_joint.py:193 scan points; their bounds reduction (the vote grid shape) runs under the network
+        scan_points = (coords4[:, 1:].to(feats.device) * res).float().contiguous()
+        hv_cuda.prefetch_geometry(scan_points)
         x = ME.SparseTensor(feats, coords4, device=feats.device)
         y = model(x)
         xyz, scale, prob, cls = head_joint(y.F, nclasses, log_scale)
-        dets, raw = decode.detect(hv, coords4[:, 1:], xyz, scale, prob, cls, res, nclasses, **decode_kw)
+        dets, raw = decode.detect(hv, coords4[:, 1:], xyz, scale, prob, cls, res, nclasses,
+                                  scan_points=scan_points, **decode_kw)
     return dets, raw, y
 
 

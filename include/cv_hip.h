@@ -45,6 +45,12 @@ const char* cv_last_error(void);
 size_t cv_hv_minmax_workspace_bytes(void);
 int cv_hv_minmax_f32(const float* d_points, int64_t n, float* h_min3, float* h_max3,
                      void* d_ws, size_t ws_bytes, void* stream);
+/* The same reduction without the host wait: h_minmax6 must be PINNED host memory (min xyz, max xyz) and is
+ * valid once the work enqueued on `stream` up to this call has completed.  A pipeline can start it before the
+ * network forward of a scene, so the vote does not stall on the grid shape (hv_cuda_kernel.cu:129-134 blocks
+ * the host twelve times at that point). */
+int cv_hv_minmax_async_f32(const float* d_points, int64_t n, float* h_minmax6, void* d_ws, size_t ws_bytes,
+                           void* stream);
 
 /* Grid shape from the bounds in the reference's fp32 arithmetic
  * (hv_cuda_kernel.cu:131-134: trunc((max-min)/res) + 1).  Host only. */

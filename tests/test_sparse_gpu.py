@@ -61,6 +61,8 @@ def rel_err(a, b):
 @pytest.mark.parametrize("cin,cout,k,flavour", [(32, 32, 3, 1), (32, 64, 3, 1), (96, 96, 3, 1), (128, 96, 3, 1),
                                                (64, 128, 3, 1), (128, 256, 3, 1), (256, 256, 3, 0),
                                                (64, 64, 3, 0), (32, 32, 3, 0), (3, 32, 5, 1), (6, 32, 5, 1),
+                                               (3, 32, 5, 0), (6, 32, 5, 0), (3, 32, 3, 0),   # flavour 0: stem kernel
+
                                                (128, 96, 1, 1), (96, 64, 1, 1), (384, 256, 1, 0),
                                                # flavour 4 = pair-compacted tile kernel (every CS / KW instance)
                                                (32, 32, 3, 4), (64, 32, 3, 4), (96, 32, 3, 4), (32, 64, 3, 4),
