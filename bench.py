@@ -8,6 +8,14 @@ One "step" = one synthetic 80k-voxel scene through the hot path with its inputs 
 resident in HBM.  Scenes are independent, so N ranks run N scenes per step with no data-path
 collective ("scaling": "weak"); value = scenes all ranks processed / max-over-ranks time.
 
+Scenes in flight: --streams S (default 3) host threads, each with its own HIP stream, take the steps
+round-robin, so the launch tails, small coarse-level launches and the host syncs of one scene are filled
+with another scene's kernels (the per-scene work and its results are unchanged).  Kernels of concurrent
+scenes stretch each other's event-to-event times, so when S > 1 the per-stage times and the roofline of
+the vote op are taken in a second pass over the same K steps with ONE scene in flight, inside the same
+run, after the timed region ("measured_in" says which); `value` / `ms_per_step` always come from the timed
+region.  --streams 1 reproduces the one-scene-at-a-time number (profiles/r1/bench_streams1.json).
+
 The JSON line also carries
   roofline     the vote op (zero-fill + accumulate + normalise = every launch of
                cv_hv_forward_f32) timed with HIP events on its stream inside the timed region,
@@ -52,10 +60,11 @@ def parse():
     ap.add_argument("--cpu-scenes", type=int, default=1, help="scenes timed on the CPU oracle (0 = skip)")
     ap.add_argument("--stage", default="full", choices=["vote_decode", "full"],
                     help="full = MinkUNet34C forward + head + vote + decode + NMS (eval_joint.py path)")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=3,
                     help="scenes in flight per GPU: S host threads, each with its own HIP stream, take the steps "
                          "round-robin (scenes are independent; fills the launch tails and host syncs of one scene "
                          "with the kernels of another)")
+    ap.add_argument("--switch-interval", type=float, default=0.0005, help="sys.setswitchinterval for the scene threads")
     ap.add_argument("--large", action="store_true",
                     help="BASELINE config 5 shaped scenes: 9x3x9 m room, 40 boxes (use with --points 300000)")
     ap.add_argument("--teacher-forced", action="store_true",
@@ -187,6 +196,7 @@ def main():
             n_det += len(dets)
     else:
         import threading
+        sys.setswitchinterval(a.switch_interval)      # GIL hand-off between the scene threads
         counts = [0] * a.streams
 
         def worker(i):

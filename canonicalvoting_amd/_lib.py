@@ -40,6 +40,20 @@ class ConvDesc(ctypes.Structure):
                 ("weight_packed", vp)]
 
 
+class NetBuf(ctypes.Structure):
+    """struct cv_net_buf (include/cv_hip.h)"""
+    _fields_ = [("level", ctypes.c_int), ("channels", ctypes.c_int), ("rows_level", ctypes.c_int)]
+
+
+class NetOp(ctypes.Structure):
+    """struct cv_net_op (include/cv_hip.h)"""
+    _fields_ = [("in_buf", ctypes.c_int), ("in_col", ctypes.c_int), ("cin", ctypes.c_int),
+                ("out_buf", ctypes.c_int), ("out_col", ctypes.c_int), ("cout", ctypes.c_int),
+                ("res_buf", ctypes.c_int), ("res_col", ctypes.c_int), ("map", ctypes.c_int), ("K", ctypes.c_int),
+                ("perm", ctypes.c_int), ("perm_groups", ctypes.c_int), ("relu", ctypes.c_int),
+                ("weight", vp), ("scale", vp), ("shift", vp)]
+
+
 # symbol -> (restype, argtypes); tests check every symbol of include/cv_hip.h is here and exported
 SIGNATURES = {
     "cv_abi_version": (ctypes.c_int, []),
@@ -76,6 +90,11 @@ SIGNATURES = {
     "cv_sp_tile_plan": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, vp, vp, vp]),
     "cv_sp_tile_kw": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "cv_sp_pack_weights_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "cv_net_arena_bytes": (ctypes.c_size_t, [ctypes.POINTER(NetBuf), ctypes.c_int, c_i64_p, ctypes.c_int]),
+    "cv_net_run_f32": (ctypes.c_int, [ctypes.POINTER(NetOp), ctypes.c_int, ctypes.POINTER(NetBuf), ctypes.c_int,
+                                      c_i64_p, ctypes.c_int, vp, ctypes.c_size_t, ctypes.POINTER(vp), c_int_p,
+                                      ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(vp), ctypes.c_int, vp,
+                                      ctypes.c_size_t, vp]),
     "cv_sp_mask_keys": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_mask_perms": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t, vp]),
     "cv_sp_transpose_map": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, vp, vp]),

@@ -26,6 +26,7 @@ SOURCES = {
     "hv_decode.hip": STRICT,
     "sparse_coords.hip": [],
     "sparse_conv.hip": [],
+    "net_exec.cpp": [],
 }
 
 

@@ -1,0 +1,91 @@
+// Host-side executor for a fused eval-mode sparse network (the 63 convolutions of MinkUNet34C.forward,
+// utils/minkunet.py:122-180, with BatchNorm / bias / residual / ReLU folded into the conv epilogues).
+// The program is symbolic - feature buffers are (coordinate level, channels) slots of a per-scene arena, kernel
+// maps and processing orders are slots of per-scene pointer tables - so it is built once per model and one
+// C call per scene issues every launch: the Python layer's per-conv overhead (descriptor marshalling, tensor
+// allocation, ~35 us x 63) is what bounded the scene rate once several scenes were in flight.
+#include <vector>
+
+#include "cv_common.h"
+
+namespace {
+
+struct Slot { char* ptr; int ld; long long rows; };
+
+}  // namespace
+
+extern "C" {
+
+size_t cv_net_arena_bytes(const cv_net_buf* bufs, int n_bufs, const long long* level_rows, int n_levels) {
+    if (!bufs || !level_rows || n_bufs <= 0) return 0;
+    size_t total = 256;
+    for (int i = 0; i < n_bufs; ++i) {
+        if (bufs[i].level < 0 || bufs[i].level >= n_levels) continue;        // external buffer
+        total += cv_align_up(sizeof(float) * (size_t)level_rows[bufs[i].level] * (size_t)bufs[i].channels, 256);
+    }
+    return total;
+}
+
+int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int n_bufs, const long long* level_rows,
+                   int n_levels, void* d_arena, size_t arena_bytes, const void* const* ext_ptr, const int* ext_ld,
+                   const int32_t* const* maps, int n_maps, const int32_t* const* perms, int n_perms, void* d_ws,
+                   size_t ws_bytes, void* stream) {
+    CV_REQUIRE(ops && bufs && level_rows && d_arena && n_ops > 0 && n_bufs > 0 && n_levels > 0, CV_EINVAL,
+               "bad network program arguments");
+    CV_REQUIRE(arena_bytes >= cv_net_arena_bytes(bufs, n_bufs, level_rows, n_levels), CV_ENOMEM, "arena too small");
+    std::vector<Slot> slot((size_t)n_bufs);
+    {
+        CvCarver cv(d_arena);
+        int ext = 0;
+        for (int i = 0; i < n_bufs; ++i) {
+            const int lv = bufs[i].level;
+            if (lv < 0 || lv >= n_levels) {                                   // external: caller's tensor
+                CV_REQUIRE(ext_ptr && ext_ld && ext_ptr[ext], CV_EINVAL, "external buffer %d has no pointer", ext);
+                slot[i] = {static_cast<char*>(const_cast<void*>(ext_ptr[ext])), ext_ld[ext], bufs[i].rows_level >= 0 &&
+                           bufs[i].rows_level < n_levels ? level_rows[bufs[i].rows_level] : 0};
+                ++ext;
+            } else {
+                slot[i] = {reinterpret_cast<char*>(cv.take<float>((size_t)level_rows[lv] * bufs[i].channels)),
+                           bufs[i].channels, level_rows[lv]};
+            }
+        }
+    }
+    for (int k = 0; k < n_ops; ++k) {
+        const cv_net_op& o = ops[k];
+        CV_REQUIRE(o.in_buf >= 0 && o.in_buf < n_bufs && o.out_buf >= 0 && o.out_buf < n_bufs &&
+                       o.res_buf < n_bufs && o.map < n_maps && o.perm < n_perms, CV_EINVAL, "op %d: bad slot", k);
+        const Slot& in = slot[o.in_buf];
+        const Slot& out = slot[o.out_buf];
+        cv_conv_desc d = {};
+        d.in = reinterpret_cast<const float*>(in.ptr) + o.in_col;
+        d.n_in = in.rows;
+        d.in_ld = in.ld;
+        d.cin = o.cin;
+        d.weight = o.weight;
+        d.K = o.K;
+        d.cout = o.cout;
+        d.nbr = o.map >= 0 ? maps[o.map] : nullptr;
+        d.n_out = out.rows;
+        d.scale = o.scale;
+        d.shift = o.shift;
+        if (o.res_buf >= 0) {
+            d.residual = reinterpret_cast<const float*>(slot[o.res_buf].ptr) + o.res_col;
+            d.res_ld = slot[o.res_buf].ld;
+        }
+        d.relu = o.relu;
+        d.out = reinterpret_cast<float*>(out.ptr) + o.out_col;
+        d.out_ld = out.ld;
+        d.ws = d_ws;
+        d.ws_bytes = ws_bytes;
+        const int32_t* perm = o.perm >= 0 ? perms[o.perm] : nullptr;
+        if (perm) {
+            d.row_perm = perm;
+            d.perm_groups = o.perm_groups;
+        }
+        const int rc = cv_sp_conv_f32(&d, stream);
+        if (rc != CV_OK) return rc;
+    }
+    return CV_OK;
+}
+
+}  // extern "C"

@@ -97,7 +97,7 @@ class MinkUNetBase(ResNetBase):
     # ------------------------------------------------------------------ reference-shaped forward
     def forward(self, x):
         if (not self.training) and (not torch.is_grad_enabled()) and self.BLOCK is BasicBlock:
-            return self.fused_forward(x)
+            return self.program_forward(x) if self.USE_PROGRAM else self.fused_forward(x)
         return self.modular_forward(x)
 
     def modular_forward(self, x):
@@ -130,6 +130,11 @@ class MinkUNetBase(ResNetBase):
     # levels with at least this many rows run the mask-sorted grouped conv
     MASKED_MIN_ROWS = int(os.environ.get("CV_MASKED_MIN_ROWS", "16384"))
     MASK_GROUPS = 4
+    # eval forward through the C executor (cv_net_run_f32, one call per scene: host time 1.46 -> 0.72 ms).  Off by
+    # default: the GPU, not the host, bounds the scene rate today, and the executor's per-scene arena (257 MB at
+    # 80k points, no aliasing across levels) costs more Infinity-Cache misses with several scenes in flight than
+    # the caching allocator's recycled temporaries (227 vs 244 scenes/s at 3 scenes in flight).
+    USE_PROGRAM = os.environ.get("CV_NET_PROGRAM", "0") != "0"
 
     def _conv3(self, x, kernel, nbr, perms, n, **ep):
         if perms is not None:
@@ -187,6 +192,136 @@ class MinkUNetBase(ResNetBase):
         y = ME.conv_forward(out, self.final.kernel, out_map, n[0], shift=self.final.bias.reshape(-1))
         return x._like(y, 1)
 
+
+    # ------------------------------------------------------------------ the same forward as ONE C call per scene
+    MAP_STEM, MAP_DOWN, MAP_K3, MAP_UP, MAP_OUT = 0, 1, 5, 10, 14          # slots of the per-scene map table
+    PERM_K3, PERM_UP = 0, 5                                                 # slots of the processing-order table
+
+    def _program(self, dev):
+        """(ops, bufs, keep-alive) for cv_net_run_f32: the launch sequence of fused_forward with symbolic operands
+        (arena buffer slots, map / order slots).  Built once per parameter version."""
+        from . import _lib
+        ver = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers()) + \
+            (next(self.parameters()).data_ptr(), str(dev))
+        hit = self.__dict__.get("_prog")
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        exp = self.BLOCK.expansion
+        bufs, ops, keep, free = [], [], [], {}
+
+        def alloc(level, ch):
+            pool = free.get((level, ch))
+            if pool:
+                return pool.pop()
+            bufs.append((level, ch, level))
+            return len(bufs) - 1
+
+        def release(slot):
+            level, ch, _ = bufs[slot]
+            if level >= 0:
+                free.setdefault((level, ch), []).append(slot)
+
+        def conv(src, dst, kernel, K, map_slot, scale=None, shift=None, res=None, relu=False, perm=-1, groups=0):
+            w = (kernel if kernel.dim() == 3 else kernel[None]).detach().contiguous()
+            keep.extend([w, scale, shift])
+            ops.append(dict(in_buf=src[0], in_col=src[1], cin=w.shape[1], out_buf=dst[0], out_col=dst[1],
+                            cout=w.shape[2], res_buf=res[0] if res else -1, res_col=res[1] if res else 0,
+                            map=map_slot, K=K, perm=perm, perm_groups=groups, relu=1 if relu else 0,
+                            weight=w.data_ptr(), scale=scale.data_ptr() if scale is not None else None,
+                            shift=shift.data_ptr() if shift is not None else None))
+
+        def layer(seq, x, level, out_view):
+            """x, out_view: (slot, first column); returns the (slot, column) holding the layer's output"""
+            for bi, blk in enumerate(seq):
+                planes = blk.conv1.out_channels
+                s1, b1 = self._fold(blk.norm1)
+                t = (alloc(level, planes), 0)
+                k3 = dict(K=27, map_slot=self.MAP_K3 + level, perm=self.PERM_K3 + level, groups=self.MASK_GROUPS)
+                conv(x, t, blk.conv1.kernel, scale=s1, shift=b1, relu=True, **k3)
+                if blk.downsample is not None:
+                    sd, bd = self._fold(blk.downsample[1])
+                    res = (alloc(level, planes), 0)
+                    conv(x, res, blk.downsample[0].kernel, 1, -1, scale=sd, shift=bd)
+                else:
+                    res = x
+                s2, b2 = self._fold(blk.norm2)
+                last = bi == len(seq) - 1
+                y = out_view if (last and out_view is not None) else (alloc(level, planes), 0)
+                conv(t, y, blk.conv2.kernel, scale=s2, shift=b2, res=res, relu=True, **k3)
+                release(t[0])
+                if res is not x:
+                    release(res[0])
+                if x[1] == 0 and bufs[x[0]][1] == (blk.conv1.in_channels):       # whole buffers only, never views
+                    release(x[0])
+                x = y
+            return x
+
+        bufs.append((-1, self.conv0p1s1.in_channels, 0))          # slot 0: caller's features (original row order)
+        bufs.append((-1, self.final.out_channels, 0))             # slot 1: caller's output
+        up_c = [self.PLANES[4 + i] for i in range(4)]
+        skip_c = (self.PLANES[2] * exp, self.PLANES[1] * exp, self.PLANES[0] * exp, self.INIT_DIM)
+        cat = []
+        for i in range(4):
+            bufs.append((3 - i, up_c[i] + skip_c[i], 3 - i))
+            cat.append(len(bufs) - 1)
+        s, b = self._fold(self.bn0)
+        out = (cat[3], up_c[3])
+        conv((0, 0), out, self.conv0p1s1.kernel, self.conv0p1s1.kernel.shape[0], self.MAP_STEM, scale=s, shift=b,
+             relu=True)
+        for i, (cname, bname) in enumerate(_DOWN):
+            s, b = self._fold(getattr(self, bname))
+            c = getattr(self, cname)
+            d = (alloc(i + 1, c.out_channels), 0)
+            conv(out, d, c.kernel, 8, self.MAP_DOWN + i, scale=s, shift=b, relu=True)
+            out = layer(getattr(self, "block%d" % (i + 1)), d, i + 1, (cat[2 - i], up_c[2 - i]) if i < 3 else None)
+        for i, (cname, bname) in enumerate(_UP):
+            lvl = 3 - i
+            s, b = self._fold(getattr(self, bname))
+            conv(out, (cat[i], 0), getattr(self, cname).kernel, 8, self.MAP_UP + i, scale=s, shift=b, relu=True,
+                 perm=self.PERM_UP + i)
+            if bufs[out[0]][0] >= 0 and out[1] == 0 and out[0] not in cat:
+                release(out[0])
+            out = layer(getattr(self, "block%d" % (5 + i)), (cat[i], 0), lvl, None)
+        bias = self.final.bias.detach().reshape(-1).contiguous()
+        conv(out, (1, 0), self.final.kernel, 1, self.MAP_OUT, shift=bias)
+        c_ops = (_lib.NetOp * len(ops))(*[_lib.NetOp(**o) for o in ops])
+        c_bufs = (_lib.NetBuf * len(bufs))(*[_lib.NetBuf(*bf) for bf in bufs])
+        prog = (c_ops, c_bufs, keep)
+        self.__dict__["_prog"] = (ver, prog)
+        return prog
+
+    def program_forward(self, x):
+        """fused_forward through the C executor (cv_net_run_f32): identical launches, one call."""
+        import ctypes
+        from . import _lib
+        L = _lib.lib()
+        cm, stem_map, out_map = x.coordinate_manager.fused_plan()
+        dev = x.F.device
+        c_ops, c_bufs, _ = self._program(dev)
+        n = [cm.num_rows(1 << i) for i in range(5)]
+        maps = [stem_map] + [cm.kernel_map(2, 1 << i, 2) for i in range(4)] + [cm.kernel_map(3, 1 << i) for i in range(5)] \
+            + [cm.up_map(16 >> i) for i in range(4)] + [out_map]
+        perms = [cm.mask_perms(3, 1 << i, self.MASK_GROUPS) if n[i] >= self.MASKED_MIN_ROWS else None
+                 for i in range(5)] + [cm.up_perm(16 >> i) for i in range(4)]
+        feats = x.F.contiguous()
+        y = torch.empty((n[0], self.final.out_channels), dtype=torch.float32, device=dev)
+        rows = (ctypes.c_int64 * 5)(*n)
+        arena = torch.empty(int(L.cv_net_arena_bytes(c_bufs, len(c_bufs), rows, 5)), dtype=torch.uint8, device=dev)
+        cmax = max(self.PLANES)
+        ws_bytes = max([4 * self.MASK_GROUPS * n[i] * cmax + 256 for i in range(5) if perms[i] is not None] +
+                       [int(L.cv_sp_conv_workspace_bytes(min(n[i], 128 * 384 - 1), cmax, 27)) for i in range(5)])
+        ws = ME._workspace(dev, ws_bytes)
+        vp = ctypes.c_void_p
+        ext_ptr = (vp * 2)(feats.data_ptr(), y.data_ptr())
+        ext_ld = (ctypes.c_int * 2)(feats.stride(0), y.stride(0))
+        c_maps = (vp * len(maps))(*[m.data_ptr() for m in maps])
+        c_perms = (vp * len(perms))(*[p.data_ptr() if p is not None else None for p in perms])
+        with torch.cuda.device(dev):
+            _lib.check(L.cv_net_run_f32(c_ops, len(c_ops), c_bufs, len(c_bufs), rows, 5, vp(arena.data_ptr()),
+                                        arena.numel(), ext_ptr, ext_ld, c_maps, len(maps), c_perms, len(perms),
+                                        vp(ws.data_ptr()), ws.numel(),
+                                        vp(torch.cuda.current_stream(dev).cuda_stream)), "cv_net_run_f32")
+        return x._like(y, 1)
 
     def forward_flops(self, x):
         """Algorithmic flops of one forward on x's coordinate set:

@@ -209,6 +209,35 @@ int cv_sp_pack_weights_f32(const float* d_w, int K, int cin, int cout, float* d_
 size_t cv_sp_conv_workspace_bytes(long long n_out, int cout, int K);
 int cv_sp_conv_f32(const cv_conv_desc* desc, void* stream);
 
+/* Fused eval-mode network as ONE call per scene (host-side executor over cv_sp_conv_f32; replaces the reference's
+ * module-by-module MinkUNet34C.forward, utils/minkunet.py:122-180, for inference).  The program is symbolic and built
+ * once per model: feature buffers are slots of a per-scene arena, kernel maps / processing orders are slots of
+ * per-scene pointer tables.
+ *   cv_net_buf: level >= 0: arena buffer of level_rows[level] x channels floats;
+ *               level < 0: the caller's tensor - takes the next entry of ext_ptr / ext_ld, rows = level_rows[rows_level].
+ *   cv_net_op:  out[:, out_col:out_col+cout] = relu?( conv(in[:, in_col:in_col+cin]) * scale + shift
+ *               + res[:, res_col:res_col+cout] ), kernel map maps[map] (map < 0: K == 1), processing order
+ *               perms[perm] (perm < 0 or a NULL table entry: natural order; perm_groups > 1: mask-sorted groups). */
+typedef struct cv_net_buf {
+    int level, channels, rows_level;
+} cv_net_buf;
+typedef struct cv_net_op {
+    int in_buf, in_col, cin;
+    int out_buf, out_col, cout;
+    int res_buf, res_col;      /* res_buf < 0: no residual */
+    int map, K;
+    int perm, perm_groups;
+    int relu;
+    const float* weight;       /* [K][cin][cout] */
+    const float* scale;        /* [cout] or NULL */
+    const float* shift;        /* [cout] or NULL */
+} cv_net_op;
+size_t cv_net_arena_bytes(const cv_net_buf* bufs, int n_bufs, const long long* level_rows, int n_levels);
+int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int n_bufs, const long long* level_rows,
+                   int n_levels, void* d_arena, size_t arena_bytes, const void* const* ext_ptr, const int* ext_ld,
+                   const int32_t* const* maps, int n_maps, const int32_t* const* perms, int n_perms, void* d_ws,
+                   size_t ws_bytes, void* stream);
+
 /* d_keys[n] (int64) = bit mask of the valid neighbours among offsets [j_begin, j_end) of every row of a
  * kernel map; argsort of it is a row_perm for cv_conv_desc.  Asynchronous. */
 int cv_sp_mask_keys(const int32_t* d_nbr, long long n, int K, int j_begin, int j_end, long long* d_keys,

@@ -209,6 +209,8 @@ def test_minkunet34c_fused_and_modular_match_oracle(cuda, built_lib, n, small):
     with torch.no_grad():
         fused = model(x).F.cpu().numpy()
         modular = model.modular_forward(x).F.cpu().numpy()
+        program = model.program_forward(x).F.cpu().numpy()        # same launches through the C executor
+    assert np.array_equal(program, model.fused_forward(x).F.cpu().numpy())
     ref = so.minkunet34c_forward(sd, coords, feats).numpy()
     assert fused.shape == ref.shape == (n, 64)
     # north_star: within 1e-4 on the LCC / scale floats (outputs are O(1))
