@@ -300,3 +300,46 @@ def test_eval_script_pipeline_recovers_planted_boxes(cuda, built_lib):
     res = mod.evaluate(model, ds, teacher=True)
     assert res[0.25]["mAP"] > 0.85 and res[0.25]["AR"] > 0.85, res
     assert res[0.5]["mAP"] > 0.5, res
+
+
+def test_scenes_in_flight_on_separate_streams_match_sequential(cuda, built_lib):
+    """bench.py keeps several scenes in flight (one host thread + HIP stream each); per-scene results must be the
+    ones of the one-at-a-time path, bit for bit (per-stream workspaces, no shared mutable state)."""
+    import threading
+    from canonicalvoting_amd.hough import HoughVoting
+    scenes = []
+    for seed in (21, 22, 23):
+        coords, feats = scene_coords(seed, 6000, small=False)
+        scenes.append((torch.from_numpy(coords).int().to(cuda), torch.from_numpy(feats).to(cuda)))
+    model = MinkUNet34C(3, 64)
+    model.load_state_dict(so.make_state_dict(3, 64, seed=4))
+    model = model.cuda().eval()
+
+    def run(i, hv, out):
+        dets, raw, y = pipeline.detect_scene(model, hv, scenes[i][0], scenes[i][1], 0.03, thresh_high=5.0)
+        out[i] = (y.F.clone(), np.asarray(raw["cand_idx"]).copy(), np.asarray(raw["verdict"]).copy(),
+                  np.asarray(raw["boxes"]).copy())
+
+    seq = {}
+    for i in range(3):
+        run(i, HoughVoting(0.03, 120), seq)
+    torch.cuda.synchronize()
+    par = {}
+    streams = [torch.cuda.Stream(cuda) for _ in range(3)]
+
+    def worker(i):
+        torch.cuda.set_device(cuda)
+        with torch.cuda.stream(streams[i]):
+            for _ in range(3):                          # repeated: later rounds overlap fully
+                run(i, HoughVoting(0.03, 120), par)
+            streams[i].synchronize()
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(3):
+        assert torch.equal(seq[i][0], par[i][0])
+        for a, b in zip(seq[i][1:], par[i][1:]):
+            assert np.array_equal(a, b)
