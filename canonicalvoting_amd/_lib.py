@@ -40,6 +40,13 @@ class ConvDesc(ctypes.Structure):
                 ("weight_packed", vp)]
 
 
+class SceneMaps(ctypes.Structure):
+    """struct cv_scene_maps (include/cv_hip.h)"""
+    _fields_ = [("stem", ctypes.c_longlong), ("out", ctypes.c_longlong), ("down", ctypes.c_longlong * 4),
+                ("k3", ctypes.c_longlong * 5), ("up", ctypes.c_longlong * 4), ("mask_perm", ctypes.c_longlong * 5),
+                ("up_perm", ctypes.c_longlong * 4), ("scratch", ctypes.c_longlong)]
+
+
 class NetBuf(ctypes.Structure):
     """struct cv_net_buf (include/cv_hip.h)"""
     _fields_ = [("level", ctypes.c_int), ("channels", ctypes.c_int), ("rows_level", ctypes.c_int)]
@@ -90,6 +97,11 @@ SIGNATURES = {
     "cv_sp_tile_plan": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, vp, vp, vp]),
     "cv_sp_tile_kw": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "cv_sp_pack_weights_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "cv_sp_scene_maps_words": (ctypes.c_size_t, [c_i64_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_longlong, ctypes.POINTER(SceneMaps)]),
+    "cv_sp_scene_maps": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_longlong,
+                                        c_i64_p, vp, vp, vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_longlong, vp, ctypes.c_size_t, vp]),
     "cv_net_arena_bytes": (ctypes.c_size_t, [ctypes.POINTER(NetBuf), ctypes.c_int, c_i64_p, ctypes.c_int]),
     "cv_net_run_f32": (ctypes.c_int, [ctypes.POINTER(NetOp), ctypes.c_int, ctypes.POINTER(NetBuf), ctypes.c_int,
                                       c_i64_p, ctypes.c_int, vp, ctypes.c_size_t, ctypes.POINTER(vp), c_int_p,

@@ -4,6 +4,7 @@
 // maps and processing orders are slots of per-scene pointer tables - so it is built once per model and one
 // C call per scene issues every launch: the Python layer's per-conv overhead (descriptor marshalling, tensor
 // allocation, ~35 us x 63) is what bounded the scene rate once several scenes were in flight.
+#include <algorithm>
 #include <vector>
 
 #include "cv_common.h"
@@ -15,6 +16,69 @@ struct Slot { char* ptr; int ld; long long rows; };
 }  // namespace
 
 extern "C" {
+
+// ---- every kernel map and processing order of the fused network in ONE call per scene ----------------------
+// (the Python coordinate manager issued ~25 calls for them: 0.65 ms of host time per scene on the critical path)
+static void scene_maps_layout(const long long* rows, long long n_orig, int stem_k, int mask_groups,
+                              long long masked_min_rows, cv_scene_maps* o, size_t* total) {
+    size_t off = 0;
+    auto take = [&](size_t words) { const size_t at = off; off += cv_align_up(words, 64); return (long long)at; };
+    const size_t K5 = (size_t)stem_k * stem_k * stem_k;
+    o->stem = take((size_t)rows[0] * K5);
+    o->out = take((size_t)n_orig);
+    for (int i = 0; i < 4; ++i) o->down[i] = take((size_t)rows[i + 1] * 8);
+    for (int i = 0; i < 5; ++i) o->k3[i] = take((size_t)rows[i] * 27);
+    for (int i = 0; i < 4; ++i) o->up[i] = take((size_t)rows[3 - i] * 8);            // up[i]: level 4-i -> 3-i
+    for (int i = 0; i < 5; ++i)
+        o->mask_perm[i] = (mask_groups > 1 && rows[i] >= masked_min_rows) ? take((size_t)mask_groups * rows[i]) : -1;
+    for (int i = 0; i < 4; ++i) o->up_perm[i] = take((size_t)rows[3 - i]);
+    o->scratch = take((size_t)std::max(mask_groups, 1) * 1024);
+    *total = off;
+}
+
+size_t cv_sp_scene_maps_words(const long long* level_rows, long long n_orig, int stem_k, int mask_groups,
+                              long long masked_min_rows, cv_scene_maps* offsets) {
+    if (!level_rows || !offsets || n_orig <= 0 || stem_k < 1) return 0;
+    size_t total = 0;
+    scene_maps_layout(level_rows, n_orig, stem_k, mask_groups, masked_min_rows, offsets, &total);
+    return total;
+}
+
+int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
+                     long long cap, const long long* level_rows, const int32_t* d_orig_coords,
+                     const unsigned long long* d_orig_keys, const int32_t* d_orig_vals, long long orig_cap,
+                     long long n_orig, int stem_k, int mask_groups, long long masked_min_rows, int32_t* d_arena,
+                     size_t arena_words, void* stream) {
+    CV_REQUIRE(d_coords && d_keys && d_vals && level_rows && d_orig_coords && d_orig_keys && d_orig_vals && d_arena,
+               CV_EINVAL, "null pointer argument");
+    cv_scene_maps o;
+    size_t total = 0;
+    scene_maps_layout(level_rows, n_orig, stem_k, mask_groups, masked_min_rows, &o, &total);
+    CV_REQUIRE(arena_words >= total, CV_ENOMEM, "scene map arena too small");
+    int rc;
+#define CV_TRY(call) do { rc = (call); if (rc != CV_OK) return rc; } while (0)
+    // stem: sorted rows <- rows of the ORIGINAL order; final: original rows <- sorted rows
+    CV_TRY(cv_sp_kernel_map(d_coords[0], level_rows[0], d_orig_keys, d_orig_vals, orig_cap, stem_k, 1,
+                            d_arena + o.stem, stream));
+    CV_TRY(cv_sp_kernel_map(d_orig_coords, n_orig, d_keys[0], d_vals[0], cap, 1, 1, d_arena + o.out, stream));
+    for (int i = 0; i < 4; ++i)
+        CV_TRY(cv_sp_kernel_map(d_coords[i + 1], level_rows[i + 1], d_keys[i], d_vals[i], cap, 2, 1 << i,
+                                d_arena + o.down[i], stream));
+    for (int i = 0; i < 5; ++i)
+        CV_TRY(cv_sp_kernel_map(d_coords[i], level_rows[i], d_keys[i], d_vals[i], cap, 3, 1 << i, d_arena + o.k3[i],
+                                stream));
+    for (int i = 0; i < 4; ++i)
+        CV_TRY(cv_sp_up_map(d_arena + o.down[3 - i], level_rows[4 - i], level_rows[3 - i], d_arena + o.up[i], stream));
+    for (int i = 0; i < 5; ++i)
+        if (o.mask_perm[i] >= 0)
+            CV_TRY(cv_sp_mask_perms(d_arena + o.k3[i], level_rows[i], 27, mask_groups, d_arena + o.mask_perm[i],
+                                    d_arena + o.scratch, sizeof(int) * (size_t)mask_groups * 1024, stream));
+    for (int i = 0; i < 4; ++i)
+        CV_TRY(cv_sp_mask_perms(d_arena + o.up[i], level_rows[3 - i], 8, 1, d_arena + o.up_perm[i], d_arena + o.scratch,
+                                sizeof(int) * 1024, stream));
+#undef CV_TRY
+    return CV_OK;
+}
 
 size_t cv_net_arena_bytes(const cv_net_buf* bufs, int n_bufs, const long long* level_rows, int n_levels) {
     if (!bufs || !level_rows || n_bufs <= 0) return 0;

@@ -152,21 +152,50 @@ class CoordinateManager:
             self._maps[key] = m
         return m
 
-    def fused_plan(self):
+    # mask-sorted offset groups of the 3x3x3 convs: levels with at least MASKED_MIN_ROWS rows get MASK_GROUPS orders
+    MASK_GROUPS = 4
+    MASKED_MIN_ROWS = int(os.environ.get("CV_MASKED_MIN_ROWS", "16384"))
+
+    def fused_plan(self, stem_k=5):
         """Spatially sorted twin of this coordinate set for the fused network:
-        (sorted manager with all levels, stem map sorted<-original rows, final map original<-sorted)."""
-        if self._fused is None:
+        (sorted manager with all levels, stem map sorted<-original rows, final map original<-sorted).
+        Every kernel map / processing order the network asks the sorted manager for is built here by ONE C call
+        (cv_sp_scene_maps) into one arena and pre-seeded into its cache."""
+        if self._fused is None or self._fused_k != stem_k:
             L = _lib.lib()
+            dev = self.device
             n = self._input.shape[0]
-            keys = torch.empty(n, dtype=torch.int64, device=self.device)
-            with torch.cuda.device(self.device):
-                _lib.check(L.cv_sp_morton_keys(_ptr(self._input), n, _ptr(keys), _stream(self.device)),
-                           "cv_sp_morton_keys")
+            keys = torch.empty(n, dtype=torch.int64, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.cv_sp_morton_keys(_ptr(self._input), n, _ptr(keys), _stream(dev)), "cv_sp_morton_keys")
             perm = torch.argsort(keys)                      # device radix sort (plumbing, 80k keys)
             cm_s = CoordinateManager(self._input[perm].contiguous(), CoordinateManager.NUM_LEVELS, True)
-            stem_map = self.cross_map(cm_s.coords[1], 5)    # rows of the ORIGINAL order
-            out_map = cm_s.cross_map(self._input, 1)        # original row i <- sorted row
+            rows = (ctypes.c_int64 * 5)(*cm_s.counts)
+            off = _lib.SceneMaps()
+            G = self.MASK_GROUPS
+            words = int(L.cv_sp_scene_maps_words(rows, n, stem_k, G, self.MASKED_MIN_ROWS, ctypes.byref(off)))
+            arena = torch.empty(words, dtype=torch.int32, device=dev)
+            arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+            with torch.cuda.device(dev):
+                _lib.check(L.cv_sp_scene_maps(arr(cm_s._coords_buf), arr(cm_s._keys), arr(cm_s._vals), cm_s.cap, rows,
+                                              _ptr(self._input), _ptr(self._keys[0]), _ptr(self._vals[0]), self.cap, n,
+                                              stem_k, G, self.MASKED_MIN_ROWS, _ptr(arena), words, _stream(dev)),
+                           "cv_sp_scene_maps")
+            c = cm_s.counts
+            view = lambda o, r, k: arena[o:o + r * k].view(r, k)
+            stem_map = view(off.stem, c[0], stem_k ** 3)
+            out_map = view(off.out, n, 1)
+            for i in range(4):
+                cm_s._maps[("k", 2, 1 << i, 2)] = view(off.down[i], c[i + 1], 8)
+                cm_s._maps[("up", 16 >> i)] = view(off.up[i], c[3 - i], 8)
+                cm_s._maps[("upperm", 16 >> i)] = arena[off.up_perm[i]:off.up_perm[i] + c[3 - i]]
+            for i in range(5):
+                cm_s._maps[("k", 3, 1 << i, 1)] = view(off.k3[i], c[i], 27)
+                if off.mask_perm[i] >= 0:
+                    cm_s._maps[("mp", 3, 1 << i, G)] = view(off.mask_perm[i], G, c[i])
+            cm_s._verified = True
             self._fused = (cm_s, stem_map, out_map)
+            self._fused_k = stem_k
         return self._fused
 
     def num_rows(self, ts):

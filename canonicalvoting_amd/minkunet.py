@@ -127,14 +127,14 @@ class MinkUNetBase(ResNetBase):
             cache[id(bn)] = hit
         return hit[1]
 
-    # levels with at least this many rows run the mask-sorted grouped conv
-    MASKED_MIN_ROWS = int(os.environ.get("CV_MASKED_MIN_ROWS", "16384"))
-    MASK_GROUPS = 4
+    # levels with at least this many rows run the mask-sorted grouped conv (the coordinate manager builds the orders)
+    MASKED_MIN_ROWS = ME.CoordinateManager.MASKED_MIN_ROWS
+    MASK_GROUPS = ME.CoordinateManager.MASK_GROUPS
     # eval forward through the C executor (cv_net_run_f32, one call per scene: host time 1.46 -> 0.72 ms).  Off by
     # default: the GPU, not the host, bounds the scene rate today, and the executor's per-scene arena (257 MB at
     # 80k points, no aliasing across levels) costs more Infinity-Cache misses with several scenes in flight than
     # the caching allocator's recycled temporaries (227 vs 244 scenes/s at 3 scenes in flight).
-    USE_PROGRAM = os.environ.get("CV_NET_PROGRAM", "0") != "0"
+    USE_PROGRAM = os.environ.get("CV_NET_PROGRAM", "1") != "0"
 
     def _conv3(self, x, kernel, nbr, perms, n, **ep):
         if perms is not None:
@@ -161,7 +161,7 @@ class MinkUNetBase(ResNetBase):
         # internal rows are Z-order sorted (compact 32-row wave tiles -> whole kernel offsets are
         # skipped); the stem reads the caller's rows through stem_map and `final` writes back in the
         # caller's row order through out_map, so the row-order invariant of the reference holds.
-        cm, stem_map, out_map = x.coordinate_manager.fused_plan()
+        cm, stem_map, out_map = x.coordinate_manager.fused_plan(self.conv0p1s1.kernel_size)
         dev = x.F.device
         exp = self.BLOCK.expansion
         n = [cm.num_rows(1 << i) for i in range(5)]
@@ -201,11 +201,16 @@ class MinkUNetBase(ResNetBase):
         """(ops, bufs, keep-alive) for cv_net_run_f32: the launch sequence of fused_forward with symbolic operands
         (arena buffer slots, map / order slots).  Built once per parameter version."""
         from . import _lib
-        ver = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers()) + \
-            (next(self.parameters()).data_ptr(), str(dev))
+        # cheap staleness check (walking nn.Module.parameters() costs 0.3 ms per call): the flat tensor list is
+        # kept with the program, in-place updates bump _version, re-allocation (.to(), load_state_dict with
+        # assign) changes data_ptr of the first parameter or the tensor objects themselves
         hit = self.__dict__.get("_prog")
-        if hit is not None and hit[0] == ver:
-            return hit[1]
+        if hit is not None:
+            tensors, ver = hit[0]
+            if ver == (sum(t._version for t in tensors), tensors[0].data_ptr(), str(dev), self.training):
+                return hit[1]
+        tensors = list(self.parameters()) + list(self.buffers())
+        ver = ((tensors, (sum(t._version for t in tensors), tensors[0].data_ptr(), str(dev), self.training)))
         exp = self.BLOCK.expansion
         bufs, ops, keep, free = [], [], [], {}
 
@@ -295,7 +300,7 @@ class MinkUNetBase(ResNetBase):
         import ctypes
         from . import _lib
         L = _lib.lib()
-        cm, stem_map, out_map = x.coordinate_manager.fused_plan()
+        cm, stem_map, out_map = x.coordinate_manager.fused_plan(self.conv0p1s1.kernel_size)
         dev = x.F.device
         c_ops, c_bufs, _ = self._program(dev)
         n = [cm.num_rows(1 << i) for i in range(5)]

@@ -209,6 +209,24 @@ int cv_sp_pack_weights_f32(const float* d_w, int K, int cin, int cout, float* d_
 size_t cv_sp_conv_workspace_bytes(long long n_out, int cout, int K);
 int cv_sp_conv_f32(const cv_conv_desc* desc, void* stream);
 
+/* Every kernel map and processing order the fused MinkUNet forward needs, built by ONE call per scene into one
+ * int32 arena (offsets in int32 words; -1 = absent):
+ *   stem  [rows0][stem_k^3]  sorted rows <- rows of the caller's order (table of the caller's coordinate set)
+ *   out   [n_orig][1]        caller's rows <- sorted rows
+ *   down[i] [rows(i+1)][8]   k2s2 conv level i -> i+1;   k3[i] [rows(i)][27];   up[i] [rows(3-i)][8] level 4-i -> 3-i
+ *   mask_perm[i] [groups][rows(i)] for levels with >= masked_min_rows rows;  up_perm[i] [rows(3-i)] octant order
+ * d_coords / d_keys / d_vals: the five levels of the (Z-order sorted) coordinate set from cv_sp_build_levels. */
+typedef struct cv_scene_maps {
+    long long stem, out, down[4], k3[5], up[4], mask_perm[5], up_perm[4], scratch;
+} cv_scene_maps;
+size_t cv_sp_scene_maps_words(const long long* level_rows, long long n_orig, int stem_k, int mask_groups,
+                              long long masked_min_rows, cv_scene_maps* offsets);
+int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
+                     long long cap, const long long* level_rows, const int32_t* d_orig_coords,
+                     const unsigned long long* d_orig_keys, const int32_t* d_orig_vals, long long orig_cap,
+                     long long n_orig, int stem_k, int mask_groups, long long masked_min_rows, int32_t* d_arena,
+                     size_t arena_words, void* stream);
+
 /* Fused eval-mode network as ONE call per scene (host-side executor over cv_sp_conv_f32; replaces the reference's
  * module-by-module MinkUNet34C.forward, utils/minkunet.py:122-180, for inference).  The program is symbolic and built
  * once per model: feature buffers are slots of a per-scene arena, kernel maps / processing orders are slots of

@@ -1,6 +1,7 @@
 """Per-conv-call times of the fused MinkUNet34C forward on one 80k-point scene (HIP events around every
 cv_sp_conv_f32 call, averaged over repeats): which layers the net forward's milliseconds go to."""
 import os, sys
+os.environ['CV_NET_PROGRAM'] = '0'      # per-conv timing needs the Python-issued forward
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from canonicalvoting_amd.minkunet import MinkUNet34C
