@@ -37,7 +37,7 @@ class ConvDesc(ctypes.Structure):
                 ("flavour", ctypes.c_int), ("ws", vp), ("ws_bytes", ctypes.c_size_t), ("row_perm", vp),
                 ("j_begin", ctypes.c_int), ("j_end", ctypes.c_int), ("acc_in", vp), ("acc_ld", ctypes.c_int),
                 ("perm_groups", ctypes.c_int), ("plan_ent", vp), ("plan_cnt", vp),
-                ("weight_packed", vp)]
+                ("weight_packed", vp), ("perm_has_map", ctypes.c_int)]
 
 
 class SceneMaps(ctypes.Structure):
@@ -108,7 +108,8 @@ SIGNATURES = {
                                       ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(vp), ctypes.c_int, vp,
                                       ctypes.c_size_t, vp]),
     "cv_sp_mask_keys": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
-    "cv_sp_mask_perms": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t, vp]),
+    "cv_sp_mask_perms": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t,
+                                        ctypes.c_int, vp]),
     "cv_sp_transpose_map": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, vp, vp]),
     "cv_sp_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "cv_sp_conv_wgrad_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp,

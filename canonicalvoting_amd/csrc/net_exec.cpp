@@ -30,7 +30,8 @@ static void scene_maps_layout(const long long* rows, long long n_orig, int stem_
     for (int i = 0; i < 5; ++i) o->k3[i] = take((size_t)rows[i] * 27);
     for (int i = 0; i < 4; ++i) o->up[i] = take((size_t)rows[3 - i] * 8);            // up[i]: level 4-i -> 3-i
     for (int i = 0; i < 5; ++i)
-        o->mask_perm[i] = (mask_groups > 1 && rows[i] >= masked_min_rows) ? take((size_t)mask_groups * rows[i]) : -1;
+        o->mask_perm[i] = (mask_groups > 1 && rows[i] >= masked_min_rows)
+                              ? take((size_t)mask_groups * rows[i] * (1 + (27 + mask_groups - 1) / mask_groups)) : -1;
     for (int i = 0; i < 4; ++i) o->up_perm[i] = take((size_t)rows[3 - i]);
     o->scratch = take((size_t)std::max(mask_groups, 1) * 1024);
     *total = off;
@@ -72,10 +73,10 @@ int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* 
     for (int i = 0; i < 5; ++i)
         if (o.mask_perm[i] >= 0)
             CV_TRY(cv_sp_mask_perms(d_arena + o.k3[i], level_rows[i], 27, mask_groups, d_arena + o.mask_perm[i],
-                                    d_arena + o.scratch, sizeof(int) * (size_t)mask_groups * 1024, stream));
+                                    d_arena + o.scratch, sizeof(int) * (size_t)mask_groups * 1024, 1, stream));
     for (int i = 0; i < 4; ++i)
         CV_TRY(cv_sp_mask_perms(d_arena + o.up[i], level_rows[3 - i], 8, 1, d_arena + o.up_perm[i], d_arena + o.scratch,
-                                sizeof(int) * 1024, stream));
+                                sizeof(int) * 1024, 0, stream));
 #undef CV_TRY
     return CV_OK;
 }
@@ -145,6 +146,7 @@ int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int 
         if (perm) {
             d.row_perm = perm;
             d.perm_groups = o.perm_groups;
+            d.perm_has_map = o.perm_groups > 1;      /* scene maps build the orders with their map rows */
         }
         const int rc = cv_sp_conv_f32(&d, stream);
         if (rc != CV_OK) return rc;

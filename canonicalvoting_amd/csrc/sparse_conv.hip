@@ -54,6 +54,9 @@ struct ConvArgs {
     const int* plan_ent;   // tile flavour: compacted (input row, tile row) lists per (tile, offset), see tile_plan
     const int* plan_cnt;
     const float4* wp;      // tile flavour: weights in MFMA operand order, see pack_weights
+    int wide;              // epilogue operands are 16-byte aligned with leading dimensions % 4 == 0: float4 row stores
+    const int* nbr_perm;   // mask-sorted groups: [splits][n_out][nbr_perm_w] kernel map rows in processing order
+    int nbr_perm_w;
 };
 
 __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& acc, const int* rows,
@@ -83,6 +86,49 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& 
     }
 }
 
+// The same epilogue with 16-byte stores: the 32x32 accumulator tile goes through a wave-private LDS tile so that
+// 8 lanes write 128 contiguous bytes of one output row (4 dwordx4 stores per lane instead of 16 dword stores).
+// Measured with the instrumented twin (profiles/conv_phases.py): the dword epilogue was 63 % of the wave time
+// of the split ts16 convs and 20 % of the mask-sorted ts1 convs - it is store-ISSUE bound, not bandwidth bound.
+constexpr int EP_LD = 36;
+__device__ __forceinline__ void epilogue_store_wide(const ConvArgs& a, const f32x16& acc, const int* rows, int colbase,
+                                                    int lane, float (*T)[EP_LD]) {
+    const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[(r & 3) + 8 * (r >> 2) + 4 * h][c] = acc[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int col = colbase + (lane & 7) * 4;
+    if (col < a.cout) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rl = (lane >> 3) + 8 * it;
+            const int row = rows[rl];
+            if (row < 0) continue;
+            float4 v = *reinterpret_cast<const float4*>(&T[rl][(lane & 7) * 4]);
+            if (a.splits > 1) {
+                *reinterpret_cast<float4*>(a.partial + ((long long)blockIdx.z * a.n_out + row) * a.cout + col) = v;
+                continue;
+            }
+            if (a.acc_in) {
+                const float4 p = *reinterpret_cast<const float4*>(a.acc_in + (long long)row * a.acc_ld + col);
+                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+            const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            if (a.res) {
+                const float4 p = *reinterpret_cast<const float4*>(a.res + (long long)row * a.res_ld + col);
+                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(a.out + (long long)row * a.out_ld + col) = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();       // the tile is rewritten by the next column block
+}
+
 // VEC: Cin % 32 == 0 (float4 gathers inside one offset).  !VEC: flattened K = K*Cin (stem, Cin=3).
 template <int NB, bool VEC>
 __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
@@ -90,6 +136,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
     __shared__ float B_s[KC][NB * 32];
     __shared__ int nbr_s[TM];
     __shared__ int rows_s[TM];
+    __shared__ __attribute__((aligned(16))) float ep_s[4][32][EP_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.y * (NB * 32);
 
@@ -146,7 +193,17 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
             int my = -1;
             if (tid < TM) {
                 const int row = rows_s[tid];
-                if (row >= 0) my = a.nbr ? a.nbr[(long long)row * a.K + j] : row;
+                if (row >= 0) {
+                    // mask-sorted orders visit the rows at random: the group's map rows were copied in processing
+                    // order next to the order itself, so this is a coalesced read (the row-indexed form costs a
+                    // 64-byte sector per 4-byte entry: 140 MB per ts1 conv, 35 % of its wave time)
+                    if (a.nbr_perm) {
+                        const long long tile_id = (long long)gridDim.x - 1 - blockIdx.x;
+                        my = a.nbr_perm[((long long)blockIdx.z * a.n_out + tile_id * TM + tid) * a.nbr_perm_w +
+                                        (j - (a.j_begin + (int)((long long)nj * blockIdx.z / a.splits)))];
+                    } else
+                        my = a.nbr ? a.nbr[(long long)row * a.K + j] : row;
+                }
                 nbr_s[tid] = my;
             }
             if (!__syncthreads_or(my >= 0)) continue;    // nobody in the tile has this neighbour
@@ -233,10 +290,208 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
             compute();
         }
     }
+    if (a.wide) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            epilogue_store_wide(a, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep_s[wave]);
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            epilogue_store(a, acc[nb], rows_s + wave * 32, n0 + nb * 32 + (lane & 31), lane);
+    }
+}
+
+// Instrumented twin of conv_rows (CV_CONV_PROF=1): shader-clock ticks per phase, summed over waves into prof[16].
+template <int NB, bool VEC>
+__global__ __launch_bounds__(THREADS) void conv_rows_prof(ConvArgs a, unsigned long long* prof) {
+    unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#define TICK(p) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[p] += t_ - pt0; pt0 = t_; } while (0)
+    __shared__ float A_s[KC][A_LD];
+    __shared__ float B_s[KC][NB * 32];
+    __shared__ int nbr_s[TM];
+    __shared__ int rows_s[TM];
+    __shared__ __attribute__((aligned(16))) float ep_s[4][32][EP_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.y * (NB * 32);
+
+    if (tid < TM) {
+        // mask-sorted orders end with the rows that need the most offsets: start those tiles FIRST so the
+        // light tiles fill the tail of the launch (longest-processing-time-first)
+        const long long tile_id = a.row_perm ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
+        const long long t = tile_id * TM + tid;
+        const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)blockIdx.z * a.n_out : 0) : nullptr;
+        rows_s[tid] = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
+    }
+    __syncthreads();
+    TICK(0);
+
+    f32x16 acc[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
-        epilogue_store(a, acc[nb], rows_s + wave * 32, n0 + nb * 32 + (lane & 31), lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    auto compute = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 2) {
+            const float av = A_s[kk + (lane >> 5)][wave * 32 + (lane & 31)];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float bv = B_s[kk + (lane >> 5)][nb * 32 + (lane & 31)];
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nj = a.j_end - a.j_begin;
+    if (VEC) {
+        // thread -> (row = tid/8 + 32*i, 4 channels at (tid%8)*4) : 8 lanes cover one 128 B row chunk
+        const int a_col = (tid & 7) * 4;
+        const int a_row = tid >> 3;                      // + 32*i, i = 0..3
+        constexpr int B_F4 = KC * NB * 32 / 4;           // float4s in the weight slab
+        constexpr int B_PER = (B_F4 + THREADS - 1) / THREADS;
+        // work units = (kernel offset, 32-channel chunk); a split owns a contiguous range of units,
+        // or a whole offset group when every group has its own row order
+        const int nch = a.cin / KC;
+        int u_lo, u_hi;
+        if (a.perm_per_split) {
+            u_lo = (int)((long long)nj * blockIdx.z / a.splits) * nch;
+            u_hi = (int)((long long)nj * (blockIdx.z + 1) / a.splits) * nch;
+        } else {
+            u_lo = (int)((long long)nj * nch * blockIdx.z / a.splits);
+            u_hi = (int)((long long)nj * nch * (blockIdx.z + 1) / a.splits);
+        }
+        const int j_first = a.j_begin + u_lo / nch, j_last = a.j_begin + (u_hi - 1) / nch;
+        for (int j = j_first; j <= j_last && u_hi > u_lo; ++j) {
+            const int kc_begin = (j == j_first ? u_lo % nch : 0) * KC;
+            const int kc_end = (j == j_last ? (u_hi - 1) % nch + 1 : nch) * KC;
+            int my = -1;
+            if (tid < TM) {
+                const int row = rows_s[tid];
+                if (row >= 0) {
+                    // mask-sorted orders visit the rows at random: the group's map rows were copied in processing
+                    // order next to the order itself, so this is a coalesced read (the row-indexed form costs a
+                    // 64-byte sector per 4-byte entry: 140 MB per ts1 conv, 35 % of its wave time)
+                    if (a.nbr_perm) {
+                        const long long tile_id = (long long)gridDim.x - 1 - blockIdx.x;
+                        my = a.nbr_perm[((long long)blockIdx.z * a.n_out + tile_id * TM + tid) * a.nbr_perm_w +
+                                        (j - (a.j_begin + (int)((long long)nj * blockIdx.z / a.splits)))];
+                    } else
+                        my = a.nbr ? a.nbr[(long long)row * a.K + j] : row;
+                }
+                nbr_s[tid] = my;
+            }
+            const int anyone = __syncthreads_or(my >= 0);
+            TICK(1);
+            if (!anyone) continue;    // nobody in the tile has this neighbour
+            // a wave whose 32 rows all miss this neighbour skips its MFMAs; it still takes part in
+            // the staging and the barriers.  Rows are processed in an order that groups equal
+            // neighbour masks (row_perm), which is what makes whole waves / tiles skippable.
+            const bool wave_live = __any(nbr_s[wave * 32 + (lane & 31)] >= 0);
+            float4 ra[4], rb[B_PER];
+            auto load = [&](int kc) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int src = nbr_s[a_row + 32 * i];
+                    ra[i] = src >= 0 ? *reinterpret_cast<const float4*>(a.in + (long long)src * a.in_ld + kc + a_col)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < B_PER; ++i) {
+                    const int f = tid + i * THREADS;
+                    if (f < B_F4) {
+                        const int kr = f / (NB * 8), c4 = (f % (NB * 8)) * 4;
+                        const int col = n0 + c4;
+                        const float* wp = a.w + ((long long)j * a.cin + kc + kr) * a.cout + col;
+                        if (col + 3 < a.cout) rb[i] = *reinterpret_cast<const float4*>(wp);
+                        else {
+                            rb[i].x = col < a.cout ? wp[0] : 0.f;
+                            rb[i].y = col + 1 < a.cout ? wp[1] : 0.f;
+                            rb[i].z = col + 2 < a.cout ? wp[2] : 0.f;
+                            rb[i].w = 0.f;
+                        }
+                    }
+                }
+            };
+            auto stage = [&]() {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = a_row + 32 * i;
+                    A_s[a_col + 0][r] = ra[i].x; A_s[a_col + 1][r] = ra[i].y;
+                    A_s[a_col + 2][r] = ra[i].z; A_s[a_col + 3][r] = ra[i].w;
+                }
+#pragma unroll
+                for (int i = 0; i < B_PER; ++i) {
+                    const int f = tid + i * THREADS;
+                    if (f < B_F4) {
+                        const int kr = f / (NB * 8), c4 = (f % (NB * 8)) * 4;
+                        *reinterpret_cast<float4*>(&B_s[kr][c4]) = rb[i];
+                    }
+                }
+            };
+            load(kc_begin);
+            TICK(2);
+            for (int kc = kc_begin; kc < kc_end; kc += KC) {
+                __syncthreads();                 // previous chunk's MFMAs are done with the LDS tiles
+                TICK(3);
+                stage();
+                TICK(4);
+                __syncthreads();
+                TICK(5);
+                if (kc + KC < kc_end) load(kc + KC);  // in flight while the matrix cores run
+                TICK(6);
+                if (wave_live) compute();
+                TICK(7);
+            }
+            __syncthreads();
+            TICK(8);
+        }
+    } else {
+        const int k0 = a.j_begin * a.cin, ktot = a.j_end * a.cin;
+        const int nchunks = (ktot - k0 + KC - 1) / KC;
+        const int c_lo = (int)((long long)nchunks * blockIdx.z / a.splits);
+        const int c_hi = (int)((long long)nchunks * (blockIdx.z + 1) / a.splits);
+        for (int kc = k0 + c_lo * KC; kc < k0 + c_hi * KC; kc += KC) {
+            __syncthreads();
+            for (int e = tid; e < KC * TM; e += THREADS) {
+                const int kk = e / TM, r = e % TM;
+                const int kf = kc + kk;
+                float v = 0.f;
+                const int row = rows_s[r];
+                if (kf < ktot && row >= 0) {
+                    const int j = kf / a.cin, c = kf - j * a.cin;
+                    const int src = a.nbr ? a.nbr[(long long)row * a.K + j] : row;
+                    if (src >= 0) v = a.in[(long long)src * a.in_ld + c];
+                }
+                A_s[kk][r] = v;
+            }
+            for (int e = tid; e < KC * NB * 32; e += THREADS) {
+                const int kr = e / (NB * 32), c = e % (NB * 32);
+                const int kf = kc + kr, col = n0 + c;
+                B_s[kr][c] = (kf < ktot && col < a.cout) ? a.w[(long long)kf * a.cout + col] : 0.f;
+            }
+            __syncthreads();
+            compute();
+        }
+    }
+    if (a.wide) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            epilogue_store_wide(a, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep_s[wave]);
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            epilogue_store(a, acc[nb], rows_s + wave * 32, n0 + nb * 32 + (lane & 31), lane);
+    }
+    TICK(9);
+    if (lane == 0) {
+        for (int p2 = 0; p2 < 10; ++p2) atomicAdd(&prof[p2], pacc[p2]);
+        atomicAdd(&prof[10], 1ull);
+    }
+#undef TICK
 }
+
 
 // ------------------------------------------------------------------ stem (tiny Cin, 32 outputs)
 // conv0p1s1 (utils/minkunet.py:53: 5x5x5, 3 or 6 -> 32 channels) is a kernel-map walk, not a GEMM: 13 % of its
@@ -973,7 +1228,8 @@ __global__ __launch_bounds__(MP_BINS) void mp_scan(int* __restrict__ hist) {   /
 }
 
 __global__ __launch_bounds__(MP_THREADS) void mp_scatter(const int* __restrict__ nbr, long long n, int K, int groups,
-                                                         int* __restrict__ cursor, int* __restrict__ perm) {
+                                                         int* __restrict__ cursor, int* __restrict__ perm,
+                                                         int* __restrict__ nbrp, int W) {
     __shared__ int lh[MP_BINS];
     const int g = blockIdx.y;
     const int jb = K * g / groups, je = K * (g + 1) / groups;
@@ -989,7 +1245,12 @@ __global__ __launch_bounds__(MP_THREADS) void mp_scatter(const int* __restrict__
     for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS)
         if (lh[i]) lh[i] = atomicAdd(&cursor[g * MP_BINS + i], lh[i]);
     __syncthreads();
-    if (row < n) perm[(long long)g * n + lh[key] + rank] = (int)row;
+    if (row < n) {
+        const long long pos = (long long)g * n + lh[key] + rank;
+        perm[pos] = (int)row;
+        if (nbrp)
+            for (int j = jb; j < je; ++j) nbrp[pos * W + (j - jb)] = nbr[row * K + j];
+    }
 }
 
 // ------------------------------------------------------------------ elementwise helpers
@@ -1161,7 +1422,22 @@ template <int NB>
 int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
     dim3 grid((unsigned)((a.n_out + TM - 1) / TM), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)),
               (unsigned)a.splits);
-    if (vec) conv_rows<NB, true><<<grid, THREADS, 0, st>>>(a);
+    static const bool prof_on = getenv("CV_CONV_PROF") != nullptr;
+    if (vec && prof_on) {
+        static unsigned long long* d_prof = nullptr;
+        if (!d_prof) CV_HIP_CHECK(hipMalloc(&d_prof, 16 * sizeof(unsigned long long)));
+        CV_HIP_CHECK(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st));
+        conv_rows_prof<NB, true><<<grid, THREADS, 0, st>>>(a, d_prof);
+        unsigned long long h[16];
+        CV_HIP_CHECK(hipMemcpyAsync(h, d_prof, sizeof h, hipMemcpyDeviceToHost, st));
+        CV_HIP_CHECK(hipStreamSynchronize(st));
+        static const char* names[10] = {"prologue", "nbr+or-barrier", "first-load-issue", "barrier-A", "stage(+vmcnt)",
+                                        "barrier-B", "load-issue", "compute", "end-barrier", "epilogue"};
+        fprintf(stderr, "conv_rows<%d> n_out %lld cin %d cout %d K %d splits %d: waves %llu, ticks/wave:", NB, a.n_out,
+                a.cin, a.cout, a.K, a.splits, h[10]);
+        for (int p2 = 0; p2 < 10; ++p2) fprintf(stderr, " %s %.0f", names[p2], (double)h[p2] / (double)std::max(1ull, h[10]));
+        fprintf(stderr, "\n");
+    } else if (vec) conv_rows<NB, true><<<grid, THREADS, 0, st>>>(a);
     else conv_rows<NB, false><<<grid, THREADS, 0, st>>>(a);
     CV_LAUNCH_CHECK();
     if (a.splits > 1) return launch_finish(a, st);
@@ -1272,8 +1548,13 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
     ConvArgs a{d->in, d->n_in, d->in_ld, d->cin, d->weight, d->K, d->cout, d->nbr, d->n_out, d->scale,
                d->shift, d->residual, d->res_ld, d->relu, d->out, d->out_ld, 1, nullptr, d->row_perm, 0, jb, je,
                d->acc_in, d->acc_ld, d->plan_ent, d->plan_cnt,
-               reinterpret_cast<const float4*>(d->weight_packed)};
+               reinterpret_cast<const float4*>(d->weight_packed), 0, nullptr, 0};
     CV_REQUIRE(!d->plan_ent == !d->plan_cnt, CV_EINVAL, "plan_ent and plan_cnt go together");
+    a.wide = d->cout % 4 == 0 && d->out_ld % 4 == 0 && (!d->residual || d->res_ld % 4 == 0) &&
+             (!d->acc_in || d->acc_ld % 4 == 0) &&
+             ((reinterpret_cast<uintptr_t>(d->out) | reinterpret_cast<uintptr_t>(d->residual) |
+               reinterpret_cast<uintptr_t>(d->acc_in) | reinterpret_cast<uintptr_t>(d->scale) |
+               reinterpret_cast<uintptr_t>(d->shift) | reinterpret_cast<uintptr_t>(d->ws)) & 15) == 0;
     const bool vec = (d->cin % KC == 0) && (d->in_ld % 4 == 0) && (d->cout % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(d->in) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(d->weight) & 15) == 0);
@@ -1302,6 +1583,10 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         a.splits = d->perm_groups;
         a.perm_per_split = 1;
         a.partial = static_cast<float*>(d->ws);
+        if (d->perm_has_map && jb == 0 && je == d->K && d->nbr) {
+            a.nbr_perm = d->row_perm + (long long)d->perm_groups * d->n_out;
+            a.nbr_perm_w = (d->K + d->perm_groups - 1) / d->perm_groups;
+        }
         if (d->flavour == 3 && d->in_ld % 4 == 0 && d->cout % nb_for(d->cout) == 0 &&
             (reinterpret_cast<uintptr_t>(d->weight) & 15) == 0) {
             switch (nb_for(d->cout)) {
@@ -1354,7 +1639,7 @@ int cv_sp_mask_keys(const int32_t* d_nbr, long long n, int K, int j_begin, int j
 // d_perm[groups][n] = rows ordered by the neighbour bit mask of each contiguous group of the K offsets
 // (ceil(K/groups) <= 10).  d_ws: groups*1024 ints of scratch.  Asynchronous, three launches.
 int cv_sp_mask_perms(const int32_t* d_nbr, long long n, int K, int groups, int32_t* d_perm, void* d_ws,
-                     size_t ws_bytes, void* stream) {
+                     size_t ws_bytes, int with_map, void* stream) {
     CV_REQUIRE(d_nbr && d_perm && d_ws && n > 0 && K > 0 && groups >= 1 && groups <= K, CV_EINVAL,
                "bad mask perm arguments");
     CV_REQUIRE((K + groups - 1) / groups <= 10, CV_EINVAL, "at most 10 kernel offsets per group");
@@ -1367,7 +1652,8 @@ int cv_sp_mask_perms(const int32_t* d_nbr, long long n, int K, int groups, int32
     CV_LAUNCH_CHECK();
     mp_scan<<<groups, MP_BINS, 0, st>>>(hist);
     CV_LAUNCH_CHECK();
-    mp_scatter<<<grid, MP_THREADS, 0, st>>>(d_nbr, n, K, groups, hist, d_perm);
+    mp_scatter<<<grid, MP_THREADS, 0, st>>>(d_nbr, n, K, groups, hist, d_perm,
+                                            with_map ? d_perm + (long long)groups * n : nullptr, (K + groups - 1) / groups);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

@@ -118,13 +118,10 @@ class CoordinateManager:
             L = _lib.lib()
             nbr = self.kernel_map(k, ts)
             n, K = nbr.shape
-            m = torch.empty((groups, n), dtype=torch.int32, device=self.device)
             if (K + groups - 1) // groups <= 10:
-                ws = torch.empty(groups * 4096, dtype=torch.uint8, device=self.device)
-                with torch.cuda.device(self.device):
-                    _lib.check(L.cv_sp_mask_perms(_ptr(nbr), n, K, groups, _ptr(m), _ptr(ws), ws.numel(),
-                                                  _stream(self.device)), "cv_sp_mask_perms")
+                m = _perms_with_map(nbr, groups)
             else:       # wide groups: generic key + device sort
+                m = torch.empty((groups, n), dtype=torch.int32, device=self.device)
                 keys = torch.empty(n, dtype=torch.int64, device=self.device)
                 for g in range(groups):
                     jb, je = K * g // groups, K * (g + 1) // groups      # same split as the kernel
@@ -146,7 +143,7 @@ class CoordinateManager:
             m = torch.empty((1, up.shape[0]), dtype=torch.int32, device=self.device)
             ws = torch.empty(4096, dtype=torch.uint8, device=self.device)
             with torch.cuda.device(self.device):
-                _lib.check(L.cv_sp_mask_perms(_ptr(up), up.shape[0], 8, 1, _ptr(m), _ptr(ws), ws.numel(),
+                _lib.check(L.cv_sp_mask_perms(_ptr(up), up.shape[0], 8, 1, _ptr(m), _ptr(ws), ws.numel(), 0,
                                               _stream(self.device)), "cv_sp_mask_perms")
             m = m[0]
             self._maps[key] = m
@@ -192,7 +189,9 @@ class CoordinateManager:
             for i in range(5):
                 cm_s._maps[("k", 3, 1 << i, 1)] = view(off.k3[i], c[i], 27)
                 if off.mask_perm[i] >= 0:
-                    cm_s._maps[("mp", 3, 1 << i, G)] = view(off.mask_perm[i], G, c[i])
+                    mp = view(off.mask_perm[i], G, c[i])
+                    mp._cv_has_map = True              # the map rows in processing order follow in the arena
+                    cm_s._maps[("mp", 3, 1 << i, G)] = mp
             cm_s._verified = True
             self._fused = (cm_s, stem_map, out_map)
             self._fused_k = stem_k
@@ -356,7 +355,8 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
                       ws.numel() if ws is not None else 0, p(row_perm), j_begin, j_end, p(acc_in),
                       acc_in.stride(0) if acc_in is not None else 0, perm_groups,
                       plan[0].data_ptr() if plan is not None else None,
-                      plan[0].data_ptr() + 4 * plan[1] if plan is not None else None, p(wp))
+                      plan[0].data_ptr() + 4 * plan[1] if plan is not None else None, p(wp),
+                      1 if (perm_groups > 1 and getattr(row_perm, "_cv_has_map", False)) else 0)
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
     return out
@@ -371,15 +371,25 @@ def map_mask_perms(nbr, groups):
     """[groups, n] processing orders of a kernel map (see CoordinateManager.mask_perms), cached on the map."""
     hit = getattr(nbr, "_cv_mask_perms", None)
     if hit is None or hit.shape[0] != groups:
-        L = _lib.lib()
-        n, K = nbr.shape
-        hit = torch.empty((groups, n), dtype=torch.int32, device=nbr.device)
-        ws = torch.empty(groups * 4096, dtype=torch.uint8, device=nbr.device)
-        with torch.cuda.device(nbr.device):
-            _lib.check(L.cv_sp_mask_perms(_ptr(nbr), n, K, groups, _ptr(hit), _ptr(ws), ws.numel(),
-                                          _stream(nbr.device)), "cv_sp_mask_perms")
-        nbr._cv_mask_perms = hit
+        hit = nbr._cv_mask_perms = _perms_with_map(nbr, groups)
     return hit
+
+
+def _perms_with_map(nbr, groups):
+    """[groups, n] orders (a view) followed, in the same buffer, by the kernel map rows of every group in processing
+    order [groups, n, W] (cv_sp_mask_perms with_map = 1); the view carries `_cv_has_map` for conv_forward."""
+    L = _lib.lib()
+    n, K = nbr.shape
+    W = (K + groups - 1) // groups
+    flat = torch.empty(groups * n * (1 + W), dtype=torch.int32, device=nbr.device)
+    ws = torch.empty(groups * 4096, dtype=torch.uint8, device=nbr.device)
+    with torch.cuda.device(nbr.device):
+        _lib.check(L.cv_sp_mask_perms(_ptr(nbr), n, K, groups, _ptr(flat), _ptr(ws), ws.numel(), 1,
+                                      _stream(nbr.device)), "cv_sp_mask_perms")
+    m = flat[:groups * n].view(groups, n)
+    m._cv_has_map = True
+    m._cv_flat = flat
+    return m
 
 
 # 1: flavour 0 (auto) runs the pair-compacted tile kernel wherever it applies.  Off by default: measured on MI355X

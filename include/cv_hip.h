@@ -192,6 +192,8 @@ typedef struct cv_conv_desc {
     const int32_t* plan_ent;/* optional pair lists of the kernel map (cv_sp_tile_plan, built with the same row_perm): */
     const int32_t* plan_cnt;/* lets flavour 0 / 4 run the pair-compacted tile kernel (K <= 27, Cin, Cout % 32 == 0) */
     const float* weight_packed; /* the same weights from cv_sp_pack_weights_f32; required by the tile kernel */
+    int perm_has_map;       /* with perm_groups > 1: row_perm is followed by the kernel map rows in processing order
+                               (cv_sp_mask_perms with_map = 1), which turns the random map reads into coalesced ones */
 } cv_conv_desc;
 
 /* Pair lists for the tile kernel, built once per kernel map and processing order and shared by every convolution
@@ -263,9 +265,11 @@ int cv_sp_mask_keys(const int32_t* d_nbr, long long n, int K, int j_begin, int j
 
 /* d_perm[groups][n]: for each contiguous group of the K kernel offsets, the rows ordered by the bit
  * mask of their valid neighbours in that group (counting sort; at most 10 offsets per group).
- * d_ws: groups * 4096 bytes.  Asynchronous. */
+ * d_ws: groups * 4096 bytes.  with_map = 1: d_perm holds groups*n*(1 + W) words, W = ceil(K/groups); after the
+ * orders come the kernel map rows of every group in processing order, [groups][n][W]
+ * (cv_conv_desc.perm_has_map).  Asynchronous. */
 int cv_sp_mask_perms(const int32_t* d_nbr, long long n, int K, int groups, int32_t* d_perm, void* d_ws,
-                     size_t ws_bytes, void* stream);
+                     size_t ws_bytes, int with_map, void* stream);
 
 /* Training support (train_joint.py:283 `loss.backward()` through the sparse convolutions).
  * Input gradient = cv_sp_conv_f32 on the transposed map with the transposed weights:
