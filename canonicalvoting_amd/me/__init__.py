@@ -150,7 +150,7 @@ class CoordinateManager:
         return m
 
     # mask-sorted offset groups of the 3x3x3 convs: levels with at least MASKED_MIN_ROWS rows get MASK_GROUPS orders
-    MASK_GROUPS = 4
+    MASK_GROUPS = int(os.environ.get("CV_NET_MASK_GROUPS", "4"))
     MASKED_MIN_ROWS = int(os.environ.get("CV_MASKED_MIN_ROWS", "16384"))
 
     def fused_plan(self, stem_k=5):
@@ -169,7 +169,7 @@ class CoordinateManager:
             cm_s = CoordinateManager(self._input[perm].contiguous(), CoordinateManager.NUM_LEVELS, True)
             rows = (ctypes.c_int64 * 5)(*cm_s.counts)
             off = _lib.SceneMaps()
-            G = self.MASK_GROUPS
+            G = self.MASK_GROUPS if (27 + self.MASK_GROUPS - 1) // self.MASK_GROUPS <= 10 else 0   # wide groups: lazily
             words = int(L.cv_sp_scene_maps_words(rows, n, stem_k, G, self.MASKED_MIN_ROWS, ctypes.byref(off)))
             arena = torch.empty(words, dtype=torch.int32, device=dev)
             arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
