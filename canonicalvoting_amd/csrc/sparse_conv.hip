@@ -1453,7 +1453,19 @@ int launch_wave(const ConvArgs& a, hipStream_t st) {
     return CV_OK;
 }
 
-int nb_for(int cout) { return cout <= 32 ? 1 : cout <= 64 ? 2 : cout <= 96 ? 3 : 4; }
+// 32-column blocks per workgroup.  Wider than 96 columns is split over blockIdx.y in 64-column workgroups (32 on
+// the tiny coarsest levels): measured 118 -> 97 us (2349 rows, 256 -> 256), 143 -> 117 us (9929 rows, 128 -> 128),
+// 40 -> 33 us (494 rows) against 128-column workgroups - more, lighter workgroups hide the gather latency better
+// than the saved operand re-reads are worth; 96 columns stay one workgroup (64 + 32 is uneven: 144 -> 180 us).
+int nb_full(int cout) { return cout <= 32 ? 1 : cout <= 64 ? 2 : cout <= 96 ? 3 : 4; }
+int nb_for(int cout, long long n_out) {
+    static const int nb_max = getenv("CV_NB_MAX") ? atoi(getenv("CV_NB_MAX")) : 0;
+    if (nb_max > 0) return std::min(nb_max, nb_full(cout));
+    if (cout <= 32) return 1;
+    if (cout <= 64) return 2;
+    if (cout <= 96) return 3;
+    return n_out < 1024 ? 1 : 2;
+}
 
 // ---- tile flavour dispatch: CS = waves (32-column slices) per workgroup, KW = K chunk width
 int tile_cs(int cout) {
@@ -1512,7 +1524,7 @@ int launch_tile(const ConvArgs& a, hipStream_t st) {
 // Enough workgroups to fill 256 CUs a few times with short dependent chains: split the (offset,
 // chunk) units over blockIdx.z; the partial tiles cost 8 bytes of traffic per output element per split.
 int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
-    const int nb = nb_for(cout);
+    const int nb = nb_for(cout, n_out);
     const long long tiles = ((n_out + TM - 1) / TM) * ((cout + nb * 32 - 1) / (nb * 32));
     const long long units = vec ? (long long)K * (cin / KC) : ((long long)K * cin + KC - 1) / KC;
     if (tiles >= 384 || units <= 1) return 1;
@@ -1587,9 +1599,9 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
             a.nbr_perm = d->row_perm + (long long)d->perm_groups * d->n_out;
             a.nbr_perm_w = (d->K + d->perm_groups - 1) / d->perm_groups;
         }
-        if (d->flavour == 3 && d->in_ld % 4 == 0 && d->cout % nb_for(d->cout) == 0 &&
+        if (d->flavour == 3 && d->in_ld % 4 == 0 && d->cout % nb_full(d->cout) == 0 &&
             (reinterpret_cast<uintptr_t>(d->weight) & 15) == 0) {
-            switch (nb_for(d->cout)) {
+            switch (nb_full(d->cout)) {
                 case 1: return launch_wave<1>(a, st);
                 case 2: return launch_wave<2>(a, st);
                 case 3: return launch_wave<3>(a, st);
@@ -1616,7 +1628,7 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
             a.partial = static_cast<float*>(d->ws);
         }
     }
-    switch (nb_for(d->cout)) {
+    switch (nb_for(d->cout, d->n_out)) {
         case 1: return launch_rows<1>(a, vec, st);
         case 2: return launch_rows<2>(a, vec, st);
         case 3: return launch_rows<3>(a, vec, st);
@@ -1715,7 +1727,7 @@ int cv_sp_transpose_map(const int32_t* d_nbr, long long n_out, int K, long long 
 // the centre offset of an odd cubic kernel and its face neighbours hold the most pairs: they go first and get
 // twice the splits (measured: profiles/wgrad_micro.py).
 static long long wgrad_plan(long long n_out, int cin, int cout, int K, WgradPlan* plan) {
-    const int nb = nb_for(cout);
+    const int nb = nb_full(cout);
     const int tiles = ((cin + 31) / 32) * ((cout + nb * 32 - 1) / (nb * 32));
     int ks = 1;
     while (ks * ks * ks < K) ++ks;
@@ -1772,7 +1784,7 @@ int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy,
     float* partial = static_cast<float*>(d_ws);
     // any Cin: channels beyond Cin are zero lanes of the 32-wide A operand (stem: Cin = 3)
     const unsigned grid = (unsigned)((plan.task_end[K - 1] + 3) / 4);
-    switch (nb_for(cout)) {
+    switch (nb_full(cout)) {
         case 1: conv_wgrad<1><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); break;
         case 2: conv_wgrad<2><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); break;
         case 3: conv_wgrad<3><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); break;
