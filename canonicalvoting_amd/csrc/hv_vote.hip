@@ -525,10 +525,15 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
             }
             int e_end = it0 < items ? sh.arc_cum[wave][e] : 0;          // first item of the next entry
             int rot = 0;
+            // the entry's point stays in registers while the lane walks its arc (4 LDS reads per entry instead of
+            // per step: the LDS pipe is what the expansion shares with the f64 atomics)
+            float epx = 0.f, epz = 0.f, ecx = 0.f, ecz = 0.f;
             if (it0 < items) {
                 const int e_beg = e > 0 ? sh.arc_cum[wave][e - 1] : 0;
                 rot = sh.arc_start[wave][e] + (it0 - e_beg);
                 if (rot >= R) rot -= R;
+                epx = sh.pq[wave][0][e]; epz = sh.pq[wave][1][e];
+                ecx = sh.pq[wave][2][e]; ecz = sh.pq[wave][3][e];
             }
             for (int step = 0; step < S; ++step, ++it0) {
                 bool isvote = false;
@@ -539,13 +544,14 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
                         ++e;
                         e_end = sh.arc_cum[wave][e];
                         rot = sh.arc_start[wave][e];
+                        epx = sh.pq[wave][0][e]; epz = sh.pq[wave][1][e];
+                        ecx = sh.pq[wave][2][e]; ecz = sh.pq[wave][3][e];
                     }
                     const float2 cs = sh.tab[rot];
-                    const float ecx = sh.pq[wave][2][e], ecz = sh.pq[wave][3][e];
                     const float ox = (-cs.x) * ecx + cs.y * ecz;
                     const float oz = (-cs.y) * ecx - cs.x * ecz;
-                    const float gx = grid_pos(sh.pq[wave][0][e], ox, corner.x, res);
-                    const float gz = grid_pos(sh.pq[wave][1][e], oz, corner.z, res);
+                    const float gx = grid_pos(epx, ox, corner.x, res);
+                    const float gz = grid_pos(epz, oz, corner.z, res);
                     if (gx >= 0 && gz >= 0 && gx < (float)(X - 1) && gz < (float)(Z - 1)) {
                         const int lx = (int)gx - x0, lz = (int)gz - z0;
                         if (lx >= -1 && lx < TX && lz >= -1 && lz < TZ) {

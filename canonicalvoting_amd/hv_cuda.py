@@ -80,6 +80,7 @@ def _f3(vals):
 
 
 _prefetched = {}
+_pinned_pool = []
 
 
 def prefetch_geometry(points):
@@ -89,7 +90,8 @@ def prefetch_geometry(points):
     L = _lib.lib()
     dev = points.device
     ws = torch.empty(L.cv_hv_minmax_workspace_bytes(), dtype=torch.uint8, device=dev)
-    host = torch.empty(6, dtype=torch.float32).pin_memory()
+    # pinned landing buffers are recycled: allocating page-locked memory costs about a millisecond per call
+    host = _pinned_pool.pop() if _pinned_pool else torch.empty(6, dtype=torch.float32).pin_memory()
     with torch.cuda.device(dev):
         _lib.check(L.cv_hv_minmax_async_f32(_ptr(points), points.shape[0], ctypes.c_void_p(host.data_ptr()),
                                             _ptr(ws), ws.numel(), _stream(dev)), "cv_hv_minmax_async_f32")
@@ -107,6 +109,8 @@ def _take_prefetched(points):
         return None
     hit[3].synchronize()
     h = hit[2].tolist()
+    if len(_pinned_pool) < 32:
+        _pinned_pool.append(hit[2])
     return h[:3], h[3:]
 
 
