@@ -343,3 +343,44 @@ def test_scenes_in_flight_on_separate_streams_match_sequential(cuda, built_lib):
         assert torch.equal(seq[i][0], par[i][0])
         for a, b in zip(seq[i][1:], par[i][1:]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("case", ["single_voxel", "ragged_batch", "extreme_coordinates", "float_coordinates"])
+def test_minkunet_edge_case_coordinate_sets(cuda, built_lib, case):
+    """edge cases of the coordinate manager through the whole network: one voxel, a batch of very unequal scenes,
+    coordinates near the +-32767 key range with negative values crossing the stride-16 floor division, float
+    coordinates (floored like ME.SparseTensor does, train_joint.py:250)"""
+    rng = np.random.default_rng(3)
+    if case == "single_voxel":
+        coords = np.array([[0, 5, -3, 7]], np.int64)
+    elif case == "ragged_batch":
+        a, _ = scene_coords(31, 1500)
+        b = np.array([[1, 0, 0, 0], [1, 1, 0, 0], [1, 40, -7, 3]], np.int64)
+        coords = np.concatenate([a, b])
+    elif case == "extreme_coordinates":
+        base, _ = scene_coords(32, 800)
+        lo, hi = base.copy(), base.copy()
+        lo[:, 1:] += np.array([-32700, -32000, -31000]) - base[:, 1:].min(0)
+        hi[:, 1:] += np.array([32700, 32000, 31000]) - base[:, 1:].max(0)
+        hi[:, 0] = 1
+        coords = np.concatenate([lo, hi])
+    else:
+        coords, _ = scene_coords(33, 600)
+    feats = rng.normal(0, 1, (len(coords), 3)).astype(np.float32)
+    sd = so.make_state_dict(3, 8, seed=7)
+    model = MinkUNet34C(3, 8)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    tc = torch.from_numpy(coords)
+    if case == "float_coordinates":
+        tc = tc.float() + torch.from_numpy(rng.uniform(0.0, 0.9, coords.shape).astype(np.float32))
+        tc[:, 0] = torch.from_numpy(coords[:, 0]).float()
+    else:
+        tc = tc.int()
+    with torch.no_grad():
+        x = ME.SparseTensor(torch.from_numpy(feats), tc, device="cuda")
+        y = model(x).F.cpu().numpy()
+        ym = model.modular_forward(x).F.cpu().numpy()
+    ref = so.minkunet34c_forward(sd, coords, feats).numpy()
+    tol = 1e-4 * max(1.0, np.abs(ref).max())
+    assert y.shape == ref.shape and np.abs(y - ref).max() < tol and np.abs(ym - ref).max() < tol
