@@ -65,6 +65,12 @@ def parse():
                          "round-robin (scenes are independent; fills the launch tails and host syncs of one scene "
                          "with the kernels of another)")
     ap.add_argument("--switch-interval", type=float, default=0.0005, help="sys.setswitchinterval for the scene threads")
+    ap.add_argument("--mode", default="eval", choices=["eval", "train"],
+                    help="eval (default, the BASELINE metric): eval_joint.py path.  train: train_joint.py step "
+                         "(fwd + bwd + Adam, fp32) on --train-batch scenes per GPU-step, DDP gradient all-reduce over "
+                         "RCCL when launched on several GPUs (BASELINE configs 3-4; a side measurement, not the "
+                         "headline metric)")
+    ap.add_argument("--train-batch", type=int, default=3, help="scenes per GPU-step in --mode train (config.yaml:15)")
     ap.add_argument("--large", action="store_true",
                     help="BASELINE config 5 shaped scenes: 9x3x9 m room, 40 boxes (use with --points 300000)")
     ap.add_argument("--teacher-forced", action="store_true",
@@ -143,8 +149,53 @@ def cpu_baseline(scenes, n, model, full):
     return n / dt, dt, boxes
 
 
+def main_train(a):
+    """train_joint.py:244-288 steps on synthetic ScanNet-shaped batches: one process per GPU, each with its own
+    batch of scenes (weak scaling), gradients all-reduced by torch DDP over RCCL, BatchNorm statistics per GPU."""
+    from canonicalvoting_amd import train
+    world, rank, local = cvd.world()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cvd.init("nccl", dev)
+    _lib.lib()
+    B, n = a.train_batch, a.points
+    scenes = [make_scene(seed, n_points=n, res=RES) for seed in cvd.scene_seeds(rank, B)]
+    coords = torch.cat([torch.cat([torch.full((n, 1), b, dtype=torch.int32), torch.from_numpy(s.coords)], 1)
+                        for b, s in enumerate(scenes)]).to(dev)
+    feats = torch.cat([torch.from_numpy(s.feats) for s in scenes]).to(dev) * 2 - 1
+    xyz = torch.cat([torch.from_numpy(s.xyz_labels) for s in scenes]).to(dev)
+    scale = torch.cat([torch.from_numpy(s.scale_labels) for s in scenes]).to(dev)
+    cls = torch.cat([torch.from_numpy(s.class_labels) for s in scenes]).to(dev)
+    torch.manual_seed(0)
+    model = MinkUNet34C(3, 6 * 9 + 9 + 1).cuda().train()
+    net = train.make_ddp(model, dev) if world > 1 else model
+    opt = train.make_optimizer(model)
+    for _ in range(max(a.warmup, 1)):
+        train.train_step(net, opt, coords, feats, xyz, scale, cls)
+    cvd.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, _ = train.train_step(net, opt, coords, feats, xyz, scale, cls)
+    cvd.barrier(dev)
+    dt = cvd.reduce_scalar(time.perf_counter() - t0, "max", dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "scenes/sec (train_joint.py step: fwd + bwd + Adam, 80k-pt synthetic scans)",
+            "value": a.steps * B * world / dt, "unit": "scenes/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "train_joint.py step on %d x %d-point synthetic scenes per GPU-step, MinkUNet34C(3, 64) "
+                                   "fp32, Adam lr 1e-3" % (B, n),
+                       "parallelism": "scene-parallel DDP x%d (RCCL gradient all-reduce, per-GPU BatchNorm statistics)"
+                                      % world if world > 1 else "single GPU"},
+            "final_loss": float(loss)}), flush=True)
+    cvd.finalize()
+
+
 def main():
     a = parse()
+    if a.mode == "train":
+        return main_train(a)
     world, rank, local = cvd.world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     torch.cuda.set_device(local)

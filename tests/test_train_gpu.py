@@ -176,3 +176,70 @@ def test_batchnorm_training_kernels_match_torch(cuda, built_lib):
         assert rel_err(rd.grad.cpu().numpy(), rr.grad.numpy()) < 1e-5
         assert rel_err(mine.bn.weight.grad.cpu().numpy(), ref.weight.grad.numpy()) < 1e-4
         assert rel_err(mine.bn.bias.grad.cpu().numpy(), ref.bias.grad.numpy()) < 1e-4
+
+
+def _ddp_worker(rank, world_size, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world_size),
+                      RANK=str(rank), LOCAL_RANK="0")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from canonicalvoting_amd import train
+    from canonicalvoting_amd.minkunet import MinkUNet34C
+    from canonicalvoting_amd.synth import make_scene
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo")            # both ranks share the one GPU of the test box: gloo, not RCCL
+
+    def batch(seed):
+        sc = make_scene(seed, n_points=1500, res=0.06, room=(1.5, 0.9, 1.5), n_boxes=2, margin=0.5, box_scale=0.4)
+        c = torch.cat([torch.zeros((1500, 1), dtype=torch.int32), torch.from_numpy(sc.coords).int()], 1).to(dev)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        return c, t(sc.feats) * 2 - 1, t(sc.xyz_labels), t(sc.scale_labels), t(sc.class_labels)
+
+    def grads(net, model, data):
+        model.zero_grad(set_to_none=True)
+        from canonicalvoting_amd import me as ME
+        out = net(ME.SparseTensor(data[1], data[0], device=dev))
+        loss, _ = train.joint_loss(out.F, data[2], data[3], data[4])
+        loss.backward()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+
+    torch.manual_seed(0)
+    model = MinkUNet34C(3, 64).cuda().train()
+    ddp = train.make_ddp(model, dev)
+    g = grads(ddp, model, batch(40 + rank))                       # every rank its own scene
+    if rank == 0:
+        torch.manual_seed(0)
+        ref_model = MinkUNet34C(3, 64).cuda().train()
+        ref = [grads(ref_model, ref_model, batch(40 + r)) for r in range(world_size)]
+        worst = 0.0
+        for n in g:
+            mean = sum(r[n] for r in ref) / world_size
+            worst = max(worst, float((g[n] - mean).abs().max() / (mean.abs().max() + 1e-6)))
+        q.put(("rank0", worst))
+    names = ["final.kernel", "conv0p1s1.kernel", "block4.5.conv2.kernel"]
+    q.put(("sig%d" % rank, [float(g[n].double().sum()) for n in names]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_gradient_allreduce_two_ranks(cuda, built_lib):
+    """BASELINE configs 3-4: scene-parallel DDP.  Two ranks (gloo, sharing this box's one GPU) each run the HIP
+    forward/backward on their own scene through train.make_ddp; the reduced gradients are identical on both ranks and
+    equal the mean of the two single-scene gradients (custom autograd Functions fire DDP's hooks correctly)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(3))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got["rank0"] < 1e-4, got
+    np.testing.assert_allclose(got["sig0"], got["sig1"], rtol=1e-6)
