@@ -345,16 +345,35 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {
                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
 }
 
-// LDS fp32 atomic add runs at 0.33 lane-ops/clk/CU on gfx950 (204 G/s chip-wide, measured:
-// profiles/microbench/lds_atomic_rate.hip) while ds_add_f64 sustains 3.1 (1.9 T/s), so the
-// tile accumulates in double.  Side effect: the sums are far more accurate than the
-// reference's fp32 atomics and reproducible run to run after the final rounding to float.
-__device__ __forceinline__ void lds_add(double* p, float v) {
-    __hip_atomic_fetch_add(p, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// LDS atomic add rates on gfx950 (lane-ops/clk/CU, measured: profiles/microbench/lds_atomic_rate.hip):
+// f32 0.33, f64 3.1, u64 5.6, u32 7.4.  The LDS atomics are 63 % of this kernel's time (ablation: 0.68 ms ->
+// 0.25 ms without them).  The objectness channel - the one the decode thresholds and takes argmax of, and the
+// one that defines which cells are touched at all - accumulates in f64 (exact sums of the fp32 contributions).
+// The five quotient numerators (rot cos/sin, scale xyz) accumulate in 64-bit FIXED POINT with ds_add_u64: every
+// fp32 contribution is rounded once to a multiple of 2^-36 (1.5e-11; |sum| < 1.3e8 per cell and channel) and
+// integer addition is exact and order independent, so all six sums are reproducible run to run; the rounding is
+// 1e-11 relative on cells with weight >= 1 and only matters on cells whose total weight is below ~1e-6 (their
+// rot / scale quotients lose digits; the reference's own fp32 atomics lose ~1e-7 relative per add everywhere).
+constexpr double FX_SCALE = 68719476736.0;            // 2^36
+constexpr double FX_MAGIC = 6755399441055744.0;       // 1.5 * 2^52: (x*2^36 + MAGIC) has round(x*2^36) in its low bits
+__device__ __forceinline__ void lds_add(unsigned long long* p, float v) {
+    const double d = __builtin_fma((double)v, FX_SCALE, FX_MAGIC);
+    const unsigned long long q = (unsigned long long)__double_as_longlong(d) -
+                                 (unsigned long long)__double_as_longlong(FX_MAGIC);
+    __hip_atomic_fetch_add(p, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ double fx_value(unsigned long long q) { return (double)(long long)q * (1.0 / FX_SCALE); }
+__device__ __forceinline__ void lds_add_f64(unsigned long long* p, float v) {
+    __hip_atomic_fetch_add(reinterpret_cast<double*>(p), (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// value of accumulator word i of the [6][TCELLS] tile (channel 0 holds f64 bits, the others fixed point)
+__device__ __forceinline__ double acc_value(unsigned long long q, int i) {
+    return i < TCELLS ? __longlong_as_double((long long)q) : fx_value(q);
 }
 
 struct TileShared {
-    double acc[6][TCELLS];     // obj, rot.cos, rot.sin, scale.xyz  (SoA: random banks per lane)
+    unsigned long long acc[6][TCELLS];   // [0]: objectness weight as f64 BITS; [1..5]: rot.cos, rot.sin, scale.xyz in
+                                         // 2^-36 fixed point (SoA: random banks per lane)
     float pq[TW][9][PQ];       // px, pz, cx, cz, wy, obj, s0, s1, s2 of surviving points
     int arc_start[TW][PQ];     // first rotation whose vote can reach the tile
     int arc_cum[TW][PQ];       // inclusive prefix sum of the arc lengths
@@ -383,7 +402,7 @@ __device__ __forceinline__ void drain64(TileShared& sh, int wave, int slot, bool
             // hv_cuda_kernel.cu:52-59 order: ((wx*wy)*wz)*objness
             const float w = wx[bx] * wy * wz[bz] * ob;
             const int cell = cxl * TZ + czl;
-            lds_add(&sh.acc[0][cell], w);
+            lds_add_f64(&sh.acc[0][cell], w);
             lds_add(&sh.acc[1][cell], w * cs.x);
             lds_add(&sh.acc[2][cell], w * cs.y);
             lds_add(&sh.acc[3][cell], w * s0);
@@ -405,9 +424,20 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     const int* __restrict__ ystart, const int* __restrict__ part_start, const float* __restrict__ rec,
     int64_t rec_stride, int tiles_x, int tiles_z, float* __restrict__ partials,
     int* __restrict__ arrivals, float* __restrict__ g_obj, float* __restrict__ g_rot,
-    float* __restrict__ g_scale) {
+    float* __restrict__ g_scale, unsigned long long* __restrict__ prof) {
     __shared__ TileShared sh;
     __shared__ int last_flag;
+    // VARIANT 4: shader-clock ticks per phase, summed over waves into prof[0..7], prof[8] = waves
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pt0 = VARIANT == 4 ? __builtin_amdgcn_s_memtime() : 0;
+#define HV_TICK(p)                                                        \
+    do {                                                                  \
+        if (VARIANT == 4) {                                               \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+            pacc[p] += t_ - pt0;                                          \
+            pt0 = t_;                                                     \
+        }                                                                 \
+    } while (0)
     const int X = dims.x, Y = dims.y, Z = dims.z;
     const int ntiles = tiles_x * tiles_z;
     const int tile = blockIdx.x % ntiles;
@@ -426,9 +456,10 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     const int x0 = (tile / tiles_z) * TX, z0 = (tile % tiles_z) * TZ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) (&sh.acc[0][0])[i] = 0.0;
+    for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) (&sh.acc[0][0])[i] = 0ull;
     for (int i = threadIdx.x; i < R; i += TW * 64) sh.tab[i] = tab[i];
     __syncthreads();
+    HV_TICK(0);
 
     // a vote at grid position g touches cells floor(g), floor(g)+1, so it reaches this
     // tile iff g in [x0-1, x0+TX) x [z0-1, z0+TZ); slack covers fp32 rounding of the test.
@@ -482,6 +513,7 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
             }
             const uint64_t m = __ballot(keep);
             const int nq = __popcll(m);
+            HV_TICK(1);
             if (nq == 0) continue;
             // inclusive scan of the arc lengths in compacted (lane) order
             int cum = keep ? a_len : 0;
@@ -507,6 +539,7 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
                 sh.arc_cum[wave][p] = cum;
             }
             wave_sync_lds();
+            HV_TICK(2);
 
             // lane l walks items [l*S, (l+1)*S): at any step the 64 lanes sit on 64 different arcs
             // (different cells -> few same-address LDS atomic collisions), and a lane only advances
@@ -535,6 +568,7 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
                 epx = sh.pq[wave][0][e]; epz = sh.pq[wave][1][e];
                 ecx = sh.pq[wave][2][e]; ecz = sh.pq[wave][3][e];
             }
+            HV_TICK(2);
             for (int step = 0; step < S; ++step, ++it0) {
                 bool isvote = false;
                 uint32_t vrec = 0;
@@ -573,28 +607,33 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
                 }
                 vq_len += __popcll(mv);
                 wave_sync_lds();
+                HV_TICK(4);
                 if (vq_len >= 64) {
                     vq_len -= 64;
                     if (VARIANT != 1) drain64(sh, wave, vq_len + lane, true);
+                    HV_TICK(5);
                 }
             }
             // queued votes index this chunk's pq entries: flush before pq is overwritten
             if (vq_len > 0) {
                 if (VARIANT != 1) drain64(sh, wave, lane, lane < vq_len);
                 else if (lane < vq_len)
-                    sh.acc[0][lane] = sh.vq_rx[wave][lane] + sh.vq_rz[wave][lane] + (float)sh.vq_rec[wave][lane];
+                    sh.acc[1][lane] = (unsigned long long)(sh.vq_rx[wave][lane] + sh.vq_rz[wave][lane] + (float)sh.vq_rec[wave][lane]);
                 vq_len = 0;
             }
             wave_sync_lds();
+            HV_TICK(6);
         }
     }
+    HV_TICK(1);
     __syncthreads();
+    HV_TICK(3);
 
     if (nparts > 1) {
         // publish this part's tile, the last arriver sums the parts in part order (deterministic):
         // plain stores -> per-wave vmcnt(0) -> barrier -> one-lane agent release -> ticket.
         float* mine = partials + ((int64_t)q * ntiles + tile) * (6 * TCELLS);
-        for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) mine[i] = (float)(&sh.acc[0][0])[i];
+        for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) mine[i] = (float)acc_value((&sh.acc[0][0])[i], i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -611,7 +650,8 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
         for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) {
             double sum = 0.0;
             for (int p2 = 0; p2 < nparts; ++p2) sum += (double)base[(int64_t)p2 * ntiles * (6 * TCELLS) + i];
-            (&sh.acc[0][0])[i] = sum;
+            (&sh.acc[0][0])[i] = i < TCELLS ? (unsigned long long)__double_as_longlong(sum)
+                                            : (unsigned long long)__double2ll_rn(sum * FX_SCALE);
         }
         __syncthreads();
     }
@@ -619,29 +659,39 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     // fused normalise (hv_cuda_kernel.cu:112-117) + single store of the tile.  The weight the
     // reference divides by is the fp32 grid value, so round the double sum to float first.
     const int nx = min(TX, X - x0), nz = min(TZ, Z - z0);
+    if (VARIANT == 5) {                       // ablation: no normalise / store
+        if (threadIdx.x == 0) g_obj[((int64_t)x0 * Y + y) * Z + z0] = (float)acc_value(sh.acc[0][0], 0);
+        return;
+    }
     for (int i = threadIdx.x; i < TCELLS; i += TW * 64) {
         const int lx = i / TZ, lz = i % TZ;
         if (lx < nx && lz < nz)
-            g_obj[((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz] = (float)sh.acc[0][i];
+            g_obj[((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz] = (float)acc_value(sh.acc[0][i], 0);
     }
     for (int i = threadIdx.x; i < TCELLS * 2; i += TW * 64) {
         const int cell = i >> 1, j = i & 1;
         const int lx = cell / TZ, lz = cell % TZ;
         if (lx < nx && lz < nz) {
-            const double d = (double)(float)sh.acc[0][cell] + 1e-7;
+            const double d = (double)(float)acc_value(sh.acc[0][cell], 0) + 1e-7;
             g_rot[(((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz) * 2 + j] =
-                (float)((double)(float)sh.acc[1 + j][cell] / d);
+                (float)((double)(float)fx_value(sh.acc[1 + j][cell]) / d);
         }
     }
     for (int i = threadIdx.x; i < TCELLS * 3; i += TW * 64) {
         const int cell = i / 3, j = i - cell * 3;
         const int lx = cell / TZ, lz = cell % TZ;
         if (lx < nx && lz < nz) {
-            const double d = (double)(float)sh.acc[0][cell] + 1e-7;
+            const double d = (double)(float)acc_value(sh.acc[0][cell], 0) + 1e-7;
             g_scale[(((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz) * 3 + j] =
-                (float)((double)(float)sh.acc[3 + j][cell] / d);
+                (float)((double)(float)fx_value(sh.acc[3 + j][cell]) / d);
         }
     }
+    HV_TICK(7);
+    if (VARIANT == 4 && lane == 0) {
+        for (int p2 = 0; p2 < 8; ++p2) atomicAdd(&prof[p2], pacc[p2]);
+        atomicAdd(&prof[8], 1ull);
+    }
+#undef HV_TICK
 }
 
 // ---------------------------------------------------------------------------
@@ -767,7 +817,7 @@ int check_common(const void* a, const void* b, const void* c, int64_t n, float r
 int64_t tiles_q_bound(int64_t n, int Y) { return (int64_t)Y + (2 * n + PART_RECORDS - 1) / PART_RECORDS; }
 
 int pick_algo(int algo, int64_t n, int num_rots, const int* dims) {
-    if (algo >= 21 && algo <= 23) return 2;   // profiling ablations of the tiles kernel
+    if (algo >= 21 && algo <= 25) return 2;   // profiling ablations of the tiles kernel
     if (algo == 1 || algo == 2) return algo;
     if (num_rots <= MAX_R_TILES && n < (1ll << 31)) return 2;
     return 1;
@@ -902,8 +952,27 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
 #define CV_TILES_LAUNCH(V)                                                                          \
     hv_fwd_tiles<V><<<(unsigned)wgs, TW * 64, 0, st>>>(num_rots, res, corner, d3, tab, ystart, part_start, \
                                                       rec, n, tiles_x, tiles_z, partials, arrivals,    \
-                                                      d_grid_obj, d_grid_rot, d_grid_scale)
-    if (algo == 21) CV_TILES_LAUNCH(1);
+                                                      d_grid_obj, d_grid_rot, d_grid_scale, prof)
+    unsigned long long* prof = nullptr;
+    if (algo == 24) {
+        static unsigned long long* d_prof = nullptr;
+        if (!d_prof) CV_HIP_CHECK(hipMalloc(&d_prof, 16 * sizeof(unsigned long long)));
+        CV_HIP_CHECK(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st));
+        prof = d_prof;
+        CV_TILES_LAUNCH(4);
+        unsigned long long h[16];
+        CV_HIP_CHECK(hipMemcpyAsync(h, d_prof, sizeof h, hipMemcpyDeviceToHost, st));
+        CV_HIP_CHECK(hipStreamSynchronize(st));
+        static const char* names[8] = {"init", "stream+cull", "scan+pq+arc-search", "end-wait", "walk", "drain",
+                                       "tail-flush", "merge+store"};
+        double tot = 0;
+        for (int p2 = 0; p2 < 8; ++p2) tot += (double)h[p2];
+        fprintf(stderr, "hv_fwd_tiles waves %llu ticks/wave %.0f:", h[8], tot / (double)std::max(1ull, h[8]));
+        for (int p2 = 0; p2 < 8; ++p2) fprintf(stderr, " %s %.1f%%", names[p2], 100.0 * (double)h[p2] / tot);
+        fprintf(stderr, "\n");
+    } else
+    if (algo == 25) CV_TILES_LAUNCH(5);
+    else if (algo == 21) CV_TILES_LAUNCH(1);
     else if (algo == 22) CV_TILES_LAUNCH(2);
     else if (algo == 23) CV_TILES_LAUNCH(3);
     else CV_TILES_LAUNCH(0);

@@ -59,6 +59,24 @@ __global__ __launch_bounds__(256) void k64(float* out, int iters) {
     if (s == (T)12345) out[blockIdx.x] = (float)s;
 }
 
+// address sharing: SHARE lanes of a wave hit the same (random) address with lane-dependent values
+template <typename T, int SHARE>
+__global__ __launch_bounds__(256) void kshare(float* out, int iters) {
+    __shared__ T acc[6144];
+    for (int i = threadIdx.x; i < 6144; i += 256) acc[i] = 0;
+    __syncthreads();
+    uint32_t h = (threadIdx.x / SHARE) * 2654435761u + blockIdx.x * 40503u;
+    for (int it = 0; it < iters; ++it) {
+        h = h * 1664525u + 1013904223u;
+        int idx = (h >> 8) % 6144;
+        __hip_atomic_fetch_add(&acc[idx], (T)(1 + (threadIdx.x & 3)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    T s = 0;
+    for (int i = threadIdx.x; i < 6144; i += 256) s += acc[i];
+    if (s == (T)12345) out[blockIdx.x] = (float)s;
+}
+
 template <typename F>
 void run(const char* name, F launch, int iters, int blocks) {
     hipEvent_t a, b;
@@ -88,5 +106,11 @@ int main() {
     run("u64 random", [&] { k64<unsigned long long><<<blocks, 256>>>(out, iters); }, iters, blocks);
     run("f64 random", [&] { k64<double><<<blocks, 256>>>(out, iters); }, iters, blocks);
     run("i32 random", [&] { k64<int><<<blocks, 256>>>(out, iters); }, iters, blocks);
+    run("f64 4 lanes share address", [&] { kshare<double, 4><<<blocks, 256>>>(out, iters); }, iters, blocks);
+    run("u64 4 lanes share address", [&] { kshare<unsigned long long, 4><<<blocks, 256>>>(out, iters); }, iters, blocks);
+    run("f64 16 lanes share address", [&] { kshare<double, 16><<<blocks, 256>>>(out, iters); }, iters, blocks);
+    run("u64 16 lanes share address", [&] { kshare<unsigned long long, 16><<<blocks, 256>>>(out, iters); }, iters, blocks);
+    run("f64 64 lanes share address", [&] { kshare<double, 64><<<blocks, 256>>>(out, iters); }, iters, blocks);
+    run("u64 64 lanes share address", [&] { kshare<unsigned long long, 64><<<blocks, 256>>>(out, iters); }, iters, blocks);
     return 0;
 }
