@@ -381,6 +381,7 @@ struct TileShared {
     float vq_rx[TW][VQ];
     float vq_rz[TW][VQ];
     float2 tab[MAX_R_TILES];
+    int next_chunk[2];         // dynamic hand-out of 64-record chunks of the two y-bins to the waves
 };
 
 __device__ __forceinline__ void drain64(TileShared& sh, int wave, int slot, bool active) {
@@ -458,6 +459,7 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
 
     for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) (&sh.acc[0][0])[i] = 0ull;
     for (int i = threadIdx.x; i < R; i += TW * 64) sh.tab[i] = tab[i];
+    if (threadIdx.x < 2) sh.next_chunk[threadIdx.x] = 0;
     __syncthreads();
     HV_TICK(0);
 
@@ -471,7 +473,14 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     for (int s = y - 1; s <= y; ++s) {
         if (s < 0 || s > Y - 2 || VARIANT == 3) continue;
         const int beg = ystart[s], end = ystart[s + 1];
-        for (int base = beg + (wave * nparts + part) * 64; base < end; base += TW * nparts * 64) {
+        // waves take chunks from a shared counter: a wave whose chunk expands into many votes takes fewer chunks
+        // (static striding left the waves of a workgroup waiting 22 % of their time for the slowest one)
+        for (;;) {
+            int c = 0;
+            if (lane == 0) c = atomicAdd(&sh.next_chunk[s - (y - 1)], 1);
+            c = __builtin_amdgcn_readfirstlane(c);
+            const int base = beg + (c * nparts + part) * 64;
+            if (base >= end) break;
             const int idx = base + lane;
             bool keep = false;
             int a_start = 0, a_len = 0;
