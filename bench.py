@@ -327,8 +327,14 @@ def main():
             "achieved": net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
             "frac": net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12 / 157.3,
             "flops_per_forward": net_flops[0], "dense_equivalent_flops": net_flops[1],
-            "note": "fp32 matrix cores (v_mfma_f32_32x32x2_f32); achieved counts only existing "
-                    "(input,output) pairs, sum 2*P*Cin*Cout over the 63 conv layers"},
+            "bf16_piece_flops_per_forward": 6 * net_flops[0] if ME.CONV_X6 else None,
+            "frac_of_bf16_peak": (6 * net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12 / 2500.0) if ME.CONV_X6 else None,
+            "note": ("fp32 results; every fp32 product is computed as six exact bf16 x bf16 piece products "
+                     "(operands split h+m+l) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation - 0.375x the "
+                     "matrix time of v_mfma_f32_32x32x2_f32 at fp32-level accuracy; " if ME.CONV_X6 else
+                     "fp32 matrix cores (v_mfma_f32_32x32x2_f32); ") +
+                    "achieved counts only existing (input,output) pairs, sum 2*P*Cin*Cout over the 63 conv layers, "
+                    "against the fp32 matrix peak"},
         "detections_per_scene": n_det / a.steps,
         "stage_ms": stage_ms,
         "stage_ms_measured_in": roofline_pass,

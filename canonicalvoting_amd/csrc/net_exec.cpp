@@ -127,6 +127,7 @@ int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int 
         d.in_ld = in.ld;
         d.cin = o.cin;
         d.weight = o.weight;
+        d.weight_x6 = o.weight_x6;
         d.K = o.K;
         d.cout = o.cout;
         d.nbr = o.map >= 0 ? maps[o.map] : nullptr;

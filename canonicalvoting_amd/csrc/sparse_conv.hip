@@ -57,6 +57,8 @@ struct ConvArgs {
     int wide;              // epilogue operands are 16-byte aligned with leading dimensions % 4 == 0: float4 row stores
     const int* nbr_perm;   // mask-sorted groups: [splits][n_out][nbr_perm_w] kernel map rows in processing order
     int nbr_perm_w;
+    int dbg;               // instrumented twin only (CV_CONV_DBG): 1 no MFMA, 2 no gathers, 4 no weight loads, 8 no epilogue
+    const unsigned short* wp6;   // weights split into bf16 pieces, see pack_weights_x6 (conv_rows_x6)
 };
 
 __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& acc, const int* rows,
@@ -301,6 +303,214 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ fp32 products on the bf16 matrix cores
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate, and wall-time ablations (profiles/conv_ablate.py) show the
+// fp32 MFMAs to be half of the conv time (ts1 96->96: 192 us, 95 us without them, gathers / weights / epilogue
+// each ~10 us) with the pipe only 60 % busy while they run.  conv_rows_x6 computes the SAME fp32 products on
+// v_mfma_f32_32x32x16_bf16: every fp32 operand is split exactly into three bf16 pieces x = h + m + l (8 + 8 + 8
+// significant bits; the pieces of an operand sum to it to within half an fp32 ulp), and the six piece products whose
+// magnitude is >= 2^-16 of the full product (hh, hm, mh, mm, hl, lh) are accumulated in fp32 - bf16 x bf16 products
+// are exact in fp32, the dropped ml / lm / ll terms are <= 2^-23 of the product, i.e. fp32 rounding level.
+// Six bf16 MFMAs (K = 16, 32 cycles) replace eight fp32 MFMAs (K = 2, 64 cycles) per 16 channels: 0.375x the matrix
+// time at fp32 accuracy (network output still within 1e-6 of the fp32 oracle).
+// Activations are split when they are staged (5.5 VALU ops per value); weights are split, transposed to [col][k]
+// and laid out per (offset, 32-channel chunk) once per weight tensor (cv_sp_pack_weights_x6_f32).
+// LDS operand tiles: [plane][row][32 k] bf16, 64-byte rows whose 16-byte chunks are XOR-swizzled with (row >> 2) & 3
+// so that the ds_read_b128 of the 16 lanes served together hit 16 different bank groups.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {      // RNE, lo in bits 0-15
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// two fp32 values -> their h / m / l bf16 pieces, packed (first value in the low half)
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
+}
+
+// wp6 layout (unsigned short): ((((j*nch + c)*3 + plane)*cout + col)*32 + k) for channel c*32 + k of offset j
+__global__ __launch_bounds__(256) void pack_weights_x6(const float* __restrict__ w, int K, int cin, int cout,
+                                                       unsigned short* __restrict__ wp) {
+    const long long total = (long long)K * cin * cout / 2;                   // pairs of consecutive k
+    const int nch = cin / 32;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long r = i;
+        const int k2 = (int)(r % 16); r /= 16;                               // k = 2*k2, 2*k2 + 1
+        const int col = (int)(r % cout); r /= cout;
+        const int c = (int)(r % nch); r /= nch;
+        const int j = (int)r;
+        const float* p = w + ((long long)j * cin + c * 32 + 2 * k2) * cout + col;
+        unsigned h, m, l;
+        split3(p[0], p[cout], h, m, l);
+        const long long base = ((long long)(j * nch + c) * 3 * cout + col) * 32 + 2 * k2;
+        *reinterpret_cast<unsigned*>(wp + base) = h;
+        *reinterpret_cast<unsigned*>(wp + base + (long long)cout * 32) = m;
+        *reinterpret_cast<unsigned*>(wp + base + 2ll * cout * 32) = l;
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
+    // operand tiles and the epilogue tile share one buffer (the epilogue starts after the last MFMA)
+    constexpr int A_BYTES = 3 * TM * 64, B_BYTES = 3 * NB * 32 * 64, EP_BYTES = 4 * 32 * EP_LD * 4;
+    constexpr int SM_BYTES = A_BYTES + B_BYTES > EP_BYTES ? A_BYTES + B_BYTES : EP_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[SM_BYTES];
+    __shared__ int nbr_s[TM];
+    __shared__ int rows_s[TM];
+    unsigned char* const A_h = sm;                    // [plane][row][64 B]
+    unsigned char* const B_h = sm + A_BYTES;          // [plane][col][64 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.y * (NB * 32);
+
+    if (tid < TM) {
+        const long long tile_id = a.row_perm ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
+        const long long t = tile_id * TM + tid;
+        const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)blockIdx.z * a.n_out : 0) : nullptr;
+        rows_s[tid] = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
+    }
+    __syncthreads();
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    const int half = lane >> 5, l31 = lane & 31;
+    auto compute = [&]() {
+        const int arow = wave * 32 + l31;
+        const int aswz = (arow >> 2) & 3, bswz = (l31 >> 2) & 3;     // (nb*32 + l31) >> 2 & 3 == (l31 >> 2) & 3
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = 2 * ks + half;
+            bf16x8 av[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                av[p] = *reinterpret_cast<const bf16x8*>(A_h + (p * TM + arow) * 64 + ((chunk ^ aswz) << 4));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                bf16x8 bv[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bv[p] = *reinterpret_cast<const bf16x8*>(B_h + (p * NB * 32 + nb * 32 + l31) * 64 + ((chunk ^ bswz) << 4));
+                // smallest terms first
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[2], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[0], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[1], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[0], acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc[nb], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nj = a.j_end - a.j_begin;
+    // thread -> (row = tid/8 + 32*i, 4 channels at (tid%8)*4) : 8 lanes cover one 128 B row chunk
+    const int a_col = (tid & 7) * 4;
+    const int a_row = tid >> 3;                      // + 32*i, i = 0..3
+    constexpr int B_U4 = 3 * NB * 32 * 4;            // 16-byte pieces of the packed weight slab of one unit
+    constexpr int B_PER = (B_U4 + THREADS - 1) / THREADS;
+    const int nch = a.cin / KC;
+    int u_lo, u_hi;
+    if (a.perm_per_split) {
+        u_lo = (int)((long long)nj * blockIdx.z / a.splits) * nch;
+        u_hi = (int)((long long)nj * (blockIdx.z + 1) / a.splits) * nch;
+    } else {
+        u_lo = (int)((long long)nj * nch * blockIdx.z / a.splits);
+        u_hi = (int)((long long)nj * nch * (blockIdx.z + 1) / a.splits);
+    }
+    const int j_first = a.j_begin + u_lo / nch, j_last = a.j_begin + (u_hi - 1) / nch;
+    for (int j = j_first; j <= j_last && u_hi > u_lo; ++j) {
+        const int kc_begin = (j == j_first ? u_lo % nch : 0) * KC;
+        const int kc_end = (j == j_last ? (u_hi - 1) % nch + 1 : nch) * KC;
+        int my = -1;
+        if (tid < TM) {
+            const int row = rows_s[tid];
+            if (row >= 0) {
+                if (a.nbr_perm) {
+                    const long long tile_id = (long long)gridDim.x - 1 - blockIdx.x;
+                    my = a.nbr_perm[((long long)blockIdx.z * a.n_out + tile_id * TM + tid) * a.nbr_perm_w +
+                                    (j - (a.j_begin + (int)((long long)nj * blockIdx.z / a.splits)))];
+                } else
+                    my = a.nbr ? a.nbr[(long long)row * a.K + j] : row;
+            }
+            nbr_s[tid] = my;
+        }
+        if (!__syncthreads_or(my >= 0)) continue;    // nobody in the tile has this neighbour
+        const bool wave_live = __any(nbr_s[wave * 32 + l31] >= 0);
+        float4 ra[4];
+        uint4 rb[B_PER];
+        auto load = [&](int kc) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int src = nbr_s[a_row + 32 * i];
+                ra[i] = src >= 0 ? *reinterpret_cast<const float4*>(a.in + (long long)src * a.in_ld + kc + a_col)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            // packed slab of (j, chunk): [plane][cout][32 k] bf16; this workgroup's columns n0 .. n0 + NB*32
+            const unsigned short* slab = a.wp6 + (long long)(j * nch + kc / KC) * 3 * a.cout * 32;
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) {
+                const int f = tid + i * THREADS;
+                if (f < B_U4) {
+                    const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
+                    const int col = rem >> 2, ch = rem & 3;
+                    rb[i] = n0 + col < a.cout
+                                ? *reinterpret_cast<const uint4*>(slab + ((long long)p * a.cout + n0 + col) * 32 + ch * 8)
+                                : make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+        };
+        auto stage = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = a_row + 32 * i;
+                unsigned h0, m0, l0, h1, m1, l1;
+                split3(ra[i].x, ra[i].y, h0, m0, l0);
+                split3(ra[i].z, ra[i].w, h1, m1, l1);
+                // channels a_col .. a_col+3 -> 8 bytes at offset (a_col & 7) * 2 of chunk a_col >> 3
+                unsigned char* dst = A_h + r * 64 + ((((a_col >> 3) ^ ((r >> 2) & 3))) << 4) + ((a_col & 7) << 1);
+                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(dst + TM * 64) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2*>(dst + 2 * TM * 64) = make_uint2(l0, l1);
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) {
+                const int f = tid + i * THREADS;
+                if (f < B_U4) {
+                    const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
+                    const int col = rem >> 2, ch = rem & 3;
+                    *reinterpret_cast<uint4*>(B_h + (p * NB * 32 + col) * 64 + ((ch ^ ((col >> 2) & 3)) << 4)) = rb[i];
+                }
+            }
+        };
+        load(kc_begin);
+        for (int kc = kc_begin; kc < kc_end; kc += KC) {
+            __syncthreads();                 // previous chunk's MFMAs are done with the LDS tiles
+            stage();
+            __syncthreads();
+            if (kc + KC < kc_end) load(kc + KC);  // in flight while the matrix cores run
+            if (wave_live) compute();
+        }
+        __syncthreads();
+    }
+    __syncthreads();                         // operand tiles are dead: the epilogue tile reuses their LDS
+    float (*ep)[EP_LD] = reinterpret_cast<float (*)[EP_LD]>(sm + wave * 32 * EP_LD * 4);
+    if (a.wide) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) epilogue_store_wide(a, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep);
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            epilogue_store(a, acc[nb], rows_s + wave * 32, n0 + nb * 32 + (lane & 31), lane);
+    }
+}
+
 // Instrumented twin of conv_rows (CV_CONV_PROF=1): shader-clock ticks per phase, summed over waves into prof[16].
 template <int NB, bool VEC>
 __global__ __launch_bounds__(THREADS) void conv_rows_prof(ConvArgs a, unsigned long long* prof) {
@@ -394,7 +604,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_prof(ConvArgs a, unsigned l
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int src = nbr_s[a_row + 32 * i];
-                    ra[i] = src >= 0 ? *reinterpret_cast<const float4*>(a.in + (long long)src * a.in_ld + kc + a_col)
+                    ra[i] = (src >= 0 && !(a.dbg & 2)) ? *reinterpret_cast<const float4*>(a.in + (long long)src * a.in_ld + kc + a_col)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
@@ -404,7 +614,8 @@ __global__ __launch_bounds__(THREADS) void conv_rows_prof(ConvArgs a, unsigned l
                         const int kr = f / (NB * 8), c4 = (f % (NB * 8)) * 4;
                         const int col = n0 + c4;
                         const float* wp = a.w + ((long long)j * a.cin + kc + kr) * a.cout + col;
-                        if (col + 3 < a.cout) rb[i] = *reinterpret_cast<const float4*>(wp);
+                        if (a.dbg & 4) rb[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+                        else if (col + 3 < a.cout) rb[i] = *reinterpret_cast<const float4*>(wp);
                         else {
                             rb[i].x = col < a.cout ? wp[0] : 0.f;
                             rb[i].y = col + 1 < a.cout ? wp[1] : 0.f;
@@ -441,7 +652,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_prof(ConvArgs a, unsigned l
                 TICK(5);
                 if (kc + KC < kc_end) load(kc + KC);  // in flight while the matrix cores run
                 TICK(6);
-                if (wave_live) compute();
+                if (wave_live && !(a.dbg & 1)) compute();
                 TICK(7);
             }
             __syncthreads();
@@ -475,7 +686,9 @@ __global__ __launch_bounds__(THREADS) void conv_rows_prof(ConvArgs a, unsigned l
             compute();
         }
     }
-    if (a.wide) {
+    if (a.dbg & 8) {
+        if (acc[0][0] == 123.456f) a.out[0] = 1.f;
+    } else if (a.wide) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
             epilogue_store_wide(a, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep_s[wave]);
@@ -485,7 +698,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_prof(ConvArgs a, unsigned l
             epilogue_store(a, acc[nb], rows_s + wave * 32, n0 + nb * 32 + (lane & 31), lane);
     }
     TICK(9);
-    if (lane == 0) {
+    if (lane == 0 && prof) {
         for (int p2 = 0; p2 < 10; ++p2) atomicAdd(&prof[p2], pacc[p2]);
         atomicAdd(&prof[10], 1ull);
     }
@@ -1423,11 +1636,22 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
     dim3 grid((unsigned)((a.n_out + TM - 1) / TM), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)),
               (unsigned)a.splits);
     static const bool prof_on = getenv("CV_CONV_PROF") != nullptr;
+    if (vec && a.wp6 && !prof_on) {
+        conv_rows_x6<NB><<<grid, THREADS, 0, st>>>(a);
+        CV_LAUNCH_CHECK();
+        if (a.splits > 1) return launch_finish(a, st);
+        return CV_OK;
+    }
     if (vec && prof_on) {
         static unsigned long long* d_prof = nullptr;
         if (!d_prof) CV_HIP_CHECK(hipMalloc(&d_prof, 16 * sizeof(unsigned long long)));
         CV_HIP_CHECK(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st));
-        conv_rows_prof<NB, true><<<grid, THREADS, 0, st>>>(a, d_prof);
+        static const bool quiet = getenv("CV_CONV_PROF")[0] == 'q';      // ablation timing: no counters, no print
+        conv_rows_prof<NB, true><<<grid, THREADS, 0, st>>>(a, quiet ? nullptr : d_prof);
+        if (quiet) {
+            CV_LAUNCH_CHECK();
+            return a.splits > 1 ? launch_finish(a, st) : CV_OK;
+        }
         unsigned long long h[16];
         CV_HIP_CHECK(hipMemcpyAsync(h, d_prof, sizeof h, hipMemcpyDeviceToHost, st));
         CV_HIP_CHECK(hipStreamSynchronize(st));
@@ -1560,7 +1784,12 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
     ConvArgs a{d->in, d->n_in, d->in_ld, d->cin, d->weight, d->K, d->cout, d->nbr, d->n_out, d->scale,
                d->shift, d->residual, d->res_ld, d->relu, d->out, d->out_ld, 1, nullptr, d->row_perm, 0, jb, je,
                d->acc_in, d->acc_ld, d->plan_ent, d->plan_cnt,
-               reinterpret_cast<const float4*>(d->weight_packed), 0, nullptr, 0};
+               reinterpret_cast<const float4*>(d->weight_packed), 0, nullptr, 0, 0,
+               static_cast<const unsigned short*>(d->weight_x6)};
+    {
+        static const int dbg = getenv("CV_CONV_DBG") ? atoi(getenv("CV_CONV_DBG")) : 0;
+        a.dbg = dbg;
+    }
     CV_REQUIRE(!d->plan_ent == !d->plan_cnt, CV_EINVAL, "plan_ent and plan_cnt go together");
     a.wide = d->cout % 4 == 0 && d->out_ld % 4 == 0 && (!d->residual || d->res_ld % 4 == 0) &&
              (!d->acc_in || d->acc_ld % 4 == 0) &&
@@ -1706,6 +1935,20 @@ int cv_sp_pack_weights_f32(const float* d_w, int K, int cin, int cout, float* d_
     const long long total = (long long)K * cin * cout / 4;
     pack_weights<<<(unsigned)std::min<long long>((total + 255) / 256, 4096), 256, 0, st>>>(
         d_w, K, cin, cout, kw, reinterpret_cast<float4*>(d_wp));
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+// d_wp6[3*K*cin*cout] (16-bit words) = d_w[K][cin][cout] split into three bf16 pieces per value and laid out per
+// (offset, 32-channel chunk) as [piece][cout][32 channels] for conv_rows_x6 (cin % 32 == 0).  Redo when weights change.
+int cv_sp_pack_weights_x6_f32(const float* d_w, int K, int cin, int cout, void* d_wp6, void* stream) {
+    CV_REQUIRE(d_w && d_wp6 && K > 0 && cin > 0 && cout > 0, CV_EINVAL, "bad pack_weights_x6 arguments");
+    CV_REQUIRE(cin % 32 == 0, CV_EINVAL, "pack_weights_x6 needs Cin %% 32 == 0 (got %d)", cin);
+    CV_REQUIRE((reinterpret_cast<uintptr_t>(d_wp6) & 15) == 0, CV_EINVAL, "d_wp6 must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long total = (long long)K * cin * cout / 2;
+    pack_weights_x6<<<(unsigned)std::min<long long>((total + 255) / 256, 8192), 256, 0, st>>>(
+        d_w, K, cin, cout, static_cast<unsigned short*>(d_wp6));
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

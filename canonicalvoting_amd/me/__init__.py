@@ -322,7 +322,8 @@ def _workspace(dev, nbytes):
 
 
 def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=None, relu=False,
-                 out=None, flavour=0, row_perm=None, j_begin=0, j_end=0, acc_in=None, perm_groups=0):
+                 out=None, flavour=0, row_perm=None, j_begin=0, j_end=0, acc_in=None, perm_groups=0,
+                 cache_weights=True):
     """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout]."""
     L = _lib.lib()
     dev = x_feats.device
@@ -342,7 +343,10 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
     if ((flavour == 4 or (TILE_KERNEL and flavour == 0)) and perm_groups == 0 and K <= 27 and cin % 32 == 0
             and cout % 32 == 0 and L.cv_sp_tile_kw(cin, cout) > 0):
         plan = tile_plan(nbr, row_perm) if nbr is not None else None
-        wp = packed_weights(weight, w)
+        wp = packed_weights(weight, w, cache_weights)
+    wp6 = None
+    if CONV_X6 and flavour in (0, 1) and cin % 32 == 0 and cout % 4 == 0 and plan is None:
+        wp6 = packed_weights_x6(weight, w, cache_weights)
     ws = None
     if perm_groups > 1:
         ws = _workspace(dev, 4 * perm_groups * n_out * cout + 256)
@@ -355,7 +359,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
                       ws.numel() if ws is not None else 0, p(row_perm), j_begin, j_end, p(acc_in),
                       acc_in.stride(0) if acc_in is not None else 0, perm_groups,
                       plan[0].data_ptr() if plan is not None else None,
-                      plan[0].data_ptr() + 4 * plan[1] if plan is not None else None, p(wp),
+                      plan[0].data_ptr() + 4 * plan[1] if plan is not None else None, p(wp), p(wp6),
                       1 if (perm_groups > 1 and getattr(row_perm, "_cv_has_map", False)) else 0)
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
@@ -398,14 +402,51 @@ TILE_KERNEL = os.environ.get("CV_TILE_KERNEL", "0") != "0"
 
 
 _packed = {}
+_packed_x6 = {}
+# 1 (default): vector-path convs run their fp32 products as six bf16 piece products on the bf16 matrix cores
+# (conv_rows_x6); 0: v_mfma_f32_32x32x2_f32
+CONV_X6 = os.environ.get("CV_CONV_X6", "1") != "0"
 
 
-def packed_weights(weight, w3):
+def invalidate_weight_caches():
+    """Drop every cached re-packing of a weight tensor.  The caches are keyed by tensor version, and fused
+    optimizers (torch.optim.Adam(fused=True)) update parameters WITHOUT bumping it: modules call this when they
+    switch between train and eval mode, and the training path never caches."""
+    _packed.clear()
+    _packed_x6.clear()
+
+
+def packed_weights_x6(weight, w3, cache=True):
+    """weights split into bf16 pieces for conv_rows_x6 (cv_sp_pack_weights_x6_f32), cached per parameter tensor and
+    re-packed when it is modified in place or re-allocated."""
+    key = id(weight)
+    ver = (weight.data_ptr(), weight._version, tuple(weight.shape))
+    hit = _packed_x6.get(key)
+    if not cache:            # training: the weights change every step (see invalidate_weight_caches)
+        hit = None
+    if hit is None or hit[0] != ver or hit[2]() is not weight:
+        import weakref
+        L = _lib.lib()
+        K, cin, cout = w3.shape
+        wp = torch.empty(3 * w3.numel(), dtype=torch.int16, device=w3.device)
+        with torch.cuda.device(w3.device):
+            _lib.check(L.cv_sp_pack_weights_x6_f32(_ptr(w3), K, cin, cout, _ptr(wp), _stream(w3.device)),
+                       "cv_sp_pack_weights_x6_f32")
+        try:
+            ref = weakref.ref(weight, lambda _r, k=key: _packed_x6.pop(k, None))
+        except TypeError:
+            ref = lambda: weight
+        hit = _packed_x6[key] = (ver, wp, ref)
+    return hit[1]
+
+
+
+def packed_weights(weight, w3, cache=True):
     """weights in the tile kernel's MFMA operand order (cv_sp_pack_weights_f32), cached per parameter tensor and
     re-packed when it is modified in place (optimizer step, load_state_dict) or re-allocated."""
     key = id(weight)
     ver = (weight.data_ptr(), weight._version, tuple(weight.shape))
-    hit = _packed.get(key)
+    hit = _packed.get(key) if cache else None
     if hit is None or hit[0] != ver or hit[2]() is not weight:
         import weakref
         L = _lib.lib()
@@ -501,7 +542,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.has_nbr = nbr is not None
         ctx.has_bias = bias is not None
         shift = bias.reshape(-1).contiguous() if bias is not None else None
-        return conv_forward(feats, kernel, nbr, n_out, shift=shift)
+        return conv_forward(feats, kernel, nbr, n_out, shift=shift, cache_weights=False)
 
     @staticmethod
     def backward(ctx, grad):
@@ -513,7 +554,7 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             w_t = k3.detach().permute(0, 2, 1).contiguous()
             nbr_t = transposed_map(nbr, feats.shape[0]) if nbr is not None else None
-            d_feats = conv_forward(grad, w_t, nbr_t, feats.shape[0])
+            d_feats = conv_forward(grad, w_t, nbr_t, feats.shape[0], cache_weights=False)
         if ctx.needs_input_grad[1]:
             d_kernel = conv_wgrad(feats, grad, nbr, k3.shape[0]).reshape(kernel.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -547,6 +588,10 @@ class MinkowskiConvolutionBase(nn.Module):
             self.kernel.uniform_(-stdv, stdv)
             if self.bias is not None:
                 self.bias.uniform_(-stdv, stdv)
+
+    def train(self, mode=True):
+        invalidate_weight_caches()
+        return super().train(mode)
 
     def _map(self, x):
         cm, ts = x.coordinate_manager, x.tensor_stride

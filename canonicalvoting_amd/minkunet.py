@@ -94,6 +94,14 @@ class MinkUNetBase(ResNetBase):
                                              dimension=D)
         self.relu = ME.MinkowskiReLU(inplace=True)
 
+    def train(self, mode=True):
+        # every derived cache (folded BatchNorm affines, packed weights, the C program) is keyed by tensor versions,
+        # which fused optimizers do not bump: drop them whenever the mode is switched
+        self.__dict__.pop("_fold_cache", None)
+        self.__dict__.pop("_prog", None)
+        ME.invalidate_weight_caches()
+        return super().train(mode)
+
     # ------------------------------------------------------------------ reference-shaped forward
     def forward(self, x):
         if (not self.training) and (not torch.is_grad_enabled()) and self.BLOCK is BasicBlock:
@@ -228,12 +236,14 @@ class MinkUNetBase(ResNetBase):
 
         def conv(src, dst, kernel, K, map_slot, scale=None, shift=None, res=None, relu=False, perm=-1, groups=0):
             w = (kernel if kernel.dim() == 3 else kernel[None]).detach().contiguous()
-            keep.extend([w, scale, shift])
+            w6 = ME.packed_weights_x6(kernel, w) if (ME.CONV_X6 and w.shape[1] % 32 == 0 and w.shape[2] % 4 == 0) else None
+            keep.extend([w, scale, shift, w6])
             ops.append(dict(in_buf=src[0], in_col=src[1], cin=w.shape[1], out_buf=dst[0], out_col=dst[1],
                             cout=w.shape[2], res_buf=res[0] if res else -1, res_col=res[1] if res else 0,
                             map=map_slot, K=K, perm=perm, perm_groups=groups, relu=1 if relu else 0,
                             weight=w.data_ptr(), scale=scale.data_ptr() if scale is not None else None,
-                            shift=shift.data_ptr() if shift is not None else None))
+                            shift=shift.data_ptr() if shift is not None else None,
+                            weight_x6=w6.data_ptr() if w6 is not None else None))
 
         def layer(seq, x, level, out_view):
             """x, out_view: (slot, first column); returns the (slot, column) holding the layer's output"""

@@ -243,3 +243,37 @@ def test_ddp_gradient_allreduce_two_ranks(cuda, built_lib):
         assert p.exitcode == 0
     assert got["rank0"] < 1e-4, got
     np.testing.assert_allclose(got["sig0"], got["sig1"], rtol=1e-6)
+
+
+def test_training_then_eval_uses_current_weights(cuda, built_lib):
+    """fused optimizers update parameters without bumping tensor versions: the training path must not reuse packed
+    weights of the previous step, and switching to eval mode must rebuild every derived cache (folded BatchNorm,
+    packed weights, the C program)."""
+    from canonicalvoting_amd import train
+    from canonicalvoting_amd.synth import make_scene
+    sc = make_scene(50, n_points=1500, res=0.06, room=(1.5, 0.9, 1.5), n_boxes=2, margin=0.5, box_scale=0.4)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    coords = torch.cat([torch.zeros((1500, 1), dtype=torch.int32), torch.from_numpy(sc.coords).int()], 1).to(cuda)
+    feats, xyz, scale, cls = t(sc.feats) * 2 - 1, t(sc.xyz_labels), t(sc.scale_labels), t(sc.class_labels)
+    torch.manual_seed(0)
+    model = MinkUNet34C(3, 64).cuda().train()
+    opt = train.make_optimizer(model)                       # fused Adam on the GPU
+    losses = [float(train.train_step(model, opt, coords, feats, xyz, scale, cls)[0]) for _ in range(6)]
+    assert losses[-1] < 0.7 * losses[0], losses            # stale weights made the loss stall near its start value
+    model.eval()
+    with torch.no_grad():
+        x = ME.SparseTensor(feats, coords, device=cuda)
+        y_prog = model.program_forward(x).F
+        y_fused = model.fused_forward(x).F
+        y_mod = model.modular_forward(x).F
+    assert torch.equal(y_prog, y_fused)
+    assert float((y_mod - y_fused).abs().max()) < 1e-4 * max(1.0, float(y_mod.abs().max()))
+    # one more training step, then eval again: the eval caches must follow
+    model.train()
+    train.train_step(model, opt, coords, feats, xyz, scale, cls)
+    model.eval()
+    with torch.no_grad():
+        y2 = model(ME.SparseTensor(feats, coords, device=cuda)).F
+        y2_mod = model.modular_forward(ME.SparseTensor(feats, coords, device=cuda)).F
+    assert float((y2 - y_prog).abs().max()) > 1e-6                      # the weights did move
+    assert float((y2 - y2_mod).abs().max()) < 1e-4 * max(1.0, float(y2_mod.abs().max()))
