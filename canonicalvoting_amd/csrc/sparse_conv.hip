@@ -362,6 +362,8 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char sm[SM_BYTES];
     __shared__ int nbr_s[TM];
     __shared__ int rows_s[TM];
+    constexpr int NPRE = 8;
+    __shared__ int nbr_all[NPRE][TM];
     unsigned char* const A_h = sm;                    // [plane][row][64 B]
     unsigned char* const B_h = sm + A_BYTES;          // [plane][col][64 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -425,20 +427,35 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
         u_hi = (int)((long long)nj * nch * (blockIdx.z + 1) / a.splits);
     }
     const int j_first = a.j_begin + u_lo / nch, j_last = a.j_begin + (u_hi - 1) / nch;
+    // kernel-map entry of tile row t for offset j
+    auto map_entry = [&](int t, int j) {
+        const int row = rows_s[t];
+        if (row < 0) return -1;
+        if (a.nbr_perm) {
+            const long long tile_id = (long long)gridDim.x - 1 - blockIdx.x;
+            return a.nbr_perm[((long long)blockIdx.z * a.n_out + tile_id * TM + t) * a.nbr_perm_w +
+                              (j - (a.j_begin + (int)((long long)nj * blockIdx.z / a.splits)))];
+        }
+        return a.nbr ? a.nbr[(long long)row * a.K + j] : row;
+    };
+    // up to NPRE offsets per workgroup (mask groups, split-K ranges): all their map entries come in with ONE round of
+    // independent loads - a fetch per offset costs a global-memory latency per offset, dead offsets included
+    // (7 in a row for a mask group: about a third of the workgroup's lifetime once the MFMAs are cheap)
+    const int njl = u_hi > u_lo ? j_last - j_first + 1 : 0;
+    const bool pre = njl <= NPRE;
+    if (pre) {
+        for (int e = tid; e < njl * TM; e += THREADS) {
+            const int jj = e / TM, t = e - jj * TM;
+            nbr_all[jj][t] = map_entry(t, j_first + jj);
+        }
+        __syncthreads();
+    }
     for (int j = j_first; j <= j_last && u_hi > u_lo; ++j) {
         const int kc_begin = (j == j_first ? u_lo % nch : 0) * KC;
         const int kc_end = (j == j_last ? (u_hi - 1) % nch + 1 : nch) * KC;
         int my = -1;
         if (tid < TM) {
-            const int row = rows_s[tid];
-            if (row >= 0) {
-                if (a.nbr_perm) {
-                    const long long tile_id = (long long)gridDim.x - 1 - blockIdx.x;
-                    my = a.nbr_perm[((long long)blockIdx.z * a.n_out + tile_id * TM + tid) * a.nbr_perm_w +
-                                    (j - (a.j_begin + (int)((long long)nj * blockIdx.z / a.splits)))];
-                } else
-                    my = a.nbr ? a.nbr[(long long)row * a.K + j] : row;
-            }
+            my = pre ? nbr_all[j - j_first][tid] : map_entry(tid, j);
             nbr_s[tid] = my;
         }
         if (!__syncthreads_or(my >= 0)) continue;    // nobody in the tile has this neighbour
@@ -449,7 +466,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int src = nbr_s[a_row + 32 * i];
-                ra[i] = src >= 0 ? *reinterpret_cast<const float4*>(a.in + (long long)src * a.in_ld + kc + a_col)
+                ra[i] = (src >= 0 && !(a.dbg & 2)) ? *reinterpret_cast<const float4*>(a.in + (long long)src * a.in_ld + kc + a_col)
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             // packed slab of (j, chunk): [plane][cout][32 k] bf16; this workgroup's columns n0 .. n0 + NB*32
@@ -460,7 +477,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
                 if (f < B_U4) {
                     const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
                     const int col = rem >> 2, ch = rem & 3;
-                    rb[i] = n0 + col < a.cout
+                    rb[i] = (n0 + col < a.cout && !(a.dbg & 4))
                                 ? *reinterpret_cast<const uint4*>(slab + ((long long)p * a.cout + n0 + col) * 32 + ch * 8)
                                 : make_uint4(0u, 0u, 0u, 0u);
                 }
@@ -470,9 +487,11 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = a_row + 32 * i;
-                unsigned h0, m0, l0, h1, m1, l1;
-                split3(ra[i].x, ra[i].y, h0, m0, l0);
-                split3(ra[i].z, ra[i].w, h1, m1, l1);
+                unsigned h0 = 0, m0 = 0, l0 = 0, h1 = 0, m1 = 0, l1 = 0;
+                if (!(a.dbg & 16)) {
+                    split3(ra[i].x, ra[i].y, h0, m0, l0);
+                    split3(ra[i].z, ra[i].w, h1, m1, l1);
+                }
                 // channels a_col .. a_col+3 -> 8 bytes at offset (a_col & 7) * 2 of chunk a_col >> 3
                 unsigned char* dst = A_h + r * 64 + ((((a_col >> 3) ^ ((r >> 2) & 3))) << 4) + ((a_col & 7) << 1);
                 *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
@@ -492,16 +511,18 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
         load(kc_begin);
         for (int kc = kc_begin; kc < kc_end; kc += KC) {
             __syncthreads();                 // previous chunk's MFMAs are done with the LDS tiles
-            stage();
+            if (!(a.dbg & 32)) stage();
             __syncthreads();
             if (kc + KC < kc_end) load(kc + KC);  // in flight while the matrix cores run
-            if (wave_live) compute();
+            if (wave_live && !(a.dbg & 1)) compute();
         }
         __syncthreads();
     }
     __syncthreads();                         // operand tiles are dead: the epilogue tile reuses their LDS
     float (*ep)[EP_LD] = reinterpret_cast<float (*)[EP_LD]>(sm + wave * 32 * EP_LD * 4);
-    if (a.wide) {
+    if (a.dbg & 8) {
+        if (acc[0][0] == 123.456f) a.out[0] = 1.f;
+    } else if (a.wide) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) epilogue_store_wide(a, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep);
     } else {

@@ -1,5 +1,5 @@
-"""Wall-time ablations of conv_rows (instrumented twin, CV_CONV_PROF=q, CV_CONV_DBG bits: 1 no MFMA, 2 no gathers,
-4 no weight loads, 8 no epilogue) on the conv shapes of one 80k scene."""
+"""Wall-time ablations of conv_rows_x6 (default) or, with ABLATE_FP32=1, of the fp32-MFMA conv_rows (instrumented
+twin with the counters off); CV_CONV_DBG bits: 1 no MFMA, 2 no gathers, 4 no weight loads, 8 no epilogue."""
 import os, sys, subprocess
 if len(sys.argv) > 1:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,6 +32,8 @@ if len(sys.argv) > 1:
     print('dbg %2s: ' % os.environ.get('CV_CONV_DBG', '0') + ' '.join(out))
 else:
     print('us per conv (+finish): ts1 96>96  ts2 96>96  ts4 128>128  ts8 256>256  ts16 256>256')
-    for dbg in (0, 1, 2, 4, 8, 3, 6, 7, 15):
-        env = dict(os.environ, CV_CONV_DBG=str(dbg), CV_CONV_PROF='q', CV_NET_PROGRAM='0')
+    for dbg in (0, 1, 15, 47):
+        env = dict(os.environ, CV_CONV_DBG=str(dbg), CV_NET_PROGRAM='0')
+        if os.environ.get('ABLATE_FP32'):
+            env.update(CV_CONV_PROF='q', CV_CONV_X6='0')      # the fp32-MFMA kernel (instrumented twin, counters off)
         subprocess.run([sys.executable, __file__, 'run'], env=env)
