@@ -103,3 +103,34 @@ def test_host_iou_and_nms_match_oracle(built_lib):
     assert [(x[0], x[2]) for x in a] == [(x[0], x[2]) for x in b]
     assert all(np.array_equal(x[1], y[1]) for x, y in zip(a, b))
     assert decode.nms(boxes[:0], scores[:0], 0.3) == []
+
+
+def test_host_side_layout_functions(built_lib):
+    """pure host functions of the network executor / scene maps / tile plan: sizes and offsets (no GPU needed)"""
+    import ctypes
+    L = _lib.lib()
+    rows = (ctypes.c_int64 * 5)(80000, 36822, 9929, 2349, 494)
+    off = _lib.SceneMaps()
+    words = L.cv_sp_scene_maps_words(rows, 80000, 5, 4, 16384, ctypes.byref(off))
+    spans = [(off.stem, 80000 * 125), (off.out, 80000)] + [(off.down[i], rows[i + 1] * 8) for i in range(4)] + \
+            [(off.k3[i], rows[i] * 27) for i in range(5)] + [(off.up[i], rows[3 - i] * 8) for i in range(4)] + \
+            [(off.up_perm[i], rows[3 - i]) for i in range(4)] + [(off.scratch, 4 * 1024)]
+    for i in range(5):
+        if rows[i] >= 16384:
+            assert off.mask_perm[i] >= 0
+            spans.append((off.mask_perm[i], 4 * rows[i] * (1 + 7)))          # orders + map rows in processing order
+        else:
+            assert off.mask_perm[i] == -1
+    spans.sort()
+    for (a, la), (b, _) in zip(spans[:-1], spans[1:]):
+        assert a % 64 == 0 and a + la <= b                                   # aligned, non-overlapping
+    assert spans[-1][0] + spans[-1][1] <= words
+    # arena of a two-buffer program: one external, one level-1 buffer of 96 channels
+    bufs = (_lib.NetBuf * 2)(_lib.NetBuf(-1, 3, 0), _lib.NetBuf(1, 96, 1))
+    assert L.cv_net_arena_bytes(bufs, 2, rows, 5) >= 36822 * 96 * 4
+    # tile plan and K-chunk helpers
+    coff = ctypes.c_size_t(0)
+    n_words = L.cv_sp_tile_plan_ints(1000, 27, ctypes.byref(coff))
+    assert coff.value >= 8 * 27 * 128 and n_words == coff.value + 8 * 32
+    assert [L.cv_sp_tile_kw(c, o) for c, o in ((96, 96), (128, 96), (128, 128), (256, 256), (160, 64), (3, 32))] == \
+        [96, 64, 128, 128, 32, 0]
