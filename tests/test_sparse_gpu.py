@@ -384,3 +384,34 @@ def test_minkunet_edge_case_coordinate_sets(cuda, built_lib, case):
     ref = so.minkunet34c_forward(sd, coords, feats).numpy()
     tol = 1e-4 * max(1.0, np.abs(ref).max())
     assert y.shape == ref.shape and np.abs(y - ref).max() < tol and np.abs(ym - ref).max() < tol
+
+
+def test_bf16x6_products_keep_fp32_accuracy(cuda, built_lib):
+    """conv_rows_x6 computes every fp32 product as six exact bf16 piece products: against a float64 reference its
+    error must stay at fp32-rounding level, next to the fp32-MFMA kernel's own error on the same inputs (operands with
+    a wide dynamic range, so the low pieces matter)."""
+    coords, _ = scene_coords(41, 3000, small=False)
+    rng = np.random.default_rng(9)
+    n = len(coords)
+    x = (rng.normal(0, 1, (n, 96)) * np.exp(rng.normal(0, 2, (n, 96)))).astype(np.float32)
+    w = (rng.normal(0, 1, (27, 96, 128)) * np.exp(rng.normal(0, 1.5, (27, 96, 128))) / 50).astype(np.float32)
+    onbr = so.kernel_map(coords, coords, 3, 1, 1)
+    ref = np.zeros((n, 128), np.float64)
+    mag = np.zeros((n, 128), np.float64)
+    for j in range(27):
+        sel = np.nonzero(onbr[:, j] >= 0)[0]
+        ref[sel] += x[onbr[sel, j]].astype(np.float64) @ w[j].astype(np.float64)
+        mag[sel] += np.abs(x[onbr[sel, j]]).astype(np.float64) @ np.abs(w[j]).astype(np.float64)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(cuda, torch.int32))
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    errs = {}
+    saved = ME.CONV_X6
+    try:
+        for mode in (True, False):
+            ME.CONV_X6 = mode
+            got = ME.conv_forward(t(x), t(w), cm.kernel_map(3, 1), n, flavour=1).cpu().numpy().astype(np.float64)
+            errs[mode] = float((np.abs(got - ref) / (mag + 1e-30)).max())     # error relative to sum |x||w|
+    finally:
+        ME.CONV_X6 = saved
+    assert errs[False] < 2e-6 and errs[True] < 2e-6, errs                    # both at fp32 accumulation level
+    assert errs[True] < 4 * errs[False] + 1e-7, errs
