@@ -356,10 +356,15 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {
 // rot / scale quotients lose digits; the reference's own fp32 atomics lose ~1e-7 relative per add everywhere).
 constexpr double FX_SCALE = 68719476736.0;            // 2^36
 constexpr double FX_MAGIC = 6755399441055744.0;       // 1.5 * 2^52: (x*2^36 + MAGIC) has round(x*2^36) in its low bits
+template <bool SMALL>
 __device__ __forceinline__ void lds_add(unsigned long long* p, float v) {
-    const double d = __builtin_fma((double)v, FX_SCALE, FX_MAGIC);
-    const unsigned long long q = (unsigned long long)__double_as_longlong(d) -
-                                 (unsigned long long)__double_as_longlong(FX_MAGIC);
+    unsigned long long q;
+    if (SMALL) {                              // the magic-number conversion holds for |v * 2^36| < 2^51
+        const double d = __builtin_fma((double)v, FX_SCALE, FX_MAGIC);
+        q = (unsigned long long)__double_as_longlong(d) - (unsigned long long)__double_as_longlong(FX_MAGIC);
+    } else {                                  // huge contributions (a diverged scale head): exact up to 6e7, clamped beyond
+        q = (unsigned long long)__double2ll_rn((double)fminf(fmaxf(v, -6.0e7f), 6.0e7f) * FX_SCALE);
+    }
     __hip_atomic_fetch_add(p, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ double fx_value(unsigned long long q) { return (double)(long long)q * (1.0 / FX_SCALE); }
@@ -384,15 +389,9 @@ struct TileShared {
     int next_chunk[2];         // dynamic hand-out of 64-record chunks of the two y-bins to the waves
 };
 
-__device__ __forceinline__ void drain64(TileShared& sh, int wave, int slot, bool active) {
-    if (!active) return;
-    const uint32_t rec = sh.vq_rec[wave][slot];
-    const float rx = sh.vq_rx[wave][slot], rz = sh.vq_rz[wave][slot];
-    const int e = rec & 63, rot = (rec >> 6) & 255;
-    const int lx = (int)((rec >> 14) & 63) - 1, lz = (int)((rec >> 20) & 63) - 1;
-    const float wy = sh.pq[wave][4][e], ob = sh.pq[wave][5][e];
-    const float s0 = sh.pq[wave][6][e], s1 = sh.pq[wave][7][e], s2 = sh.pq[wave][8][e];
-    const float2 cs = sh.tab[rot];
+template <bool SMALL>
+__device__ __forceinline__ void drain_vote(TileShared& sh, int lx, int lz, float rx, float rz, float wy, float ob,
+                                           float s0, float s1, float s2, float2 cs) {
     const float wx[2] = {1.f - rx, rx}, wz[2] = {1.f - rz, rz};
 #pragma unroll
     for (int bx = 0; bx < 2; ++bx)
@@ -404,12 +403,35 @@ __device__ __forceinline__ void drain64(TileShared& sh, int wave, int slot, bool
             const float w = wx[bx] * wy * wz[bz] * ob;
             const int cell = cxl * TZ + czl;
             lds_add_f64(&sh.acc[0][cell], w);
-            lds_add(&sh.acc[1][cell], w * cs.x);
-            lds_add(&sh.acc[2][cell], w * cs.y);
-            lds_add(&sh.acc[3][cell], w * s0);
-            lds_add(&sh.acc[4][cell], w * s1);
-            lds_add(&sh.acc[5][cell], w * s2);
+            lds_add<SMALL>(&sh.acc[1][cell], w * cs.x);
+            lds_add<SMALL>(&sh.acc[2][cell], w * cs.y);
+            lds_add<SMALL>(&sh.acc[3][cell], w * s0);
+            lds_add<SMALL>(&sh.acc[4][cell], w * s1);
+            lds_add<SMALL>(&sh.acc[5][cell], w * s2);
         }
+}
+
+__device__ __forceinline__ void drain64(TileShared& sh, int wave, int slot, bool active) {
+    float rx = 0.f, rz = 0.f, wy = 0.f, ob = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    float2 cs = make_float2(0.f, 0.f);
+    int lx = 0, lz = 0;
+    if (active) {
+        const uint32_t rec = sh.vq_rec[wave][slot];
+        rx = sh.vq_rx[wave][slot]; rz = sh.vq_rz[wave][slot];
+        const int e = rec & 63, rot = (rec >> 6) & 255;
+        lx = (int)((rec >> 14) & 63) - 1; lz = (int)((rec >> 20) & 63) - 1;
+        wy = sh.pq[wave][4][e]; ob = sh.pq[wave][5][e];
+        s0 = sh.pq[wave][6][e]; s1 = sh.pq[wave][7][e]; s2 = sh.pq[wave][8][e];
+        cs = sh.tab[rot];
+    }
+    // every contribution of a vote is bounded by |obj| * max(1, |scale|) (the trilinear weights are <= 1); the
+    // wave takes the fast fixed-point conversion unless one of its 64 votes could exceed its range
+    const bool small = fabsf(ob) * fmaxf(1.f, fmaxf(fabsf(s0), fmaxf(fabsf(s1), fabsf(s2)))) < 16384.f;
+    if (__all(small)) {
+        if (active) drain_vote<true>(sh, lx, lz, rx, rz, wy, ob, s0, s1, s2, cs);
+    } else {
+        if (active) drain_vote<false>(sh, lx, lz, rx, rz, wy, ob, s0, s1, s2, cs);
+    }
 }
 
 __device__ __forceinline__ void wave_sync_lds() {

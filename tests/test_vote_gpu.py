@@ -178,3 +178,20 @@ def test_full_size_80k_properties(cuda, built_lib, algo):
     hip2 = run_hip(cuda, sc.points, xyz, scale, (prob * 2).astype(np.float32), sc.res, 120, algo)
     np.testing.assert_allclose(hip2[0], 2 * hip[0], rtol=RTOL, atol=1e-4)
     np.testing.assert_allclose(hip2[0].sum(dtype=np.float64), 2 * ref[0].sum(dtype=np.float64), rtol=1e-5)
+
+
+def test_huge_scale_contributions_take_the_exact_slow_path(cuda, built_lib):
+    """the fixed-point accumulation converts contributions with a magic-number trick valid below 2^14; a diverged
+    scale head (exp of a large logit) must still give the oracle's sums"""
+    sc = make_scene(13, n_points=1500, res=0.06, room=(1.5, 0.9, 1.5), n_boxes=2, margin=0.5, box_scale=0.4)
+    xyz, scale, prob, _ = synth_predictions(sc)
+    scale = scale.copy()
+    scale[::7] *= 1.0e5                      # w * s up to ~1e5: above the fast-path bound
+    xyz = (xyz * 1e-5 * (scale > 1e3) + xyz * (scale <= 1e3)).astype(np.float32)   # keep those votes in bounds
+    ref = oracle.hv_forward(sc.points, xyz, scale, prob, sc.res, 24)
+    hip = run_hip(cuda, sc.points, xyz, scale, prob, sc.res, 24, 2)
+    assert np.array_equal(hip[0] == 0, ref[0] == 0)
+    np.testing.assert_allclose(hip[0], ref[0], rtol=1e-4, atol=1e-6 * max(1.0, float(np.abs(ref[0]).max())))
+    live = ref[0] > 1e-3 * max(1.0, float(np.abs(ref[0]).max()))
+    np.testing.assert_allclose(hip[2][live], ref[2][live], rtol=1e-4, atol=1e-4)
+    assert float(np.abs(ref[2]).max()) > 2e4                    # the slow path was exercised
