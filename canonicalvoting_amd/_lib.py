@@ -37,7 +37,8 @@ class ConvDesc(ctypes.Structure):
                 ("flavour", ctypes.c_int), ("ws", vp), ("ws_bytes", ctypes.c_size_t), ("row_perm", vp),
                 ("j_begin", ctypes.c_int), ("j_end", ctypes.c_int), ("acc_in", vp), ("acc_ld", ctypes.c_int),
                 ("perm_groups", ctypes.c_int), ("plan_ent", vp), ("plan_cnt", vp),
-                ("weight_packed", vp), ("weight_x6", vp), ("perm_has_map", ctypes.c_int)]
+                ("weight_packed", vp), ("weight_x6", vp), ("in2", vp), ("in2_ld", ctypes.c_int), ("cin2", ctypes.c_int),
+                ("weight2_x6", vp), ("perm_has_map", ctypes.c_int)]
 
 
 class SceneMaps(ctypes.Structure):
@@ -58,7 +59,8 @@ class NetOp(ctypes.Structure):
                 ("out_buf", ctypes.c_int), ("out_col", ctypes.c_int), ("cout", ctypes.c_int),
                 ("res_buf", ctypes.c_int), ("res_col", ctypes.c_int), ("map", ctypes.c_int), ("K", ctypes.c_int),
                 ("perm", ctypes.c_int), ("perm_groups", ctypes.c_int), ("relu", ctypes.c_int),
-                ("weight", vp), ("scale", vp), ("shift", vp), ("weight_x6", vp)]
+                ("weight", vp), ("scale", vp), ("shift", vp), ("weight_x6", vp), ("in2_buf", ctypes.c_int),
+                ("in2_col", ctypes.c_int), ("cin2", ctypes.c_int), ("weight2_x6", vp)]
 
 
 # symbol -> (restype, argtypes); tests check every symbol of include/cv_hip.h is here and exported
@@ -95,7 +97,7 @@ SIGNATURES = {
     "cv_sp_conv_f32": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp]),
     "cv_sp_tile_plan_ints": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
     "cv_sp_tile_plan": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, vp, vp, vp]),
-    "cv_sp_pack_weights_x6_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "cv_sp_pack_weights_x6_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     "cv_sp_tile_kw": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "cv_sp_pack_weights_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_scene_maps_words": (ctypes.c_size_t, [c_i64_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,

@@ -128,6 +128,13 @@ int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int 
         d.cin = o.cin;
         d.weight = o.weight;
         d.weight_x6 = o.weight_x6;
+        if (o.in2_buf >= 0) {
+            CV_REQUIRE(o.in2_buf < n_bufs, CV_EINVAL, "op %d: bad second-source slot", k);
+            d.in2 = reinterpret_cast<const float*>(slot[o.in2_buf].ptr) + o.in2_col;
+            d.in2_ld = slot[o.in2_buf].ld;
+            d.cin2 = o.cin2;
+            d.weight2_x6 = o.weight2_x6;
+        }
         d.K = o.K;
         d.cout = o.cout;
         d.nbr = o.map >= 0 ? maps[o.map] : nullptr;

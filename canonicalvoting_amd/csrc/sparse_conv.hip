@@ -59,6 +59,9 @@ struct ConvArgs {
     int nbr_perm_w;
     int dbg;               // instrumented twin only (CV_CONV_DBG): 1 no MFMA, 2 no gathers, 4 no weight loads, 8 no epilogue
     const unsigned short* wp6;   // weights split into bf16 pieces, see pack_weights_x6 (conv_rows_x6)
+    const float* in2;            // conv_rows_x6: second source on the output rows (out += in2 @ W2), or NULL
+    int in2_ld, cin2;
+    const unsigned short* wp6_2;
 };
 
 __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& acc, const int* rows,
@@ -335,6 +338,7 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
 
 // wp6 layout (unsigned short): ((((j*nch + c)*3 + plane)*cout + col)*32 + k) for channel c*32 + k of offset j
 __global__ __launch_bounds__(256) void pack_weights_x6(const float* __restrict__ w, int K, int cin, int cout,
+                                                       const float* __restrict__ col_scale,
                                                        unsigned short* __restrict__ wp) {
     const long long total = (long long)K * cin * cout / 2;                   // pairs of consecutive k
     const int nch = cin / 32;
@@ -346,7 +350,8 @@ __global__ __launch_bounds__(256) void pack_weights_x6(const float* __restrict__
         const int j = (int)r;
         const float* p = w + ((long long)j * cin + c * 32 + 2 * k2) * cout + col;
         unsigned h, m, l;
-        split3(p[0], p[cout], h, m, l);
+        const float sc = col_scale ? col_scale[col] : 1.f;
+        split3(p[0] * sc, p[cout] * sc, h, m, l);
         const long long base = ((long long)(j * nch + c) * 3 * cout + col) * 32 + 2 * k2;
         *reinterpret_cast<unsigned*>(wp + base) = h;
         *reinterpret_cast<unsigned*>(wp + base + (long long)cout * 32) = m;
@@ -426,6 +431,46 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
         u_lo = (int)((long long)nj * nch * blockIdx.z / a.splits);
         u_hi = (int)((long long)nj * nch * (blockIdx.z + 1) / a.splits);
     }
+    float4 ra[4];
+    uint4 rb[B_PER];
+    auto load_b = [&](const unsigned short* slab) {
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int f = tid + i * THREADS;
+            if (f < B_U4) {
+                const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
+                const int col = rem >> 2, ch = rem & 3;
+                rb[i] = (n0 + col < a.cout && !(a.dbg & 4))
+                            ? *reinterpret_cast<const uint4*>(slab + ((long long)p * a.cout + n0 + col) * 32 + ch * 8)
+                            : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = a_row + 32 * i;
+                unsigned h0 = 0, m0 = 0, l0 = 0, h1 = 0, m1 = 0, l1 = 0;
+                if (!(a.dbg & 16)) {
+                    split3(ra[i].x, ra[i].y, h0, m0, l0);
+                    split3(ra[i].z, ra[i].w, h1, m1, l1);
+                }
+                // channels a_col .. a_col+3 -> 8 bytes at offset (a_col & 7) * 2 of chunk a_col >> 3
+                unsigned char* dst = A_h + r * 64 + ((((a_col >> 3) ^ ((r >> 2) & 3))) << 4) + ((a_col & 7) << 1);
+                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(dst + TM * 64) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2*>(dst + 2 * TM * 64) = make_uint2(l0, l1);
+            }
+#pragma unroll
+            for (int i = 0; i < B_PER; ++i) {
+                const int f = tid + i * THREADS;
+                if (f < B_U4) {
+                    const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
+                    const int col = rem >> 2, ch = rem & 3;
+                    *reinterpret_cast<uint4*>(B_h + (p * NB * 32 + col) * 64 + ((ch ^ ((col >> 2) & 3)) << 4)) = rb[i];
+                }
+            }
+    };
     const int j_first = a.j_begin + u_lo / nch, j_last = a.j_begin + (u_hi - 1) / nch;
     // kernel-map entry of tile row t for offset j
     auto map_entry = [&](int t, int j) {
@@ -460,8 +505,6 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
         }
         if (!__syncthreads_or(my >= 0)) continue;    // nobody in the tile has this neighbour
         const bool wave_live = __any(nbr_s[wave * 32 + l31] >= 0);
-        float4 ra[4];
-        uint4 rb[B_PER];
         auto load = [&](int kc) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -470,43 +513,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             // packed slab of (j, chunk): [plane][cout][32 k] bf16; this workgroup's columns n0 .. n0 + NB*32
-            const unsigned short* slab = a.wp6 + (long long)(j * nch + kc / KC) * 3 * a.cout * 32;
-#pragma unroll
-            for (int i = 0; i < B_PER; ++i) {
-                const int f = tid + i * THREADS;
-                if (f < B_U4) {
-                    const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
-                    const int col = rem >> 2, ch = rem & 3;
-                    rb[i] = (n0 + col < a.cout && !(a.dbg & 4))
-                                ? *reinterpret_cast<const uint4*>(slab + ((long long)p * a.cout + n0 + col) * 32 + ch * 8)
-                                : make_uint4(0u, 0u, 0u, 0u);
-                }
-            }
-        };
-        auto stage = [&]() {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = a_row + 32 * i;
-                unsigned h0 = 0, m0 = 0, l0 = 0, h1 = 0, m1 = 0, l1 = 0;
-                if (!(a.dbg & 16)) {
-                    split3(ra[i].x, ra[i].y, h0, m0, l0);
-                    split3(ra[i].z, ra[i].w, h1, m1, l1);
-                }
-                // channels a_col .. a_col+3 -> 8 bytes at offset (a_col & 7) * 2 of chunk a_col >> 3
-                unsigned char* dst = A_h + r * 64 + ((((a_col >> 3) ^ ((r >> 2) & 3))) << 4) + ((a_col & 7) << 1);
-                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(dst + TM * 64) = make_uint2(m0, m1);
-                *reinterpret_cast<uint2*>(dst + 2 * TM * 64) = make_uint2(l0, l1);
-            }
-#pragma unroll
-            for (int i = 0; i < B_PER; ++i) {
-                const int f = tid + i * THREADS;
-                if (f < B_U4) {
-                    const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
-                    const int col = rem >> 2, ch = rem & 3;
-                    *reinterpret_cast<uint4*>(B_h + (p * NB * 32 + col) * 64 + ((ch ^ ((col >> 2) & 3)) << 4)) = rb[i];
-                }
-            }
+            load_b(a.wp6 + (long long)(j * nch + kc / KC) * 3 * a.cout * 32);
         };
         load(kc_begin);
         for (int kc = kc_begin; kc < kc_end; kc += KC) {
@@ -515,6 +522,33 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
             __syncthreads();
             if (kc + KC < kc_end) load(kc + KC);  // in flight while the matrix cores run
             if (wave_live && !(a.dbg & 1)) compute();
+        }
+        __syncthreads();
+    }
+    // second source (BasicBlock's 1x1 downsample branch folded into conv2: out += in2 @ W2 on the same rows): its
+    // 32-channel chunks are dealt round-robin to the offset splits / mask groups, whose partial sums add up anyway
+    if (a.in2) {
+        if (tid < TM) nbr_s[tid] = rows_s[tid];
+        __syncthreads();
+        const bool wave_live = __any(nbr_s[wave * 32 + l31] >= 0);
+        const int nch2 = a.cin2 / KC;
+        auto load2 = [&](int c2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int src = nbr_s[a_row + 32 * i];
+                ra[i] = src >= 0 ? *reinterpret_cast<const float4*>(a.in2 + (long long)src * a.in2_ld + c2 * KC + a_col)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            load_b(a.wp6_2 + (long long)c2 * 3 * a.cout * 32);
+        };
+        int c2 = blockIdx.z;
+        if (c2 < nch2) load2(c2);
+        for (; c2 < nch2; c2 += a.splits) {
+            __syncthreads();
+            stage();
+            __syncthreads();
+            if (c2 + a.splits < nch2) load2(c2 + a.splits);
+            if (wave_live) compute();
         }
         __syncthreads();
     }
@@ -1657,7 +1691,7 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
     dim3 grid((unsigned)((a.n_out + TM - 1) / TM), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)),
               (unsigned)a.splits);
     static const bool prof_on = getenv("CV_CONV_PROF") != nullptr;
-    if (vec && a.wp6 && !prof_on) {
+    if (vec && a.wp6 && (!prof_on || a.in2)) {
         conv_rows_x6<NB><<<grid, THREADS, 0, st>>>(a);
         CV_LAUNCH_CHECK();
         if (a.splits > 1) return launch_finish(a, st);
@@ -1806,7 +1840,9 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
                d->shift, d->residual, d->res_ld, d->relu, d->out, d->out_ld, 1, nullptr, d->row_perm, 0, jb, je,
                d->acc_in, d->acc_ld, d->plan_ent, d->plan_cnt,
                reinterpret_cast<const float4*>(d->weight_packed), 0, nullptr, 0, 0,
-               static_cast<const unsigned short*>(d->weight_x6)};
+               static_cast<const unsigned short*>(d->weight_x6), d->in2, d->in2_ld, d->cin2,
+               static_cast<const unsigned short*>(d->weight2_x6)};
+
     {
         static const int dbg = getenv("CV_CONV_DBG") ? atoi(getenv("CV_CONV_DBG")) : 0;
         a.dbg = dbg;
@@ -1820,6 +1856,12 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
     const bool vec = (d->cin % KC == 0) && (d->in_ld % 4 == 0) && (d->cout % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(d->in) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(d->weight) & 15) == 0);
+    if (d->in2) {
+        CV_REQUIRE(vec && d->weight_x6 && d->weight2_x6 && d->cin2 > 0 && d->cin2 % KC == 0 && d->in2_ld >= d->cin2 &&
+                       d->in2_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->in2) & 15) == 0 && d->flavour != 4,
+                   CV_EINVAL, "a second source needs the bf16x6 vector path (weight_x6, weight2_x6, Cin2 %% 32 == 0, "
+                              "16-byte aligned rows)");
+    }
     if (!vec && d->cout == 32 && (d->cin == 3 || d->cin == 6) && d->nbr && !d->row_perm && d->perm_groups <= 1 &&
         d->flavour == 0 && (size_t)STEM_ROWS * (d->K | 1) * sizeof(int) <= 96 * 1024) {
         const unsigned grid = (unsigned)((d->n_out + STEM_ROWS - 1) / STEM_ROWS);
@@ -1862,7 +1904,7 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         CV_REQUIRE(false, CV_EINVAL, "flavour 4 needs Cin %% 32 == 0, Cout %% 32 == 0, K <= 27, 16-byte aligned "
                                      "operands, packed weights (cv_sp_pack_weights_f32) and a tile plan "
                                      "(cv_sp_tile_plan) for the kernel map");
-    } else if ((d->flavour == 0 || d->flavour == 4) && tile_ok(a, vec)) {
+    } else if ((d->flavour == 0 || d->flavour == 4) && !d->in2 && tile_ok(a, vec)) {
         const int sp = tile_splits(d->n_out, d->cout, je - jb);
         const size_t need = sizeof(float) * (size_t)sp * (size_t)d->n_out * (size_t)d->cout;
         if (sp > 1 && d->ws && d->ws_bytes >= need) {
@@ -1962,14 +2004,15 @@ int cv_sp_pack_weights_f32(const float* d_w, int K, int cin, int cout, float* d_
 
 // d_wp6[3*K*cin*cout] (16-bit words) = d_w[K][cin][cout] split into three bf16 pieces per value and laid out per
 // (offset, 32-channel chunk) as [piece][cout][32 channels] for conv_rows_x6 (cin % 32 == 0).  Redo when weights change.
-int cv_sp_pack_weights_x6_f32(const float* d_w, int K, int cin, int cout, void* d_wp6, void* stream) {
+int cv_sp_pack_weights_x6_f32(const float* d_w, int K, int cin, int cout, const float* d_col_scale, void* d_wp6,
+                              void* stream) {
     CV_REQUIRE(d_w && d_wp6 && K > 0 && cin > 0 && cout > 0, CV_EINVAL, "bad pack_weights_x6 arguments");
     CV_REQUIRE(cin % 32 == 0, CV_EINVAL, "pack_weights_x6 needs Cin %% 32 == 0 (got %d)", cin);
     CV_REQUIRE((reinterpret_cast<uintptr_t>(d_wp6) & 15) == 0, CV_EINVAL, "d_wp6 must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long long total = (long long)K * cin * cout / 2;
     pack_weights_x6<<<(unsigned)std::min<long long>((total + 255) / 256, 8192), 256, 0, st>>>(
-        d_w, K, cin, cout, static_cast<unsigned short*>(d_wp6));
+        d_w, K, cin, cout, d_col_scale, static_cast<unsigned short*>(d_wp6));
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

@@ -359,7 +359,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
                       ws.numel() if ws is not None else 0, p(row_perm), j_begin, j_end, p(acc_in),
                       acc_in.stride(0) if acc_in is not None else 0, perm_groups,
                       plan[0].data_ptr() if plan is not None else None,
-                      plan[0].data_ptr() + 4 * plan[1] if plan is not None else None, p(wp), p(wp6),
+                      plan[0].data_ptr() + 4 * plan[1] if plan is not None else None, p(wp), p(wp6), None, 0, 0, None,
                       1 if (perm_groups > 1 and getattr(row_perm, "_cv_has_map", False)) else 0)
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
@@ -416,6 +416,17 @@ def invalidate_weight_caches():
     _packed_x6.clear()
 
 
+def packed_weights_x6_scaled(w3, col_scale):
+    """uncached: weights times a per-output-column scale (a folded BatchNorm), split into bf16 pieces"""
+    L = _lib.lib()
+    K, cin, cout = w3.shape
+    wp = torch.empty(3 * w3.numel(), dtype=torch.int16, device=w3.device)
+    with torch.cuda.device(w3.device):
+        _lib.check(L.cv_sp_pack_weights_x6_f32(_ptr(w3), K, cin, cout, _ptr(col_scale), _ptr(wp), _stream(w3.device)),
+                   "cv_sp_pack_weights_x6_f32")
+    return wp
+
+
 def packed_weights_x6(weight, w3, cache=True):
     """weights split into bf16 pieces for conv_rows_x6 (cv_sp_pack_weights_x6_f32), cached per parameter tensor and
     re-packed when it is modified in place or re-allocated."""
@@ -430,7 +441,7 @@ def packed_weights_x6(weight, w3, cache=True):
         K, cin, cout = w3.shape
         wp = torch.empty(3 * w3.numel(), dtype=torch.int16, device=w3.device)
         with torch.cuda.device(w3.device):
-            _lib.check(L.cv_sp_pack_weights_x6_f32(_ptr(w3), K, cin, cout, _ptr(wp), _stream(w3.device)),
+            _lib.check(L.cv_sp_pack_weights_x6_f32(_ptr(w3), K, cin, cout, None, _ptr(wp), _stream(w3.device)),
                        "cv_sp_pack_weights_x6_f32")
         try:
             ref = weakref.ref(weight, lambda _r, k=key: _packed_x6.pop(k, None))

@@ -143,6 +143,8 @@ class MinkUNetBase(ResNetBase):
     # 80k points, no aliasing across levels) costs more Infinity-Cache misses with several scenes in flight than
     # the caching allocator's recycled temporaries (227 vs 244 scenes/s at 3 scenes in flight).
     USE_PROGRAM = os.environ.get("CV_NET_PROGRAM", "1") != "0"
+    # program mode: the 1x1 downsample conv of a block's first BasicBlock is folded into its conv2 (second source)
+    FUSE_DOWNSAMPLE = os.environ.get("CV_FUSE_DOWNSAMPLE", "1") != "0"
 
     def _conv3(self, x, kernel, nbr, perms, n, **ep):
         if perms is not None:
@@ -234,16 +236,30 @@ class MinkUNetBase(ResNetBase):
             if level >= 0:
                 free.setdefault((level, ch), []).append(slot)
 
-        def conv(src, dst, kernel, K, map_slot, scale=None, shift=None, res=None, relu=False, perm=-1, groups=0):
+        def conv(src, dst, kernel, K, map_slot, scale=None, shift=None, res=None, relu=False, perm=-1, groups=0,
+                 second=None):
+            """second = (src2, kernel2 [cin2, cout], scale2): out += scale2 * (src2 @ kernel2) on the output rows; the
+            BatchNorm scales are then folded into both packed weight sets and only `shift` remains in the epilogue"""
             w = (kernel if kernel.dim() == 3 else kernel[None]).detach().contiguous()
-            w6 = ME.packed_weights_x6(kernel, w) if (ME.CONV_X6 and w.shape[1] % 32 == 0 and w.shape[2] % 4 == 0) else None
-            keep.extend([w, scale, shift, w6])
+            in2 = (-1, 0)
+            cin2, w6_2 = 0, None
+            if second is not None:
+                src2, kernel2, scale2 = second
+                w2 = (kernel2 if kernel2.dim() == 3 else kernel2[None]).detach().contiguous()
+                w6 = ME.packed_weights_x6_scaled(w, scale)
+                w6_2 = ME.packed_weights_x6_scaled(w2, scale2)
+                in2, cin2, scale = src2, w2.shape[1], None
+            else:
+                w6 = ME.packed_weights_x6(kernel, w) if (ME.CONV_X6 and w.shape[1] % 32 == 0 and w.shape[2] % 4 == 0) else None
+            keep.extend([w, scale, shift, w6, w6_2])
             ops.append(dict(in_buf=src[0], in_col=src[1], cin=w.shape[1], out_buf=dst[0], out_col=dst[1],
                             cout=w.shape[2], res_buf=res[0] if res else -1, res_col=res[1] if res else 0,
                             map=map_slot, K=K, perm=perm, perm_groups=groups, relu=1 if relu else 0,
                             weight=w.data_ptr(), scale=scale.data_ptr() if scale is not None else None,
                             shift=shift.data_ptr() if shift is not None else None,
-                            weight_x6=w6.data_ptr() if w6 is not None else None))
+                            weight_x6=w6.data_ptr() if w6 is not None else None,
+                            in2_buf=in2[0], in2_col=in2[1], cin2=cin2,
+                            weight2_x6=w6_2.data_ptr() if w6_2 is not None else None))
 
         def layer(seq, x, level, out_view):
             """x, out_view: (slot, first column); returns the (slot, column) holding the layer's output"""
@@ -253,16 +269,27 @@ class MinkUNetBase(ResNetBase):
                 t = (alloc(level, planes), 0)
                 k3 = dict(K=27, map_slot=self.MAP_K3 + level, perm=self.PERM_K3 + level, groups=self.MASK_GROUPS)
                 conv(x, t, blk.conv1.kernel, scale=s1, shift=b1, relu=True, **k3)
-                if blk.downsample is not None:
-                    sd, bd = self._fold(blk.downsample[1])
-                    res = (alloc(level, planes), 0)
-                    conv(x, res, blk.downsample[0].kernel, 1, -1, scale=sd, shift=bd)
-                else:
-                    res = x
                 s2, b2 = self._fold(blk.norm2)
                 last = bi == len(seq) - 1
                 y = out_view if (last and out_view is not None) else (alloc(level, planes), 0)
-                conv(t, y, blk.conv2.kernel, scale=s2, shift=b2, res=res, relu=True, **k3)
+                fuse_ds = (blk.downsample is not None and self.FUSE_DOWNSAMPLE and ME.CONV_X6 and
+                           blk.conv1.in_channels % 32 == 0 and planes % 32 == 0)
+                if fuse_ds:
+                    # the 1x1 downsample branch rides in conv2 as a second source: one launch (and one split-K
+                    # reduction) less per block; BatchNorm scales folded into the packed weights, shifts added
+                    sd, bd = self._fold(blk.downsample[1])
+                    shift = (b2 + bd).contiguous()
+                    conv(t, y, blk.conv2.kernel, scale=s2, shift=shift, relu=True,
+                         second=(x, blk.downsample[0].kernel, sd), **k3)
+                    res = x
+                else:
+                    if blk.downsample is not None:
+                        sd, bd = self._fold(blk.downsample[1])
+                        res = (alloc(level, planes), 0)
+                        conv(x, res, blk.downsample[0].kernel, 1, -1, scale=sd, shift=bd)
+                    else:
+                        res = x
+                    conv(t, y, blk.conv2.kernel, scale=s2, shift=b2, res=res, relu=True, **k3)
                 release(t[0])
                 if res is not x:
                     release(res[0])

@@ -195,6 +195,9 @@ typedef struct cv_conv_desc {
     const void* weight_x6;  /* optional: the same weights from cv_sp_pack_weights_x6_f32.  When given (and Cin % 32 == 0)
                                the products run on the bf16 matrix cores as six bf16 x bf16 piece products per fp32
                                product (fp32-level accuracy, 0.375x the matrix time of v_mfma_f32_32x32x2_f32) */
+    const float* in2;       /* optional second source on the OUTPUT rows (bf16x6 path only): the accumulator also gets */
+    int in2_ld, cin2;       /* in2[u][0:cin2] @ W2 - BasicBlock's 1x1 downsample branch folded into conv2             */
+    const void* weight2_x6; /* cv_sp_pack_weights_x6_f32 of W2 [1][cin2][cout]                                         */
     int perm_has_map;       /* with perm_groups > 1: row_perm is followed by the kernel map rows in processing order
                                (cv_sp_mask_perms with_map = 1), which turns the random map reads into coalesced ones */
 } cv_conv_desc;
@@ -211,7 +214,9 @@ int cv_sp_tile_plan(const int32_t* d_nbr, long long n_out, int K, const int32_t*
 /* Weights of the bf16x6 path: [K][cin][cout] fp32 split into three bf16 pieces per value (h + m + l == value to half
  * an fp32 ulp), laid out per (offset, 32-channel chunk) as [piece][cout][32]: 3*K*cin*cout 16-bit words, 16-byte aligned;
  * cin % 32 == 0; redo whenever the weights change.  Asynchronous. */
-int cv_sp_pack_weights_x6_f32(const float* d_w, int K, int cin, int cout, void* d_wp6, void* stream);
+int cv_sp_pack_weights_x6_f32(const float* d_w, int K, int cin, int cout, const float* d_col_scale, void* d_wp6,
+                              void* stream);   /* d_col_scale[cout] (optional): weights are multiplied per output
+                                                  column before the split (a folded BatchNorm scale) */
 int cv_sp_tile_kw(int cin, int cout);
 int cv_sp_pack_weights_f32(const float* d_w, int K, int cin, int cout, float* d_wp, void* stream);
 
@@ -259,6 +264,8 @@ typedef struct cv_net_op {
     const float* scale;        /* [cout] or NULL */
     const float* shift;        /* [cout] or NULL */
     const void* weight_x6;     /* cv_sp_pack_weights_x6_f32 of weight, or NULL */
+    int in2_buf, in2_col, cin2;/* second source (in2_buf < 0: none), see cv_conv_desc.in2 */
+    const void* weight2_x6;
 } cv_net_op;
 size_t cv_net_arena_bytes(const cv_net_buf* bufs, int n_bufs, const long long* level_rows, int n_levels);
 int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int n_bufs, const long long* level_rows,

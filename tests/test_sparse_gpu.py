@@ -210,7 +210,18 @@ def test_minkunet34c_fused_and_modular_match_oracle(cuda, built_lib, n, small):
         fused = model(x).F.cpu().numpy()
         modular = model.modular_forward(x).F.cpu().numpy()
         program = model.program_forward(x).F.cpu().numpy()        # same launches through the C executor
-    assert np.array_equal(program, model.fused_forward(x).F.cpu().numpy())
+    # the C program folds the 1x1 downsample branches into conv2 (BatchNorm scales folded into the packed weights):
+    # same math, different rounding - equal to the Python-issued launches within fp32 noise, identical without the fusion
+    assert np.abs(program - fused).max() < 2e-5 * max(1.0, np.abs(fused).max())
+    saved = model.FUSE_DOWNSAMPLE
+    try:
+        type(model).FUSE_DOWNSAMPLE = False
+        model.__dict__.pop("_prog", None)
+        with torch.no_grad():
+            assert np.array_equal(model.program_forward(x).F.cpu().numpy(), model.fused_forward(x).F.cpu().numpy())
+    finally:
+        type(model).FUSE_DOWNSAMPLE = saved
+        model.__dict__.pop("_prog", None)
     ref = so.minkunet34c_forward(sd, coords, feats).numpy()
     assert fused.shape == ref.shape == (n, 64)
     # north_star: within 1e-4 on the LCC / scale floats (outputs are O(1))

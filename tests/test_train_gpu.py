@@ -266,7 +266,7 @@ def test_training_then_eval_uses_current_weights(cuda, built_lib):
         y_prog = model.program_forward(x).F
         y_fused = model.fused_forward(x).F
         y_mod = model.modular_forward(x).F
-    assert torch.equal(y_prog, y_fused)
+    assert float((y_prog - y_fused).abs().max()) < 2e-5 * max(1.0, float(y_fused.abs().max()))
     assert float((y_mod - y_fused).abs().max()) < 1e-4 * max(1.0, float(y_mod.abs().max()))
     # one more training step, then eval again: the eval caches must follow
     model.train()
