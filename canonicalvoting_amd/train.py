@@ -38,7 +38,9 @@ def joint_loss(out_feats, xyz_labels, scale_labels, class_labels, nclasses=9, lo
         tgt_scale = torch.log(scale_labels[mask]) if log_scale else scale_labels[mask]     # :266-269
         losses["loss_scale"] = torch.mean((out_scale[mask] - tgt_scale) ** 2 * w) * scale_factor
         losses["loss_xyz"] = torch.mean((out_xyz[mask] - xyz_labels[mask]) ** 2 * w) * xyz_factor
-    losses["loss_class"] = F.cross_entropy(out_class, labels.clamp(min=0))      # :273 (labels in 0..9)
+    # :273; the reference's labels are 0..9 (9 = background, utils/dataloader.py:172) - a negative label would make its
+    # CrossEntropyLoss raise, here it counts as background
+    losses["loss_class"] = F.cross_entropy(out_class, torch.where(labels < 0, torch.full_like(labels, nclasses), labels))
     return sum(losses.values()), losses
 
 

@@ -110,3 +110,35 @@ def test_detect_end_to_end_80k(cuda, built_lib):
     gt = sc.boxes[:, :3]
     for b in raw["boxes"]:
         assert np.min(np.linalg.norm(gt - b.mean(0)[None], axis=1)) < 0.15
+
+
+@pytest.mark.parametrize("name", ["decode_ref_8k", "decode_ref_5k"])
+def test_hip_path_matches_reference_lines_executed_on_cpu(cuda, built_lib, name):
+    """head split + vote + decode on the GPU against the golden vectors the reference's own lines produced
+    (eval_joint.py:173-190 and :195-263 exec()'d on CPU torch, tests/golden/make_decode_golden.py)"""
+    import os
+    from canonicalvoting_amd import pipeline
+    from tests.golden.make_decode_golden import make_case
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    sc, F = make_case(int(z["seed"]), int(z["n"]), 1.0)
+    res = float(z["res"])
+    xyz, scale, prob, cls = pipeline.head_joint(t(cuda, F))
+    assert np.array_equal(cls.cpu().numpy(), z["class_pred"].astype(np.int32))
+    np.testing.assert_array_equal(xyz.cpu().numpy(), z["xyz_pred"])
+    np.testing.assert_allclose(scale.cpu().numpy(), z["scale_pred"], rtol=2e-6)
+    np.testing.assert_allclose(prob.cpu().numpy(), z["prob_pred"], rtol=2e-6, atol=1e-7)
+    # vote + decode from the REFERENCE's head outputs (so a last-bit difference of expf cannot move a vote)
+    th, tl, vr, el = z["consts"]
+    pts = t(cuda, (sc.coords * np.float32(res)).astype(np.float32))
+    hv = HoughVoting(res, 120)
+    with torch.no_grad():
+        g = hv(pts, t(cuda, z["xyz_pred"]), t(cuda, z["scale_pred"]), t(cuda, z["prob_pred"]))
+    before = g[0].cpu().numpy().copy()
+    raw = decode.decode_boxes(g[0], g[1], g[2], pts, t(cuda, z["xyz_pred"]), t(cuda, z["prob_pred"]),
+                              t(cuda, z["class_pred"].astype(np.int32)), res, thresh_high=float(th), thresh_low=float(tl),
+                              valid_ratio=float(vr), elimination=int(el), mutate_grid=True)
+    assert len(raw["boxes"]) == len(z["boxes"]) and list(raw["classes"]) == list(z["classes"])
+    np.testing.assert_allclose(raw["boxes"], z["boxes"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(raw["scores"], z["scores"], rtol=1e-6)
+    zeroed = np.flatnonzero((before != 0) & (g[0].cpu().numpy() == 0))
+    assert np.array_equal(zeroed, z["zeroed"].astype(zeroed.dtype))

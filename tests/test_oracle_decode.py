@@ -1,6 +1,7 @@
 """Known-answer tests for the CPU decode oracle (oracle/decode_oracle.c), the restatement of
 eval_joint.py:195-280 + utils/calc_map.py:6-21."""
 import numpy as np
+import pytest
 
 import oracle
 
@@ -113,3 +114,55 @@ def test_nms_order_and_suppression():
     assert oracle.nms(boxes[:0], scores[:0], 0.3) == []
     dets = oracle.nms_per_class(boxes, scores, np.array([2, 2, 0, 0]))
     assert [d[0] for d in dets] == [0, 2] and dets[0][2] == np.float32(0.7)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Pinned by the reference itself: tests/golden/decode_ref_*.npz hold what eval_joint.py:173-190 (head split) and
+# :195-263 (greedy decode loop) produced when those very lines were exec()'d on CPU torch tensors in the build
+# container (tests/golden/make_decode_golden.py).  The oracle has to reproduce them.
+@pytest.mark.parametrize("name", ["decode_ref_8k", "decode_ref_5k"])
+def test_oracle_matches_reference_lines_executed_on_cpu(name):
+    import os
+    import torch
+    from oracle import sparse_oracle as so
+    from tests.golden.make_decode_golden import make_case
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    sc, F = make_case(int(z["seed"]), int(z["n"]), 1.0)
+    res = float(z["res"])
+    # head split (eval_joint.py:173-190)
+    xyz, scale, prob, cls = [t.numpy() for t in so.head_joint_eval(torch.from_numpy(F))]
+    assert np.array_equal(cls, z["class_pred"].astype(cls.dtype))
+    np.testing.assert_array_equal(xyz, z["xyz_pred"])
+    np.testing.assert_allclose(scale, z["scale_pred"], rtol=1e-6)
+    np.testing.assert_allclose(prob, z["prob_pred"], rtol=1e-6, atol=1e-7)
+    # decode loop (eval_joint.py:195-263) on the oracle's vote grids of the REFERENCE's head outputs
+    pts = (sc.coords * np.float32(res)).astype(np.float32)
+    g = oracle.hv_forward(pts, z["xyz_pred"], z["scale_pred"], z["prob_pred"], res, 120)
+    corner, _, _ = oracle.grid_geometry(pts, res)
+    th, tl, vr, el = z["consts"]
+    d = oracle.decode(g[0], g[1], g[2], corner, res, pts, z["xyz_pred"], z["prob_pred"], z["class_pred"].astype(np.int32),
+                      oracle.DecodeParams.default(thresh_high=th, thresh_low=tl, valid_ratio=vr, elimination=int(el)))
+    assert len(d["boxes"]) == len(z["boxes"])
+    assert list(d["classes"]) == list(z["classes"])
+    np.testing.assert_allclose(d["boxes"], z["boxes"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(d["scores"], z["scores"], rtol=1e-6)
+    zeroed = np.flatnonzero((g[0] != 0) & (d["grid_obj_after"] == 0))
+    assert np.array_equal(zeroed, z["zeroed"].astype(zeroed.dtype))
+
+
+def test_joint_loss_matches_reference_lines_executed_on_cpu():
+    """train.joint_loss against train_joint.py:253-283 exec()'d on CPU torch (tests/golden/make_loss_golden.py):
+    the three terms, their sum and the gradient w.r.t. the network output"""
+    import os
+    import torch
+    from canonicalvoting_amd import train
+    from tests.golden.make_loss_golden import make_inputs
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_ref.npz"))
+    F, labels, xyz, scale = make_inputs(int(z["seed"]), int(z["n"]))
+    out = torch.from_numpy(F.copy()).requires_grad_(True)
+    loss, parts = train.joint_loss(out, torch.from_numpy(xyz), torch.from_numpy(scale), torch.from_numpy(labels))
+    loss.backward()
+    for k in ("loss_xyz", "loss_scale", "loss_class"):
+        assert abs(float(parts[k]) - float(z[k])) < 1e-6 * max(1.0, abs(float(z[k]))), k
+    assert abs(float(loss) - float(z["loss"])) < 1e-6 * max(1.0, abs(float(z["loss"])))
+    np.testing.assert_allclose(out.grad.numpy(), z["grad"], rtol=1e-5, atol=1e-8)
