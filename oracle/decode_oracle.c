@@ -14,9 +14,13 @@
  *                        convex-quad clipping in double)
  *   cv_oracle_nms     <- eval_joint.py:75-89, applied per class as :270-280
  *
- * PARITY STATUS: "parity unpinned" -- the reference loop is inline in main(),
- * needs hydra/MinkowskiEngine/hv_cuda/shapely to import and ships no tests.
- * Pinned by hand-built known-answer grids in tests/test_decode_oracle.py.
+ * PARITY STATUS: cv_oracle_decode is PINNED BY REFERENCE EXECUTION: the reference
+ * loop is inline in main() (not importable), so tests/golden/make_decode_golden.py
+ * slices eval_joint.py:195-263 out of the file and exec()s it on CPU torch in the
+ * build container; tests/test_oracle_decode.py checks this file against the
+ * resulting tests/golden/decode_ref_*.npz (box count, classes, zeroed cells exact;
+ * boxes <= 2e-6), next to the hand-built known-answer grids.  The IoU/NMS pair is
+ * pinned by tests/golden/map_golden.npz and analytic values (shapely is absent).
  *
  * fp32 conventions where torch-on-GPU leaves the rounding implementation
  * defined (all shared with the HIP decode so both agree bit for bit):

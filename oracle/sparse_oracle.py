@@ -9,7 +9,12 @@ that the reference network uses, and the reference's own topology:
                               change); BasicBlock is ME's (conv1,norm1,relu,conv2,norm2,+res,relu)
   head split (eval)        <- eval_joint.py:173-190
 
-PARITY STATUS: "parity unpinned".  MinkowskiEngine v0.5.3 (README.md:53) is an external
+PARITY STATUS: the COMPOSITION (layer order, widths, strides, concatenations, residual adds,
+BN/ReLU placement, parameter names and shapes) and the head split are PINNED BY REFERENCE
+EXECUTION: tests/golden/make_net_golden.py imports the reference's own MinkUNet34C class and
+runs its forward with the MinkowskiEngine names bound to the primitives below
+(tests/golden/net_ref.npz); make_decode_golden.py exec()s eval_joint.py:173-190 for the head.
+The PRIMITIVE ARITHMETIC is "parity unpinned": MinkowskiEngine v0.5.3 (README.md:53) is an external
 dependency that is neither vendored in the reference nor installed here, and the reference
 has no test at this boundary.  The [ME-ext] semantics below are the published algorithm
 (Choy et al., 4D Spatio-Temporal ConvNets, generalized sparse convolution):

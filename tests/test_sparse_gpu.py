@@ -426,3 +426,26 @@ def test_bf16x6_products_keep_fp32_accuracy(cuda, built_lib):
         ME.CONV_X6 = saved
     assert errs[False] < 2e-6 and errs[True] < 2e-6, errs                    # both at fp32 accumulation level
     assert errs[True] < 4 * errs[False] + 1e-7, errs
+
+
+def test_hip_network_matches_reference_class_executed_on_cpu(cuda, built_lib):
+    """tests/golden/net_ref.npz: the reference's own MinkUNet34C module tree and forward (utils/minkunet.py:36-180,
+    utils/resnet.py:118-154) executed on CPU over the oracle's primitive ops (tests/golden/make_net_golden.py).
+    The HIP network (C program, Python-issued fused launches, module-by-module) loads the same state dict and must
+    give the same per-point outputs within north_star's 1e-4, eval and training-mode BatchNorm."""
+    import json, os
+    from tests.golden.make_net_golden import make_inputs
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "net_ref.npz"))
+    coords, feats = make_inputs()
+    model = MinkUNet34C(3, 64)
+    assert [[k, list(v.shape)] for k, v in model.state_dict().items()] == json.loads(str(z["state_dict"]))
+    model.load_state_dict(so.make_state_dict(3, 64, seed=int(z["seed_w"])))
+    model = model.cuda().eval()
+    x = ME.SparseTensor(torch.from_numpy(feats), torch.from_numpy(coords).int(), device="cuda")
+    tol = 1e-4 * max(1.0, np.abs(z["out_eval"]).max())
+    with torch.no_grad():
+        for fwd in (model.program_forward, model.fused_forward, model.modular_forward):
+            assert np.abs(fwd(x).F.cpu().numpy() - z["out_eval"]).max() < tol
+        model.train()
+        y = model(x).F.cpu().numpy()
+    assert np.abs(y - z["out_train"]).max() < 1e-4 * max(1.0, np.abs(z["out_train"]).max())

@@ -153,3 +153,36 @@ def test_kernel_offset_order_conversion_is_the_axis_swap():
     finally:
         so.KERNEL_OFFSET_ORDER = old
     torch.testing.assert_close(y_x, y_z, rtol=1e-5, atol=1e-5)
+
+
+def _net_golden():
+    import json, os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "net_ref.npz"))
+    return z, json.loads(str(z["state_dict"])), json.loads(str(z["trace"]))
+
+
+def test_oracle_forward_matches_reference_class_executed_on_cpu():
+    """tests/golden/net_ref.npz is the output of the REFERENCE's MinkUNet34C.forward (utils/minkunet.py:122-180 as
+    it lies, module tree built by its own network_initialization/_make_layer) over the oracle's primitive ops: the
+    restated composition in sparse_oracle.minkunet34c_forward must reproduce it, eval and training-mode BatchNorm."""
+    from tests.golden.make_net_golden import make_inputs
+    z, names, trace = _net_golden()
+    coords, feats = make_inputs()
+    sd = so.make_state_dict(3, 64, seed=int(z["seed_w"]))
+    assert [[k, list(v.shape)] for k, v in sd.items()] == names          # same names, shapes AND registration order
+    np.testing.assert_allclose(so.minkunet34c_forward(sd, coords, feats).numpy(), z["out_eval"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(so.minkunet34c_forward(sd, coords, feats, training=True).numpy(), z["out_train"],
+                               rtol=0, atol=2e-6)
+    # what the reference's forward executed, counted from its own trace (SURVEY 8a A2: 63 convs, 62 BN)
+    kinds = [t.split()[0] for t in trace]
+    assert kinds.count("conv") == 59 and kinds.count("convtr") == 4 and kinds.count("bn") == 62
+    assert kinds.count("cat") == 4 and kinds.count("add") == 23
+    assert [t for t in trace if t.startswith("cat")] == ["cat 256+128", "cat 128+64", "cat 96+32", "cat 96+32"]
+
+
+def test_product_module_tree_has_the_reference_state_dict():
+    """names/shapes/order of canonicalvoting_amd.minkunet.MinkUNet34C().state_dict() == the reference module tree's"""
+    from canonicalvoting_amd.minkunet import MinkUNet34C
+    _, names, _ = _net_golden()
+    mine = [[k, list(v.shape)] for k, v in MinkUNet34C(3, 64).state_dict().items()]
+    assert mine == names
