@@ -17,7 +17,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from canonicalvoting_amd import calc_map, decode, pipeline  # noqa: E402
 from canonicalvoting_amd import me as ME  # noqa: E402
-from canonicalvoting_amd.data import SyntheticScanDataset, collate_fn  # noqa: E402
+from canonicalvoting_amd.data import (ScanNetXYZProbMultiDataset, SyntheticScanDataset, collate_fn,  # noqa: E402
+                                     load_config)
 from canonicalvoting_amd.hough import HoughVoting  # noqa: E402
 from canonicalvoting_amd.minkunet import MinkUNet34C  # noqa: E402
 from canonicalvoting_amd.synth import synth_predictions  # noqa: E402
@@ -39,12 +40,7 @@ def evaluate(model, dataset, res=0.03, teacher=False, nclasses=9, device="cuda")
             xyz, scale, prob, cls = [t(a) for a in synth_predictions(dataset.scene(index))]
         dets, _ = decode.detect(hv, coords[:, 1:], xyz, scale, prob, cls, res, nclasses)
         pred_map_cls[id_scan] = dets
-        gt = []
-        for line in dataset.gt_lines(index):                                 # eval_joint.py:285-301
-            v = line.split(" ")
-            tx, ty, tz, ry, sx, sy, sz = [float(x) for x in v[:7]]
-            gt.append((int(v[-1]), calc_map.gt_box(tx, ty, tz, ry, sx, sy, sz)))
-        gt_map_cls[id_scan] = gt
+        gt_map_cls[id_scan] = [(c, calc_map.gt_box(*p)) for c, p in dataset.gt(index)]     # eval_joint.py:285-301
     return {thr: calc_map.compute_map(pred_map_cls, gt_map_cls, thr) for thr in (0.25, 0.5)}
 
 
@@ -54,12 +50,17 @@ def main():
     ap.add_argument("--points", type=int, default=80000)
     ap.add_argument("--weights", default=None)
     ap.add_argument("--teacher", action="store_true")
+    ap.add_argument("--config", default=None, help="the reference's config.yaml: evaluate on real ScanNet/Scan2CAD files")
     a = ap.parse_args()
-    model = MinkUNet34C(3, 6 * 9 + 9 + 1)
+    cfg = load_config(a.config, category="all") if a.config else None
+    model = MinkUNet34C(6 if (cfg and cfg.use_xyz) else 3, 6 * 9 + 9 + 1)
     if a.weights:
         model.load_state_dict(torch.load(a.weights, map_location="cpu"))
     model = model.cuda().eval()
-    res = evaluate(model, SyntheticScanDataset(a.scenes, a.points, seed0=100), teacher=a.teacher)
+    if cfg:
+        res = evaluate(model, ScanNetXYZProbMultiDataset(cfg, training=False, augment=False), res=cfg.scannet_res)
+    else:
+        res = evaluate(model, SyntheticScanDataset(a.scenes, a.points, seed0=100), teacher=a.teacher)
     for thr, r in res.items():
         print("IoU %.2f: mAP %.4f  AR %.4f" % (thr, r["mAP"], r["AR"]))
 

@@ -15,7 +15,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from canonicalvoting_amd import dist as cvd  # noqa: E402
 from canonicalvoting_amd import train  # noqa: E402
-from canonicalvoting_amd.data import SyntheticScanDataset, collate_fn  # noqa: E402
+from canonicalvoting_amd.data import (ScanNetXYZProbMultiDataset, SyntheticScanDataset, collate_fn,  # noqa: E402
+                                     load_config)
 from canonicalvoting_amd.minkunet import MinkUNet34C  # noqa: E402
 
 
@@ -27,17 +28,26 @@ def main():
     ap.add_argument("--batch", type=int, default=3)
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--save", default=None)
+    ap.add_argument("--config", default=None, help="the reference's config.yaml: train on real ScanNet/Scan2CAD files")
     a = ap.parse_args()
+    cfg = load_config(a.config, category="all") if a.config else None
     world, rank, local = cvd.world()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cvd.init("nccl", dev)
     torch.manual_seed(0)
-    model = MinkUNet34C(3, 6 * 9 + 9 + 1).to(dev)
+    model = MinkUNet34C(6 if (cfg and cfg.use_xyz) else 3, 6 * 9 + 9 + 1).to(dev)
     net = train.make_ddp(model, dev) if world > 1 else model
     opt = train.make_optimizer(model, lr=a.lr)
-    ds = SyntheticScanDataset(a.scenes, a.points, seed0=1000 * rank)          # every rank owns its scenes
-    loader = torch.utils.data.DataLoader(ds, batch_size=a.batch, shuffle=True, collate_fn=collate_fn, drop_last=True)
+    if cfg:
+        # train_joint.py:205-211; every rank reads its own slice of the scans (DistributedSampler)
+        ds = ScanNetXYZProbMultiDataset(cfg, training=True, augment=cfg.augment)
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=True) if world > 1 else None
+        loader = torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, shuffle=sampler is None, sampler=sampler,
+                                             collate_fn=collate_fn, drop_last=True, num_workers=cfg.num_workers)
+    else:
+        ds = SyntheticScanDataset(a.scenes, a.points, seed0=1000 * rank)      # every rank owns its scenes
+        loader = torch.utils.data.DataLoader(ds, batch_size=a.batch, shuffle=True, collate_fn=collate_fn, drop_last=True)
     for epoch in range(a.epochs):
         train.adjust_learning_rate(opt, epoch, a.lr)
         net.train()

@@ -313,6 +313,33 @@ def test_eval_script_pipeline_recovers_planted_boxes(cuda, built_lib):
     assert res[0.5]["mAP"] > 0.5, res
 
 
+def test_real_file_dataset_through_eval_and_train_step(cuda, built_lib, tmp_path):
+    """ScanNet/Scan2CAD-format files (tests/golden/scannet_mini) -> reader -> collate -> eval loop and one training
+    step: the real data path reaches the HIP network with the shapes/dtypes the synthetic one has."""
+    import importlib.util
+    import os
+    from canonicalvoting_amd import data, train
+    from tests.golden.make_data_golden import mini_cfg
+    spec = importlib.util.spec_from_file_location(
+        "cv_eval_joint", os.path.join(os.path.dirname(os.path.dirname(__file__)), "scripts", "eval_joint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg = mini_cfg()
+    cfg.data.gt_path = str(tmp_path)
+    for sid in ("scene0000_00", "scene0001_00"):
+        (tmp_path / (sid + ".txt")).write_text("0.5 0.4 -1.0 0.3 0.4 0.5 0.6 03001627\n")
+    ds = data.ScanNetXYZProbMultiDataset(cfg, training=False, augment=False)
+    torch.manual_seed(0)
+    model = MinkUNet34C(3, 64).cuda().eval()
+    res = mod.evaluate(model, ds, res=cfg.scannet_res)
+    assert set(res) == {0.25, 0.5} and 0.0 <= res[0.25]["mAP"] <= 1.0
+    _, coords, feats, xyz, scale, cls = data.collate_fn([ds[0], ds[1]])
+    model.train()
+    opt = train.make_optimizer(model, lr=1e-3)
+    loss, _ = train.train_step(model, opt, coords.to(cuda), feats.to(cuda) * 2 - 1, xyz.to(cuda), scale.to(cuda), cls.to(cuda))
+    assert np.isfinite(float(loss))
+
+
 def test_scenes_in_flight_on_separate_streams_match_sequential(cuda, built_lib):
     """bench.py keeps several scenes in flight (one host thread + HIP stream each); per-scene results must be the
     ones of the one-at-a-time path, bit for bit (per-stream workspaces, no shared mutable state)."""
