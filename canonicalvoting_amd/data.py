@@ -266,3 +266,92 @@ class ScanNetXYZProbMultiDataset(torch.utils.data.Dataset):
                                         return_index=True)[1]
         coords = np.floor(points[keep] / self.cfg.scannet_res).astype(np.float32)
         return id_scan, coords, feats[keep], xyz[keep], scale[keep], cls[keep]
+
+
+def _roty4(angle):
+    c, s = np.cos(angle), np.sin(angle)
+    return np.array([[c, 0, -s, 0], [0, 1, 0, 0], [s, 0, c, 0], [0, 0, 0, 1]])
+
+
+# rotations about the up axis under which a CAD model looks the same (utils/dataloader.py:444-453)
+SYMMETRY_ANGLES = {"__SYM_ROTATE_UP_2": [np.pi], "__SYM_ROTATE_UP_4": [np.pi / 2, np.pi, -np.pi / 2],
+                   "__SYM_ROTATE_UP_INF": [2 * np.pi / 36 * i for i in range(1, 36)]}
+
+
+class ScanNetXYZProbSymDataset(ScanNetXYZProbMultiDataset):
+    """utils/dataloader.py:339-476, the dataset of train_separate.py: same files, but the scan is quantised FIRST and
+    the object labels are kept per aligned model as ``[rows of the model's points, [their LCC coordinates under each
+    symmetry-equivalent pose]]`` so the loss can take the best pose; item = (id_scan, coords, feats, xyz_labels,
+    scale_labels, obj_labels (0/1), class_labels (0 = background or 'others'))."""
+
+    def __getitem__(self, index):
+        import os
+        ann = self.annotations[index]
+        id_scan = ann["id_scan"]
+        if not np.all(np.abs(np.asarray(ann["trs"]["scale"]) - 1.0) < 1e-7):
+            raise ValueError("%s: scan transform has a non-unit scale" % id_scan)
+        path = os.path.join(self.cfg.data.scannet, "scans", id_scan, id_scan + "_vh_clean_2.ply")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path + " does not exist.")
+        v = read_ply_vertices(path)
+        rgb = np.stack([v["red"], v["green"], v["blue"]], -1)               # stays uint8 until after quantisation (:383)
+        to_world = trs_matrix(ann["trs"]["translation"], ann["trs"]["rotation"], ann["trs"]["scale"])
+        points = transform_points(np.stack([v["x"], v["y"], v["z"]], -1), to_world)
+        for model, seg in zip(ann["aligned_models"], self.segments[id_scan]):
+            model["segments"] = seg
+        models = self._select(ann["aligned_models"])
+        if not models:
+            return self[np.random.randint(len(self))]
+        aug = np.eye(4)
+        if self.augment:
+            if self.cfg.augment_color:                                   # :400-404 (on the raw 0..255 colours)
+                rgb = rgb.astype(np.float64)
+                rgb *= (1 + 0.4 * np.random.random(3) - 0.2)
+                rgb += (0.1 * np.random.random(3) - 0.05)
+                rgb += (0.05 * np.random.random(points.shape[0]) - 0.025)[:, None]
+                rgb = np.clip(rgb, 0, 1)
+            angle = np.random.randint(4) * np.pi / 2.0 + (np.random.random() - 0.5) * 2.0 * np.pi / 9.0
+            c, s = np.cos(angle), np.sin(angle)
+            Ry = np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]])
+            points = points @ Ry.T
+            aug[:3, :3] = Ry
+        points = points.astype(np.float32)
+        keep = me_utils.sparse_quantize(np.ascontiguousarray(points), quantization_size=self.cfg.scannet_res,
+                                        return_index=True)[1]
+        points = points[keep]
+        rgb = (rgb[keep] / 255.0).astype(np.float32)
+        new_row = np.full(v.shape[0], -1, np.int64)
+        new_row[keep] = np.arange(len(keep))
+        coords = np.floor(points / self.cfg.scannet_res).astype(np.float32)
+        n = points.shape[0]
+        scale = np.zeros((n, 3), np.float32)
+        obj = np.zeros(n, np.int32)
+        cls = np.zeros(n, np.int32)
+        xyz_labels = []
+        for m in models:
+            s32 = np.asarray(m["trs"]["scale"], np.float32)
+            if s32.min() < 1e-3:
+                continue
+            M = bbox_matrix(m)
+            poses = [M] + [M @ _roty4(a) for a in SYMMETRY_ANGLES.get(m["sym"], [])]
+            rows = new_row[np.asarray(m["segments"], np.int64)]
+            rows = rows[rows >= 0]                                       # the model's points that survived quantisation
+            pts = points[rows]
+            xyzs = [transform_points(pts, np.linalg.inv(aug @ P)) for P in poses]
+            scale[rows] = s32 * np.asarray(m["bbox"], np.float32)
+            obj[rows] = 1
+            cls[rows] = self.class_index(m["catid_cad"])
+            xyz_labels.append([rows, xyzs])
+        feats = np.concatenate([points, rgb], -1) if self.cfg.use_xyz else rgb
+        return id_scan, coords, feats, xyz_labels, scale, obj, cls
+
+
+def collate_fn_separate(batch):
+    """train_separate.py:78-97: like collate_fn, the per-model label lists stay per scan"""
+    id_scans, coords, feats, xyz_labels, scale_labels, obj_labels, class_labels = list(zip(*batch))
+    xyz_batch = [[[torch.from_numpy(np.asarray(rows)).long(), [torch.from_numpy(x).float() for x in xyzs]]
+                  for rows, xyzs in per_scan] for per_scan in xyz_labels]
+    return (id_scans, me_utils.batched_coordinates(coords), torch.from_numpy(np.concatenate(feats, 0)).float(), xyz_batch,
+            torch.from_numpy(np.concatenate(scale_labels, 0)).float(),
+            torch.from_numpy(np.concatenate(obj_labels, 0)).long(),
+            torch.from_numpy(np.concatenate(class_labels, 0)).long())

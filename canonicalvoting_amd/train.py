@@ -2,6 +2,8 @@
 
     joint_loss          head gather by ground-truth class + masked MSE(xyz) + MSE(log scale) + CE(class)
                         (train_joint.py:253-283; defaults from config/config.yaml)
+    separate_loss       the per-category model's loss with the minimum over symmetry-equivalent poses
+                        (train_separate.py:247-287)
     train_step          zero_grad -> forward -> loss -> backward -> optimizer.step (:246-288)
     adjust_learning_rate step LR decay (:128-138, config.yaml:32-36)
     make_ddp            scene-parallel data parallelism: torch DDP (bucketed gradient all-reduce over
@@ -44,12 +46,57 @@ def joint_loss(out_feats, xyz_labels, scale_labels, class_labels, nclasses=9, lo
     return sum(losses.values()), losses
 
 
+def separate_loss(out_feats, xyz_labels, scale_labels, obj_labels, coords4=None, log_scale=True, xyz_factor=1.0,
+                  scale_factor=1.0, xyz_component_weights=(1.0, 1.0, 1.0), reference_indexing=True):
+    """Loss of the per-category model (train_separate.py:247-287): out_feats [N, 8] = xyz, (log) scale, 2 objectness
+    logits; ``xyz_labels`` per scan a list of [rows, [xyz under each symmetry-equivalent pose]]
+    (data.collate_fn_separate); the coordinate loss of a model is the MINIMUM over its poses (:271-275), averaged
+    over models.  ``reference_indexing``: the reference indexes the BATCH output with each scan's own row numbers
+    (:270, `batch_idx` is computed and never used), which is only right for the first scan of a batch; True keeps
+    that, False offsets the rows of scan j by the rows of scans < j (needs ``coords4``)."""
+    obj = obj_labels.long()
+    mask = obj == 1
+    w = torch.as_tensor(xyz_component_weights, dtype=out_feats.dtype, device=out_feats.device)
+    losses = {"loss_obj": F.cross_entropy(out_feats[:, 6:8], obj)}
+    tgt = torch.log(scale_labels[mask]) if log_scale else scale_labels[mask]
+    losses["loss_scale"] = torch.mean((out_feats[:, 3:6][mask] - tgt) ** 2 * w) * scale_factor
+    out_xyz = out_feats[:, :3]
+    first_row = None
+    if not reference_indexing:
+        counts = torch.bincount(coords4[:, 0].long(), minlength=len(xyz_labels))
+        first_row = torch.cumsum(counts, 0) - counts
+    per_model = []
+    for j, per_scan in enumerate(xyz_labels):
+        for rows, xyzs in per_scan:
+            rows = rows.to(out_feats.device)
+            if first_row is not None:
+                rows = rows + first_row[j]
+            pred = out_xyz[rows]
+            per_model.append(torch.stack([torch.mean((pred - x.to(out_feats.device)) ** 2 * w) for x in xyzs]).min())
+    losses["loss_xyz"] = torch.mean(torch.stack(per_model)) * xyz_factor
+    return sum(losses.values()), losses
+
+
 def train_step(model, optimizer, coords4, feats, xyz_labels, scale_labels, class_labels, **loss_kw):
     """one iteration of train_joint.py:246-288; feats already recentred (:248-249)."""
     optimizer.zero_grad(set_to_none=True)
     x = ME.SparseTensor(feats, coords4, device=feats.device)
     out = model(x)
     loss, parts = joint_loss(out.F, xyz_labels, scale_labels, class_labels, **loss_kw)
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), {k: v.detach() for k, v in parts.items()}
+
+
+def train_step_separate(model, optimizer, coords4, feats, xyz_labels, scale_labels, obj_labels, **loss_kw):
+    """one iteration of train_separate.py:236-292 (8-channel per-category model); feats already recentred (:241-242).
+    Returns None for a batch without object points, which the reference skips (:238-240)."""
+    if not bool((obj_labels == 1).any()):
+        return None
+    optimizer.zero_grad(set_to_none=True)
+    out = model(ME.SparseTensor(feats, coords4, device=feats.device))
+    dev = feats.device
+    loss, parts = separate_loss(out.F, xyz_labels, scale_labels.to(dev), obj_labels.to(dev), coords4=coords4, **loss_kw)
     loss.backward()
     optimizer.step()
     return loss.detach(), {k: v.detach() for k, v in parts.items()}

@@ -1,5 +1,5 @@
 """Golden vectors for the data contract, produced by running the reference's own
-``ScanNetXYZProbMultiDataset`` (utils/dataloader.py:89-210, imported as it lies) over a miniature dataset written here
+``ScanNetXYZProbMultiDataset`` / ``ScanNetXYZProbSymDataset`` (utils/dataloader.py:89-210, :339-476, imported as they lie) over a miniature dataset written here
 in the real on-disk formats: ScanNet ``scans/<id>/<id>_vh_clean_2.ply`` (binary little-endian, float xyz + uchar rgba
 vertices, a face list after them), Scan2CAD ``full_annotations.json`` (scan trs + aligned models with trs / bbox /
 center / catid_cad / sym), the per-model vertex-index ``segments`` pickle and the split text files.
@@ -170,7 +170,7 @@ if __name__ == "__main__":
     sys.modules.update(standins())
     sys.path.insert(0, "/root/reference")
     try:
-        from utils.dataloader import ScanNetXYZProbMultiDataset          # the reference's class, as it lies
+        from utils.dataloader import ScanNetXYZProbMultiDataset, ScanNetXYZProbSymDataset   # the reference's classes, as they lie
         out = {}
 
         def put(tag, item):
@@ -194,6 +194,21 @@ if __name__ == "__main__":
             out["scans_" + cat] = np.array([a["id_scan"] for a in ds.annotations])
             if cat in ("others", "02871439"):
                 put("cat_" + cat, ds[0])
+        # the symmetric dataset of train_separate.py (utils/dataloader.py:339-476)
+        def put_sym(tag, item):
+            out[tag + "_id"] = item[0]
+            for name, a in zip(("coords", "feats", "scale", "obj", "cls"), (item[1], item[2], item[4], item[5], item[6])):
+                out[tag + "_" + name] = a
+            out[tag + "_nmodels"] = len(item[3])
+            for mi, (rows, xyzs) in enumerate(item[3]):
+                out["%s_m%d_rows" % (tag, mi)] = np.asarray(rows)
+                out["%s_m%d_xyz" % (tag, mi)] = np.stack(xyzs).astype(np.float32)    # as collate_fn stores them
+
+        ds = ScanNetXYZProbSymDataset(mini_cfg(), training=False, augment=False)
+        put_sym("sym0", ds[0])
+        ds = ScanNetXYZProbSymDataset(mini_cfg(category="03001627"), training=False, augment=True)
+        np.random.seed(11)
+        put_sym("symaug1", ds[1])
         np.savez_compressed(os.path.join(HERE, "data_ref.npz"), **out)
         print({k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.endswith(("coords", "_id")) or k.startswith("scans")})
     finally:

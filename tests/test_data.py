@@ -151,3 +151,28 @@ def test_config_yaml_and_gt_files(tmp_path):
     syn = data.SyntheticScanDataset(n_scenes=1, n_points=1500, res=0.06, room=(1.5, 0.9, 1.5), n_boxes=2, margin=0.5,
                                     box_scale=0.4)
     assert [c for c, _ in syn.gt(0)] == [int(b[7]) for b in syn.scene(0).boxes]
+
+
+def check_sym(tag, item):
+    assert item[0] == str(GOLD[tag + "_id"])
+    for name, a in zip(("coords", "feats", "scale", "obj", "cls"), (item[1], item[2], item[4], item[5], item[6])):
+        g = GOLD[tag + "_" + name]
+        assert a.dtype == g.dtype and np.array_equal(a, g), (tag, name)
+    assert len(item[3]) == int(GOLD[tag + "_nmodels"])
+    for mi, (rows, xyzs) in enumerate(item[3]):
+        assert np.array_equal(rows, GOLD["%s_m%d_rows" % (tag, mi)])
+        assert np.array_equal(np.stack(xyzs).astype(np.float32), GOLD["%s_m%d_xyz" % (tag, mi)])
+
+
+def test_symmetric_dataset_matches_reference_class():
+    ds = data.ScanNetXYZProbSymDataset(mini_cfg(), training=False, augment=False)
+    item = ds[0]
+    check_sym("sym0", item)
+    # poses per model: none 1, UP_2 2, (unknown-category model) 1, [singular one skipped], UP_INF 36
+    assert [len(x) for _, x in item[3]] == [1, 2, 1, 36]
+    ds = data.ScanNetXYZProbSymDataset(mini_cfg(category="03001627"), training=False, augment=True)
+    np.random.seed(11)
+    check_sym("symaug1", ds[1])
+    batch = data.collate_fn_separate([item, item])
+    assert batch[1].shape[1] == 4 and len(batch[3]) == 2 and batch[3][0][1][1][0].dtype.is_floating_point
+    assert batch[5].dtype == batch[6].dtype and int(batch[5].max()) == 1

@@ -166,3 +166,34 @@ def test_joint_loss_matches_reference_lines_executed_on_cpu():
         assert abs(float(parts[k]) - float(z[k])) < 1e-6 * max(1.0, abs(float(z[k]))), k
     assert abs(float(loss) - float(z["loss"])) < 1e-6 * max(1.0, abs(float(z["loss"])))
     np.testing.assert_allclose(out.grad.numpy(), z["grad"], rtol=1e-5, atol=1e-8)
+
+
+def test_separate_loss_matches_reference_lines_executed_on_cpu():
+    """train.separate_loss against train_separate.py:247-286 exec()'d on CPU torch over a two-scan batch of the mini
+    dataset: objectness CE, log-scale MSE, minimum-over-symmetric-poses coordinate loss, sum, gradient.  The
+    reference indexes the batch output with per-scan row numbers (:271); reference_indexing=True reproduces that,
+    False is the repaired variant (differs as soon as the batch holds a second scan)."""
+    import os
+    import torch
+    from canonicalvoting_amd import train
+    from tests.golden.make_loss_golden import make_separate_inputs
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_ref.npz"))
+    batch, F = make_separate_inputs()
+    out = torch.from_numpy(F.copy()).requires_grad_(True)
+    loss, parts = train.separate_loss(out, batch[3], batch[4], batch[5])
+    loss.backward()
+    for k in ("loss_obj", "loss_xyz", "loss_scale"):
+        assert abs(float(parts[k]) - float(z["sep_" + k])) < 1e-6 * max(1.0, abs(float(z["sep_" + k]))), k
+    assert abs(float(loss) - float(z["sep_loss"])) < 1e-6
+    np.testing.assert_allclose(out.grad.numpy(), z["sep_grad"], rtol=1e-5, atol=1e-8)
+    fixed, parts2 = train.separate_loss(torch.from_numpy(F), batch[3], batch[4], batch[5], coords4=batch[1],
+                                        reference_indexing=False)
+    assert abs(float(parts2["loss_xyz"]) - float(parts["loss_xyz"])) > 1e-4
+    assert float(parts2["loss_scale"]) == float(parts["loss_scale"].detach())
+    # a single-scan batch: both indexings coincide
+    one = [batch[3][0]]
+    n0 = int((batch[1][:, 0] == 0).sum())
+    a, _ = train.separate_loss(torch.from_numpy(F[:n0]), one, batch[4][:n0], batch[5][:n0])
+    b, _ = train.separate_loss(torch.from_numpy(F[:n0]), one, batch[4][:n0], batch[5][:n0], coords4=batch[1][:n0],
+                               reference_indexing=False)
+    assert float(a) == float(b)

@@ -338,6 +338,16 @@ def test_real_file_dataset_through_eval_and_train_step(cuda, built_lib, tmp_path
     opt = train.make_optimizer(model, lr=1e-3)
     loss, _ = train.train_step(model, opt, coords.to(cuda), feats.to(cuda) * 2 - 1, xyz.to(cuda), scale.to(cuda), cls.to(cuda))
     assert np.isfinite(float(loss))
+    # the per-category model of train_separate.py on the symmetric dataset: the loss falls over a few steps
+    ds = data.ScanNetXYZProbSymDataset(mini_cfg(category="03001627"), training=False, augment=False)
+    _, coords, feats, xyz_l, scale_l, obj_l, _ = data.collate_fn_separate([ds[0], ds[1]])
+    torch.manual_seed(1)
+    sep = MinkUNet34C(3, 8).cuda().train()
+    opt = train.make_optimizer(sep, lr=1e-3)
+    hist = [float(train.train_step_separate(sep, opt, coords.to(cuda), feats.to(cuda) * 2 - 1, xyz_l, scale_l, obj_l)[0])
+            for _ in range(6)]
+    assert np.isfinite(hist).all() and hist[-1] < hist[0], hist
+    assert train.train_step_separate(sep, opt, coords.to(cuda), feats.to(cuda), xyz_l, scale_l, torch.zeros_like(obj_l)) is None
 
 
 def test_scenes_in_flight_on_separate_streams_match_sequential(cuda, built_lib):
