@@ -11,7 +11,7 @@ from .hough import HVFunction
 
 
 def unravel_index(index, shape):
-    """sunrgbd/brnetcanon.py:85-90"""
+    """sunrgbd/brnetcanon.py:86-91"""
     out = []
     for dim in reversed(shape):
         out.append(index % dim)

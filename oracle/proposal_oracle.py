@@ -1,7 +1,8 @@
 """CPU restatement of the reference's SUN RGB-D proposal sampler - TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 Follows sunrgbd/brnetcanon.py:114-162 line by line in numpy, given the vote grids and the sequence of multinomial
-draws (the only stochastic step, :137).  "Parity unpinned": the reference has no test or golden vector for it and
-its module cannot be imported here (mmdet3d / BRNet / cv2 / visdom are absent)."""
+draws (the only stochastic step, :137).  PINNED BY REFERENCE EXECUTION: the module cannot be imported here (mmdet3d /
+BRNet / cv2 / visdom are absent), so tests/golden/make_proposal_golden.py exec()s the class's own lines on CPU torch
+with the draws recorded; tests/test_oracle_vote.py checks this file against the result."""
 import numpy as np
 
 

@@ -184,3 +184,20 @@ def test_oracle_reproduces_golden(name):
     assert np.array_equal(dec["verdict"], z["dec_verdict"])
     assert np.array_equal(dec["boxes"], z["dec_boxes"])
     assert np.array_equal(dec["classes"], z["dec_classes"])
+
+
+def test_proposal_oracle_matches_reference_lines_executed_on_cpu():
+    """oracle/proposal_oracle.py against sunrgbd/brnetcanon.py:104-162 exec()'d on CPU torch over the oracle's vote
+    grids with the multinomial draws recorded (tests/golden/make_proposal_golden.py)"""
+    import os
+    import oracle
+    from oracle import proposal_oracle as po
+    from tests.golden.make_proposal_golden import make_inputs, RES, ROTS, NPROP
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "proposal_ref.npz"))
+    pts, xyz, scale, prob, corners, votes = make_inputs(int(z["seed"]))
+    g = oracle.hv_forward(pts, xyz, scale, prob, RES, ROTS, corners=corners)
+    cand, scales, _, used = po.sample_proposals(g[0], g[2], corners[0], RES, votes, list(z["draws"]), NPROP)
+    assert used == len(z["draws"])
+    np.testing.assert_allclose(cand, z["candidates"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(scales, z["scales"])
+    assert float(np.abs(z["probs"]).max()) == 0.0
