@@ -110,7 +110,8 @@ def run_step(model, hv, s, ev=None, teacher_forced=False):
         hv_cuda.prefetch_geometry(s.points)       # bounds reduction of the vote grid starts before the network
         if model is not None:
             x = ME.SparseTensor(s.feats_in, s.coords4, device=s.feats_in.device)   # coordinate hash + levels
-            y = model(x)
+            # the fp16-range flag of the network's convolutions is read after decode's wait (no extra wait per scene)
+            y = model(x, defer_check=True)
             rec(1)
             xyz, scale, prob, cls = pipeline.head_joint(y.F)
         else:
@@ -122,6 +123,15 @@ def run_step(model, hv, s, ev=None, teacher_forced=False):
         rec(3)
     raw = decode.decode_boxes(grid_obj, grid_rot, grid_scale, s.points, xyz, prob, cls, RES)
     rec(4)
+    if model is not None and model.check_range(x, y) is not y:
+        # an activation left the fp16 range: the scene is redone on the bf16 triples (never happens behind BatchNorm;
+        # counted in config.range_fallbacks so that it cannot happen silently)
+        with torch.no_grad():
+            y = model.program_forward(x, pieces=3)
+            if not teacher_forced:
+                xyz, scale, prob, cls = pipeline.head_joint(y.F)
+            grid_obj, grid_rot, grid_scale = hv(s.points, xyz, scale, prob)
+        raw = decode.decode_boxes(grid_obj, grid_rot, grid_scale, s.points, xyz, prob, cls, RES)
     return decode.nms_per_class(raw["boxes"], raw["scores"], raw["classes"]), raw
 
 
@@ -293,6 +303,7 @@ def main():
     tj = os.path.join(ROOT, "profiles", "r1", "vote_hbm_traffic.json")
     if os.path.exists(tj) and a.points == N_POINTS and not a.large and a.algo in (0, 2):
         traffic = json.load(open(tj))["hbm_bytes_per_launch"]
+    pieces_n = 3 if (full and model.USE_PROGRAM and model.PIECES == 2) else 6
     out = {
         "metric": "scenes/sec (80k-pt synthetic scans)",
         "value": cvd.throughput(a.steps, world, dt),
@@ -327,11 +338,18 @@ def main():
             "achieved": net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
             "frac": net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12 / 157.3,
             "flops_per_forward": net_flops[0], "dense_equivalent_flops": net_flops[1],
-            "bf16_piece_flops_per_forward": 6 * net_flops[0] if ME.CONV_X6 else None,
-            "frac_of_bf16_peak": (6 * net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12 / 2500.0) if ME.CONV_X6 else None,
-            "note": ("fp32 results; every fp32 product is computed as six exact bf16 x bf16 piece products "
-                     "(operands split h+m+l) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation - 0.375x the "
-                     "matrix time of v_mfma_f32_32x32x2_f32 at fp32-level accuracy; " if ME.CONV_X6 else
+            "piece_products_per_fp32_product": pieces_n if ME.CONV_X6 else None,
+            "piece_flops_per_forward": pieces_n * net_flops[0] if ME.CONV_X6 else None,
+            "frac_of_16bit_matrix_peak": (pieces_n * net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12 / 2500.0) if ME.CONV_X6 else None,
+            "range_fallbacks": int(getattr(model, "range_fallbacks", 0)),
+            "note": (("fp32 results; every fp32 product is computed as three exact fp16 x fp16 piece products "
+                      "(operands split h+l: 22 significant bits and the sign of l; weights pre-scaled by a power of two) "
+                      "on v_mfma_f32_32x32x16_f16 with fp32 accumulation; a convolution input beyond the fp16 range "
+                      "raises a flag and the scene is redone on the bf16 triples (range_fallbacks); "
+                      if pieces_n == 3 else
+                      "fp32 results; every fp32 product is computed as six exact bf16 x bf16 piece products "
+                      "(operands split h+m+l) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation - 0.375x the "
+                      "matrix time of v_mfma_f32_32x32x2_f32 at fp32-level accuracy; ") if ME.CONV_X6 else
                      "fp32 matrix cores (v_mfma_f32_32x32x2_f32); ") +
                     "achieved counts only existing (input,output) pairs, sum 2*P*Cin*Cout over the 63 conv layers, "
                     "against the fp32 matrix peak"},

@@ -38,7 +38,8 @@ class ConvDesc(ctypes.Structure):
                 ("j_begin", ctypes.c_int), ("j_end", ctypes.c_int), ("acc_in", vp), ("acc_ld", ctypes.c_int),
                 ("perm_groups", ctypes.c_int), ("plan_ent", vp), ("plan_cnt", vp),
                 ("weight_packed", vp), ("weight_x6", vp), ("in2", vp), ("in2_ld", ctypes.c_int), ("cin2", ctypes.c_int),
-                ("weight2_x6", vp), ("perm_has_map", ctypes.c_int)]
+                ("weight2_x6", vp), ("perm_has_map", ctypes.c_int), ("weight_pieces", ctypes.c_int),
+                ("acc_scale", ctypes.c_float), ("range_flag", vp)]
 
 
 class SceneMaps(ctypes.Structure):
@@ -60,7 +61,7 @@ class NetOp(ctypes.Structure):
                 ("res_buf", ctypes.c_int), ("res_col", ctypes.c_int), ("map", ctypes.c_int), ("K", ctypes.c_int),
                 ("perm", ctypes.c_int), ("perm_groups", ctypes.c_int), ("relu", ctypes.c_int),
                 ("weight", vp), ("scale", vp), ("shift", vp), ("weight_x6", vp), ("in2_buf", ctypes.c_int),
-                ("in2_col", ctypes.c_int), ("cin2", ctypes.c_int), ("weight2_x6", vp)]
+                ("in2_col", ctypes.c_int), ("cin2", ctypes.c_int), ("weight2_x6", vp), ("weight_pieces", ctypes.c_int), ("acc_scale", ctypes.c_float)]
 
 
 # symbol -> (restype, argtypes); tests check every symbol of include/cv_hip.h is here and exported
@@ -98,6 +99,7 @@ SIGNATURES = {
     "cv_sp_tile_plan_ints": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
     "cv_sp_tile_plan": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, vp, vp, vp]),
     "cv_sp_pack_weights_x6_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
+    "cv_sp_pack_weights_h2_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
     "cv_sp_tile_kw": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "cv_sp_pack_weights_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_scene_maps_words": (ctypes.c_size_t, [c_i64_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
@@ -109,7 +111,7 @@ SIGNATURES = {
     "cv_net_run_f32": (ctypes.c_int, [ctypes.POINTER(NetOp), ctypes.c_int, ctypes.POINTER(NetBuf), ctypes.c_int,
                                       c_i64_p, ctypes.c_int, vp, ctypes.c_size_t, ctypes.POINTER(vp), c_int_p,
                                       ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(vp), ctypes.c_int, vp,
-                                      ctypes.c_size_t, vp]),
+                                      ctypes.c_size_t, vp, vp]),
     "cv_sp_mask_keys": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_mask_perms": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t,
                                         ctypes.c_int, vp]),

@@ -94,7 +94,7 @@ size_t cv_net_arena_bytes(const cv_net_buf* bufs, int n_bufs, const long long* l
 int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int n_bufs, const long long* level_rows,
                    int n_levels, void* d_arena, size_t arena_bytes, const void* const* ext_ptr, const int* ext_ld,
                    const int32_t* const* maps, int n_maps, const int32_t* const* perms, int n_perms, void* d_ws,
-                   size_t ws_bytes, void* stream) {
+                   size_t ws_bytes, int32_t* range_flag, void* stream) {
     CV_REQUIRE(ops && bufs && level_rows && d_arena && n_ops > 0 && n_bufs > 0 && n_levels > 0, CV_EINVAL,
                "bad network program arguments");
     CV_REQUIRE(arena_bytes >= cv_net_arena_bytes(bufs, n_bufs, level_rows, n_levels), CV_ENOMEM, "arena too small");
@@ -128,6 +128,9 @@ int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int 
         d.cin = o.cin;
         d.weight = o.weight;
         d.weight_x6 = o.weight_x6;
+        d.weight_pieces = o.weight_pieces;
+        d.acc_scale = o.acc_scale;
+        d.range_flag = o.weight_pieces == 2 ? range_flag : nullptr;
         if (o.in2_buf >= 0) {
             CV_REQUIRE(o.in2_buf < n_bufs, CV_EINVAL, "op %d: bad second-source slot", k);
             d.in2 = reinterpret_cast<const float*>(slot[o.in2_buf].ptr) + o.in2_col;

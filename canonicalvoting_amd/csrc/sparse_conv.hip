@@ -62,6 +62,9 @@ struct ConvArgs {
     const float* in2;            // conv_rows_x6: second source on the output rows (out += in2 @ W2), or NULL
     int in2_ld, cin2;
     const unsigned short* wp6_2;
+    int pieces;                  // 3: wp6 holds bf16 triples (six piece products), 2: fp16 pairs (three piece products)
+    float acc_scale;             // fp16 pairs: the packed weights carry a power-of-two factor; accumulators *= acc_scale
+    int* range_flag;             // fp16 pairs: set to 1 when a staged input magnitude does not fit fp16
 };
 
 __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& acc, const int* rows,
@@ -336,6 +339,41 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
     l = cvt_pk_bf16(s0, s1);
 }
 
+// fp16 pairs: x = h + l with h = RNE16(x), l = RNE16(x - h): 11 + 11 significant bits and l's own sign, i.e. x to
+// 2^-24 relative as long as neither piece leaves the fp16 range (|x| < 65504; below 2^-14 the absolute error floor is
+// 2^-25).  Three piece products (hh, hl, lh; the dropped ll is <= 2^-24 of the product) instead of six.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigned& l) {
+    const f16x2 hv = {(_Float16)x0, (_Float16)x1};                          // v_cvt_pk_f16_f32 (RNE)
+    const f16x2 lv = {(_Float16)(x0 - (float)hv[0]), (_Float16)(x1 - (float)hv[1])};
+    h = __builtin_bit_cast(unsigned, hv);
+    l = __builtin_bit_cast(unsigned, lv);
+}
+
+// wp layout of the fp16 pairs (unsigned short): ((((j*nch + c)*2 + plane)*cout + col)*32 + k); values are
+// w * col_scale * mult (mult = 2^scale_log2 keeps the low pieces of small weights out of the fp16 subnormals)
+__global__ __launch_bounds__(256) void pack_weights_h2(const float* __restrict__ w, int K, int cin, int cout,
+                                                       const float* __restrict__ col_scale, float mult,
+                                                       unsigned short* __restrict__ wp) {
+    const long long total = (long long)K * cin * cout / 2;
+    const int nch = cin / 32;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long r = i;
+        const int k2 = (int)(r % 16); r /= 16;
+        const int col = (int)(r % cout); r /= cout;
+        const int c = (int)(r % nch); r /= nch;
+        const int j = (int)r;
+        const float* p = w + ((long long)j * cin + c * 32 + 2 * k2) * cout + col;
+        const float sc = (col_scale ? col_scale[col] : 1.f) * mult;
+        unsigned h, l;
+        split2h(p[0] * sc, p[cout] * sc, h, l);
+        const long long base = ((long long)(j * nch + c) * 2 * cout + col) * 32 + 2 * k2;
+        *reinterpret_cast<unsigned*>(wp + base) = h;
+        *reinterpret_cast<unsigned*>(wp + base + (long long)cout * 32) = l;
+    }
+}
+
 // wp6 layout (unsigned short): ((((j*nch + c)*3 + plane)*cout + col)*32 + k) for channel c*32 + k of offset j
 __global__ __launch_bounds__(256) void pack_weights_x6(const float* __restrict__ w, int K, int cin, int cout,
                                                        const float* __restrict__ col_scale,
@@ -359,10 +397,11 @@ __global__ __launch_bounds__(256) void pack_weights_x6(const float* __restrict__
     }
 }
 
-template <int NB>
+// P = 3: bf16 triples, six piece products.  P = 2: fp16 pairs, three piece products (same tiles with two planes).
+template <int NB, int P>
 __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
     // operand tiles and the epilogue tile share one buffer (the epilogue starts after the last MFMA)
-    constexpr int A_BYTES = 3 * TM * 64, B_BYTES = 3 * NB * 32 * 64, EP_BYTES = 4 * 32 * EP_LD * 4;
+    constexpr int A_BYTES = P * TM * 64, B_BYTES = P * NB * 32 * 64, EP_BYTES = 4 * 32 * EP_LD * 4;
     constexpr int SM_BYTES = A_BYTES + B_BYTES > EP_BYTES ? A_BYTES + B_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char sm[SM_BYTES];
     __shared__ int nbr_s[TM];
@@ -395,23 +434,31 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int chunk = 2 * ks + half;
-            bf16x8 av[3];
+            bf16x8 av[P];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < P; ++p)
                 av[p] = *reinterpret_cast<const bf16x8*>(A_h + (p * TM + arow) * 64 + ((chunk ^ aswz) << 4));
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                bf16x8 bv[3];
+                bf16x8 bv[P];
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < P; ++p)
                     bv[p] = *reinterpret_cast<const bf16x8*>(B_h + (p * NB * 32 + nb * 32 + l31) * 64 + ((chunk ^ bswz) << 4));
                 // smallest terms first
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[2], acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[0], acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1], acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[1], acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[0], acc[nb], 0, 0, 0);
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc[nb], 0, 0, 0);
+                if constexpr (P == 3) {
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[2], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[0], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[1], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[0], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc[nb], 0, 0, 0);
+                } else {
+                    const f16x8 a0 = __builtin_bit_cast(f16x8, av[0]), a1 = __builtin_bit_cast(f16x8, av[P - 1]);
+                    const f16x8 b0 = __builtin_bit_cast(f16x8, bv[0]), b1 = __builtin_bit_cast(f16x8, bv[P - 1]);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[nb], 0, 0, 0);
+                }
             }
         }
     };
@@ -420,7 +467,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
     // thread -> (row = tid/8 + 32*i, 4 channels at (tid%8)*4) : 8 lanes cover one 128 B row chunk
     const int a_col = (tid & 7) * 4;
     const int a_row = tid >> 3;                      // + 32*i, i = 0..3
-    constexpr int B_U4 = 3 * NB * 32 * 4;            // 16-byte pieces of the packed weight slab of one unit
+    constexpr int B_U4 = P * NB * 32 * 4;            // 16-byte pieces of the packed weight slab of one unit
     constexpr int B_PER = (B_U4 + THREADS - 1) / THREADS;
     const int nch = a.cin / KC;
     int u_lo, u_hi;
@@ -433,6 +480,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
     }
     float4 ra[4];
     uint4 rb[B_PER];
+    float in_max = 0.f;                              // fp16 pairs: largest staged input magnitude
     auto load_b = [&](const unsigned short* slab) {
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
@@ -451,15 +499,25 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const int r = a_row + 32 * i;
                 unsigned h0 = 0, m0 = 0, l0 = 0, h1 = 0, m1 = 0, l1 = 0;
-                if (!(a.dbg & 16)) {
-                    split3(ra[i].x, ra[i].y, h0, m0, l0);
-                    split3(ra[i].z, ra[i].w, h1, m1, l1);
-                }
                 // channels a_col .. a_col+3 -> 8 bytes at offset (a_col & 7) * 2 of chunk a_col >> 3
                 unsigned char* dst = A_h + r * 64 + ((((a_col >> 3) ^ ((r >> 2) & 3))) << 4) + ((a_col & 7) << 1);
-                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(dst + TM * 64) = make_uint2(m0, m1);
-                *reinterpret_cast<uint2*>(dst + 2 * TM * 64) = make_uint2(l0, l1);
+                if constexpr (P == 3) {
+                    if (!(a.dbg & 16)) {
+                        split3(ra[i].x, ra[i].y, h0, m0, l0);
+                        split3(ra[i].z, ra[i].w, h1, m1, l1);
+                    }
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(dst + TM * 64) = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2*>(dst + 2 * TM * 64) = make_uint2(l0, l1);
+                } else {
+                    in_max = fmaxf(fmaxf(in_max, fmaxf(fabsf(ra[i].x), fabsf(ra[i].y))), fmaxf(fabsf(ra[i].z), fabsf(ra[i].w)));
+                    if (!(a.dbg & 16)) {
+                        split2h(ra[i].x, ra[i].y, h0, l0);
+                        split2h(ra[i].z, ra[i].w, h1, l1);
+                    }
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(dst + TM * 64) = make_uint2(l0, l1);
+                }
             }
 #pragma unroll
             for (int i = 0; i < B_PER; ++i) {
@@ -513,7 +571,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             // packed slab of (j, chunk): [plane][cout][32 k] bf16; this workgroup's columns n0 .. n0 + NB*32
-            load_b(a.wp6 + (long long)(j * nch + kc / KC) * 3 * a.cout * 32);
+            load_b(a.wp6 + (long long)(j * nch + kc / KC) * P * a.cout * 32);
         };
         load(kc_begin);
         for (int kc = kc_begin; kc < kc_end; kc += KC) {
@@ -539,7 +597,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
                 ra[i] = src >= 0 ? *reinterpret_cast<const float4*>(a.in2 + (long long)src * a.in2_ld + c2 * KC + a_col)
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            load_b(a.wp6_2 + (long long)c2 * 3 * a.cout * 32);
+            load_b(a.wp6_2 + (long long)c2 * P * a.cout * 32);
         };
         int c2 = blockIdx.z;
         if (c2 < nch2) load2(c2);
@@ -553,6 +611,16 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
         __syncthreads();
     }
     __syncthreads();                         // operand tiles are dead: the epilogue tile reuses their LDS
+    if constexpr (P == 2) {
+        // an input beyond the fp16 range makes h infinite: the caller is told and must redo the convolution on the
+        // bf16 triples (inputs that large do not occur behind BatchNorm; the flag makes that an observed fact)
+        if (in_max > 65000.f && a.range_flag) *a.range_flag = 1;
+        const float k = a.acc_scale;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] *= k;
+    }
     float (*ep)[EP_LD] = reinterpret_cast<float (*)[EP_LD]>(sm + wave * 32 * EP_LD * 4);
     if (a.dbg & 8) {
         if (acc[0][0] == 123.456f) a.out[0] = 1.f;
@@ -1692,7 +1760,8 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
               (unsigned)a.splits);
     static const bool prof_on = getenv("CV_CONV_PROF") != nullptr;
     if (vec && a.wp6 && (!prof_on || a.in2)) {
-        conv_rows_x6<NB><<<grid, THREADS, 0, st>>>(a);
+        if (a.pieces == 2) conv_rows_x6<NB, 2><<<grid, THREADS, 0, st>>>(a);
+        else conv_rows_x6<NB, 3><<<grid, THREADS, 0, st>>>(a);
         CV_LAUNCH_CHECK();
         if (a.splits > 1) return launch_finish(a, st);
         return CV_OK;
@@ -1841,7 +1910,12 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
                d->acc_in, d->acc_ld, d->plan_ent, d->plan_cnt,
                reinterpret_cast<const float4*>(d->weight_packed), 0, nullptr, 0, 0,
                static_cast<const unsigned short*>(d->weight_x6), d->in2, d->in2_ld, d->cin2,
-               static_cast<const unsigned short*>(d->weight2_x6)};
+               static_cast<const unsigned short*>(d->weight2_x6), d->weight_pieces == 2 ? 2 : 3,
+               d->acc_scale != 0.f ? d->acc_scale : 1.f, d->range_flag};
+    CV_REQUIRE(d->weight_pieces == 0 || d->weight_pieces == 2 || d->weight_pieces == 3, CV_EINVAL,
+               "weight_pieces is 0/3 (bf16 triples) or 2 (fp16 pairs)");
+    CV_REQUIRE(d->weight_pieces != 2 || (d->weight_x6 && d->cin % KC == 0), CV_EINVAL,
+               "weight_pieces = 2 needs weight_x6 from cv_sp_pack_weights_h2_f32 and Cin %% 32 == 0");
 
     {
         static const int dbg = getenv("CV_CONV_DBG") ? atoi(getenv("CV_CONV_DBG")) : 0;
@@ -2013,6 +2087,24 @@ int cv_sp_pack_weights_x6_f32(const float* d_w, int K, int cin, int cout, const 
     const long long total = (long long)K * cin * cout / 2;
     pack_weights_x6<<<(unsigned)std::min<long long>((total + 255) / 256, 8192), 256, 0, st>>>(
         d_w, K, cin, cout, d_col_scale, static_cast<unsigned short*>(d_wp6));
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+// d_wp[2*K*cin*cout] (16-bit words) = d_w * d_col_scale * 2^scale_log2 split into two fp16 pieces per value, laid
+// out per (offset, 32-channel chunk) as [piece][cout][32 channels] (cv_conv_desc.weight_pieces = 2; pass
+// acc_scale = 2^-scale_log2).  Choose scale_log2 so that the largest scaled magnitude is about 2^13: the low pieces
+// of weights down to 2^-14 of the largest one then stay normal fp16 numbers.
+int cv_sp_pack_weights_h2_f32(const float* d_w, int K, int cin, int cout, const float* d_col_scale, int scale_log2,
+                              void* d_wp, void* stream) {
+    CV_REQUIRE(d_w && d_wp && K > 0 && cin > 0 && cout > 0, CV_EINVAL, "bad pack_weights_h2 arguments");
+    CV_REQUIRE(cin % 32 == 0, CV_EINVAL, "pack_weights_h2 needs Cin %% 32 == 0 (got %d)", cin);
+    CV_REQUIRE(scale_log2 >= -60 && scale_log2 <= 60, CV_EINVAL, "scale_log2 out of range");
+    CV_REQUIRE((reinterpret_cast<uintptr_t>(d_wp) & 15) == 0, CV_EINVAL, "d_wp must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long total = (long long)K * cin * cout / 2;
+    pack_weights_h2<<<(unsigned)std::min<long long>((total + 255) / 256, 8192), 256, 0, st>>>(
+        d_w, K, cin, cout, d_col_scale, ldexpf(1.f, scale_log2), static_cast<unsigned short*>(d_wp));
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

@@ -321,10 +321,24 @@ def _workspace(dev, nbytes):
     return ws
 
 
+_range_flags = {}
+
+
+def range_flag(dev):
+    """one int32 word of pinned (device-visible) host memory per (device, stream): fp16-pair convolutions set it when
+    an input magnitude leaves the fp16 range (cv_conv_desc.range_flag); read it after synchronising the stream"""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    f = _range_flags.get(key)
+    if f is None:
+        f = _range_flags[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    return f
+
+
 def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=None, relu=False,
                  out=None, flavour=0, row_perm=None, j_begin=0, j_end=0, acc_in=None, perm_groups=0,
-                 cache_weights=True):
-    """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout]."""
+                 cache_weights=True, pieces=3):
+    """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout].
+    pieces=2: fp16-pair products (weights packed per call; the caller reads range_flag(dev) after synchronising)."""
     L = _lib.lib()
     dev = x_feats.device
     w = weight if weight.dim() == 3 else weight[None]
@@ -345,8 +359,13 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
         plan = tile_plan(nbr, row_perm) if nbr is not None else None
         wp = packed_weights(weight, w, cache_weights)
     wp6 = None
+    acc_scale, flag = 0.0, None
     if CONV_X6 and flavour in (0, 1) and cin % 32 == 0 and cout % 4 == 0 and plan is None:
-        wp6 = packed_weights_x6(weight, w, cache_weights)
+        if pieces == 2:
+            k = h2_scale_log2((w, None))
+            wp6, acc_scale, flag = packed_weights_h2(w, None, k), 2.0 ** -k, range_flag(dev)
+        else:
+            wp6 = packed_weights_x6(weight, w, cache_weights)
     ws = None
     if perm_groups > 1:
         ws = _workspace(dev, 4 * perm_groups * n_out * cout + 256)
@@ -360,7 +379,8 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
                       acc_in.stride(0) if acc_in is not None else 0, perm_groups,
                       plan[0].data_ptr() if plan is not None else None,
                       plan[0].data_ptr() + 4 * plan[1] if plan is not None else None, p(wp), p(wp6), None, 0, 0, None,
-                      1 if (perm_groups > 1 and getattr(row_perm, "_cv_has_map", False)) else 0)
+                      1 if (perm_groups > 1 and getattr(row_perm, "_cv_has_map", False)) else 0,
+                      2 if flag is not None else 0, acc_scale, p(flag))
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
     return out
@@ -424,6 +444,30 @@ def packed_weights_x6_scaled(w3, col_scale):
     with torch.cuda.device(w3.device):
         _lib.check(L.cv_sp_pack_weights_x6_f32(_ptr(w3), K, cin, cout, _ptr(col_scale), _ptr(wp), _stream(w3.device)),
                    "cv_sp_pack_weights_x6_f32")
+    return wp
+
+
+def h2_scale_log2(*scaled_weights):
+    """power of two that brings the largest magnitude of the given (weight [K,Cin,Cout], column scale or None) sets
+    to about 2^13 (cv_sp_pack_weights_h2_f32); one host sync, at pack time only"""
+    import math
+    amax = 0.0
+    for w3, col_scale in scaled_weights:
+        a = w3.abs().amax(dim=(0, 1)) if col_scale is not None else w3.abs().max()
+        amax = max(amax, float((a * col_scale.abs()).max()) if col_scale is not None else float(a))
+    if not math.isfinite(amax) or amax <= 0.0:
+        return 0
+    return max(-60, min(60, 13 - math.ceil(math.log2(amax))))
+
+
+def packed_weights_h2(w3, col_scale, scale_log2):
+    """uncached: weights (times an optional per-output-column scale and 2^scale_log2) split into two fp16 pieces"""
+    L = _lib.lib()
+    K, cin, cout = w3.shape
+    wp = torch.empty(2 * w3.numel(), dtype=torch.int16, device=w3.device)
+    with torch.cuda.device(w3.device):
+        _lib.check(L.cv_sp_pack_weights_h2_f32(_ptr(w3), K, cin, cout, _ptr(col_scale), int(scale_log2), _ptr(wp),
+                                               _stream(w3.device)), "cv_sp_pack_weights_h2_f32")
     return wp
 
 

@@ -103,9 +103,9 @@ class MinkUNetBase(ResNetBase):
         return super().train(mode)
 
     # ------------------------------------------------------------------ reference-shaped forward
-    def forward(self, x):
+    def forward(self, x, defer_check=None):
         if (not self.training) and (not torch.is_grad_enabled()) and self.BLOCK is BasicBlock:
-            return self.program_forward(x) if self.USE_PROGRAM else self.fused_forward(x)
+            return self.program_forward(x, defer_check=defer_check) if self.USE_PROGRAM else self.fused_forward(x)
         return self.modular_forward(x)
 
     def modular_forward(self, x):
@@ -145,6 +145,13 @@ class MinkUNetBase(ResNetBase):
     USE_PROGRAM = os.environ.get("CV_NET_PROGRAM", "1") != "0"
     # program mode: the 1x1 downsample conv of a block's first BasicBlock is folded into its conv2 (second source)
     FUSE_DOWNSAMPLE = os.environ.get("CV_FUSE_DOWNSAMPLE", "1") != "0"
+    # program mode: fp32 products as three fp16 x fp16 piece products (operands split h + l, 22 significant bits and
+    # the sign of l) instead of six bf16 ones.  fp16 has a range: a convolution whose input holds a magnitude above
+    # 65000 raises a flag in pinned host memory and the forward is redone on the bf16 triples (check_range).
+    PIECES = 2 if os.environ.get("CV_CONV_H2", "1") != "0" else 3
+    # False: forward() waits for the launches and checks the range flag itself; True: the caller does it after its
+    # own synchronisation point (pipeline.detect_scene: no extra wait per scene)
+    defer_range_check = False
 
     def _conv3(self, x, kernel, nbr, perms, n, **ep):
         if perms is not None:
@@ -207,14 +214,15 @@ class MinkUNetBase(ResNetBase):
     MAP_STEM, MAP_DOWN, MAP_K3, MAP_UP, MAP_OUT = 0, 1, 5, 10, 14          # slots of the per-scene map table
     PERM_K3, PERM_UP = 0, 5                                                 # slots of the processing-order table
 
-    def _program(self, dev):
+    def _program(self, dev, pieces=3):
         """(ops, bufs, keep-alive) for cv_net_run_f32: the launch sequence of fused_forward with symbolic operands
-        (arena buffer slots, map / order slots).  Built once per parameter version."""
+        (arena buffer slots, map / order slots).  Built once per parameter version and piece format."""
         from . import _lib
         # cheap staleness check (walking nn.Module.parameters() costs 0.3 ms per call): the flat tensor list is
         # kept with the program, in-place updates bump _version, re-allocation (.to(), load_state_dict with
         # assign) changes data_ptr of the first parameter or the tensor objects themselves
-        hit = self.__dict__.get("_prog")
+        progs = self.__dict__.setdefault("_prog", {})
+        hit = progs.get(pieces)
         if hit is not None:
             tensors, ver = hit[0]
             if ver == (sum(t._version for t in tensors), tensors[0].data_ptr(), str(dev), self.training):
@@ -243,14 +251,25 @@ class MinkUNetBase(ResNetBase):
             w = (kernel if kernel.dim() == 3 else kernel[None]).detach().contiguous()
             in2 = (-1, 0)
             cin2, w6_2 = 0, None
+            vec = ME.CONV_X6 and w.shape[1] % 32 == 0 and w.shape[2] % 4 == 0
+            op_pieces, acc_scale = 3, 1.0
             if second is not None:
                 src2, kernel2, scale2 = second
                 w2 = (kernel2 if kernel2.dim() == 3 else kernel2[None]).detach().contiguous()
-                w6 = ME.packed_weights_x6_scaled(w, scale)
-                w6_2 = ME.packed_weights_x6_scaled(w2, scale2)
+                if pieces == 2:
+                    k = ME.h2_scale_log2((w, scale), (w2, scale2))           # one accumulator: one common factor
+                    w6, w6_2 = ME.packed_weights_h2(w, scale, k), ME.packed_weights_h2(w2, scale2, k)
+                    op_pieces, acc_scale = 2, 2.0 ** -k
+                else:
+                    w6 = ME.packed_weights_x6_scaled(w, scale)
+                    w6_2 = ME.packed_weights_x6_scaled(w2, scale2)
                 in2, cin2, scale = src2, w2.shape[1], None
+            elif vec and pieces == 2:
+                k = ME.h2_scale_log2((w, None))
+                w6 = ME.packed_weights_h2(w, None, k)
+                op_pieces, acc_scale = 2, 2.0 ** -k
             else:
-                w6 = ME.packed_weights_x6(kernel, w) if (ME.CONV_X6 and w.shape[1] % 32 == 0 and w.shape[2] % 4 == 0) else None
+                w6 = ME.packed_weights_x6(kernel, w) if vec else None
             keep.extend([w, scale, shift, w6, w6_2])
             ops.append(dict(in_buf=src[0], in_col=src[1], cin=w.shape[1], out_buf=dst[0], out_col=dst[1],
                             cout=w.shape[2], res_buf=res[0] if res else -1, res_col=res[1] if res else 0,
@@ -259,7 +278,8 @@ class MinkUNetBase(ResNetBase):
                             shift=shift.data_ptr() if shift is not None else None,
                             weight_x6=w6.data_ptr() if w6 is not None else None,
                             in2_buf=in2[0], in2_col=in2[1], cin2=cin2,
-                            weight2_x6=w6_2.data_ptr() if w6_2 is not None else None))
+                            weight2_x6=w6_2.data_ptr() if w6_2 is not None else None,
+                            weight_pieces=op_pieces, acc_scale=acc_scale))
 
         def layer(seq, x, level, out_view):
             """x, out_view: (slot, first column); returns the (slot, column) holding the layer's output"""
@@ -329,17 +349,29 @@ class MinkUNetBase(ResNetBase):
         c_ops = (_lib.NetOp * len(ops))(*[_lib.NetOp(**o) for o in ops])
         c_bufs = (_lib.NetBuf * len(bufs))(*[_lib.NetBuf(*bf) for bf in bufs])
         prog = (c_ops, c_bufs, keep)
-        self.__dict__["_prog"] = (ver, prog)
+        progs[pieces] = (ver, prog)
         return prog
 
-    def program_forward(self, x):
+    def check_range(self, x, y):
+        """After the stream has been synchronised: if a convolution of the last fp16-pair forward on this stream
+        saw an input beyond the fp16 range, redo the forward on the bf16 triples.  Returns the valid output."""
+        flag = ME.range_flag(x.F.device)
+        if int(flag[0]) == 0:
+            return y
+        flag.zero_()
+        self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1
+        return self.program_forward(x, pieces=3)
+
+    def program_forward(self, x, pieces=None, defer_check=None):
         """fused_forward through the C executor (cv_net_run_f32): identical launches, one call."""
         import ctypes
         from . import _lib
         L = _lib.lib()
         cm, stem_map, out_map = x.coordinate_manager.fused_plan(self.conv0p1s1.kernel_size)
         dev = x.F.device
-        c_ops, c_bufs, _ = self._program(dev)
+        pieces = self.PIECES if pieces is None else pieces
+        c_ops, c_bufs, _ = self._program(dev, pieces)
+        flag = ME.range_flag(dev) if pieces == 2 else None
         n = [cm.num_rows(1 << i) for i in range(5)]
         maps = [stem_map] + [cm.kernel_map(2, 1 << i, 2) for i in range(4)] + [cm.kernel_map(3, 1 << i) for i in range(5)] \
             + [cm.up_map(16 >> i) for i in range(4)] + [out_map]
@@ -361,9 +393,13 @@ class MinkUNetBase(ResNetBase):
         with torch.cuda.device(dev):
             _lib.check(L.cv_net_run_f32(c_ops, len(c_ops), c_bufs, len(c_bufs), rows, 5, vp(arena.data_ptr()),
                                         arena.numel(), ext_ptr, ext_ld, c_maps, len(maps), c_perms, len(perms),
-                                        vp(ws.data_ptr()), ws.numel(),
+                                        vp(ws.data_ptr()), ws.numel(), vp(flag.data_ptr()) if flag is not None else None,
                                         vp(torch.cuda.current_stream(dev).cuda_stream)), "cv_net_run_f32")
-        return x._like(y, 1)
+        out = x._like(y, 1)
+        if flag is not None and not (self.defer_range_check if defer_check is None else defer_check):
+            torch.cuda.current_stream(dev).synchronize()
+            out = self.check_range(x, out)
+        return out
 
     def forward_flops(self, x):
         """Algorithmic flops of one forward on x's coordinate set:

@@ -34,10 +34,17 @@ def detect_scene(model, hv, coords4, feats, res, nclasses=9, log_scale=True, **d
         scan_points = (coords4[:, 1:].to(feats.device) * res).float().contiguous()
         hv_cuda.prefetch_geometry(scan_points)
         x = ME.SparseTensor(feats, coords4, device=feats.device)
-        y = model(x)
-        xyz, scale, prob, cls = head_joint(y.F, nclasses, log_scale)
-        dets, raw = decode.detect(hv, coords4[:, 1:], xyz, scale, prob, cls, res, nclasses,
-                                  scan_points=scan_points, **decode_kw)
+        deferred = hasattr(model, "check_range")
+        y = model(x, defer_check=True) if deferred else model(x)
+        for attempt in range(2):
+            xyz, scale, prob, cls = head_joint(y.F, nclasses, log_scale)
+            dets, raw = decode.detect(hv, coords4[:, 1:], xyz, scale, prob, cls, res, nclasses,
+                                      scan_points=scan_points, **decode_kw)
+            # decode has waited for the stream: the fp16-range flag of the network's convolutions is final now
+            y2 = model.check_range(x, y) if (deferred and attempt == 0) else y
+            if y2 is y:
+                break
+            y = y2
     return dets, raw, y
 
 

@@ -200,6 +200,13 @@ typedef struct cv_conv_desc {
     const void* weight2_x6; /* cv_sp_pack_weights_x6_f32 of W2 [1][cin2][cout]                                         */
     int perm_has_map;       /* with perm_groups > 1: row_perm is followed by the kernel map rows in processing order
                                (cv_sp_mask_perms with_map = 1), which turns the random map reads into coalesced ones */
+    int weight_pieces;      /* 0 / 3: weight_x6 (and weight2_x6) hold bf16 triples (cv_sp_pack_weights_x6_f32);
+                               2: fp16 pairs (cv_sp_pack_weights_h2_f32): three fp16 x fp16 piece products per fp32
+                               product - fp32-level accuracy (operands to 2^-24) while every input magnitude is below
+                               65504, half the matrix time of the triples                                            */
+    float acc_scale;        /* fp16 pairs: 2^-scale_log2 of the pack call (0 = 1): multiplies the accumulators        */
+    int32_t* range_flag;    /* fp16 pairs: optional device-visible word, set to 1 when an input magnitude > 65000 was
+                               staged (the result is then invalid: redo the convolution with the bf16 triples)        */
 } cv_conv_desc;
 
 /* Pair lists for the tile kernel, built once per kernel map and processing order and shared by every convolution
@@ -217,6 +224,11 @@ int cv_sp_tile_plan(const int32_t* d_nbr, long long n_out, int K, const int32_t*
 int cv_sp_pack_weights_x6_f32(const float* d_w, int K, int cin, int cout, const float* d_col_scale, void* d_wp6,
                               void* stream);   /* d_col_scale[cout] (optional): weights are multiplied per output
                                                   column before the split (a folded BatchNorm scale) */
+/* Weights of the fp16-pair path: (w * d_col_scale * 2^scale_log2) split into h + l fp16 pieces, same layout with two
+ * planes: 2*K*cin*cout 16-bit words.  The caller picks scale_log2 (largest scaled magnitude about 2^13; both weight
+ * sets of a two-source convolution share it) and passes acc_scale = 2^-scale_log2 in the descriptor. */
+int cv_sp_pack_weights_h2_f32(const float* d_w, int K, int cin, int cout, const float* d_col_scale, int scale_log2,
+                              void* d_wp, void* stream);
 int cv_sp_tile_kw(int cin, int cout);
 int cv_sp_pack_weights_f32(const float* d_w, int K, int cin, int cout, float* d_wp, void* stream);
 
@@ -266,12 +278,15 @@ typedef struct cv_net_op {
     const void* weight_x6;     /* cv_sp_pack_weights_x6_f32 of weight, or NULL */
     int in2_buf, in2_col, cin2;/* second source (in2_buf < 0: none), see cv_conv_desc.in2 */
     const void* weight2_x6;
+    int weight_pieces;         /* see cv_conv_desc.weight_pieces / acc_scale */
+    float acc_scale;
 } cv_net_op;
 size_t cv_net_arena_bytes(const cv_net_buf* bufs, int n_bufs, const long long* level_rows, int n_levels);
 int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int n_bufs, const long long* level_rows,
                    int n_levels, void* d_arena, size_t arena_bytes, const void* const* ext_ptr, const int* ext_ld,
                    const int32_t* const* maps, int n_maps, const int32_t* const* perms, int n_perms, void* d_ws,
-                   size_t ws_bytes, void* stream);
+                   size_t ws_bytes, int32_t* range_flag, void* stream);   /* range_flag: cv_conv_desc.range_flag of
+                                                                             every fp16-pair op, or NULL */
 
 /* d_keys[n] (int64) = bit mask of the valid neighbours among offsets [j_begin, j_end) of every row of a
  * kernel map; argsort of it is a row_perm for cv_conv_desc.  Asynchronous. */

@@ -218,7 +218,7 @@ def test_minkunet34c_fused_and_modular_match_oracle(cuda, built_lib, n, small):
         type(model).FUSE_DOWNSAMPLE = False
         model.__dict__.pop("_prog", None)
         with torch.no_grad():
-            assert np.array_equal(model.program_forward(x).F.cpu().numpy(), model.fused_forward(x).F.cpu().numpy())
+            assert np.array_equal(model.program_forward(x, pieces=3).F.cpu().numpy(), model.fused_forward(x).F.cpu().numpy())
     finally:
         type(model).FUSE_DOWNSAMPLE = saved
         model.__dict__.pop("_prog", None)
@@ -463,6 +463,50 @@ def test_bf16x6_products_keep_fp32_accuracy(cuda, built_lib):
         ME.CONV_X6 = saved
     assert errs[False] < 2e-6 and errs[True] < 2e-6, errs                    # both at fp32 accumulation level
     assert errs[True] < 4 * errs[False] + 1e-7, errs
+    # fp16 pairs (three piece products, weights pre-scaled by a power of two): the same bar, on the plain and the
+    # mask-grouped launch; no input leaves the fp16 range here, so the flag stays down
+    flag = ME.range_flag(torch.device(cuda))
+    flag.zero_()
+    for kw in (dict(flavour=1), dict()):
+        got = ME.conv_forward(t(x), t(w), cm.kernel_map(3, 1), n, pieces=2, **kw).cpu().numpy().astype(np.float64)
+        e2 = float((np.abs(got - ref) / (mag + 1e-30)).max())
+        assert e2 < 2e-6 and e2 < 4 * errs[False] + 1e-7, (e2, errs)
+    assert int(flag[0]) == 0
+    # tiny and huge magnitudes: subnormal low pieces cost absolute, not relative accuracy; 7e4 raises the flag
+    xs = x.copy()
+    xs[:, :8] *= 1e-6
+    got = ME.conv_forward(t(xs), t(w), cm.kernel_map(3, 1), n, pieces=2, flavour=1).cpu().numpy().astype(np.float64)
+    want = ME.conv_forward(t(xs), t(w), cm.kernel_map(3, 1), n, flavour=1).cpu().numpy().astype(np.float64)
+    assert float((np.abs(got - want) / (mag + 1e-30)).max()) < 2e-6
+    assert int(flag[0]) == 0
+    xs[5, 3] = 7e4
+    ME.conv_forward(t(xs), t(w), cm.kernel_map(3, 1), n, pieces=2, flavour=1)
+    torch.cuda.synchronize()
+    assert int(flag[0]) == 1
+    flag.zero_()
+
+
+def test_fp16_range_overflow_falls_back_to_bf16_triples(cuda, built_lib):
+    """An activation beyond the fp16 range (forced here by a BatchNorm gain of 3e6) must not corrupt the output: the
+    flag goes up, the forward is redone on the bf16 triples, and the result equals the bf16 program's bit for bit."""
+    coords, feats = scene_coords(43, 1500)
+    torch.manual_seed(3)
+    model = MinkUNet34C(3, 64).cuda().eval()
+    x = ME.SparseTensor(torch.from_numpy(feats), torch.from_numpy(coords).int(), device="cuda")
+    with torch.no_grad():
+        calm = model(x).F.clone()
+        assert getattr(model, "range_fallbacks", 0) == 0
+        assert float((calm - model.program_forward(x, pieces=3).F).abs().max()) < 2e-5 * max(1.0, float(calm.abs().max()))
+        model.bn0.bn.weight.mul_(3e6)
+        model.train(False)                                   # drops the folded affines and the programs
+        want = model.program_forward(x, pieces=3).F.clone()
+        got = model(x).F
+        assert model.range_fallbacks == 1 and torch.equal(got, want)
+        # the deferred form used by the per-scene pipeline
+        y = model(x, defer_check=True)
+        torch.cuda.synchronize()
+        y2 = model.check_range(x, y)
+        assert y2 is not y and torch.equal(y2.F, want) and model.range_fallbacks == 2
 
 
 def test_hip_network_matches_reference_class_executed_on_cpu(cuda, built_lib):
