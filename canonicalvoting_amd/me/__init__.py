@@ -362,8 +362,17 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
     acc_scale, flag = 0.0, None
     if CONV_X6 and flavour in (0, 1) and cin % 32 == 0 and cout % 4 == 0 and plan is None:
         if pieces == 2:
-            k = h2_scale_log2((w, None))
-            wp6, acc_scale, flag = packed_weights_h2(w, None, k), 2.0 ** -k, range_flag(dev)
+            key = id(weight)
+            ver = (weight.data_ptr(), weight._version, tuple(weight.shape))
+            hit = _packed_h2.get(key) if cache_weights else None
+            if hit is None or hit[0] != ver:
+                k = h2_scale_log2((w, None))
+                hit = (ver, packed_weights_h2(w, None, k), k)
+                if cache_weights:
+                    if len(_packed_h2) > 512:
+                        _packed_h2.clear()
+                    _packed_h2[key] = hit
+            wp6, acc_scale, flag = hit[1], 2.0 ** -hit[2], range_flag(dev)
         else:
             wp6 = packed_weights_x6(weight, w, cache_weights)
     ws = None
@@ -423,6 +432,7 @@ TILE_KERNEL = os.environ.get("CV_TILE_KERNEL", "0") != "0"
 
 _packed = {}
 _packed_x6 = {}
+_packed_h2 = {}
 # 1 (default): vector-path convs run their fp32 products as six bf16 piece products on the bf16 matrix cores
 # (conv_rows_x6); 0: v_mfma_f32_32x32x2_f32
 CONV_X6 = os.environ.get("CV_CONV_X6", "1") != "0"
@@ -434,6 +444,7 @@ def invalidate_weight_caches():
     switch between train and eval mode, and the training path never caches."""
     _packed.clear()
     _packed_x6.clear()
+    _packed_h2.clear()
 
 
 def packed_weights_x6_scaled(w3, col_scale):

@@ -21,7 +21,11 @@ records = []
 REPS = 10
 
 
+PIECES = int(os.environ.get("CV_LAYER_PIECES", "2"))      # 2: fp16 pairs (the default program's format), 3: bf16 triples
+
+
 def timed(x_feats, weight, nbr, n_out, **kw):
+    kw.setdefault("pieces", PIECES)
     w = weight if weight.dim() == 3 else weight[None]
     K, cin, cout = w.shape
     for _ in range(2):
