@@ -376,9 +376,21 @@ __device__ __forceinline__ double acc_value(unsigned long long q, int i) {
     return i < TCELLS ? __longlong_as_double((long long)q) : fx_value(q);
 }
 
+// LDS layout of the tile accumulators: word of (channel ch, cell (cx, cz)) = ch * ACC_CH + cx * ACC_PITCH + cz.
+// With a pitch of 32 words the bank of a cell (64 banks x 4 B, a 64-bit word takes two) depended on cz alone, so the
+// lanes of one atomic instruction whose votes spread along x - a ring crossing the tile, the cluster around a Hough
+// peak - serialised on one bank.  Pitch 40: +1 in z = 2 banks, +1 in x = 80 = 16 banks (mod 64): every cell of a 4x4
+// neighbourhood has its own bank.  Vote op 0.512 -> 0.447 ms on the network's predictions (pitches 34 / 36 / 40 / 44:
+// 0.457 / 0.445 / 0.447 / 0.443).  Measured and dropped: walking the (corner, channel) slots of a vote in a per-lane
+// rotated order so that lanes voting into the SAME cell hit different words in different banks at any one instruction -
+// 0.62 ms (same-address lanes of one ds_add are evidently merged more cheaply than 24 rotated selects cost), rotating
+// the channel order only - 0.45 / 0.47 ms (no gain).
+constexpr int ACC_PITCH = TZ + 8, ACC_CH = TX * ACC_PITCH + 4, ACC_WORDS = 6 * ACC_CH;
+__device__ __forceinline__ int acc_idx(int ch, int cell) { return ch * ACC_CH + (cell >> 5) * ACC_PITCH + (cell & 31); }
+
 struct TileShared {
-    unsigned long long acc[6][TCELLS];   // [0]: objectness weight as f64 BITS; [1..5]: rot.cos, rot.sin, scale.xyz in
-                                         // 2^-36 fixed point (SoA: random banks per lane)
+    unsigned long long acc[ACC_WORDS];   // channel 0: objectness weight as f64 BITS; 1..5: rot.cos, rot.sin, scale.xyz
+                                         // in 2^-36 fixed point
     float pq[TW][9][PQ];       // px, pz, cx, cz, wy, obj, s0, s1, s2 of surviving points
     int arc_start[TW][PQ];     // first rotation whose vote can reach the tile
     int arc_cum[TW][PQ];       // inclusive prefix sum of the arc lengths
@@ -401,13 +413,13 @@ __device__ __forceinline__ void drain_vote(TileShared& sh, int lx, int lz, float
             if (cxl < 0 || cxl >= TX || czl < 0 || czl >= TZ) continue;
             // hv_cuda_kernel.cu:52-59 order: ((wx*wy)*wz)*objness
             const float w = wx[bx] * wy * wz[bz] * ob;
-            const int cell = cxl * TZ + czl;
-            lds_add_f64(&sh.acc[0][cell], w);
-            lds_add<SMALL>(&sh.acc[1][cell], w * cs.x);
-            lds_add<SMALL>(&sh.acc[2][cell], w * cs.y);
-            lds_add<SMALL>(&sh.acc[3][cell], w * s0);
-            lds_add<SMALL>(&sh.acc[4][cell], w * s1);
-            lds_add<SMALL>(&sh.acc[5][cell], w * s2);
+            unsigned long long* a = sh.acc + cxl * ACC_PITCH + czl;
+            lds_add_f64(a, w);
+            lds_add<SMALL>(a + ACC_CH, w * cs.x);
+            lds_add<SMALL>(a + 2 * ACC_CH, w * cs.y);
+            lds_add<SMALL>(a + 3 * ACC_CH, w * s0);
+            lds_add<SMALL>(a + 4 * ACC_CH, w * s1);
+            lds_add<SMALL>(a + 5 * ACC_CH, w * s2);
         }
 }
 
@@ -479,7 +491,7 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     const int x0 = (tile / tiles_z) * TX, z0 = (tile % tiles_z) * TZ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) (&sh.acc[0][0])[i] = 0ull;
+    for (int i = threadIdx.x; i < ACC_WORDS; i += TW * 64) sh.acc[i] = 0ull;
     for (int i = threadIdx.x; i < R; i += TW * 64) sh.tab[i] = tab[i];
     if (threadIdx.x < 2) sh.next_chunk[threadIdx.x] = 0;
     __syncthreads();
@@ -649,7 +661,7 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
             if (vq_len > 0) {
                 if (VARIANT != 1) drain64(sh, wave, lane, lane < vq_len);
                 else if (lane < vq_len)
-                    sh.acc[1][lane] = (unsigned long long)(sh.vq_rx[wave][lane] + sh.vq_rz[wave][lane] + (float)sh.vq_rec[wave][lane]);
+                    sh.acc[ACC_CH + lane] = (unsigned long long)(sh.vq_rx[wave][lane] + sh.vq_rz[wave][lane] + (float)sh.vq_rec[wave][lane]);
                 vq_len = 0;
             }
             wave_sync_lds();
@@ -664,7 +676,8 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
         // publish this part's tile, the last arriver sums the parts in part order (deterministic):
         // plain stores -> per-wave vmcnt(0) -> barrier -> one-lane agent release -> ticket.
         float* mine = partials + ((int64_t)q * ntiles + tile) * (6 * TCELLS);
-        for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) mine[i] = (float)acc_value((&sh.acc[0][0])[i], i);
+        for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64)
+            mine[i] = (float)acc_value(sh.acc[acc_idx(i / TCELLS, i % TCELLS)], i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -681,8 +694,8 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
         for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) {
             double sum = 0.0;
             for (int p2 = 0; p2 < nparts; ++p2) sum += (double)base[(int64_t)p2 * ntiles * (6 * TCELLS) + i];
-            (&sh.acc[0][0])[i] = i < TCELLS ? (unsigned long long)__double_as_longlong(sum)
-                                            : (unsigned long long)__double2ll_rn(sum * FX_SCALE);
+            sh.acc[acc_idx(i / TCELLS, i % TCELLS)] = i < TCELLS ? (unsigned long long)__double_as_longlong(sum)
+                                                                 : (unsigned long long)__double2ll_rn(sum * FX_SCALE);
         }
         __syncthreads();
     }
@@ -691,30 +704,30 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     // reference divides by is the fp32 grid value, so round the double sum to float first.
     const int nx = min(TX, X - x0), nz = min(TZ, Z - z0);
     if (VARIANT == 5) {                       // ablation: no normalise / store
-        if (threadIdx.x == 0) g_obj[((int64_t)x0 * Y + y) * Z + z0] = (float)acc_value(sh.acc[0][0], 0);
+        if (threadIdx.x == 0) g_obj[((int64_t)x0 * Y + y) * Z + z0] = (float)acc_value(sh.acc[0], 0);
         return;
     }
     for (int i = threadIdx.x; i < TCELLS; i += TW * 64) {
         const int lx = i / TZ, lz = i % TZ;
         if (lx < nx && lz < nz)
-            g_obj[((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz] = (float)acc_value(sh.acc[0][i], 0);
+            g_obj[((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz] = (float)acc_value(sh.acc[acc_idx(0, i)], 0);
     }
     for (int i = threadIdx.x; i < TCELLS * 2; i += TW * 64) {
         const int cell = i >> 1, j = i & 1;
         const int lx = cell / TZ, lz = cell % TZ;
         if (lx < nx && lz < nz) {
-            const double d = (double)(float)acc_value(sh.acc[0][cell], 0) + 1e-7;
+            const double d = (double)(float)acc_value(sh.acc[acc_idx(0, cell)], 0) + 1e-7;
             g_rot[(((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz) * 2 + j] =
-                (float)((double)(float)fx_value(sh.acc[1 + j][cell]) / d);
+                (float)((double)(float)fx_value(sh.acc[acc_idx(1 + j, cell)]) / d);
         }
     }
     for (int i = threadIdx.x; i < TCELLS * 3; i += TW * 64) {
         const int cell = i / 3, j = i - cell * 3;
         const int lx = cell / TZ, lz = cell % TZ;
         if (lx < nx && lz < nz) {
-            const double d = (double)(float)acc_value(sh.acc[0][cell], 0) + 1e-7;
+            const double d = (double)(float)acc_value(sh.acc[acc_idx(0, cell)], 0) + 1e-7;
             g_scale[(((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz) * 3 + j] =
-                (float)((double)(float)fx_value(sh.acc[3 + j][cell]) / d);
+                (float)((double)(float)fx_value(sh.acc[acc_idx(3 + j, cell)]) / d);
         }
     }
     HV_TICK(7);
