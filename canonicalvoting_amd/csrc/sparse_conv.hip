@@ -1309,7 +1309,11 @@ struct WgradPlan {
     int task_end[WG_MAX_K];       // by rank: cumulative (splits x ci blocks x co blocks)
 };
 
-template <int NB>
+// X6: the 16 rows of a step group are ONE K = 16 bf16 MFMA group: the eight values a lane holds for the steps t = 0..7
+// (row 2t + half) are exactly its eight k slots (k = 8 * half + t, the same rows on the A and the B side), so the
+// fp32 operands are split into bf16 triples in registers and six piece products replace eight fp32 MFMAs per nb
+// (see conv_rows_x6; gradients keep the fp32 exponent range, which fp16 pairs would not).
+template <int NB, bool X6>
 __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ x, int x_ld, int cin,
                                                       const float* __restrict__ dy, int dy_ld, int cout,
                                                       const int* __restrict__ nbr, int K, long long n_out,
@@ -1375,12 +1379,39 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
                     nsteps = t + 1;
                 }
             }
+            if constexpr (X6) {
+                static_assert(STEPS == 8, "one bf16 MFMA group = 8 k slots per lane");
+                unsigned ap[3][4];
 #pragma unroll
-            for (int t = 0; t < STEPS; ++t)
-                if (t < nsteps)
+                for (int q = 0; q < 4; ++q) split3(av[2 * q], av[2 * q + 1], ap[0][q], ap[1][q], ap[2][q]);
+                bf16x8 a3[3];
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb)
-                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t][nb], acc[nb], 0, 0, 0);
+                for (int pc = 0; pc < 3; ++pc)
+                    a3[pc] = __builtin_bit_cast(bf16x8, make_uint4(ap[pc][0], ap[pc][1], ap[pc][2], ap[pc][3]));
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    unsigned bp[3][4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) split3(bv[2 * q][nb], bv[2 * q + 1][nb], bp[0][q], bp[1][q], bp[2][q]);
+                    bf16x8 b3[3];
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        b3[pc] = __builtin_bit_cast(bf16x8, make_uint4(bp[pc][0], bp[pc][1], bp[pc][2], bp[pc][3]));
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[2], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[2], b3[0], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[1], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[1], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[0], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[0], acc[nb], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < STEPS; ++t)
+                    if (t < nsteps)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t][nb], acc[nb], 0, 0, 0);
+            }
         }
     }
     float* p = partial + (long long)(plan.first[j] + split) * cin * cout;
@@ -1658,14 +1689,27 @@ __global__ __launch_bounds__(256) void bn_col_reduce(const float* __restrict__ x
 
 // MODE 0: mean/var from the partials, running statistics update (momentum, unbiased variance), folded
 // scale/shift for the apply pass.  MODE 1: out0 = sum dy' (d beta), out1 = sum dy'*xhat (d gamma).
+// 16 lanes per channel: each sums every 16th chunk (independent loads in flight instead of one thread walking 256
+// dependent ones: 23 -> a few us per call, 124 calls per training step), then a fixed-order butterfly.
 template <int MODE>
-__global__ void bn_col_finish(const double* __restrict__ partial, int chunks, long long n, int c, float* out0,
-                              float* out1, float* running_mean, float* running_var, float momentum,
-                              const float* gamma, const float* beta, float eps, float* scale, float* shift) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= c) return;
+__global__ __launch_bounds__(256) void bn_col_finish(const double* __restrict__ partial, int chunks, long long n, int c,
+                                                     float* out0, float* out1, float* running_mean, float* running_var,
+                                                     float momentum, const float* gamma, const float* beta, float eps,
+                                                     float* scale, float* shift) {
+    const int sub = threadIdx.x & 15;
+    const int k = blockIdx.x * 16 + (threadIdx.x >> 4);
     double t0 = 0.0, t1 = 0.0;
-    for (int q = 0; q < chunks; ++q) { t0 += partial[((long long)q * c + k) * 2]; t1 += partial[((long long)q * c + k) * 2 + 1]; }
+    if (k < c)
+        for (int q = sub; q < chunks; q += 16) {
+            t0 += partial[((long long)q * c + k) * 2];
+            t1 += partial[((long long)q * c + k) * 2 + 1];
+        }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+        t0 += __shfl_xor(t0, off);
+        t1 += __shfl_xor(t1, off);
+    }
+    if (k >= c || sub != 0) return;
     if (MODE == 0) {
         const double mu = t0 / (double)n;
         double v = t1 / (double)n - mu * mu;
@@ -2183,12 +2227,20 @@ int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy,
     float* partial = static_cast<float*>(d_ws);
     // any Cin: channels beyond Cin are zero lanes of the 32-wide A operand (stem: Cin = 3)
     const unsigned grid = (unsigned)((plan.task_end[K - 1] + 3) / 4);
+    // CV_WGRAD_X6=0: exact fp32 products on v_mfma_f32_32x32x2_f32 instead of six bf16 piece products
+    static const bool x6 = !(getenv("CV_WGRAD_X6") && atoi(getenv("CV_WGRAD_X6")) == 0);
+#define CV_WGRAD_LAUNCH(NBV)                                                                                         \
+    do {                                                                                                             \
+        if (x6) conv_wgrad<NBV, true><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); \
+        else conv_wgrad<NBV, false><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial);   \
+    } while (0)
     switch (nb_full(cout)) {
-        case 1: conv_wgrad<1><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); break;
-        case 2: conv_wgrad<2><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); break;
-        case 3: conv_wgrad<3><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); break;
-        default: conv_wgrad<4><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); break;
+        case 1: CV_WGRAD_LAUNCH(1); break;
+        case 2: CV_WGRAD_LAUNCH(2); break;
+        case 3: CV_WGRAD_LAUNCH(3); break;
+        default: CV_WGRAD_LAUNCH(4); break;
     }
+#undef CV_WGRAD_LAUNCH
     CV_LAUNCH_CHECK();
     const long long per = (long long)K * cin * cout;
     wgrad_reduce<<<(unsigned)((per + 255) / 256), 256, 0, st>>>(partial, cin * cout, K, plan, d_dw);
@@ -2245,7 +2297,7 @@ int cv_sp_bn_stats_f32(const float* d_x, long long n, int c, int ld, const float
     dim3 grid((unsigned)((c + 31) / 32), (unsigned)chunks);
     bn_col_reduce<0><<<grid, 256, 0, st>>>(d_x, nullptr, nullptr, n, c, ld, nullptr, nullptr, eps, partial);
     CV_LAUNCH_CHECK();
-    bn_col_finish<0><<<(c + 127) / 128, 128, 0, st>>>(partial, chunks, n, c, d_mean, d_var, d_running_mean,
+    bn_col_finish<0><<<(c + 15) / 16, 256, 0, st>>>(partial, chunks, n, c, d_mean, d_var, d_running_mean,
                                                      d_running_var, momentum, d_gamma, d_beta, eps, d_scale, d_shift);
     CV_LAUNCH_CHECK();
     return CV_OK;
@@ -2266,7 +2318,7 @@ int cv_sp_bn_backward_f32(const float* d_x, const float* d_dy, const float* d_y,
     dim3 grid((unsigned)((c + 31) / 32), (unsigned)chunks);
     bn_col_reduce<1><<<grid, 256, 0, st>>>(d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, partial);
     CV_LAUNCH_CHECK();
-    bn_col_finish<1><<<(c + 127) / 128, 128, 0, st>>>(partial, chunks, n, c, d_dbeta, d_dgamma, nullptr, nullptr, 0.f,
+    bn_col_finish<1><<<(c + 15) / 16, 256, 0, st>>>(partial, chunks, n, c, d_dbeta, d_dgamma, nullptr, nullptr, 0.f,
                                                      nullptr, nullptr, eps, nullptr, nullptr);
     CV_LAUNCH_CHECK();
     bn_backward_apply<<<(unsigned)std::min<long long>((n * c + 255) / 256, 8192), 256, 0, st>>>(
