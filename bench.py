@@ -52,15 +52,15 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--scenes", type=int, default=4, help="distinct resident scenes per rank")
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--algo", type=int, default=0, help="vote algorithm: 0 auto, 1 direct, 2 tiles")
     ap.add_argument("--cpu-scenes", type=int, default=1, help="scenes timed on the CPU oracle (0 = skip)")
     ap.add_argument("--stage", default="full", choices=["vote_decode", "full"],
                     help="full = MinkUNet34C forward + head + vote + decode + NMS (eval_joint.py path)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=6,
                     help="scenes in flight per GPU: S host threads, each with its own HIP stream, take the steps "
                          "round-robin (scenes are independent; fills the launch tails and host syncs of one scene "
                          "with the kernels of another)")

@@ -9,5 +9,5 @@ python bench.py --teacher-forced --streams 1 --cpu-scenes 0 2>/dev/null | tail -
 python bench.py --mode train --steps 10 --warmup 2 2>/dev/null | tail -1 > $O/bench_train.json
 python profiles/layer_times.py 2>&1 | tail -66 > $O/layer_times.txt
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python $GRAFT_REPO_ROOT/bench.py --streams 1 --steps 10 --warmup 3 --cpu-scenes 0 > /tmp/p1.log 2>&1; f=$(find /tmp/p1 -name "*kernel_stats.csv" | head -1); cp "$f" $O/full_path_kernel_stats.csv)
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p3 -- python $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 3 --cpu-scenes 0 > /tmp/p3.log 2>&1; f=$(find /tmp/p3 -name "*kernel_stats.csv" | head -1); cp "$f" $O/full_path_kernel_stats_streams3.csv)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p3 -- python $GRAFT_REPO_ROOT/bench.py --steps 24 --warmup 6 --cpu-scenes 0 > /tmp/p3.log 2>&1; f=$(find /tmp/p3 -name "*kernel_stats.csv" | head -1); cp "$f" $O/full_path_kernel_stats_streams6.csv)
 ls -la $O
