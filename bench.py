@@ -70,6 +70,11 @@ def parse():
                          "(fwd + bwd + Adam, fp32) on --train-batch scenes per GPU-step, DDP gradient all-reduce over "
                          "RCCL when launched on several GPUs (BASELINE configs 3-4; a side measurement, not the "
                          "headline metric)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="product precision of the sparse convolutions.  f32 (default, the parity path): fp32-level "
+                         "products on the 16-bit matrix cores (fp16 pairs / bf16 triples).  bf16: operands rounded to "
+                         "bf16, one product, fp32 accumulation and storage (BASELINE configs 3-4 name bf16 for "
+                         "training; outside the 1e-4 parity bar, reported as dtype bf16)")
     ap.add_argument("--train-batch", type=int, default=3, help="scenes per GPU-step in --mode train (config.yaml:15)")
     ap.add_argument("--large", action="store_true",
                     help="BASELINE config 5 shaped scenes: 9x3x9 m room, 40 boxes (use with --points 300000)")
@@ -176,6 +181,7 @@ def main_train(a):
     xyz = torch.cat([torch.from_numpy(s.xyz_labels) for s in scenes]).to(dev)
     scale = torch.cat([torch.from_numpy(s.scale_labels) for s in scenes]).to(dev)
     cls = torch.cat([torch.from_numpy(s.class_labels) for s in scenes]).to(dev)
+    ME.set_compute_dtype("bf16" if a.dtype == "bf16" else "fp32")
     torch.manual_seed(0)
     model = MinkUNet34C(3, 6 * 9 + 9 + 1).cuda().train()
     net = train.make_ddp(model, dev) if world > 1 else model
@@ -193,9 +199,10 @@ def main_train(a):
             "metric": "scenes/sec (train_joint.py step: fwd + bwd + Adam, 80k-pt synthetic scans)",
             "value": a.steps * B * world / dt, "unit": "scenes/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": "train_joint.py step on %d x %d-point synthetic scenes per GPU-step, MinkUNet34C(3, 64) "
-                                   "fp32, Adam lr 1e-3" % (B, n),
+                                   "%s, Adam lr 1e-3" % (B, n, "bf16 conv products, fp32 accumulation / storage / "
+                                                         "BatchNorm / optimizer" if a.dtype == "bf16" else "fp32"),
                        "parallelism": "scene-parallel DDP x%d (RCCL gradient all-reduce, per-GPU BatchNorm statistics)"
                                       % world if world > 1 else "single GPU"},
             "final_loss": float(loss)}), flush=True)
@@ -213,6 +220,7 @@ def main():
     cvd.init("nccl", dev)
     _lib.lib()
     hv_cuda.set_algorithm(a.algo)
+    ME.set_compute_dtype("bf16" if a.dtype == "bf16" else "fp32")
     hv = HoughVoting(RES, NUM_ROTS)
     full = a.stage == "full"
     model = None
@@ -303,7 +311,8 @@ def main():
     tj = os.path.join(ROOT, "profiles", "r1", "vote_hbm_traffic.json")
     if os.path.exists(tj) and a.points == N_POINTS and not a.large and a.algo in (0, 2):
         traffic = json.load(open(tj))["hbm_bytes_per_launch"]
-    pieces_n = 3 if (full and model.USE_PROGRAM and model.PIECES == 2) else 6
+    conv_peak = 2500.0 if a.dtype == "bf16" else 157.3       # dense bf16 / fp32 matrix peak, TFLOP/s
+    pieces_n = 1 if a.dtype == "bf16" else 3 if (full and model.USE_PROGRAM and model.PIECES == 2) else 6
     out = {
         "metric": "scenes/sec (80k-pt synthetic scans)",
         "value": cvd.throughput(a.steps, world, dt),
@@ -315,11 +324,12 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": a.dtype,
         "data": "synthetic",
         "config": {"workload": ("single %d-point synthetic scene per GPU-step, eval_joint.py path: "
-                                "HIP sparse MinkUNet34C forward (fp32, random init) + head + HIP vote "
-                                "accumulation + decode + NMS" % a.points) if full else
+                                "HIP sparse MinkUNet34C forward (%s, random init) + head + HIP vote "
+                                "accumulation + decode + NMS" % (a.points, "bf16 conv products" if a.dtype == "bf16"
+                                                                 else "fp32")) if full else
                                ("single %d-point synthetic scene per GPU-step: vote + decode + NMS only "
                                 "(synthesised predictions)" % a.points),
                    "predictions": "synthesised from labels (teacher-forced)" if (a.teacher_forced or not full)
@@ -335,14 +345,16 @@ def main():
                      "measured_in": roofline_pass},
         "roofline_conv": None if not full else {
             "bound": "mfma", "kernel": "sparse MinkUNet34C forward (all conv launches + coordinate manager)",
-            "achieved": net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-            "frac": net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12 / 157.3,
+            "achieved": net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12, "peak": conv_peak, "unit": "TFLOP/s",
+            "frac": net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12 / conv_peak,
             "flops_per_forward": net_flops[0], "dense_equivalent_flops": net_flops[1],
             "piece_products_per_fp32_product": pieces_n if ME.CONV_X6 else None,
             "piece_flops_per_forward": pieces_n * net_flops[0] if ME.CONV_X6 else None,
             "frac_of_16bit_matrix_peak": (pieces_n * net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12 / 2500.0) if ME.CONV_X6 else None,
             "range_fallbacks": int(getattr(model, "range_fallbacks", 0)),
-            "note": (("fp32 results; every fp32 product is computed as three exact fp16 x fp16 piece products "
+            "note": ("opt-in bf16 compute mode: operands rounded to bf16, one product on v_mfma_f32_32x32x16_bf16, fp32 "
+                     "accumulation and storage; outside the 1e-4 parity bar; " if pieces_n == 1 else
+                     ("fp32 results; every fp32 product is computed as three exact fp16 x fp16 piece products "
                       "(operands split h+l: 22 significant bits and the sign of l; weights pre-scaled by a power of two) "
                       "on v_mfma_f32_32x32x16_f16 with fp32 accumulation; a convolution input beyond the fp16 range "
                       "raises a flag and the scene is redone on the bf16 triples (range_fallbacks); "
@@ -352,7 +364,7 @@ def main():
                       "matrix time of v_mfma_f32_32x32x2_f32 at fp32-level accuracy; ") if ME.CONV_X6 else
                      "fp32 matrix cores (v_mfma_f32_32x32x2_f32); ") +
                     "achieved counts only existing (input,output) pairs, sum 2*P*Cin*Cout over the 63 conv layers, "
-                    "against the fp32 matrix peak"},
+                    "against the %s matrix peak" % ("bf16" if a.dtype == "bf16" else "fp32")},
         "detections_per_scene": n_det / a.steps,
         "stage_ms": stage_ms,
         "stage_ms_measured_in": roofline_pass,

@@ -100,6 +100,7 @@ SIGNATURES = {
     "cv_sp_tile_plan": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, vp, vp, vp]),
     "cv_sp_pack_weights_x6_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     "cv_sp_pack_weights_h2_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
+    "cv_sp_pack_weights_bf16_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     "cv_sp_tile_kw": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "cv_sp_pack_weights_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_scene_maps_words": (ctypes.c_size_t, [c_i64_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
@@ -119,6 +120,9 @@ SIGNATURES = {
     "cv_sp_wgrad_workspace_bytes": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "cv_sp_conv_wgrad_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp,
                                             ctypes.c_int, ctypes.c_longlong, vp, vp, ctypes.c_size_t, vp]),
+    "cv_sp_conv_wgrad_px_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp,
+                                               ctypes.c_int, ctypes.c_longlong, vp, vp, ctypes.c_size_t, ctypes.c_int,
+                                               vp]),
     "cv_sp_col_sum_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_bn_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "cv_sp_bn_stats_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_float,

@@ -397,7 +397,28 @@ __global__ __launch_bounds__(256) void pack_weights_x6(const float* __restrict__
     }
 }
 
+// one bf16 plane (RNE): ((j*nch + c)*cout + col)*32 + k
+__global__ __launch_bounds__(256) void pack_weights_b1(const float* __restrict__ w, int K, int cin, int cout,
+                                                       const float* __restrict__ col_scale,
+                                                       unsigned short* __restrict__ wp) {
+    const long long total = (long long)K * cin * cout / 2;
+    const int nch = cin / 32;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long r = i;
+        const int k2 = (int)(r % 16); r /= 16;
+        const int col = (int)(r % cout); r /= cout;
+        const int c = (int)(r % nch); r /= nch;
+        const int j = (int)r;
+        const float* p = w + ((long long)j * cin + c * 32 + 2 * k2) * cout + col;
+        const float sc = col_scale ? col_scale[col] : 1.f;
+        *reinterpret_cast<unsigned*>(wp + ((long long)(j * nch + c) * cout + col) * 32 + 2 * k2) =
+            cvt_pk_bf16(p[0] * sc, p[cout] * sc);
+    }
+}
+
 // P = 3: bf16 triples, six piece products.  P = 2: fp16 pairs, three piece products (same tiles with two planes).
+// P = 1: operands rounded to bf16 (RNE), ONE bf16 x bf16 product with fp32 accumulation - the opt-in bf16 compute
+// mode of the training configuration (BASELINE configs 3-4); not an fp32-parity path.
 template <int NB, int P>
 __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
     // operand tiles and the epilogue tile share one buffer (the epilogue starts after the last MFMA)
@@ -445,7 +466,9 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
                 for (int p = 0; p < P; ++p)
                     bv[p] = *reinterpret_cast<const bf16x8*>(B_h + (p * NB * 32 + nb * 32 + l31) * 64 + ((chunk ^ bswz) << 4));
                 // smallest terms first
-                if constexpr (P == 3) {
+                if constexpr (P == 1) {
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc[nb], 0, 0, 0);
+                } else if constexpr (P == 3) {
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[2], acc[nb], 0, 0, 0);
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[0], acc[nb], 0, 0, 0);
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1], acc[nb], 0, 0, 0);
@@ -501,7 +524,9 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
                 unsigned h0 = 0, m0 = 0, l0 = 0, h1 = 0, m1 = 0, l1 = 0;
                 // channels a_col .. a_col+3 -> 8 bytes at offset (a_col & 7) * 2 of chunk a_col >> 3
                 unsigned char* dst = A_h + r * 64 + ((((a_col >> 3) ^ ((r >> 2) & 3))) << 4) + ((a_col & 7) << 1);
-                if constexpr (P == 3) {
+                if constexpr (P == 1) {
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pk_bf16(ra[i].x, ra[i].y), cvt_pk_bf16(ra[i].z, ra[i].w));
+                } else if constexpr (P == 3) {
                     if (!(a.dbg & 16)) {
                         split3(ra[i].x, ra[i].y, h0, m0, l0);
                         split3(ra[i].z, ra[i].w, h1, m1, l1);
@@ -1313,7 +1338,7 @@ struct WgradPlan {
 // (row 2t + half) are exactly its eight k slots (k = 8 * half + t, the same rows on the A and the B side), so the
 // fp32 operands are split into bf16 triples in registers and six piece products replace eight fp32 MFMAs per nb
 // (see conv_rows_x6; gradients keep the fp32 exponent range, which fp16 pairs would not).
-template <int NB, bool X6>
+template <int NB, int PIECES>      // 0: fp32 MFMA; 3: bf16 triples, six piece products; 1: operands rounded to bf16, one product
 __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ x, int x_ld, int cin,
                                                       const float* __restrict__ dy, int dy_ld, int cout,
                                                       const int* __restrict__ nbr, int K, long long n_out,
@@ -1379,7 +1404,18 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
                     nsteps = t + 1;
                 }
             }
-            if constexpr (X6) {
+            if constexpr (PIECES == 1) {
+                static_assert(STEPS == 8, "one bf16 MFMA group = 8 k slots per lane");
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, make_uint4(cvt_pk_bf16(av[0], av[1]), cvt_pk_bf16(av[2], av[3]),
+                                                                        cvt_pk_bf16(av[4], av[5]), cvt_pk_bf16(av[6], av[7])));
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const bf16x8 b1 = __builtin_bit_cast(
+                        bf16x8, make_uint4(cvt_pk_bf16(bv[0][nb], bv[1][nb]), cvt_pk_bf16(bv[2][nb], bv[3][nb]),
+                                           cvt_pk_bf16(bv[4][nb], bv[5][nb]), cvt_pk_bf16(bv[6][nb], bv[7][nb])));
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[nb], 0, 0, 0);
+                }
+            } else if constexpr (PIECES == 3) {
                 static_assert(STEPS == 8, "one bf16 MFMA group = 8 k slots per lane");
                 unsigned ap[3][4];
 #pragma unroll
@@ -1805,6 +1841,7 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
     static const bool prof_on = getenv("CV_CONV_PROF") != nullptr;
     if (vec && a.wp6 && (!prof_on || a.in2)) {
         if (a.pieces == 2) conv_rows_x6<NB, 2><<<grid, THREADS, 0, st>>>(a);
+        else if (a.pieces == 1) conv_rows_x6<NB, 1><<<grid, THREADS, 0, st>>>(a);
         else conv_rows_x6<NB, 3><<<grid, THREADS, 0, st>>>(a);
         CV_LAUNCH_CHECK();
         if (a.splits > 1) return launch_finish(a, st);
@@ -1954,10 +1991,12 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
                d->acc_in, d->acc_ld, d->plan_ent, d->plan_cnt,
                reinterpret_cast<const float4*>(d->weight_packed), 0, nullptr, 0, 0,
                static_cast<const unsigned short*>(d->weight_x6), d->in2, d->in2_ld, d->cin2,
-               static_cast<const unsigned short*>(d->weight2_x6), d->weight_pieces == 2 ? 2 : 3,
+               static_cast<const unsigned short*>(d->weight2_x6), d->weight_pieces == 2 ? 2 : d->weight_pieces == 1 ? 1 : 3,
                d->acc_scale != 0.f ? d->acc_scale : 1.f, d->range_flag};
-    CV_REQUIRE(d->weight_pieces == 0 || d->weight_pieces == 2 || d->weight_pieces == 3, CV_EINVAL,
-               "weight_pieces is 0/3 (bf16 triples) or 2 (fp16 pairs)");
+    CV_REQUIRE(d->weight_pieces >= 0 && d->weight_pieces <= 3, CV_EINVAL,
+               "weight_pieces is 0/3 (bf16 triples), 2 (fp16 pairs) or 1 (single bf16 product)");
+    CV_REQUIRE(d->weight_pieces != 1 || (d->weight_x6 && d->cin % KC == 0), CV_EINVAL,
+               "weight_pieces = 1 needs weight_x6 from cv_sp_pack_weights_bf16_f32 and Cin %% 32 == 0");
     CV_REQUIRE(d->weight_pieces != 2 || (d->weight_x6 && d->cin % KC == 0), CV_EINVAL,
                "weight_pieces = 2 needs weight_x6 from cv_sp_pack_weights_h2_f32 and Cin %% 32 == 0");
 
@@ -2135,6 +2174,21 @@ int cv_sp_pack_weights_x6_f32(const float* d_w, int K, int cin, int cout, const 
     return CV_OK;
 }
 
+// d_wp[K*cin*cout] (16-bit words) = d_w * d_col_scale rounded to bf16 (RNE), laid out per (offset, 32-channel
+// chunk) as [cout][32 channels] (cv_conv_desc.weight_pieces = 1: the opt-in bf16 compute mode).
+int cv_sp_pack_weights_bf16_f32(const float* d_w, int K, int cin, int cout, const float* d_col_scale, void* d_wp,
+                                void* stream) {
+    CV_REQUIRE(d_w && d_wp && K > 0 && cin > 0 && cout > 0, CV_EINVAL, "bad pack_weights_bf16 arguments");
+    CV_REQUIRE(cin % 32 == 0, CV_EINVAL, "pack_weights_bf16 needs Cin %% 32 == 0 (got %d)", cin);
+    CV_REQUIRE((reinterpret_cast<uintptr_t>(d_wp) & 15) == 0, CV_EINVAL, "d_wp must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long total = (long long)K * cin * cout / 2;
+    pack_weights_b1<<<(unsigned)std::min<long long>((total + 255) / 256, 8192), 256, 0, st>>>(
+        d_w, K, cin, cout, d_col_scale, static_cast<unsigned short*>(d_wp));
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
 // d_wp[2*K*cin*cout] (16-bit words) = d_w * d_col_scale * 2^scale_log2 split into two fp16 pieces per value, laid
 // out per (offset, 32-channel chunk) as [piece][cout][32 channels] (cv_conv_desc.weight_pieces = 2; pass
 // acc_scale = 2^-scale_log2).  Choose scale_log2 so that the largest scaled magnitude is about 2^13: the low pieces
@@ -2213,9 +2267,9 @@ size_t cv_sp_wgrad_workspace_bytes(long long n_out, int cin, int cout, int K) {
     return 256 + sizeof(float) * (size_t)wgrad_plan(n_out, cin, cout, K, nullptr) * (size_t)cin * cout;
 }
 
-int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy, int dy_ld, int cout,
-                         const int32_t* d_nbr, int K, long long n_out, float* d_dw, void* d_ws, size_t ws_bytes,
-                         void* stream) {
+int cv_sp_conv_wgrad_px_f32(const float* d_x, int x_ld, int cin, const float* d_dy, int dy_ld, int cout,
+                            const int32_t* d_nbr, int K, long long n_out, float* d_dw, void* d_ws, size_t ws_bytes,
+                            int pieces, void* stream) {
     CV_REQUIRE(d_x && d_dy && d_dw && d_ws, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(n_out > 0 && cin > 0 && cout > 0 && K > 0 && x_ld >= cin && dy_ld >= cout, CV_EINVAL, "bad wgrad sizes");
     CV_REQUIRE(K <= WG_MAX_K, CV_EINVAL, "kernel volume above 128 is not supported");
@@ -2227,12 +2281,13 @@ int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy,
     float* partial = static_cast<float*>(d_ws);
     // any Cin: channels beyond Cin are zero lanes of the 32-wide A operand (stem: Cin = 3)
     const unsigned grid = (unsigned)((plan.task_end[K - 1] + 3) / 4);
-    // CV_WGRAD_X6=0: exact fp32 products on v_mfma_f32_32x32x2_f32 instead of six bf16 piece products
-    static const bool x6 = !(getenv("CV_WGRAD_X6") && atoi(getenv("CV_WGRAD_X6")) == 0);
+    CV_REQUIRE(pieces == 0 || pieces == 1 || pieces == 3, CV_EINVAL,
+               "pieces is 0 (fp32 MFMA), 3 (six bf16 piece products per fp32 product) or 1 (one bf16 product)");
 #define CV_WGRAD_LAUNCH(NBV)                                                                                         \
     do {                                                                                                             \
-        if (x6) conv_wgrad<NBV, true><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); \
-        else conv_wgrad<NBV, false><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial);   \
+        if (pieces == 3) conv_wgrad<NBV, 3><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); \
+        else if (pieces == 1) conv_wgrad<NBV, 1><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); \
+        else conv_wgrad<NBV, 0><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial);   \
     } while (0)
     switch (nb_full(cout)) {
         case 1: CV_WGRAD_LAUNCH(1); break;
@@ -2246,6 +2301,15 @@ int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy,
     wgrad_reduce<<<(unsigned)((per + 255) / 256), 256, 0, st>>>(partial, cin * cout, K, plan, d_dw);
     CV_LAUNCH_CHECK();
     return CV_OK;
+}
+
+int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy, int dy_ld, int cout,
+                         const int32_t* d_nbr, int K, long long n_out, float* d_dw, void* d_ws, size_t ws_bytes,
+                         void* stream) {
+    // CV_WGRAD_X6=0: exact fp32 products on v_mfma_f32_32x32x2_f32 instead of six bf16 piece products
+    static const bool x6 = !(getenv("CV_WGRAD_X6") && atoi(getenv("CV_WGRAD_X6")) == 0);
+    return cv_sp_conv_wgrad_px_f32(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, d_dw, d_ws, ws_bytes,
+                                   x6 ? 3 : 0, stream);
 }
 
 int cv_sp_col_sum_f32(const float* d_x, long long n, int c, int ld, float* d_out, void* stream) {

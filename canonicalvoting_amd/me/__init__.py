@@ -336,9 +336,12 @@ def range_flag(dev):
 
 def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=None, relu=False,
                  out=None, flavour=0, row_perm=None, j_begin=0, j_end=0, acc_in=None, perm_groups=0,
-                 cache_weights=True, pieces=3):
+                 cache_weights=True, pieces=None):
     """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout].
-    pieces=2: fp16-pair products (weights packed per call; the caller reads range_flag(dev) after synchronising)."""
+    pieces=2: fp16-pair products (weights packed per call; the caller reads range_flag(dev) after synchronising);
+    pieces=1: single bf16 products (the opt-in bf16 compute mode); None: 1 under COMPUTE_DTYPE == "bf16", else 3."""
+    if pieces is None:
+        pieces = 1 if COMPUTE_DTYPE == "bf16" else 3
     L = _lib.lib()
     dev = x_feats.device
     w = weight if weight.dim() == 3 else weight[None]
@@ -373,6 +376,8 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
                         _packed_h2.clear()
                     _packed_h2[key] = hit
             wp6, acc_scale, flag = hit[1], 2.0 ** -hit[2], range_flag(dev)
+        elif pieces == 1:
+            wp6 = packed_weights_bf16(w)
         else:
             wp6 = packed_weights_x6(weight, w, cache_weights)
     ws = None
@@ -389,7 +394,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
                       plan[0].data_ptr() if plan is not None else None,
                       plan[0].data_ptr() + 4 * plan[1] if plan is not None else None, p(wp), p(wp6), None, 0, 0, None,
                       1 if (perm_groups > 1 and getattr(row_perm, "_cv_has_map", False)) else 0,
-                      2 if flag is not None else 0, acc_scale, p(flag))
+                      2 if flag is not None else (1 if (pieces == 1 and wp6 is not None) else 0), acc_scale, p(flag))
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
     return out
@@ -436,6 +441,32 @@ _packed_h2 = {}
 # 1 (default): vector-path convs run their fp32 products as six bf16 piece products on the bf16 matrix cores
 # (conv_rows_x6); 0: v_mfma_f32_32x32x2_f32
 CONV_X6 = os.environ.get("CV_CONV_X6", "1") != "0"
+
+
+# Product precision of the vector-path convolutions (forward, input gradient, weight gradient):
+#   "fp32" (default): fp32-level products (bf16 triples / fp16 pairs, see sparse_conv.hip) - the parity path;
+#   "bf16": operands rounded to bf16, one bf16 x bf16 product, fp32 accumulation and fp32 storage - the opt-in
+#           compute mode BASELINE configs 3-4 name for training (bench.py --dtype bf16); NOT within the 1e-4 bar.
+COMPUTE_DTYPE = "bf16" if os.environ.get("CV_COMPUTE_DTYPE", "fp32") == "bf16" else "fp32"
+
+
+def set_compute_dtype(dtype):
+    """"fp32" or "bf16" (see COMPUTE_DTYPE); returns the previous setting.  Cached eval programs are keyed by it."""
+    global COMPUTE_DTYPE
+    assert dtype in ("fp32", "bf16"), dtype
+    prev, COMPUTE_DTYPE = COMPUTE_DTYPE, dtype
+    return prev
+
+
+def packed_weights_bf16(w3, col_scale=None):
+    """uncached: weights (times an optional per-output-column scale) rounded to bf16 in conv_rows_x6's layout"""
+    L = _lib.lib()
+    K, cin, cout = w3.shape
+    wp = torch.empty(w3.numel(), dtype=torch.int16, device=w3.device)
+    with torch.cuda.device(w3.device):
+        _lib.check(L.cv_sp_pack_weights_bf16_f32(_ptr(w3), K, cin, cout, _ptr(col_scale), _ptr(wp),
+                                                 _stream(w3.device)), "cv_sp_pack_weights_bf16_f32")
+    return wp
 
 
 def invalidate_weight_caches():
@@ -582,9 +613,14 @@ def conv_wgrad(x_feats, grad_out, nbr, K):
     dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
     ws = _workspace(dev, int(L.cv_sp_wgrad_workspace_bytes(n_out, cin, cout, K)))
     with torch.cuda.device(dev):
-        _lib.check(L.cv_sp_conv_wgrad_f32(_ptr(x_feats), x_feats.stride(0), cin, _ptr(grad_out), grad_out.stride(0),
-                                          cout, _ptr(nbr), K, n_out, _ptr(dw), _ptr(ws), ws.numel(), _stream(dev)),
-                   "cv_sp_conv_wgrad_f32")
+        if COMPUTE_DTYPE == "bf16":
+            _lib.check(L.cv_sp_conv_wgrad_px_f32(_ptr(x_feats), x_feats.stride(0), cin, _ptr(grad_out),
+                                                 grad_out.stride(0), cout, _ptr(nbr), K, n_out, _ptr(dw), _ptr(ws),
+                                                 ws.numel(), 1, _stream(dev)), "cv_sp_conv_wgrad_px_f32")
+        else:
+            _lib.check(L.cv_sp_conv_wgrad_f32(_ptr(x_feats), x_feats.stride(0), cin, _ptr(grad_out),
+                                              grad_out.stride(0), cout, _ptr(nbr), K, n_out, _ptr(dw), _ptr(ws),
+                                              ws.numel(), _stream(dev)), "cv_sp_conv_wgrad_f32")
     return dw
 
 

@@ -256,7 +256,10 @@ class MinkUNetBase(ResNetBase):
             if second is not None:
                 src2, kernel2, scale2 = second
                 w2 = (kernel2 if kernel2.dim() == 3 else kernel2[None]).detach().contiguous()
-                if pieces == 2:
+                if pieces == 1:
+                    w6, w6_2 = ME.packed_weights_bf16(w, scale), ME.packed_weights_bf16(w2, scale2)
+                    op_pieces = 1
+                elif pieces == 2:
                     k = ME.h2_scale_log2((w, scale), (w2, scale2))           # one accumulator: one common factor
                     w6, w6_2 = ME.packed_weights_h2(w, scale, k), ME.packed_weights_h2(w2, scale2, k)
                     op_pieces, acc_scale = 2, 2.0 ** -k
@@ -264,6 +267,8 @@ class MinkUNetBase(ResNetBase):
                     w6 = ME.packed_weights_x6_scaled(w, scale)
                     w6_2 = ME.packed_weights_x6_scaled(w2, scale2)
                 in2, cin2, scale = src2, w2.shape[1], None
+            elif vec and pieces == 1:
+                w6, op_pieces = ME.packed_weights_bf16(w), 1
             elif vec and pieces == 2:
                 k = ME.h2_scale_log2((w, None))
                 w6 = ME.packed_weights_h2(w, None, k)
@@ -369,7 +374,8 @@ class MinkUNetBase(ResNetBase):
         L = _lib.lib()
         cm, stem_map, out_map = x.coordinate_manager.fused_plan(self.conv0p1s1.kernel_size)
         dev = x.F.device
-        pieces = self.PIECES if pieces is None else pieces
+        if pieces is None:
+            pieces = 1 if ME.COMPUTE_DTYPE == "bf16" else self.PIECES
         c_ops, c_bufs, _ = self._program(dev, pieces)
         flag = ME.range_flag(dev) if pieces == 2 else None
         n = [cm.num_rows(1 << i) for i in range(5)]

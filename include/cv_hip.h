@@ -200,7 +200,9 @@ typedef struct cv_conv_desc {
     const void* weight2_x6; /* cv_sp_pack_weights_x6_f32 of W2 [1][cin2][cout]                                         */
     int perm_has_map;       /* with perm_groups > 1: row_perm is followed by the kernel map rows in processing order
                                (cv_sp_mask_perms with_map = 1), which turns the random map reads into coalesced ones */
-    int weight_pieces;      /* 0 / 3: weight_x6 (and weight2_x6) hold bf16 triples (cv_sp_pack_weights_x6_f32);
+    int weight_pieces;      /* 1: one bf16 plane (cv_sp_pack_weights_bf16_f32): operands rounded to bf16, one product -
+                               the opt-in bf16 compute mode, NOT fp32-level accuracy;
+                               0 / 3: weight_x6 (and weight2_x6) hold bf16 triples (cv_sp_pack_weights_x6_f32);
                                2: fp16 pairs (cv_sp_pack_weights_h2_f32): three fp16 x fp16 piece products per fp32
                                product - fp32-level accuracy (operands to 2^-24) while every input magnitude is below
                                65504, half the matrix time of the triples                                            */
@@ -229,6 +231,11 @@ int cv_sp_pack_weights_x6_f32(const float* d_w, int K, int cin, int cout, const 
  * sets of a two-source convolution share it) and passes acc_scale = 2^-scale_log2 in the descriptor. */
 int cv_sp_pack_weights_h2_f32(const float* d_w, int K, int cin, int cout, const float* d_col_scale, int scale_log2,
                               void* d_wp, void* stream);
+/* Weights of the opt-in bf16 compute mode (cv_conv_desc.weight_pieces = 1): w * d_col_scale rounded to bf16 (RNE),
+ * one plane of the same layout: K*cin*cout 16-bit words.  Not an fp32-parity path (operands carry 8 significant
+ * bits); the reference trains and evaluates in fp32 (train_joint.py:218), BASELINE config 3 asks for bf16. */
+int cv_sp_pack_weights_bf16_f32(const float* d_w, int K, int cin, int cout, const float* d_col_scale, void* d_wp,
+                                void* stream);
 int cv_sp_tile_kw(int cin, int cout);
 int cv_sp_pack_weights_f32(const float* d_w, int K, int cin, int cout, float* d_wp, void* stream);
 
@@ -310,6 +317,12 @@ size_t cv_sp_wgrad_workspace_bytes(long long n_out, int cin, int cout, int K);
 int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy, int dy_ld, int cout,
                          const int32_t* d_nbr, int K, long long n_out, float* d_dw, void* d_ws, size_t ws_bytes,
                          void* stream);
+/* The same with the product precision chosen by the caller: pieces = 0 fp32 matrix cores, 3 six bf16 piece products
+ * per fp32 product (fp32-level accuracy; what cv_sp_conv_wgrad_f32 runs), 1 operands rounded to bf16 and ONE
+ * bf16 x bf16 product with fp32 accumulation (the opt-in bf16 compute mode, BASELINE configs 3-4). */
+int cv_sp_conv_wgrad_px_f32(const float* d_x, int x_ld, int cin, const float* d_dy, int dy_ld, int cout,
+                            const int32_t* d_nbr, int K, long long n_out, float* d_dw, void* d_ws, size_t ws_bytes,
+                            int pieces, void* stream);
 /* out[c] = sum over rows of x[:, c] (bias gradient). */
 int cv_sp_col_sum_f32(const float* d_x, long long n, int c, int ld, float* d_out, void* stream);
 
