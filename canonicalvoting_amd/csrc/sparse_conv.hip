@@ -1338,13 +1338,17 @@ struct WgradPlan {
 // (row 2t + half) are exactly its eight k slots (k = 8 * half + t, the same rows on the A and the B side), so the
 // fp32 operands are split into bf16 triples in registers and six piece products replace eight fp32 MFMAs per nb
 // (see conv_rows_x6; gradients keep the fp32 exponent range, which fp16 pairs would not).
-template <int NB, int PIECES>      // 0: fp32 MFMA; 3: bf16 triples, six piece products; 1: operands rounded to bf16, one product
-__global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ x, int x_ld, int cin,
+// NA x NB blocks of 32 x 32 per wave: a wave that owns NA input-channel blocks reads each dy row segment once for all
+// of them (and each x segment once for all NB output blocks).  With one input block per wave (the first version) a
+// 96 -> 96 convolution moved 1536 bytes per (input, output) pair from L2 for three tiles - the kernel ran at the L2
+// bandwidth (6.3 TB/s), not at the matrix rate; 3 x 3 blocks move 768 bytes for nine tiles.
+template <int NA, int NB, int PIECES>      // PIECES 0: fp32 MFMA; 3: bf16 triples, six piece products; 1: operands rounded to bf16, one product
+__global__ __launch_bounds__(THREADS, (NA * NB >= 8 ? 2 : 1)) void conv_wgrad(const float* __restrict__ x, int x_ld, int cin,
                                                       const float* __restrict__ dy, int dy_ld, int cout,
                                                       const int* __restrict__ nbr, int K, long long n_out,
                                                       WgradPlan plan, float* __restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ci_blocks = (cin + 31) / 32, co_blocks = (cout + NB * 32 - 1) / (NB * 32);
+    const int ci_blocks = (cin + NA * 32 - 1) / (NA * 32), co_blocks = (cout + NB * 32 - 1) / (NB * 32);
     int task = blockIdx.x * 4 + wave;
     if (task >= plan.task_end[K - 1]) return;
     int rank = 0;
@@ -1356,12 +1360,14 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
     const int cib = task / co_blocks;
     const long long r_lo = n_out * split / row_splits, r_hi = n_out * (split + 1) / row_splits;
     const int half = lane >> 5, l31 = lane & 31;
-    const int ci0 = cib * 32, co0 = cob * NB * 32;
-    f32x16 acc[NB];
+    const int ci0 = cib * NA * 32, co0 = cob * NB * 32;
+    f32x16 acc[NA][NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int na = 0; na < NA; ++na)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[na][nb][r] = 0.f;
     // 64 output rows per batch: every lane fetches one neighbour index (the next batch's is already in
     // flight), the rows that HAVE the neighbour are taken two at a time from the ballot mask (work
     // proportional to the existing pairs), and the operand loads of up to STEPS MFMA steps are issued back
@@ -1377,11 +1383,12 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
         src_next = fetch(u0 + 64);
         unsigned long long m = __ballot(src_l >= 0);
         while (m) {
-            float av[STEPS], bv[STEPS][NB];
+            float av[STEPS][NA], bv[STEPS][NB];
             int nsteps = 0;
 #pragma unroll
             for (int t = 0; t < STEPS; ++t) {
-                av[t] = 0.f;
+#pragma unroll
+                for (int na = 0; na < NA; ++na) av[t][na] = 0.f;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) bv[t][nb] = 0.f;
                 if (m) {                                                   // wave-uniform
@@ -1394,7 +1401,11 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
                     const int got = __shfl(src_l, r >= 0 ? r : 0);
                     const int src = r >= 0 ? got : -1;
                     if (src >= 0) {
-                        if (ci0 + l31 < cin) av[t] = x[(long long)src * x_ld + ci0 + l31];
+#pragma unroll
+                        for (int na = 0; na < NA; ++na) {
+                            const int ci = ci0 + na * 32 + l31;
+                            if (ci < cin) av[t][na] = x[(long long)src * x_ld + ci];
+                        }
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
                             const int col = co0 + nb * 32 + l31;
@@ -1406,24 +1417,33 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
             }
             if constexpr (PIECES == 1) {
                 static_assert(STEPS == 8, "one bf16 MFMA group = 8 k slots per lane");
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, make_uint4(cvt_pk_bf16(av[0], av[1]), cvt_pk_bf16(av[2], av[3]),
-                                                                        cvt_pk_bf16(av[4], av[5]), cvt_pk_bf16(av[6], av[7])));
+                bf16x8 a1[NA];
+#pragma unroll
+                for (int na = 0; na < NA; ++na)
+                    a1[na] = __builtin_bit_cast(
+                        bf16x8, make_uint4(cvt_pk_bf16(av[0][na], av[1][na]), cvt_pk_bf16(av[2][na], av[3][na]),
+                                           cvt_pk_bf16(av[4][na], av[5][na]), cvt_pk_bf16(av[6][na], av[7][na])));
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const bf16x8 b1 = __builtin_bit_cast(
                         bf16x8, make_uint4(cvt_pk_bf16(bv[0][nb], bv[1][nb]), cvt_pk_bf16(bv[2][nb], bv[3][nb]),
                                            cvt_pk_bf16(bv[4][nb], bv[5][nb]), cvt_pk_bf16(bv[6][nb], bv[7][nb])));
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[nb], 0, 0, 0);
+#pragma unroll
+                    for (int na = 0; na < NA; ++na)
+                        acc[na][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[na], b1, acc[na][nb], 0, 0, 0);
                 }
             } else if constexpr (PIECES == 3) {
                 static_assert(STEPS == 8, "one bf16 MFMA group = 8 k slots per lane");
-                unsigned ap[3][4];
+                bf16x8 a3[NA][3];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) split3(av[2 * q], av[2 * q + 1], ap[0][q], ap[1][q], ap[2][q]);
-                bf16x8 a3[3];
+                for (int na = 0; na < NA; ++na) {
+                    unsigned ap[3][4];
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    a3[pc] = __builtin_bit_cast(bf16x8, make_uint4(ap[pc][0], ap[pc][1], ap[pc][2], ap[pc][3]));
+                    for (int q = 0; q < 4; ++q) split3(av[2 * q][na], av[2 * q + 1][na], ap[0][q], ap[1][q], ap[2][q]);
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc)
+                        a3[na][pc] = __builtin_bit_cast(bf16x8, make_uint4(ap[pc][0], ap[pc][1], ap[pc][2], ap[pc][3]));
+                }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     unsigned bp[3][4];
@@ -1433,34 +1453,41 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad(const float* __restrict__ 
 #pragma unroll
                     for (int pc = 0; pc < 3; ++pc)
                         b3[pc] = __builtin_bit_cast(bf16x8, make_uint4(bp[pc][0], bp[pc][1], bp[pc][2], bp[pc][3]));
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[2], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[2], b3[0], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[1], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[1], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[0], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[0], acc[nb], 0, 0, 0);
+#pragma unroll
+                    for (int na = 0; na < NA; ++na) {
+                        acc[na][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[na][0], b3[2], acc[na][nb], 0, 0, 0);
+                        acc[na][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[na][2], b3[0], acc[na][nb], 0, 0, 0);
+                        acc[na][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[na][1], b3[1], acc[na][nb], 0, 0, 0);
+                        acc[na][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[na][0], b3[1], acc[na][nb], 0, 0, 0);
+                        acc[na][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[na][1], b3[0], acc[na][nb], 0, 0, 0);
+                        acc[na][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[na][0], b3[0], acc[na][nb], 0, 0, 0);
+                    }
                 }
             } else {
 #pragma unroll
                 for (int t = 0; t < STEPS; ++t)
                     if (t < nsteps)
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t][nb], acc[nb], 0, 0, 0);
+                        for (int na = 0; na < NA; ++na)
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[na][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][na], bv[t][nb], acc[na][nb], 0, 0, 0);
             }
         }
     }
     float* p = partial + (long long)(plan.first[j] + split) * cin * cout;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int col = co0 + nb * 32 + l31;
-        if (col >= cout) continue;
+    for (int na = 0; na < NA; ++na)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (ci < cin) p[(long long)ci * cout + col] = acc[nb][r];
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = co0 + nb * 32 + l31;
+            if (col >= cout) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + na * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (ci < cin) p[(long long)ci * cout + col] = acc[na][nb][r];
+            }
         }
-    }
 }
 
 // dW[j] = sum of offset j's partial tiles, in slot order (deterministic)
@@ -1471,9 +1498,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
     const int j = (int)(e / cc);
     const int w = (int)(e - (long long)j * cc);
     const float* p = partial + (long long)plan.first[j] * cc + w;
-    float s = 0.f;
-    for (int k = 0; k < plan.nsplit[j]; ++k) s += p[(long long)k * cc];
-    dw[e] = s;
+    // four interleaved running sums (slots k % 4), combined in a fixed order: four independent load chains in flight
+    const int ns = plan.nsplit[j];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < ns; k += 4) {
+        s0 += p[(long long)k * cc];
+        s1 += p[(long long)(k + 1) * cc];
+        s2 += p[(long long)(k + 2) * cc];
+        s3 += p[(long long)(k + 3) * cc];
+    }
+    for (; k < ns; ++k) s0 += p[(long long)k * cc];
+    dw[e] = (s0 + s1) + (s2 + s3);
 }
 
 // transposed kernel map: nbr_t[i][j] = u with nbr[u][j] == i  (per offset the map is injective)
@@ -1674,6 +1710,33 @@ __global__ __launch_bounds__(256) void affine_rows(const float* __restrict__ x, 
     }
 }
 
+// float4 flavour (c, leading dimensions % 4 == 0, 16-byte aligned bases): one thread = 4 consecutive channels of a row
+__global__ __launch_bounds__(256) void affine_rows4(const float* __restrict__ x, long long n, int c,
+                                                    int x_ld, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift,
+                                                    const float* __restrict__ residual, int res_ld, int relu,
+                                                    float* __restrict__ y, int y_ld) {
+    const int cq = c >> 2;
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < n * cq; t += (long long)gridDim.x * 256) {
+        const long long r = t / cq;
+        const int k = (int)(t - r * cq) * 4;
+        float4 v = *reinterpret_cast<const float4*>(x + r * x_ld + k);
+        if (scale) {
+            const float4 sc = *reinterpret_cast<const float4*>(scale + k);
+            const float4 sh = shift ? *reinterpret_cast<const float4*>(shift + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        }
+        if (residual) {
+            const float4 p = *reinterpret_cast<const float4*>(residual + r * res_ld + k);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(y + r * y_ld + k) = v;
+    }
+}
+
+__host__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 // scale = gamma * rsqrt(var + eps), shift = beta - mean*scale (+ bias*scale)
 __global__ void bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
                         const float* bias, float eps, int c, float* scale, float* shift) {
@@ -1688,7 +1751,7 @@ __global__ void bn_fold(const float* gamma, const float* beta, const float* mean
 // MinkowskiBatchNorm = nn.BatchNorm1d over the [N, C] feature rows (utils/minkunet.py:56): batch mean and
 // biased variance per channel.  Two-level column reduction: blocks of (32 channels x 8 row lanes) over row
 // chunks accumulate in double, a second tiny kernel combines the chunks.
-constexpr int BN_CHUNKS = 256;
+constexpr int BN_CHUNKS = 1024;
 
 template <int MODE>   // 0: sum x, sum x^2      1: sum dy', sum dy'*xhat   (dy' = dy masked by y > 0 if y given)
 __global__ __launch_bounds__(256) void bn_col_reduce(const float* __restrict__ x, const float* __restrict__ dy,
@@ -1720,6 +1783,80 @@ __global__ __launch_bounds__(256) void bn_col_reduce(const float* __restrict__ x
         for (int k = 0; k < 8; ++k) { t0 += s0[k][threadIdx.x & 31]; t1 += s1[k][threadIdx.x & 31]; }
         partial[((long long)blockIdx.y * c + col) * 2 + 0] = t0;
         partial[((long long)blockIdx.y * c + col) * 2 + 1] = t1;
+    }
+}
+
+// float4 flavour of bn_col_reduce (c % 4 == 0, c <= 1024, ld % 4 == 0, 16-byte aligned): a thread owns a quad of
+// channels, 256 / (c/4) row lanes per block, four rows of loads in flight per thread; the scalar kernel above kept
+// one 4-byte load per thread in flight (1.8 TB/s on the ts1 levels).  Same partial layout, fixed summation order.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_col_reduce4(const float* __restrict__ x, const float* __restrict__ dy,
+                                                      const float* __restrict__ y, long long n, int c, int ld,
+                                                      const float* __restrict__ mean, const float* __restrict__ var,
+                                                      float eps, double* __restrict__ partial) {
+    __shared__ double red[256][9];                     // [thread][2 x 4 sums], padded
+    const int cq = c >> 2, rl = 256 / cq;              // row lanes
+    const int quad = threadIdx.x % cq, lane_r = threadIdx.x / cq;
+    const long long r_lo = n * blockIdx.x / gridDim.x, r_hi = n * (blockIdx.x + 1) / gridDim.x;
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (lane_r < rl) {
+        const int k = quad * 4;
+        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+        if (MODE == 1) {
+            mu = *reinterpret_cast<const float4*>(mean + k);
+            const float4 v = *reinterpret_cast<const float4*>(var + k);
+            is = make_float4(1.0f / sqrtf(v.x + eps), 1.0f / sqrtf(v.y + eps), 1.0f / sqrtf(v.z + eps), 1.0f / sqrtf(v.w + eps));
+        }
+        auto take = [&](const float4& xv, float4 g, const float4& yv, bool has_y) {
+            if (MODE == 0) {
+                a[0] += (double)xv.x; a[1] += (double)xv.y; a[2] += (double)xv.z; a[3] += (double)xv.w;
+                a[4] += (double)xv.x * (double)xv.x; a[5] += (double)xv.y * (double)xv.y;
+                a[6] += (double)xv.z * (double)xv.z; a[7] += (double)xv.w * (double)xv.w;
+            } else {
+                if (has_y) {
+                    if (!(yv.x > 0.f)) g.x = 0.f;
+                    if (!(yv.y > 0.f)) g.y = 0.f;
+                    if (!(yv.z > 0.f)) g.z = 0.f;
+                    if (!(yv.w > 0.f)) g.w = 0.f;
+                }
+                a[0] += (double)g.x; a[1] += (double)g.y; a[2] += (double)g.z; a[3] += (double)g.w;
+                a[4] += (double)(g.x * ((xv.x - mu.x) * is.x)); a[5] += (double)(g.y * ((xv.y - mu.y) * is.y));
+                a[6] += (double)(g.z * ((xv.z - mu.z) * is.z)); a[7] += (double)(g.w * ((xv.w - mu.w) * is.w));
+            }
+        };
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        long long r = r_lo + lane_r;
+        for (; r + 3ll * rl < r_hi; r += 4ll * rl) {
+            float4 xv[4], gv[4], yv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long o = (r + (long long)u * rl) * ld + k;
+                xv[u] = *reinterpret_cast<const float4*>(x + o);
+                gv[u] = MODE == 1 ? *reinterpret_cast<const float4*>(dy + o) : z4;
+                yv[u] = (MODE == 1 && y) ? *reinterpret_cast<const float4*>(y + o) : z4;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) take(xv[u], gv[u], yv[u], y != nullptr);
+        }
+        for (; r < r_hi; r += rl) {
+            const long long o = r * ld + k;
+            take(*reinterpret_cast<const float4*>(x + o), MODE == 1 ? *reinterpret_cast<const float4*>(dy + o) : z4,
+                 (MODE == 1 && y) ? *reinterpret_cast<const float4*>(y + o) : z4, y != nullptr);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = a[i];
+    __syncthreads();
+    if (threadIdx.x < cq) {
+        double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < rl; ++q)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] += red[q * cq + threadIdx.x][i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            partial[((long long)blockIdx.x * c + threadIdx.x * 4 + i) * 2 + 0] = t[i];
+            partial[((long long)blockIdx.x * c + threadIdx.x * 4 + i) * 2 + 1] = t[4 + i];
+        }
     }
 }
 
@@ -1784,6 +1921,42 @@ __global__ __launch_bounds__(256) void bn_backward_apply(const float* __restrict
         if (y && !(y[r * ld + k] > 0.f)) g = 0.f;
         dx[r * ld + k] = gamma[k] * istd * (g - sum_dy[k] * inv_n - xh * sum_dy_xhat[k] * inv_n);
         if (dres) dres[r * ld + k] = g;
+    }
+}
+
+// float4 flavour (c, ld % 4 == 0, 16-byte aligned)
+__global__ __launch_bounds__(256) void bn_backward_apply4(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ y, long long n, int c, int ld,
+                                                          const float* __restrict__ mean, const float* __restrict__ var,
+                                                          float eps, const float* __restrict__ gamma,
+                                                          const float* __restrict__ sum_dy,
+                                                          const float* __restrict__ sum_dy_xhat, float* __restrict__ dx,
+                                                          float* __restrict__ dres) {
+    const float inv_n = 1.0f / (float)n;
+    const int cq = c >> 2;
+    for (long long t = blockIdx.x * 256ll + threadIdx.x; t < n * cq; t += (long long)gridDim.x * 256) {
+        const long long r = t / cq;
+        const int k = (int)(t - r * cq) * 4;
+        const long long o = r * ld + k;
+        const float4 xv = *reinterpret_cast<const float4*>(x + o);
+        float4 g = *reinterpret_cast<const float4*>(dy + o);
+        if (y) {
+            const float4 yv = *reinterpret_cast<const float4*>(y + o);
+            if (!(yv.x > 0.f)) g.x = 0.f;
+            if (!(yv.y > 0.f)) g.y = 0.f;
+            if (!(yv.z > 0.f)) g.z = 0.f;
+            if (!(yv.w > 0.f)) g.w = 0.f;
+        }
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {g.x, g.y, g.z, g.w};
+        float d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float istd = 1.0f / sqrtf(var[k + i] + eps);
+            const float xh = (xs[i] - mean[k + i]) * istd;
+            d[i] = gamma[k + i] * istd * (gs[i] - sum_dy[k + i] * inv_n - xh * sum_dy_xhat[k + i] * inv_n);
+        }
+        *reinterpret_cast<float4*>(dx + o) = make_float4(d[0], d[1], d[2], d[3]);
+        if (dres) *reinterpret_cast<float4*>(dres + o) = g;
     }
 }
 
@@ -2223,9 +2396,23 @@ int cv_sp_transpose_map(const int32_t* d_nbr, long long n_out, int K, long long 
 // 256 CUs x 4 SIMDs a few times over even on the coarse levels (a few thousand rows), at least 128 rows each;
 // the centre offset of an odd cubic kernel and its face neighbours hold the most pairs: they go first and get
 // twice the splits (measured: profiles/wgrad_micro.py).
-static long long wgrad_plan(long long n_out, int cin, int cout, int K, WgradPlan* plan) {
+// input-channel blocks per wave (see conv_wgrad): as many as divide Cin / 32 while NA x NB accumulators fit
+static int wgrad_na(int cin, int cout) {
+    static const int na_max = getenv("CV_WGRAD_NA") ? atoi(getenv("CV_WGRAD_NA")) : 4;
     const int nb = nb_full(cout);
-    const int tiles = ((cin + 31) / 32) * ((cout + nb * 32 - 1) / (nb * 32));
+    int na = 1;
+    if (cin % 32 == 0 && cin >= 64) {
+        const int b = cin / 32;
+        if (nb == 4) na = b % 2 == 0 ? 2 : 1;
+        else if (nb == 3) na = b % 3 == 0 ? 3 : (b % 2 == 0 ? 2 : 1);
+        else na = b % 4 == 0 ? 4 : (b % 2 == 0 ? 2 : (b % 3 == 0 ? 3 : 1));
+    }
+    return std::max(1, std::min(na, na_max));
+}
+
+static long long wgrad_plan(long long n_out, int cin, int cout, int K, WgradPlan* plan) {
+    const int nb = nb_full(cout), na = wgrad_na(cin, cout);
+    const int tiles = ((cin + na * 32 - 1) / (na * 32)) * ((cout + nb * 32 - 1) / (nb * 32));
     int ks = 1;
     while (ks * ks * ks < K) ++ks;
     const bool cubic = ks * ks * ks == K && (ks & 1) && ks > 1;
@@ -2241,8 +2428,11 @@ static long long wgrad_plan(long long n_out, int cin, int cout, int K, WgradPlan
         msum += mult[j];
     }
     const long long want = (WGRAD_TARGET_TASKS + (long long)msum * tiles - 1) / ((long long)msum * tiles);
-    const long long ws_cap = (256ll << 20) / ((long long)msum * cin * cout * 4);      // partial tiles <= 256 MB
-    const long long base = std::max<long long>(1, std::min({64ll, want, n_out / 256, ws_cap}));
+    // partial tiles <= 96 MB (they are written once and read once by wgrad_reduce); few-offset kernels (1x1, 2x2x2)
+    // have few (offset, block) tasks and get their parallelism from the rows instead: up to 1024 row splits
+    const long long ws_cap = (96ll << 20) / ((long long)msum * cin * cout * 4);
+    const long long cap = K <= 8 ? 1024 : 64;
+    const long long base = std::max<long long>(1, std::min({cap, want, n_out / (K <= 8 ? 128 : 256), ws_cap}));
     long long slots = 0;
     int rank = 0, tasks = 0;
     for (int pass = 0; pass < 3; ++pass)
@@ -2283,17 +2473,28 @@ int cv_sp_conv_wgrad_px_f32(const float* d_x, int x_ld, int cin, const float* d_
     const unsigned grid = (unsigned)((plan.task_end[K - 1] + 3) / 4);
     CV_REQUIRE(pieces == 0 || pieces == 1 || pieces == 3, CV_EINVAL,
                "pieces is 0 (fp32 MFMA), 3 (six bf16 piece products per fp32 product) or 1 (one bf16 product)");
-#define CV_WGRAD_LAUNCH(NBV)                                                                                         \
+#define CV_WGRAD_LAUNCH(NAV, NBV)                                                                                    \
     do {                                                                                                             \
-        if (pieces == 3) conv_wgrad<NBV, 3><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); \
-        else if (pieces == 1) conv_wgrad<NBV, 1><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); \
-        else conv_wgrad<NBV, 0><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial);   \
+        if (pieces == 3) conv_wgrad<NAV, NBV, 3><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); \
+        else if (pieces == 1) conv_wgrad<NAV, NBV, 1><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial); \
+        else conv_wgrad<NAV, NBV, 0><<<grid, THREADS, 0, st>>>(d_x, x_ld, cin, d_dy, dy_ld, cout, d_nbr, K, n_out, plan, partial);   \
     } while (0)
-    switch (nb_full(cout)) {
-        case 1: CV_WGRAD_LAUNCH(1); break;
-        case 2: CV_WGRAD_LAUNCH(2); break;
-        case 3: CV_WGRAD_LAUNCH(3); break;
-        default: CV_WGRAD_LAUNCH(4); break;
+    const int na = wgrad_na(cin, cout);
+    switch (nb_full(cout) * 10 + na) {
+        case 11: CV_WGRAD_LAUNCH(1, 1); break;
+        case 12: CV_WGRAD_LAUNCH(2, 1); break;
+        case 13: CV_WGRAD_LAUNCH(3, 1); break;
+        case 14: CV_WGRAD_LAUNCH(4, 1); break;
+        case 21: CV_WGRAD_LAUNCH(1, 2); break;
+        case 22: CV_WGRAD_LAUNCH(2, 2); break;
+        case 23: CV_WGRAD_LAUNCH(3, 2); break;
+        case 24: CV_WGRAD_LAUNCH(4, 2); break;
+        case 31: CV_WGRAD_LAUNCH(1, 3); break;
+        case 32: CV_WGRAD_LAUNCH(2, 3); break;
+        case 33: CV_WGRAD_LAUNCH(3, 3); break;
+        case 41: CV_WGRAD_LAUNCH(1, 4); break;
+        case 42: CV_WGRAD_LAUNCH(2, 4); break;
+        default: CV_REQUIRE(false, CV_EINVAL, "no weight-gradient kernel for this block shape");
     }
 #undef CV_WGRAD_LAUNCH
     CV_LAUNCH_CHECK();
@@ -2328,8 +2529,13 @@ int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float
     CV_REQUIRE(d_x && d_y && n > 0 && c > 0 && x_ld >= c && y_ld >= c, CV_EINVAL, "bad affine arguments");
     CV_REQUIRE(!d_residual || res_ld >= c, CV_EINVAL, "bad residual stride");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    affine_rows<<<(unsigned)std::min<long long>((n * c + 255) / 256, 8192), 256, 0, st>>>(
-        d_x, n, c, x_ld, d_scale, d_shift, d_residual, res_ld, relu, d_y, y_ld);
+    if (c % 4 == 0 && x_ld % 4 == 0 && y_ld % 4 == 0 && (!d_residual || res_ld % 4 == 0) && aligned16(d_x) &&
+        aligned16(d_y) && aligned16(d_residual) && aligned16(d_scale) && aligned16(d_shift))
+        affine_rows4<<<(unsigned)std::min<long long>((n * (c / 4) + 255) / 256, 16384), 256, 0, st>>>(
+            d_x, n, c, x_ld, d_scale, d_shift, d_residual, res_ld, relu, d_y, y_ld);
+    else
+        affine_rows<<<(unsigned)std::min<long long>((n * c + 255) / 256, 8192), 256, 0, st>>>(
+            d_x, n, c, x_ld, d_scale, d_shift, d_residual, res_ld, relu, d_y, y_ld);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }
@@ -2345,7 +2551,7 @@ int cv_sp_bn_fold_f32(const float* d_gamma, const float* d_beta, const float* d_
 
 size_t cv_sp_bn_workspace_bytes(int c) { return c > 0 ? 256 + sizeof(double) * 2 * (size_t)BN_CHUNKS * c : 0; }
 
-static int bn_chunks(long long n) { return (int)std::min<long long>(BN_CHUNKS, std::max<long long>(1, n / 512)); }
+static int bn_chunks(long long n) { return (int)std::min<long long>(BN_CHUNKS, std::max<long long>(1, n / 256)); }
 
 // Training-mode BatchNorm statistics of x[n][c]: d_mean, d_var (biased), running statistics updated in place
 // (may be NULL), and the folded d_scale/d_shift for cv_sp_affine_f32 (y = x*scale + shift).
@@ -2359,7 +2565,10 @@ int cv_sp_bn_stats_f32(const float* d_x, long long n, int c, int ld, const float
     double* partial = static_cast<double*>(d_ws);
     const int chunks = bn_chunks(n);
     dim3 grid((unsigned)((c + 31) / 32), (unsigned)chunks);
-    bn_col_reduce<0><<<grid, 256, 0, st>>>(d_x, nullptr, nullptr, n, c, ld, nullptr, nullptr, eps, partial);
+    if (c % 4 == 0 && c <= 1024 && ld % 4 == 0 && aligned16(d_x))
+        bn_col_reduce4<0><<<chunks, 256, 0, st>>>(d_x, nullptr, nullptr, n, c, ld, nullptr, nullptr, eps, partial);
+    else
+        bn_col_reduce<0><<<grid, 256, 0, st>>>(d_x, nullptr, nullptr, n, c, ld, nullptr, nullptr, eps, partial);
     CV_LAUNCH_CHECK();
     bn_col_finish<0><<<(c + 15) / 16, 256, 0, st>>>(partial, chunks, n, c, d_mean, d_var, d_running_mean,
                                                      d_running_var, momentum, d_gamma, d_beta, eps, d_scale, d_shift);
@@ -2380,13 +2589,22 @@ int cv_sp_bn_backward_f32(const float* d_x, const float* d_dy, const float* d_y,
     double* partial = static_cast<double*>(d_ws);
     const int chunks = bn_chunks(n);
     dim3 grid((unsigned)((c + 31) / 32), (unsigned)chunks);
-    bn_col_reduce<1><<<grid, 256, 0, st>>>(d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, partial);
+    const bool v4 = c % 4 == 0 && c <= 1024 && ld % 4 == 0 && aligned16(d_x) && aligned16(d_dy) && aligned16(d_y) &&
+                    aligned16(d_dx) && aligned16(d_dres) && aligned16(d_mean) && aligned16(d_var);
+    if (v4)
+        bn_col_reduce4<1><<<chunks, 256, 0, st>>>(d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, partial);
+    else
+        bn_col_reduce<1><<<grid, 256, 0, st>>>(d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, partial);
     CV_LAUNCH_CHECK();
     bn_col_finish<1><<<(c + 15) / 16, 256, 0, st>>>(partial, chunks, n, c, d_dbeta, d_dgamma, nullptr, nullptr, 0.f,
                                                      nullptr, nullptr, eps, nullptr, nullptr);
     CV_LAUNCH_CHECK();
-    bn_backward_apply<<<(unsigned)std::min<long long>((n * c + 255) / 256, 8192), 256, 0, st>>>(
-        d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dbeta, d_dgamma, d_dx, d_dres);
+    if (v4)
+        bn_backward_apply4<<<(unsigned)std::min<long long>((n * (c / 4) + 255) / 256, 16384), 256, 0, st>>>(
+            d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dbeta, d_dgamma, d_dx, d_dres);
+    else
+        bn_backward_apply<<<(unsigned)std::min<long long>((n * c + 255) / 256, 8192), 256, 0, st>>>(
+            d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dbeta, d_dgamma, d_dx, d_dres);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }
