@@ -1570,6 +1570,22 @@ __global__ __launch_bounds__(256) void conv_finish(ConvArgs a) {
             const long long e = e4 * 4;
             const long long row = e / a.cout;
             const int col = (int)(e - row * a.cout);
+            if (a.wide) {                        // 16-byte aligned operands: one float4 per operand instead of four words
+                float4 x = make_float4(v[0], v[1], v[2], v[3]);
+                if (a.acc_in) {
+                    const float4 p = *reinterpret_cast<const float4*>(a.acc_in + row * a.acc_ld + col);
+                    x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
+                }
+                const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                x.x = x.x * sc.x + sh.x; x.y = x.y * sc.y + sh.y; x.z = x.z * sc.z + sh.z; x.w = x.w * sc.w + sh.w;
+                if (a.res) {
+                    const float4 p = *reinterpret_cast<const float4*>(a.res + row * a.res_ld + col);
+                    x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
+                }
+                if (a.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+                *reinterpret_cast<float4*>(a.out + row * a.out_ld + col) = x;
+            } else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float x = v[i];
@@ -1581,6 +1597,46 @@ __global__ __launch_bounds__(256) void conv_finish(ConvArgs a) {
             }
         }
         __syncthreads();
+    }
+}
+
+// up to FINISH_SMALL_MAX partial tiles (the mask groups, the split-K of the middle levels) with 16-byte aligned
+// operands: a thread owns a float4 of the output, has all its partial loads in flight at once and runs the epilogue
+// itself - no LDS exchange, no barriers, every thread stores (ts1 96 -> 96 conv + finish: 125 -> 104 us).  Summation
+// order = conv_finish's: four running sums over the partials k % 4, then ((s0 + s1) + s2) + s3 - bit-identical results.
+constexpr int FINISH_SMALL_MAX = 16;
+__global__ __launch_bounds__(256) void conv_finish_small(ConvArgs a) {
+    const long long total4 = a.n_out * (long long)a.cout / 4;
+    const int cq = a.cout >> 2;
+    for (long long e4 = blockIdx.x * 256ll + threadIdx.x; e4 < total4; e4 += (long long)gridDim.x * 256) {
+        const float4* p = reinterpret_cast<const float4*>(a.partial) + e4;
+        float4 pv[FINISH_SMALL_MAX];
+#pragma unroll
+        for (int k = 0; k < FINISH_SMALL_MAX; ++k)
+            pv[k] = k < a.splits ? p[(long long)k * total4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const long long row = e4 / cq;
+        const int col = (int)(e4 - row * cq) * 4;
+        float4 sq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < FINISH_SMALL_MAX; ++k)
+            if (k < a.splits) { sq[k & 3].x += pv[k].x; sq[k & 3].y += pv[k].y; sq[k & 3].z += pv[k].z; sq[k & 3].w += pv[k].w; }
+        float4 x = make_float4(sq[0].x + sq[1].x + sq[2].x + sq[3].x, sq[0].y + sq[1].y + sq[2].y + sq[3].y,
+                               sq[0].z + sq[1].z + sq[2].z + sq[3].z, sq[0].w + sq[1].w + sq[2].w + sq[3].w);
+        if (a.acc_in) {
+            const float4 q = *reinterpret_cast<const float4*>(a.acc_in + row * a.acc_ld + col);
+            x.x += q.x; x.y += q.y; x.z += q.z; x.w += q.w;
+        }
+        const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        x.x = x.x * sc.x + sh.x; x.y = x.y * sc.y + sh.y; x.z = x.z * sc.z + sh.z; x.w = x.w * sc.w + sh.w;
+        if (a.res) {
+            const float4 q = *reinterpret_cast<const float4*>(a.res + row * a.res_ld + col);
+            x.x += q.x; x.y += q.y; x.z += q.z; x.w += q.w;
+        }
+        if (a.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+        *reinterpret_cast<float4*>(a.out + row * a.out_ld + col) = x;
     }
 }
 
@@ -1602,7 +1658,9 @@ __global__ __launch_bounds__(256) void conv_finish_scalar(ConvArgs a) {
 
 int launch_finish(const ConvArgs& a, hipStream_t st) {
     const long long total = a.n_out * (long long)a.cout;
-    if (a.cout % 4 == 0)
+    if (a.wide && a.splits <= FINISH_SMALL_MAX)
+        conv_finish_small<<<(unsigned)std::min<long long>((total / 4 + 255) / 256, 16384), 256, 0, st>>>(a);
+    else if (a.cout % 4 == 0)
         conv_finish<<<(unsigned)std::min<long long>((total / 4 + 63) / 64, 8192), 256, 0, st>>>(a);
     else
         conv_finish_scalar<<<(unsigned)std::min<long long>((total + 255) / 256, 4096), 256, 0, st>>>(a);
