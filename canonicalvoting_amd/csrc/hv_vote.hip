@@ -972,17 +972,18 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
     CvCarver cv(d_ws);
     int* fy = cv.take<int>(n);
     float* rec = cv.take<float>((size_t)n * REC_F);
-    int* ycount = cv.take<int>(Y);
-    int* ystart = cv.take<int>(Y + 1);
-    int* cursor = cv.take<int>(Y);
-    int* part_start = cv.take<int>(Y + 1);
     const int tiles_x = (dims[0] + TX - 1) / TX, tiles_z = (dims[2] + TZ - 1) / TZ;
     const int ntiles = tiles_x * tiles_z;
     const int64_t max_q = tiles_q_bound(n, Y);
+    // the two zero-initialised arrays sit next to each other: one fill launch instead of two
+    int* ycount = cv.take<int>(Y);
     int* arrivals = cv.take<int>((size_t)Y * ntiles);
+    int* ystart = cv.take<int>(Y + 1);
+    int* cursor = cv.take<int>(Y);
+    int* part_start = cv.take<int>(Y + 1);
     float* partials = cv.take<float>((size_t)max_q * ntiles * 6 * TCELLS);
-    CV_HIP_CHECK(hipMemsetAsync(ycount, 0, sizeof(int) * Y, st));
-    CV_HIP_CHECK(hipMemsetAsync(arrivals, 0, sizeof(int) * (size_t)Y * ntiles, st));
+    CV_HIP_CHECK(hipMemsetAsync(ycount, 0, (size_t)(reinterpret_cast<char*>(arrivals + (size_t)Y * ntiles) -
+                                                    reinterpret_cast<char*>(ycount)), st));
     hv_prep_count<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, n, res, corner.y, Y, fy, ycount);
     CV_LAUNCH_CHECK();
