@@ -2188,7 +2188,10 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
     const long long tiles = ((n_out + TM - 1) / TM) * ((cout + nb * 32 - 1) / (nb * 32));
     const long long units = vec ? (long long)K * (cin / KC) : ((long long)K * cin + KC - 1) / KC;
     if (tiles >= 384 || units <= 1) return 1;
-    long long s = (1024 + tiles - 1) / tiles;
+    static const long long target = getenv("CV_SPLIT_TARGET") ? atoll(getenv("CV_SPLIT_TARGET")) : 1024;
+    long long s = (target + tiles - 1) / tiles;
+    // (measured without gain: sizing by the chip's resident workgroup slots, floor(256 x waves-per-SIMD / tiles), so that
+    // no second round of workgroups starts: 257 vs 265 scenes/s one scene in flight, 401-409 vs 410-412 with six)
     s = std::min(s, units);
     const long long by_traffic = (24ll << 20) / std::max<long long>(1, n_out * cout * 4);   // <= 24 MB of partials
     s = std::min(s, std::max<long long>(by_traffic, 2));
