@@ -22,7 +22,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.
 STRICT = ["-ffp-contract=off"]
 SOURCES = {
     "cv_host.cpp": STRICT,
-    "hv_vote.hip": STRICT,
+    "hv_vote.hip": STRICT + os.environ.get("CV_HV_DEFS", "").split(),     # tile-shape experiments (-DHV_TX=16 -DHV_TW=8)
     "hv_decode.hip": STRICT,
     "sparse_coords.hip": [],
     "sparse_conv.hip": [],

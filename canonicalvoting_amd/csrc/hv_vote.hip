@@ -192,8 +192,25 @@ __global__ __launch_bounds__(256) void hv_normalise(const float* __restrict__ g_
 // ---------------------------------------------------------------------------
 // tiles algorithm
 // ---------------------------------------------------------------------------
-constexpr int TX = 32, TZ = 32, TCELLS = TX * TZ;
-constexpr int TW = 16;       // waves per workgroup
+// Tile = HV_TX x 32 cells of one y plane, HV_TW waves per workgroup.  16 x 32 cells / 8 waves need 68 KB of LDS, so
+// TWO workgroups share a CU (the 32 x 32 / 16-wave shape needs 133 KB: one): the zero-fill, the part merge and the
+// normalise + store of one tile overlap the expansion of another.  Measured on the headline workload's predictions
+// (profiles/r1/vote_tile_sweep.txt): 32x32/16 waves 0.4325 ms, 16x32/8 0.4119, 16x32/16 0.570, 32x32/8 0.459,
+// 8x32/8 0.468, 16x32/4 0.414 (0.428 teacher-forced), 8x32/4 0.472.
+#ifndef HV_TX
+#define HV_TX 16
+#endif
+#ifndef HV_TW
+#define HV_TW 8
+#endif
+#ifndef HV_PART_RECORDS
+#define HV_PART_RECORDS 4096
+#endif
+#ifndef HV_MAX_PARTS
+#define HV_MAX_PARTS 8
+#endif
+constexpr int TX = HV_TX, TZ = 32, TCELLS = TX * TZ;   // TZ = 32 is built into acc_idx
+constexpr int TW = HV_TW;    // waves per workgroup
 constexpr int PQ = 64;       // surviving points per wave chunk
 constexpr int VQ = 128;      // vote queue entries per wave
 constexpr int MAX_R_TILES = 256;
@@ -233,8 +250,8 @@ __global__ __launch_bounds__(PREP_THREADS) void hv_prep_count(
 // Hough peaks concentrate votes: the hottest (tile, plane) of an 80k scene receives ~27x the mean and
 // would take 0.3 ms on one CU.  Planes whose two y-bins hold many points are therefore split into
 // up to MAX_PARTS workgroups per tile (disjoint record chunks), merged by the last arriver.
-constexpr int PART_RECORDS = 4096;
-constexpr int MAX_PARTS = 8;
+constexpr int PART_RECORDS = HV_PART_RECORDS;
+constexpr int MAX_PARTS = HV_MAX_PARTS;
 
 __global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ ycount, int Y,
                                                      int* __restrict__ ystart,
