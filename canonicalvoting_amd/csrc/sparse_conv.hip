@@ -864,47 +864,56 @@ __global__ __launch_bounds__(THREADS) void conv_rows_prof(ConvArgs a, unsigned l
 // divergence ran slower (130 us): the loop is bound by the scalar weight fetches, not by the gathers.
 constexpr int STEM_ROWS = 128;
 template <int CIN>
-__global__ __launch_bounds__(STEM_ROWS) void conv_stem(ConvArgs a) {
-    extern __shared__ int stem_nbr[];                      // [STEM_ROWS][K | 1]
-    const int K = a.K, KLD = K | 1;
+__global__ __launch_bounds__(STEM_ROWS) void conv_stem(ConvArgs a, int JC) {
+    // The tile's map rows are staged JC offsets at a time ([STEM_ROWS][JC | 1] ints): with the whole 125-offset slice
+    // resident (64 KB) two workgroups = ONE wave per SIMD fitted on a CU and every per-offset gather latency was
+    // exposed (108 us for 1.3 M pairs); 32 offsets at a time need 17 KB and leave the occupancy to the registers.
+    extern __shared__ int stem_nbr[];
+    const int K = a.K, KLD = JC | 1;
     const long long r0 = (long long)blockIdx.x * STEM_ROWS;
     const int rows = (int)min((long long)STEM_ROWS, a.n_out - r0);
-    {   // coalesced copy of the tile's map rows, 16 independent loads in flight per lane
-        const int total = rows * K;
-        const int* src_p = a.nbr + r0 * K;
-        for (int e0 = threadIdx.x; e0 < total; e0 += 16 * STEM_ROWS) {
-            int v[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int e = e0 + q * STEM_ROWS;
-                v[q] = e < total ? src_p[e] : -1;
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int e = e0 + q * STEM_ROWS;
-                if (e < total) { const int rr = e / K; stem_nbr[rr * KLD + (e - rr * K)] = v[q]; }
-            }
-        }
-    }
-    __syncthreads();
     const int r = threadIdx.x;
-    if (r >= rows) return;
     float acc[32];
 #pragma unroll
     for (int co = 0; co < 32; ++co) acc[co] = 0.f;
     const float* __restrict__ w = a.w;
-    for (int j = a.j_begin; j < a.j_end; ++j) {
-        const int src = stem_nbr[r * KLD + j];
-        if (src < 0) continue;
-        float x[CIN];
+    for (int jc = a.j_begin; jc < a.j_end; jc += JC) {
+        const int jw = min(JC, a.j_end - jc);
+        __syncthreads();                                   // the previous chunk's map entries are consumed
+        {   // copy of the tile's map entries for offsets [jc, jc + jw), 8 independent loads in flight per lane
+            const int total = rows * jw;
+            const int* src_p = a.nbr + r0 * K + jc;
+            for (int e0 = threadIdx.x; e0 < total; e0 += 8 * STEM_ROWS) {
+                int v[8];
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) x[ci] = a.in[(long long)src * a.in_ld + ci];
-        const float* wj = w + (long long)j * CIN * 32;
+                for (int q = 0; q < 8; ++q) {
+                    const int e = e0 + q * STEM_ROWS;
+                    const int rr = e / jw;
+                    v[q] = e < total ? src_p[(long long)rr * K + (e - rr * jw)] : -1;
+                }
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci)
+                for (int q = 0; q < 8; ++q) {
+                    const int e = e0 + q * STEM_ROWS;
+                    if (e < total) { const int rr = e / jw; stem_nbr[rr * KLD + (e - rr * jw)] = v[q]; }
+                }
+            }
+        }
+        __syncthreads();
+        if (r < rows)
+            for (int jj = 0; jj < jw; ++jj) {
+                const int src = stem_nbr[r * KLD + jj];
+                if (src < 0) continue;
+                float x[CIN];
 #pragma unroll
-            for (int co = 0; co < 32; ++co) acc[co] = fmaf(x[ci], wj[ci * 32 + co], acc[co]);
+                for (int ci = 0; ci < CIN; ++ci) x[ci] = a.in[(long long)src * a.in_ld + ci];
+                const float* wj = w + (long long)(jc + jj) * CIN * 32;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                    for (int co = 0; co < 32; ++co) acc[co] = fmaf(x[ci], wj[ci * 32 + co], acc[co]);
+            }
     }
+    if (r >= rows) return;
     const long long row = r0 + r;
 #pragma unroll
     for (int co = 0; co < 32; ++co) {
@@ -2254,17 +2263,19 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
                               "16-byte aligned rows)");
     }
     if (!vec && d->cout == 32 && (d->cin == 3 || d->cin == 6) && d->nbr && !d->row_perm && d->perm_groups <= 1 &&
-        d->flavour == 0 && (size_t)STEM_ROWS * (d->K | 1) * sizeof(int) <= 96 * 1024) {
+        d->flavour == 0) {
         const unsigned grid = (unsigned)((d->n_out + STEM_ROWS - 1) / STEM_ROWS);
-        const size_t lds = (size_t)STEM_ROWS * (d->K | 1) * sizeof(int);
+        static const int jc_env = getenv("CV_STEM_JC") ? atoi(getenv("CV_STEM_JC")) : 32;
+        const int JC = std::max(1, std::min(jc_env, 160));
+        const size_t lds = (size_t)STEM_ROWS * (JC | 1) * sizeof(int);
         if (d->cin == 3) {
             CV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem<3>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            conv_stem<3><<<grid, STEM_ROWS, lds, st>>>(a);
+            conv_stem<3><<<grid, STEM_ROWS, lds, st>>>(a, JC);
         } else {
             CV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem<6>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            conv_stem<6><<<grid, STEM_ROWS, lds, st>>>(a);
+            conv_stem<6><<<grid, STEM_ROWS, lds, st>>>(a, JC);
         }
         CV_LAUNCH_CHECK();
         return CV_OK;
