@@ -452,19 +452,21 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
     auto compute = [&]() {
         const int arow = wave * 32 + l31;
         const int aswz = (arow >> 2) & 3, bswz = (l31 >> 2) & 3;     // (nb*32 + l31) >> 2 & 3 == (l31 >> 2) & 3
+        bf16x8 av[P], bv[P];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int chunk = 2 * ks + half;
-            bf16x8 av[P];
-#pragma unroll
-            for (int p = 0; p < P; ++p)
-                av[p] = *reinterpret_cast<const bf16x8*>(A_h + (p * TM + arow) * 64 + ((chunk ^ aswz) << 4));
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                bf16x8 bv[P];
+            // ablation bits (CV_CONV_DBG): 128 = A fragments read once per unit, 64 = B fragments read once per unit
+            if (!(a.dbg & 128) || ks == 0)
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    bv[p] = *reinterpret_cast<const bf16x8*>(B_h + (p * NB * 32 + nb * 32 + l31) * 64 + ((chunk ^ bswz) << 4));
+                    av[p] = *reinterpret_cast<const bf16x8*>(A_h + (p * TM + arow) * 64 + ((chunk ^ aswz) << 4));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                if (!(a.dbg & 64) || (ks == 0 && nb == 0))
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        bv[p] = *reinterpret_cast<const bf16x8*>(B_h + (p * NB * 32 + nb * 32 + l31) * 64 + ((chunk ^ bswz) << 4));
                 // smallest terms first
                 if constexpr (P == 1) {
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc[nb], 0, 0, 0);
