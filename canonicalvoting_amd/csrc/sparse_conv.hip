@@ -661,6 +661,225 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
     }
 }
 
+// conv_rows_x6 with ONE workgroup barrier per (offset, 32-channel) unit instead of two plus two per offset.  The ablations
+// of conv_rows_x6 (profiles/r1/conv_ablate_h2.txt) left ~38 us of the 94 us ts1 96 -> 96 conv to the skeleton: ~56
+// workgroup barriers per workgroup at three workgroups per CU.  Two observations remove most of them:
+//  * a wave's 32 rows are its own: it gathers, splits and stages exactly the A rows it multiplies, so the A tile needs
+//    wave-level ordering only (LDS operations of one wave execute in order);
+//  * the weight tile is shared, so it is double-buffered: the B planes of unit k+1 are written while slow waves may
+//    still multiply unit k out of the other buffer, and the single barrier of unit k+1 (B visible) is also the
+//    proof that everyone is done with unit k-1's buffer.
+// The map entries of all the workgroup's offsets (<= WP_NPRE; the host falls back to conv_rows_x6 otherwise) come in
+// with one round of loads, a bit mask of the offsets that exist for the tile is reduced once, and dead offsets are
+// skipped without a barrier.  Same MFMA sequence per accumulator as conv_rows_x6: bit-identical results.
+constexpr int WP_NPRE = 8;
+template <int NB, int P>
+__global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : 1)) void conv_rows_wp(ConvArgs a) {
+    constexpr int A_BYTES = P * TM * 64, B_BYTES = P * NB * 32 * 64, EP_BYTES = 4 * 32 * EP_LD * 4;
+    constexpr int SM_BYTES = A_BYTES + 2 * B_BYTES > EP_BYTES ? A_BYTES + 2 * B_BYTES : EP_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[SM_BYTES];
+    __shared__ int rows_s[TM];
+    __shared__ int nbr_all[WP_NPRE][TM];
+    __shared__ unsigned live_mask;
+    unsigned char* const A_h = sm;                    // [plane][row][64 B]
+    unsigned char* const B_h = sm + A_BYTES;          // 2 x [plane][col][64 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.y * (NB * 32);
+
+    if (tid < TM) {
+        const long long tile_id = a.row_perm ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
+        const long long t = tile_id * TM + tid;
+        const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)blockIdx.z * a.n_out : 0) : nullptr;
+        rows_s[tid] = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
+    }
+    if (tid == 0) live_mask = 0u;
+    __syncthreads();
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    const int half = lane >> 5, l31 = lane & 31;
+    auto compute = [&](const unsigned char* Bb) {
+        const int arow = wave * 32 + l31;
+        const int aswz = (arow >> 2) & 3, bswz = (l31 >> 2) & 3;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = 2 * ks + half;
+            bf16x8 av[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                av[p] = *reinterpret_cast<const bf16x8*>(A_h + (p * TM + arow) * 64 + ((chunk ^ aswz) << 4));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                bf16x8 bv[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    bv[p] = *reinterpret_cast<const bf16x8*>(Bb + (p * NB * 32 + nb * 32 + l31) * 64 + ((chunk ^ bswz) << 4));
+                if constexpr (P == 1) {
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc[nb], 0, 0, 0);
+                } else if constexpr (P == 3) {
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[2], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[0], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[1], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[0], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc[nb], 0, 0, 0);
+                } else {
+                    const f16x8 a0 = __builtin_bit_cast(f16x8, av[0]), a1 = __builtin_bit_cast(f16x8, av[P - 1]);
+                    const f16x8 b0 = __builtin_bit_cast(f16x8, bv[0]), b1 = __builtin_bit_cast(f16x8, bv[P - 1]);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[nb], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    const int nj = a.j_end - a.j_begin;
+    // lane -> (own row = 32*wave + lane/8 + 8*i, 4 channels at (lane%8)*4): 8 lanes cover one 128 B row chunk
+    const int a_col = (lane & 7) * 4;
+    const int a_row = wave * 32 + (lane >> 3);       // + 8*i, i = 0..3
+    constexpr int B_U4 = P * NB * 32 * 4;            // 16-byte pieces of the packed weight slab of one unit
+    constexpr int B_PER = (B_U4 + THREADS - 1) / THREADS;
+    const int nch = a.cin / KC;
+    int u_lo, u_hi;
+    if (a.perm_per_split) {
+        u_lo = (int)((long long)nj * blockIdx.z / a.splits) * nch;
+        u_hi = (int)((long long)nj * (blockIdx.z + 1) / a.splits) * nch;
+    } else {
+        u_lo = (int)((long long)nj * nch * blockIdx.z / a.splits);
+        u_hi = (int)((long long)nj * nch * (blockIdx.z + 1) / a.splits);
+    }
+    const int j_first = a.j_begin + u_lo / nch, j_last = a.j_begin + (u_hi - 1) / nch;
+    const int njl = u_hi > u_lo ? j_last - j_first + 1 : 0;       // <= WP_NPRE (host)
+    auto map_entry = [&](int t, int j) {
+        const int row = rows_s[t];
+        if (row < 0) return -1;
+        if (a.nbr_perm) {
+            const long long tile_id = (long long)gridDim.x - 1 - blockIdx.x;
+            return a.nbr_perm[((long long)blockIdx.z * a.n_out + tile_id * TM + t) * a.nbr_perm_w +
+                              (j - (a.j_begin + (int)((long long)nj * blockIdx.z / a.splits)))];
+        }
+        return a.nbr ? a.nbr[(long long)row * a.K + j] : row;
+    };
+    {
+        unsigned m = 0u;
+        for (int e = tid; e < njl * TM; e += THREADS) {
+            const int jj = e / TM, t = e - jj * TM;
+            const int v = map_entry(t, j_first + jj);
+            nbr_all[jj][t] = v;
+            if (v >= 0) m |= 1u << jj;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m |= __shfl_xor(m, off);
+        if (lane == 0 && m) atomicOr(&live_mask, m);
+    }
+    __syncthreads();
+    const unsigned lm = live_mask;
+
+    float4 ra[4];
+    uint4 rb[B_PER];
+    float in_max = 0.f;                              // fp16 pairs: largest staged input magnitude
+    // (offset j, chunk c) walk over the units [u_lo, u_hi) of the offsets that exist for this tile, without divisions
+    const int c_first = u_lo - (u_lo / nch) * nch, c_last = u_hi > u_lo ? (u_hi - 1) - ((u_hi - 1) / nch) * nch + 1 : 0;
+    auto skip_dead = [&](int& j, int& c) {
+#pragma unroll 1
+        while (j <= j_last && !((lm >> (j - j_first)) & 1u)) { ++j; c = 0; }
+    };
+    auto advance = [&](int& j, int& c) {
+        if (++c >= (j == j_last ? c_last : nch)) { ++j; c = 0; skip_dead(j, c); }
+    };
+    auto load = [&](int j, int c) {
+        const int kc = c * KC;
+        const int* nb_j = nbr_all[j - j_first];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int src = nb_j[a_row + 8 * i];
+            ra[i] = src >= 0 ? *reinterpret_cast<const float4*>(a.in + (long long)src * a.in_ld + kc + a_col)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const unsigned short* slab = a.wp6 + (long long)(j * nch + c) * P * a.cout * 32;
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int f = tid + i * THREADS;
+            if (f < B_U4) {
+                const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
+                const int col = rem >> 2, ch = rem & 3;
+                rb[i] = (n0 + col < a.cout)
+                            ? *reinterpret_cast<const uint4*>(slab + ((long long)p * a.cout + n0 + col) * 32 + ch * 8)
+                            : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+    auto stage = [&](unsigned char* Bb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = a_row + 8 * i;
+            unsigned h0 = 0, m0 = 0, l0 = 0, h1 = 0, m1 = 0, l1 = 0;
+            unsigned char* dst = A_h + r * 64 + ((((a_col >> 3) ^ ((r >> 2) & 3))) << 4) + ((a_col & 7) << 1);
+            if constexpr (P == 1) {
+                *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pk_bf16(ra[i].x, ra[i].y), cvt_pk_bf16(ra[i].z, ra[i].w));
+            } else if constexpr (P == 3) {
+                split3(ra[i].x, ra[i].y, h0, m0, l0);
+                split3(ra[i].z, ra[i].w, h1, m1, l1);
+                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(dst + TM * 64) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2*>(dst + 2 * TM * 64) = make_uint2(l0, l1);
+            } else {
+                in_max = fmaxf(fmaxf(in_max, fmaxf(fabsf(ra[i].x), fabsf(ra[i].y))), fmaxf(fabsf(ra[i].z), fabsf(ra[i].w)));
+                split2h(ra[i].x, ra[i].y, h0, l0);
+                split2h(ra[i].z, ra[i].w, h1, l1);
+                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(dst + TM * 64) = make_uint2(l0, l1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int f = tid + i * THREADS;
+            if (f < B_U4) {
+                const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
+                const int col = rem >> 2, ch = rem & 3;
+                *reinterpret_cast<uint4*>(Bb + (p * NB * 32 + col) * 64 + ((ch ^ ((col >> 2) & 3)) << 4)) = rb[i];
+            }
+        }
+    };
+    int j = j_first, c = c_first, buf = 0;
+    if (njl > 0) skip_dead(j, c); else j = j_last + 1;
+    if (j <= j_last) load(j, c);
+#pragma unroll 1
+    while (j <= j_last) {
+        unsigned char* Bb = B_h + buf * B_BYTES;
+        stage(Bb);                                   // A rows of this wave, this thread's share of the weight tile
+        __syncthreads();                             // weight tile visible; everyone is done with the other buffer's previous use
+        const bool wave_live = __any(nbr_all[j - j_first][wave * 32 + l31] >= 0);
+        advance(j, c);
+        if (j <= j_last) load(j, c);                 // in flight while the matrix cores run
+        if (wave_live) compute(Bb);
+        buf ^= 1;
+    }
+    __syncthreads();                                 // operand tiles are dead: the epilogue tile reuses their LDS
+    if constexpr (P == 2) {
+        if (in_max > 65000.f && a.range_flag) *a.range_flag = 1;
+        const float k = a.acc_scale;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] *= k;
+    }
+    float (*ep)[EP_LD] = reinterpret_cast<float (*)[EP_LD]>(sm + wave * 32 * EP_LD * 4);
+    if (a.wide) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) epilogue_store_wide(a, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep);
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            epilogue_store(a, acc[nb], rows_s + wave * 32, n0 + nb * 32 + (lane & 31), lane);
+    }
+}
+
 // Instrumented twin of conv_rows (CV_CONV_PROF=1): shader-clock ticks per phase, summed over waves into prof[16].
 template <int NB, bool VEC>
 __global__ __launch_bounds__(THREADS) void conv_rows_prof(ConvArgs a, unsigned long long* prof) {
@@ -2081,6 +2300,32 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
     dim3 grid((unsigned)((a.n_out + TM - 1) / TM), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)),
               (unsigned)a.splits);
     static const bool prof_on = getenv("CV_CONV_PROF") != nullptr;
+    // one-barrier-per-unit kernel (CV_CONV_WP=0: conv_rows_x6 everywhere): no second source, no ablation switches,
+    // and every workgroup's offsets fit the map prefetch
+    static const bool wp_on = !(getenv("CV_CONV_WP") && atoi(getenv("CV_CONV_WP")) == 0);
+    int per_wg = 0;                                  // most offsets one workgroup walks (the kernel's own formulas)
+    if (vec) {
+        const int nj_wp = a.j_end - a.j_begin, nch_wp = a.cin / KC;
+        for (int z = 0; z < a.splits; ++z) {
+            long long lo, hi;
+            if (a.perm_per_split) {
+                lo = (long long)nj_wp * z / a.splits * nch_wp;
+                hi = (long long)nj_wp * (z + 1) / a.splits * nch_wp;
+            } else {
+                lo = (long long)nj_wp * nch_wp * z / a.splits;
+                hi = (long long)nj_wp * nch_wp * (z + 1) / a.splits;
+            }
+            if (hi > lo) per_wg = std::max(per_wg, (int)((hi - 1) / nch_wp - lo / nch_wp + 1));
+        }
+    }
+    if (vec && a.wp6 && !prof_on && wp_on && !a.in2 && !a.dbg && per_wg <= WP_NPRE) {
+        if (a.pieces == 2) conv_rows_wp<NB, 2><<<grid, THREADS, 0, st>>>(a);
+        else if (a.pieces == 1) conv_rows_wp<NB, 1><<<grid, THREADS, 0, st>>>(a);
+        else conv_rows_wp<NB, 3><<<grid, THREADS, 0, st>>>(a);
+        CV_LAUNCH_CHECK();
+        if (a.splits > 1) return launch_finish(a, st);
+        return CV_OK;
+    }
     if (vec && a.wp6 && (!prof_on || a.in2)) {
         if (a.pieces == 2) conv_rows_x6<NB, 2><<<grid, THREADS, 0, st>>>(a);
         else if (a.pieces == 1) conv_rows_x6<NB, 1><<<grid, THREADS, 0, st>>>(a);
