@@ -679,7 +679,7 @@ __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : 1)) void conv_rows_wp(ConvA
     constexpr int SM_BYTES = A_BYTES + 2 * B_BYTES > EP_BYTES ? A_BYTES + 2 * B_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char sm[SM_BYTES];
     __shared__ int rows_s[TM];
-    __shared__ int nbr_all[WP_NPRE][TM];
+    __shared__ int nbr_all[WP_NPRE + 1][TM];         // + the rows themselves: the "map" of the second source
     __shared__ unsigned live_mask;
     unsigned char* const A_h = sm;                    // [plane][row][64 B]
     unsigned char* const B_h = sm + A_BYTES;          // 2 x [plane][col][64 B]
@@ -776,6 +776,7 @@ __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : 1)) void conv_rows_wp(ConvA
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m |= __shfl_xor(m, off);
         if (lane == 0 && m) atomicOr(&live_mask, m);
+        if (a.in2 && tid < TM) nbr_all[njl][tid] = rows_s[tid];
     }
     __syncthreads();
     const unsigned lm = live_mask;
@@ -789,19 +790,34 @@ __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : 1)) void conv_rows_wp(ConvA
 #pragma unroll 1
         while (j <= j_last && !((lm >> (j - j_first)) & 1u)) { ++j; c = 0; }
     };
+    // after the last offset the units of the second source follow (BasicBlock's 1x1 downsample branch folded into conv2:
+    // out += in2 @ W2 on the output rows; its 32-channel chunks are dealt round-robin to the splits / mask groups):
+    // j == j_last + 1 marks them, c is then the chunk of in2; j == j_last + 2 ends the walk
+    const int nch2 = a.in2 ? a.cin2 / KC : 0;
+    const int j_second = j_last + 1, j_done = j_last + 2;
     auto advance = [&](int& j, int& c) {
-        if (++c >= (j == j_last ? c_last : nch)) { ++j; c = 0; skip_dead(j, c); }
+        if (j <= j_last) {
+            if (++c >= (j == j_last ? c_last : nch)) { ++j; c = 0; skip_dead(j, c); }
+            if (j > j_last) { j = j_second; c = blockIdx.z; }
+        } else {
+            c += a.splits;
+        }
+        if (j == j_second && c >= nch2) j = j_done;
     };
     auto load = [&](int j, int c) {
+        const bool second = j == j_second;
         const int kc = c * KC;
-        const int* nb_j = nbr_all[j - j_first];
+        const int* nb_j = nbr_all[j - j_first];          // j_second - j_first == njl: the rows themselves
+        const float* src_base = second ? a.in2 : a.in;
+        const int src_ld = second ? a.in2_ld : a.in_ld;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int src = nb_j[a_row + 8 * i];
-            ra[i] = src >= 0 ? *reinterpret_cast<const float4*>(a.in + (long long)src * a.in_ld + kc + a_col)
+            ra[i] = src >= 0 ? *reinterpret_cast<const float4*>(src_base + (long long)src * src_ld + kc + a_col)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const unsigned short* slab = a.wp6 + (long long)(j * nch + c) * P * a.cout * 32;
+        const unsigned short* slab = second ? a.wp6_2 + (long long)c * P * a.cout * 32
+                                            : a.wp6 + (long long)(j * nch + c) * P * a.cout * 32;
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int f = tid + i * THREADS;
@@ -848,15 +864,16 @@ __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : 1)) void conv_rows_wp(ConvA
     };
     int j = j_first, c = c_first, buf = 0;
     if (njl > 0) skip_dead(j, c); else j = j_last + 1;
-    if (j <= j_last) load(j, c);
+    if (j > j_last) { j = j_second; c = blockIdx.z; if (c >= nch2) j = j_done; }
+    if (j < j_done) load(j, c);
 #pragma unroll 1
-    while (j <= j_last) {
+    while (j < j_done) {
         unsigned char* Bb = B_h + buf * B_BYTES;
         stage(Bb);                                   // A rows of this wave, this thread's share of the weight tile
         __syncthreads();                             // weight tile visible; everyone is done with the other buffer's previous use
         const bool wave_live = __any(nbr_all[j - j_first][wave * 32 + l31] >= 0);
         advance(j, c);
-        if (j <= j_last) load(j, c);                 // in flight while the matrix cores run
+        if (j < j_done) load(j, c);                  // in flight while the matrix cores run
         if (wave_live) compute(Bb);
         buf ^= 1;
     }
@@ -2300,8 +2317,8 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
     dim3 grid((unsigned)((a.n_out + TM - 1) / TM), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)),
               (unsigned)a.splits);
     static const bool prof_on = getenv("CV_CONV_PROF") != nullptr;
-    // one-barrier-per-unit kernel (CV_CONV_WP=0: conv_rows_x6 everywhere): no second source, no ablation switches,
-    // and every workgroup's offsets fit the map prefetch
+    // one-barrier-per-unit kernel (CV_CONV_WP=0: conv_rows_x6 everywhere): no ablation switches, and every workgroup's
+    // offsets fit the map prefetch
     static const bool wp_on = !(getenv("CV_CONV_WP") && atoi(getenv("CV_CONV_WP")) == 0);
     int per_wg = 0;                                  // most offsets one workgroup walks (the kernel's own formulas)
     if (vec) {
@@ -2318,7 +2335,7 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
             if (hi > lo) per_wg = std::max(per_wg, (int)((hi - 1) / nch_wp - lo / nch_wp + 1));
         }
     }
-    if (vec && a.wp6 && !prof_on && wp_on && !a.in2 && !a.dbg && per_wg <= WP_NPRE) {
+    if (vec && a.wp6 && !prof_on && wp_on && !a.dbg && per_wg <= WP_NPRE) {
         if (a.pieces == 2) conv_rows_wp<NB, 2><<<grid, THREADS, 0, st>>>(a);
         else if (a.pieces == 1) conv_rows_wp<NB, 1><<<grid, THREADS, 0, st>>>(a);
         else conv_rows_wp<NB, 3><<<grid, THREADS, 0, st>>>(a);
