@@ -674,7 +674,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
 // skipped without a barrier.  Same MFMA sequence per accumulator as conv_rows_x6: bit-identical results.
 constexpr int WP_NPRE = 8;
 template <int NB, int P>
-__global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : 1)) void conv_rows_wp(ConvArgs a) {
+__global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : NB == 2 ? 4 : 5)) void conv_rows_wp(ConvArgs a) {
     constexpr int A_BYTES = P * TM * 64, B_BYTES = P * NB * 32 * 64, EP_BYTES = 4 * 32 * EP_LD * 4;
     constexpr int SM_BYTES = A_BYTES + 2 * B_BYTES > EP_BYTES ? A_BYTES + 2 * B_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char sm[SM_BYTES];
