@@ -18,13 +18,6 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
-@pytest.fixture
-def bf16_mode():
-    prev = ME.set_compute_dtype("bf16")
-    yield
-    ME.set_compute_dtype(prev)
-
-
 @pytest.mark.parametrize("cin,cout", [(32, 32), (96, 96), (128, 256)])
 def test_bf16_conv_is_the_fp32_conv_of_rounded_operands(cuda, built_lib, cin, cout):
     coords, _ = scene_coords(51, 3000, small=False)
