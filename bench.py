@@ -169,6 +169,7 @@ def main_train(a):
     batch of scenes (weak scaling), gradients all-reduced by torch DDP over RCCL, BatchNorm statistics per GPU."""
     from canonicalvoting_amd import train
     world, rank, local = cvd.world()
+    local %= torch.cuda.device_count()          # one rank per GPU on a real node; ranks share GPUs only in the launch-path test
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cvd.init("nccl", dev)
@@ -215,6 +216,7 @@ def main():
         return main_train(a)
     world, rank, local = cvd.world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    local %= torch.cuda.device_count()          # one rank per GPU on a real node; ranks share GPUs only in the launch-path test
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cvd.init("nccl", dev)

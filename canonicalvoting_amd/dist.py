@@ -15,6 +15,9 @@ def world():
 def init(backend=None, device=None):
     """Initialise the default process group when WORLD_SIZE > 1 (env:// rendezvous)."""
     ws, rank, _ = world()
+    # CV_DIST_BACKEND=gloo: the launch path (env rendezvous, barriers, max / sum reductions) on a box whose ranks
+    # share one GPU, where RCCL refuses to start (profiles/two_ranks_one_gpu.sh); never set in production
+    backend = os.environ.get("CV_DIST_BACKEND", backend)
     if ws > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -40,6 +43,8 @@ def reduce_scalar(value, op="max", device=None):
     """max / sum of a python float over ranks (identity for a single process)."""
     if not dist.is_initialized():
         return float(value)
+    if dist.get_backend() == "gloo":
+        device = None
     t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
     return float(t.item())
