@@ -13,6 +13,6 @@ w = torch.randn(27, 96, 96, device=dev) * 0.02
 nbr = cm.kernel_map(3, 1)
 perms = cm.mask_perms(3, 1, 4)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
-    y = ME.conv_forward_masked(x, w, nbr, perms, 80000, relu=True)
+    y = ME.conv_forward_masked(x, w, nbr, perms, 80000, relu=True, pieces=int(os.environ.get('MICRO_PIECES', '2')))
 torch.cuda.synchronize()
 print(float(y.abs().mean()))
