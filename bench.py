@@ -18,9 +18,11 @@ region.  --streams 1 reproduces the one-scene-at-a-time number (profiles/r1/benc
 
 The JSON line also carries
   roofline     the vote op (zero-fill + accumulate + normalise = every launch of
-               cv_hv_forward_f32) timed with HIP events on its stream inside the timed region,
-               priced with the algorithmic bytes of DESIGN.md / SURVEY.md 8d:
-               B_vote = 40 N + 192 V_in + 68 G
+               cv_hv_forward_f32) timed with HIP events on its stream, priced with the algorithmic
+               bytes of DESIGN.md / SURVEY.md 8d: B_vote = 40 N + 192 V_in + 68 G.  With one scene in
+               flight the events of the timed region are used; with S > 1 `achieved` / `frac` come from
+               the one-scene-in-flight pass and `avg_ms_in_timed_region` / `frac_in_timed_region` give
+               the same op inside the timed region, stretched by the co-running scenes' kernels
   cpu_baseline the CPU oracle (oracle/, a port - the reference has no CPU path) on a bounded
                sample of the same scenes, rank 0 only.
 """
@@ -299,7 +301,11 @@ def main():
     dt = cvd.reduce_scalar(dt, "max", dev)
 
     roofline_pass = "the timed region (one scene in flight)"
+    vote_ms_timed = None
     if a.streams > 1:
+        torch.cuda.synchronize()
+        # event-to-event time of the vote op INSIDE the timed region: stretched by the kernels of the co-running scenes
+        vote_ms_timed = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
         # kernels of concurrent scenes stretch each other's event-to-event times, so the per-stage times and
         # the roofline of the vote op come from a second, single-stream pass over the same steps
         torch.cuda.synchronize()
@@ -354,7 +360,10 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_ms": float(vote_ms.mean()), "bytes_per_launch": float(vb.mean()),
                      "compulsory_bytes": float(s0.vote_bytes_floor), "v_in": s0.v_in,
-                     "measured_in": roofline_pass},
+                     "measured_in": roofline_pass,
+                     "avg_ms_in_timed_region": vote_ms_timed,
+                     "frac_in_timed_region": (float(vb.mean()) / (vote_ms_timed * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                             if vote_ms_timed else None},
         "roofline_conv": None if not full else {
             "bound": "mfma", "kernel": "sparse MinkUNet34C forward (all conv launches + coordinate manager)",
             "achieved": net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12, "peak": conv_peak, "unit": "TFLOP/s",
