@@ -675,10 +675,10 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
 //  * the weight tile is shared, so it is double-buffered: the B planes of unit k+1 are written while slow waves may
 //    still multiply unit k out of the other buffer, and the single barrier of unit k+1 (B visible) is also the
 //    proof that everyone is done with unit k-1's buffer.
-// The map entries of all the workgroup's offsets (<= WP_NPRE; the host falls back to conv_rows_x6 otherwise) come in
+// The map entries of all the workgroup's offsets (<= WP_NPRE = 10; the host falls back to conv_rows_x6 otherwise) come in
 // with one round of loads, a bit mask of the offsets that exist for the tile is reduced once, and dead offsets are
 // skipped without a barrier.  Same MFMA sequence per accumulator as conv_rows_x6: bit-identical results.
-constexpr int WP_NPRE = 8;
+constexpr int WP_NPRE = 10;          // the traffic cap of pick_splits leaves 9 offsets per workgroup on the training ts8 level
 template <int NB, int P>
 __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : NB == 2 ? 4 : 5)) void conv_rows_wp(ConvArgs a) {
     constexpr int A_BYTES = P * TM * 64, B_BYTES = P * NB * 32 * 64, EP_BYTES = 4 * 32 * EP_LD * 4;
