@@ -1,30 +1,34 @@
 #!/usr/bin/env python
-"""Headline benchmark: scenes/sec on 80k-point synthetic scans (BASELINE.json metric).
+"""Headline benchmark: scenes/sec on 80k-point synthetic scans (BASELINE.json metric, config 2).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one synthetic 80k-voxel scene through the hot path with its inputs already
-resident in HBM.  Scenes are independent, so N ranks run N scenes per step with no data-path
-collective ("scaling": "weak"); value = scenes all ranks processed / max-over-ranks time.
+One "step" = one synthetic 80k-voxel scene through the eval_joint.py path (eval_joint.py:163-280) with its inputs
+already resident in HBM: coordinate manager + kernel maps, sparse MinkUNet34C forward, head split, vote, greedy
+decode with the back-projection check, per-class NMS.  Scenes are independent, so N ranks run N scenes per step with
+no data-path collective ("scaling": "weak"); value = scenes all ranks processed / max-over-ranks time.
 
-Scenes in flight: --streams S (default 6) host threads, each with its own HIP stream, take the K steps
-from one shared counter (whichever stream is free takes the next scene), so the launch tails, small coarse-level launches and the host syncs of one scene are filled
-with another scene's kernels (the per-scene work and its results are unchanged).  Kernels of concurrent
-scenes stretch each other's event-to-event times, so when S > 1 the per-stage times and the roofline of
-the vote op are taken in a second pass over the same K steps with ONE scene in flight, inside the same
-run, after the timed region ("measured_in" says which); `value` / `ms_per_step` always come from the timed
-region.  --streams 1 reproduces the one-scene-at-a-time number (profiles/r1/bench_streams1.json).
+Predictions (--predictions): the network is random-init (no checkpoint offline), and a random-init network never
+crosses thresh_high, which would leave decode / back-projection / NMS with nothing to do.  The default "teacher"
+therefore runs the network and the head kernel of every step as eval_joint.py does (timed), and then feeds vote + decode
+with predictions synthesised from the scene's labels (SURVEY 8d recipe: the peaked vote maps a trained network
+produces, ~12 boxes per scene).  "network" feeds the network's own output (detections_per_scene 0).
+
+Scenes in flight: --streams S (default 6) host threads, each with its own HIP stream, take the K steps from one
+shared counter.  The threads are created, bound to their streams and parked on a barrier BEFORE the timed region
+starts.  Per-scene work and results are unchanged (tests assert bit-identity with the one-at-a-time path).
 
 The JSON line also carries
-  roofline     the vote op (zero-fill + accumulate + normalise = every launch of
-               cv_hv_forward_f32) timed with HIP events on its stream, priced with the algorithmic
-               bytes of DESIGN.md / SURVEY.md 8d: B_vote = 40 N + 192 V_in + 68 G.  With one scene in
-               flight the events of the timed region are used; with S > 1 `achieved` / `frac` come from
-               the one-scene-in-flight pass and `avg_ms_in_timed_region` / `frac_in_timed_region` give
-               the same op inside the timed region, stretched by the co-running scenes' kernels
-  cpu_baseline the CPU oracle (oracle/, a port - the reference has no CPU path) on a bounded
-               sample of the same scenes, rank 0 only.
+  roofline      the vote op (every launch of cv_hv_forward_f32) timed with HIP events on the stream it runs on,
+                INSIDE the timed region, priced with the algorithmic bytes of SURVEY.md 8d:
+                B_vote = 40 N + 192 V_in + 68 G.  With S > 1 the events include the stretch from co-running scenes;
+                `isolated_*` give the same op from a one-scene-in-flight pass after the timed region.
+  stage_ms      per-stage event times inside the timed region (and `stage_ms_isolated` from that second pass)
+  parity        match flags of the SAME run against the CPU oracle on one scene: grid shape, in-bounds vote count,
+                candidate cells, box count, classes exact; network max abs error
+  cpu_baseline  the CPU oracle (oracle/, a port - the reference has no CPU path) on a bounded sample of the same
+                scenes, rank 0 only: best of --cpu-reps after one warm-up on all host threads, plus one 1-thread run.
 """
 import argparse
 import json
@@ -53,13 +57,15 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="must equal WORLD_SIZE (one rank per GPU)")
     ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--scenes", type=int, default=4, help="distinct resident scenes per rank")
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--algo", type=int, default=0, help="vote algorithm: 0 auto, 1 direct, 2 tiles")
     ap.add_argument("--cpu-scenes", type=int, default=1, help="scenes timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="all-thread repetitions of the CPU oracle after one warm-up "
+                                                            "(best is reported)")
     ap.add_argument("--stage", default="full", choices=["vote_decode", "full"],
                     help="full = MinkUNet34C forward + head + vote + decode + NMS (eval_joint.py path)")
     ap.add_argument("--streams", type=int, default=6,
@@ -78,12 +84,31 @@ def parse():
                          "bf16, one product, fp32 accumulation and storage (BASELINE configs 3-4 name bf16 for "
                          "training; outside the 1e-4 parity bar, reported as dtype bf16)")
     ap.add_argument("--train-batch", type=int, default=3, help="scenes per GPU-step in --mode train (config.yaml:15)")
+    ap.add_argument("--sync-bn", action="store_true", help="--mode train: BatchNorm statistics over all ranks' rows "
+                                                           "(the reference's batch-of-3 semantics under scene-parallel DDP)")
     ap.add_argument("--large", action="store_true",
                     help="BASELINE config 5 shaped scenes: 9x3x9 m room, 40 boxes (use with --points 300000)")
-    ap.add_argument("--teacher-forced", action="store_true",
-                    help="feed the vote/decode stage with predictions synthesised from the labels "
-                         "(realistic peak counts) instead of the random-weight network's output")
-    return ap.parse_args()
+    ap.add_argument("--predictions", default="teacher", choices=["teacher", "network"],
+                    help="what vote + decode are fed with (see the module docstring); the network forward and the head "
+                         "kernel run and are timed either way")
+    ap.add_argument("--teacher-forced", action="store_true", help="same as --predictions teacher (kept for old scripts)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launch-path check without a GPU: parse, rendezvous (CV_DIST_BACKEND=gloo on CPU), barrier, "
+                         "max-reduce, print the JSON skeleton")
+    a = ap.parse_args()
+    if a.teacher_forced:
+        a.predictions = "teacher"
+    return a
+
+
+def check_world(a):
+    """--gpus is the contract's statement of the world size: a launch line whose --gpus and --nproc-per-node disagree
+    would report a whole-job value for a job that was not run"""
+    world, rank, local = cvd.world()
+    if a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (launch with python -m torch.distributed.run "
+                         "--nproc-per-node %d ... bench.py --gpus %d)" % (a.gpus, world, a.gpus, a.gpus))
+    return world, rank, local
 
 
 class ResidentScene:
@@ -109,8 +134,9 @@ class ResidentScene:
         self.vote_bytes_floor = 40 * n_points + 24 * G                   # compulsory traffic
 
 
-def run_step(model, hv, s, ev=None, teacher_forced=False):
-    """One scene through eval_joint.py:163-280: network -> head -> vote -> decode -> per-class NMS."""
+def run_step(model, hv, s, ev=None, teacher=False, keep=None):
+    """One scene through eval_joint.py:163-280: network -> head -> vote -> decode -> per-class NMS.
+    keep: optional dict that receives the device tensors of the step (the parity check reads them)."""
     rec = (lambda i: ev[i].record()) if ev is not None else (lambda i: None)
     with torch.no_grad():
         rec(0)
@@ -120,10 +146,11 @@ def run_step(model, hv, s, ev=None, teacher_forced=False):
             # the fp16-range flag of the network's convolutions is read after decode's wait (no extra wait per scene)
             y = model(x, defer_check=True)
             rec(1)
-            xyz, scale, prob, cls = pipeline.head_joint(y.F)
+            net_pred = pipeline.head_joint(y.F)
+            xyz, scale, prob, cls = net_pred
         else:
             rec(1)
-        if model is None or teacher_forced:
+        if model is None or teacher:
             xyz, scale, prob, cls = s.xyz, s.scale, s.prob, s.cls
         rec(2)
         grid_obj, grid_rot, grid_scale = hv(s.points, xyz, scale, prob)
@@ -135,42 +162,126 @@ def run_step(model, hv, s, ev=None, teacher_forced=False):
         # counted in config.range_fallbacks so that it cannot happen silently)
         with torch.no_grad():
             y = model.program_forward(x, pieces=3)
-            if not teacher_forced:
-                xyz, scale, prob, cls = pipeline.head_joint(y.F)
+            net_pred = pipeline.head_joint(y.F)
+            if not teacher:
+                xyz, scale, prob, cls = net_pred
             grid_obj, grid_rot, grid_scale = hv(s.points, xyz, scale, prob)
         raw = decode.decode_boxes(grid_obj, grid_rot, grid_scale, s.points, xyz, prob, cls, RES)
+    if keep is not None:
+        keep.update(y=y.F if model is not None else None, net_pred=net_pred if model is not None else None,
+                    grids=(grid_obj, grid_rot, grid_scale), raw=raw)
     return decode.nms_per_class(raw["boxes"], raw["scores"], raw["classes"]), raw
 
 
-def cpu_baseline(scenes, n, model, full):
-    """CPU oracle (a port: the reference has no CPU path for the vote and its sparse engine is an
-    absent external dependency) on n of the same scenes, all host threads torch gives us."""
+def cpu_oracle_scene(s, sd, full, teacher):
+    """One scene through the CPU oracle; returns (stage seconds, results) - the results feed the parity flags."""
     import oracle
     from oracle import sparse_oracle as so
+    sc, xyz, scale, prob, cls = s.host
+    pts = sc.points
+    t0 = time.perf_counter()
+    y = net_pred = None
+    if full:
+        c4 = np.concatenate([np.zeros((len(sc.coords), 1), np.int64), sc.coords], 1)
+        y = so.minkunet34c_forward(sd, c4, sc.feats * 2 - 1)
+        net_pred = [a.numpy() for a in so.head_joint_eval(y)]
+        if not teacher:
+            xyz, scale, prob, cls = net_pred
+    t1 = time.perf_counter()
+    g = oracle.hv_forward(pts, xyz, scale, prob, RES, NUM_ROTS, return_vin=True)
+    t2 = time.perf_counter()
+    corner, _, _ = oracle.grid_geometry(pts, RES)
+    d = oracle.decode(g[0], g[1], g[2], corner, RES, pts, xyz, prob, cls)
+    dets = oracle.nms_per_class(d["boxes"], d["scores"], d["classes"])
+    t3 = time.perf_counter()
+    return dict(net=t1 - t0, vote=t2 - t1, decode=t3 - t2, total=t3 - t0), dict(y=y, net_pred=net_pred, grids=g[:3],
+                                                                                v_in=int(g[3]), raw=d, dets=dets)
+
+
+def parity_flags(gpu, ref, s, dec_ref):
+    """Match flags of one scene, HIP path vs CPU oracle (the bar of north_star: integer outputs exact, floats 1e-4).
+    Vote grids: HIP vs oracle on the same predictions.  Decode: HIP decode vs the oracle's decode of the SAME (HIP)
+    grids, so a last-bit difference of an accumulated float cannot flip a tie between two stages' checks."""
+    out = {"scene_seed_index": 0}
+    go, gr, gs = [t.cpu().numpy() for t in gpu["grids"]]
+    ro, rr, rs = ref["grids"]
+    ref = dict(ref, raw=dec_ref)
+    out["grid_shape_exact"] = bool(go.shape == ro.shape)
+    out["v_in_exact"] = bool(s.v_in_run == ref["v_in"])
+    if out["grid_shape_exact"]:
+        out["touched_cells_exact"] = bool(np.array_equal(go == 0, ro == 0))
+        out["grid_obj_max_rel_err"] = float(np.abs(go - ro).max() / max(1.0, float(np.abs(ro).max())))
+    out["candidate_cells_exact"] = bool(np.array_equal(gpu["raw"]["cand_idx"], ref["raw"]["cand_idx"]) and
+                                        np.array_equal(gpu["raw"]["verdict"], ref["raw"]["verdict"]))
+    out["box_count_exact"] = bool(len(gpu["raw"]["boxes"]) == len(ref["raw"]["boxes"]))
+    out["boxes"] = int(len(gpu["raw"]["boxes"]))
+    out["classes_exact"] = bool(list(gpu["raw"]["classes"]) == list(ref["raw"]["classes"]))
+    if out["box_count_exact"] and len(ref["raw"]["boxes"]):
+        out["box_corner_max_abs_err"] = float(np.abs(gpu["raw"]["boxes"] - ref["raw"]["boxes"]).max())
+    if gpu.get("y") is not None and ref.get("y") is not None:
+        y, r = gpu["y"].cpu().numpy(), ref["y"].numpy()
+        out["net_max_abs_err"] = float(np.abs(y - r).max())
+        out["net_out_max_abs"] = float(np.abs(r).max())
+        out["net_within_1e-4"] = bool(out["net_max_abs_err"] <= 1e-4 * max(1.0, out["net_out_max_abs"]))
+        out["head_classes_exact"] = bool(np.array_equal(gpu["net_pred"][3].cpu().numpy(), ref["net_pred"][3]))
+    return out
+
+
+def cpu_baseline(a, scenes, model, hv, full, teacher):
+    """CPU oracle (a port: the reference has no CPU path for the vote and its sparse engine is an absent external
+    dependency) on a bounded sample: scene 0, one warm-up + best of --cpu-reps on all host threads, then ONE run with
+    torch limited to 1 thread.  The same pass yields the parity flags of the HIP path on that scene."""
+    import oracle
     oracle.lib()
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()} if full else None
-    t0 = time.perf_counter()
-    boxes = 0
-    for s in scenes[:n]:
-        sc, xyz, scale, prob, cls = s.host
-        pts = sc.points
-        if full:
-            c4 = np.concatenate([np.zeros((len(sc.coords), 1), np.int64), sc.coords], 1)
-            y = so.minkunet34c_forward(sd, c4, sc.feats * 2 - 1)
-            xyz, scale, prob, cls = [a.numpy() for a in so.head_joint_eval(y)]
-        g = oracle.hv_forward(pts, xyz, scale, prob, RES, NUM_ROTS)
-        corner, _, _ = oracle.grid_geometry(pts, RES)
-        d = oracle.decode(g[0], g[1], g[2], corner, RES, pts, xyz, prob, cls)
-        boxes += len(oracle.nms_per_class(d["boxes"], d["scores"], d["classes"]))
-    dt = time.perf_counter() - t0
-    return n / dt, dt, boxes
+    s = scenes[0]
+    nthreads = torch.get_num_threads()
+    runs, ref = [], None
+    for rep in range(a.cpu_reps + 1):                 # first one is the warm-up
+        t, ref = cpu_oracle_scene(s, sd, full, teacher)
+        if rep > 0 or a.cpu_reps == 0:
+            runs.append(t)
+    best = min(runs, key=lambda t: t["total"])
+    one = None
+    if full:
+        torch.set_num_threads(1)
+        try:
+            one, _ = cpu_oracle_scene(s, sd, full, teacher)
+        finally:
+            torch.set_num_threads(nthreads)
+    keep = {}
+    run_step(model, hv, s, teacher=teacher, keep=keep)
+    torch.cuda.synchronize()
+    if full:
+        xyz, scale = (s.xyz, s.scale) if teacher else keep["net_pred"][:2]
+    else:
+        xyz, scale = s.xyz, s.scale
+    s.v_in_run = hv_cuda.count_votes(s.points, xyz, scale, RES, NUM_ROTS, s.corner, s.dims)
+    sc, hx, hs, hp, hc = s.host
+    if full and not teacher:
+        hx, hs, hp, hc = [t.cpu().numpy() for t in keep["net_pred"]]
+    corner, _, _ = oracle.grid_geometry(sc.points, RES)
+    dec_ref = oracle.decode(*[t.cpu().numpy() for t in keep["grids"]], corner, RES, sc.points, hx, hp, hc)
+    par = parity_flags(keep, ref, s, dec_ref)
+    base = {"value": 1.0 / best["total"], "unit": "scenes/s", "cores": nthreads if full else 1, "kind": "port",
+            "stage_s": {k: round(v, 4) for k, v in best.items()},
+            "one_thread": None if one is None else {"value": 1.0 / one["total"], "cores": 1,
+                                                    "stage_s": {k: round(v, 4) for k, v in one.items()}},
+            "sample": "1 of the same %d-point scenes through the CPU oracle (%s): 1 warm-up + best of %d, %.1f s of CPU "
+                      "work in total; build CPU oracle, not reference code (the reference has no CPU vote and "
+                      "MinkowskiEngine is absent)"
+                      % (a.points, "torch-CPU sparse MinkUNet34C on all host threads + C vote/decode/NMS on 1 thread"
+                         if full else "C vote/decode/NMS, 1 thread", a.cpu_reps,
+                         sum(t["total"] for t in runs) + (one["total"] if one else 0.0))}
+    return base, par
 
 
 def main_train(a):
     """train_joint.py:244-288 steps on synthetic ScanNet-shaped batches: one process per GPU, each with its own
-    batch of scenes (weak scaling), gradients all-reduced by torch DDP over RCCL, BatchNorm statistics per GPU."""
+    batch of scenes (weak scaling), gradients all-reduced by torch DDP over RCCL, BatchNorm statistics per GPU
+    (or over all ranks with --sync-bn)."""
     from canonicalvoting_amd import train
-    world, rank, local = cvd.world()
+    world, rank, local = check_world(a)
     local %= torch.cuda.device_count()          # one rank per GPU on a real node; ranks share GPUs only in the launch-path test
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -187,6 +298,8 @@ def main_train(a):
     ME.set_compute_dtype("bf16" if a.dtype == "bf16" else "fp32")
     torch.manual_seed(0)
     model = MinkUNet34C(3, 6 * 9 + 9 + 1).cuda().train()
+    if a.sync_bn and world > 1:
+        ME.convert_sync_batchnorm(model)
     net = train.make_ddp(model, dev) if world > 1 else model
     opt = train.make_optimizer(model)
     for _ in range(max(a.warmup, 1)):
@@ -206,17 +319,36 @@ def main_train(a):
             "config": {"workload": "train_joint.py step on %d x %d-point synthetic scenes per GPU-step, MinkUNet34C(3, 64) "
                                    "%s, Adam lr 1e-3" % (B, n, "bf16 conv products, fp32 accumulation / storage / "
                                                          "BatchNorm / optimizer" if a.dtype == "bf16" else "fp32"),
-                       "parallelism": "scene-parallel DDP x%d (RCCL gradient all-reduce, per-GPU BatchNorm statistics)"
-                                      % world if world > 1 else "single GPU"},
+                       "parallelism": ("scene-parallel DDP x%d (RCCL gradient all-reduce, %s BatchNorm statistics)"
+                                       % (world, "all-rank (SyncBN)" if a.sync_bn else "per-GPU")) if world > 1
+                                      else "single GPU"},
             "final_loss": float(loss)}), flush=True)
+    cvd.finalize()
+
+
+def main_rendezvous_only(a):
+    """The launch path without a GPU: what the driver's torch.distributed.run line exercises before any kernel runs."""
+    world, rank, _ = check_world(a)
+    cvd.init("gloo" if not torch.cuda.is_available() else "nccl", None)
+    cvd.barrier(None)
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    cvd.barrier(None)
+    dt = cvd.reduce_scalar(time.perf_counter() - t0, "max", None)
+    if rank == 0:
+        print(json.dumps({"metric": "scenes/sec (80k-pt synthetic scans)", "value": None, "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "rendezvous_only": True, "max_seconds": dt,
+                          "scene_seeds_rank0": cvd.scene_seeds(0, a.scenes)}), flush=True)
     cvd.finalize()
 
 
 def main():
     a = parse()
+    if a.rendezvous_only:
+        return main_rendezvous_only(a)
     if a.mode == "train":
         return main_train(a)
-    world, rank, local = cvd.world()
+    world, rank, local = check_world(a)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     local %= torch.cuda.device_count()          # one rank per GPU on a real node; ranks share GPUs only in the launch-path test
     torch.cuda.set_device(local)
@@ -227,6 +359,7 @@ def main():
     ME.set_compute_dtype("bf16" if a.dtype == "bf16" else "fp32")
     hv = HoughVoting(RES, NUM_ROTS)
     full = a.stage == "full"
+    teacher = a.predictions == "teacher" or not full
     model = None
     if full:
         torch.manual_seed(0)
@@ -239,7 +372,7 @@ def main():
         with torch.no_grad():
             x0 = ME.SparseTensor(scenes[0].feats_in, scenes[0].coords4, device=dev)
             net_flops = model.forward_flops(x0)       # (pairs-based, dense-equivalent), untimed
-            if not a.teacher_forced:
+            if not teacher:
                 # the votes that are timed come from the network's predictions: count THEIR in-bounds
                 # votes for the algorithmic byte count (untimed)
                 for s in scenes:
@@ -247,90 +380,102 @@ def main():
                     xyz, scale, prob, cls = pipeline.head_joint(y.F)
                     s.v_in = hv_cuda.count_votes(s.points, xyz, scale, RES, NUM_ROTS, s.corner, s.dims)
                     s.vote_bytes = 40 * a.points + 192 * s.v_in + 68 * s.cells
-    streams = [torch.cuda.Stream(dev) for _ in range(a.streams)] if a.streams > 1 else []
-    hvs = [hv] + [HoughVoting(RES, NUM_ROTS) for _ in range(a.streams - 1)]
+    S = max(1, a.streams)
+    streams = [torch.cuda.Stream(dev) for _ in range(S)] if S > 1 else []
+    hvs = [hv] + [HoughVoting(RES, NUM_ROTS) for _ in range(S - 1)]
     for w in range(a.warmup):
         if streams:
-            with torch.cuda.stream(streams[w % a.streams]):
-                run_step(model, hvs[w % a.streams], scenes[w % len(scenes)], teacher_forced=a.teacher_forced)
+            with torch.cuda.stream(streams[w % S]):
+                run_step(model, hvs[w % S], scenes[w % len(scenes)], teacher=teacher)
         else:
-            run_step(model, hv, scenes[w % len(scenes)], teacher_forced=a.teacher_forced)
+            run_step(model, hv, scenes[w % len(scenes)], teacher=teacher)
     torch.cuda.synchronize()
 
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(a.steps)]
-
-    barrier = lambda: cvd.barrier(dev)
-    barrier()
-    t0 = time.perf_counter()
     n_det = 0
-    if a.streams <= 1:
+    if S <= 1:
+        cvd.barrier(dev)
+        t0 = time.perf_counter()
         for k in range(a.steps):
-            dets, _ = run_step(model, hv, scenes[k % len(scenes)], events[k], a.teacher_forced)
+            dets, _ = run_step(model, hv, scenes[k % len(scenes)], events[k], teacher)
             n_det += len(dets)
+        cvd.barrier(dev)
+        dt = time.perf_counter() - t0
     else:
+        import itertools
         import threading
         sys.setswitchinterval(a.switch_interval)      # GIL hand-off between the scene threads
-        counts = [0] * a.streams
-
+        counts = [0] * S
         # the K steps are handed out from one counter: a thread whose scene was cheap takes the next step at once
-        # (a static round-robin tied thread i to scene i % 4 whenever S was a multiple of the 4 resident scenes and
-        # left the threads with the lighter scenes idle at the end: 353 scenes/s at S = 4 between 401 at 3 and 404 at 6)
-        import itertools
         ticket, ticket_lock = itertools.count(), threading.Lock()
+        # the scene threads exist, are bound to their device / stream and wait here BEFORE the clock starts: thread
+        # start-up (~0.1 ms each, serialised by the GIL) is not part of a step
+        gate = threading.Barrier(S + 1)
 
         def worker(i):
             torch.cuda.set_device(local)
             with torch.cuda.stream(streams[i]):
+                gate.wait()
                 while True:
                     with ticket_lock:
                         k = next(ticket)
                     if k >= a.steps:
                         break
-                    dets, _ = run_step(model, hvs[i], scenes[k % len(scenes)], events[k], a.teacher_forced)
+                    dets, _ = run_step(model, hvs[i], scenes[k % len(scenes)], events[k], teacher)
                     counts[i] += len(dets)
                 streams[i].synchronize()
 
-        threads = [threading.Thread(target=worker, args=(i,)) for i in range(a.streams)]
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(S)]
         for t in threads:
             t.start()
+        while gate.n_waiting < S:                      # every worker is parked
+            time.sleep(0.0005)
+        cvd.barrier(dev)
+        t0 = time.perf_counter()
+        gate.wait()
         for t in threads:
             t.join()
+        cvd.barrier(dev)
+        dt = time.perf_counter() - t0
         n_det = sum(counts)
-    barrier()
-    dt = time.perf_counter() - t0
     dt = cvd.reduce_scalar(dt, "max", dev)
+    torch.cuda.synchronize()
 
-    roofline_pass = "the timed region (one scene in flight)"
-    vote_ms_timed = None
-    if a.streams > 1:
-        torch.cuda.synchronize()
-        # event-to-event time of the vote op INSIDE the timed region: stretched by the kernels of the co-running scenes
-        vote_ms_timed = float(np.mean([e[2].elapsed_time(e[3]) for e in events]))
-        # kernels of concurrent scenes stretch each other's event-to-event times, so the per-stage times and
-        # the roofline of the vote op come from a second, single-stream pass over the same steps
-        torch.cuda.synchronize()
-        events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(a.steps)]
-        for k in range(a.steps):
-            run_step(model, hv, scenes[k % len(scenes)], events[k], a.teacher_forced)
-        torch.cuda.synchronize()
-        roofline_pass = ("a second pass over the same %d steps with one scene in flight, inside this run, after "
-                         "the timed region (which keeps %d scenes in flight)" % (a.steps, a.streams))
-    vote_ms = np.array([e[2].elapsed_time(e[3]) for e in events])
-    stage_ms = {"net": float(np.mean([e[0].elapsed_time(e[1]) for e in events])),
-                "head": float(np.mean([e[1].elapsed_time(e[2]) for e in events])),
-                "vote": float(vote_ms.mean()),
-                "decode": float(np.mean([e[3].elapsed_time(e[4]) for e in events]))}
+    def stage_times(evs):
+        return {"net": float(np.mean([e[0].elapsed_time(e[1]) for e in evs])),
+                "head": float(np.mean([e[1].elapsed_time(e[2]) for e in evs])),
+                "vote": float(np.mean([e[2].elapsed_time(e[3]) for e in evs])),
+                "decode": float(np.mean([e[3].elapsed_time(e[4]) for e in evs]))}
+
     vb = np.array([scenes[k % len(scenes)].vote_bytes for k in range(a.steps)], dtype=np.float64)
+    stage_ms = stage_times(events)
+    vote_ms = np.array([e[2].elapsed_time(e[3]) for e in events])
     achieved = float((vb / (vote_ms * 1e-3)).mean() / 1e9)
+    iso_stage = iso_achieved = iso_vote = None
+    if S > 1:
+        # kernels of concurrent scenes stretch each other's event-to-event times: the same steps once more with ONE
+        # scene in flight, after the timed region, give the op on its own (side fields; `frac` is the timed region's)
+        iso_steps = min(a.steps, 48)
+        ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(iso_steps)]
+        for k in range(iso_steps):
+            run_step(model, hv, scenes[k % len(scenes)], ev2[k], teacher)
+        torch.cuda.synchronize()
+        iso_stage = stage_times(ev2)
+        v2 = np.array([e[2].elapsed_time(e[3]) for e in ev2])
+        iso_vote = float(v2.mean())
+        iso_achieved = float((vb[:iso_steps] / (v2 * 1e-3)).mean() / 1e9)
     s0 = scenes[0]
     # HBM bytes of the vote kernel from the PMC counters are collected offline (rocprofv3 --pmc in its
-    # own passes, profiles/r1/vote_hbm_traffic.json) for the default 80k workload; null otherwise
+    # own passes, profiles/r*/vote_hbm_traffic.json) for the default 80k workload; null otherwise
     traffic = None
-    tj = os.path.join(ROOT, "profiles", "r1", "vote_hbm_traffic.json")
-    if os.path.exists(tj) and a.points == N_POINTS and not a.large and a.algo in (0, 2):
-        traffic = json.load(open(tj))["hbm_bytes_per_launch"]
+    for rnd in ("r2", "r1"):
+        tj = os.path.join(ROOT, "profiles", rnd, "vote_hbm_traffic.json")
+        if os.path.exists(tj) and a.points == N_POINTS and not a.large and a.algo in (0, 2):
+            traffic = json.load(open(tj))["hbm_bytes_per_launch"]
+            break
     conv_peak = 2500.0 if a.dtype == "bf16" else 157.3       # dense bf16 / fp32 matrix peak, TFLOP/s
     pieces_n = 1 if a.dtype == "bf16" else 3 if (full and model.USE_PROGRAM and model.PIECES == 2) else 6
+    net_ms = (iso_stage or stage_ms)["net"]
     out = {
         "metric": "scenes/sec (80k-pt synthetic scans)",
         "value": cvd.throughput(a.steps, world, dt),
@@ -350,29 +495,33 @@ def main():
                                                                  else "fp32")) if full else
                                ("single %d-point synthetic scene per GPU-step: vote + decode + NMS only "
                                 "(synthesised predictions)" % a.points),
-                   "predictions": "synthesised from labels (teacher-forced)" if (a.teacher_forced or not full)
-                                  else "network output",
+                   "predictions": ("network + head run and timed; vote/decode fed with predictions synthesised from "
+                                   "the labels (teacher-forced)" if full else "synthesised from labels")
+                                  if teacher else "network output (random init: no cell reaches thresh_high)",
                    "points": a.points, "num_rots": NUM_ROTS, "res": RES, "grid": s0.dims,
                    "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}.get(a.algo, "ablation-%d" % a.algo),
-                   "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": a.streams},
+                   "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": S},
         "roofline": {"bound": "hbm", "kernel": "vote op (all launches of cv_hv_forward_f32)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_ms": float(vote_ms.mean()), "bytes_per_launch": float(vb.mean()),
                      "compulsory_bytes": float(s0.vote_bytes_floor), "v_in": s0.v_in,
-                     "measured_in": roofline_pass,
-                     "avg_ms_in_timed_region": vote_ms_timed,
-                     "frac_in_timed_region": (float(vb.mean()) / (vote_ms_timed * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                                             if vote_ms_timed else None},
+                     "measured_in": "the timed region (HIP events on the scene's stream, %d scene%s in flight)"
+                                    % (S, "s" if S > 1 else ""),
+                     "isolated_avg_ms": iso_vote, "isolated_achieved": iso_achieved,
+                     "isolated_frac": iso_achieved / HBM_PEAK_GBS if iso_achieved else None,
+                     "note": "algorithmic-byte model of the reference's scatter (48 fp32 atomics per vote); the tile "
+                             "kernel accumulates in LDS, its real HBM traffic is `traffic`"},
         "roofline_conv": None if not full else {
             "bound": "mfma", "kernel": "sparse MinkUNet34C forward (all conv launches + coordinate manager)",
-            "achieved": net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12, "peak": conv_peak, "unit": "TFLOP/s",
-            "frac": net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12 / conv_peak,
+            "achieved": net_flops[0] / (net_ms * 1e-3) / 1e12, "peak": conv_peak, "unit": "TFLOP/s",
+            "frac": net_flops[0] / (net_ms * 1e-3) / 1e12 / conv_peak,
             "flops_per_forward": net_flops[0], "dense_equivalent_flops": net_flops[1],
             "piece_products_per_fp32_product": pieces_n if ME.CONV_X6 else None,
             "piece_flops_per_forward": pieces_n * net_flops[0] if ME.CONV_X6 else None,
-            "frac_of_16bit_matrix_peak": (pieces_n * net_flops[0] / (stage_ms["net"] * 1e-3) / 1e12 / 2500.0) if ME.CONV_X6 else None,
+            "frac_of_16bit_matrix_peak": (pieces_n * net_flops[0] / (net_ms * 1e-3) / 1e12 / 2500.0) if ME.CONV_X6 else None,
             "range_fallbacks": int(getattr(model, "range_fallbacks", 0)),
+            "measured_in": "one scene in flight" if (S == 1 or iso_stage) else "timed region",
             "note": ("opt-in bf16 compute mode: operands rounded to bf16, one product on v_mfma_f32_32x32x16_bf16, fp32 "
                      "accumulation and storage; outside the 1e-4 parity bar; " if pieces_n == 1 else
                      ("fp32 results; every fp32 product is computed as three exact fp16 x fp16 piece products "
@@ -388,20 +537,11 @@ def main():
                     "against the %s matrix peak" % ("bf16" if a.dtype == "bf16" else "fp32")},
         "detections_per_scene": n_det / a.steps,
         "stage_ms": stage_ms,
-        "stage_ms_measured_in": roofline_pass,
+        "stage_ms_isolated": iso_stage,
     }
-    if rank == 0 and world == 1 and a.cpu_scenes > 0:
-        nc = min(a.cpu_scenes, len(scenes))
-        v, secs, _ = cpu_baseline(scenes, nc, model, full)
-        out["cpu_baseline"] = {"value": v, "unit": "scenes/s", "cores": torch.get_num_threads() if full else 1,
-                               "kind": "port",
-                               "sample": "%d of the same %d-point scenes through the CPU oracle (%s), %.1f s; "
-                                         "build CPU oracle, not reference code (the reference has no CPU "
-                                         "vote and MinkowskiEngine is absent)"
-                                         % (nc, a.points, "torch-CPU sparse MinkUNet34C + C vote/decode/NMS"
-                                            if full else "C vote/decode/NMS, 1 thread", secs)}
-    else:
-        out["cpu_baseline"] = None
+    out["cpu_baseline"] = out["parity"] = None
+    if rank == 0 and a.cpu_scenes > 0:
+        out["cpu_baseline"], out["parity"] = cpu_baseline(a, scenes, model, hv, full, teacher)
     if rank == 0:
         print(json.dumps(out), flush=True)
     cvd.finalize()

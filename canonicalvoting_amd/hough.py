@@ -10,6 +10,10 @@ class HVFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points, xyz, scale, obj, res, num_rots, corners=None):
         ctx.save_for_backward(points, xyz, scale, obj, res, num_rots)
+        # the 7-argument variant votes into a grid anchored at corners[0]; its backward has to sample grad_grid
+        # at the same cells (the reference's 7-argument Function, sunrgbd/brnetcanon.py:94-103, defines no
+        # backward at all: it raises instead of returning numbers)
+        ctx.corners = None if corners is None else corners.detach()
         if corners is None:
             outputs = hv_cuda.forward(points, xyz, scale, obj, res, num_rots)
         else:
@@ -21,7 +25,8 @@ class HVFunction(torch.autograd.Function):
     def backward(ctx, grad_obj, grad_rot, grad_scale):
         # only grad_obj is propagated (eval_joint.py:33-38); grad_rot / grad_scale are ignored
         points, xyz, scale, obj, res, num_rots = ctx.saved_tensors
-        outputs = hv_cuda.backward(grad_obj.contiguous(), points, xyz, scale, obj, res, num_rots)
+        outputs = hv_cuda.backward(grad_obj.contiguous(), points, xyz, scale, obj, res, num_rots,
+                                   corners=ctx.corners)
         d_xyz_labels, d_scale_labels, d_obj_labels = outputs
         return None, d_xyz_labels, d_scale_labels, d_obj_labels, None, None, None
 

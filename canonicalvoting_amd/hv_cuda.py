@@ -31,18 +31,15 @@ def set_algorithm(algo):
     _algo = int(algo)
 
 
-_recent_corners = {}
-
-
 def _remember_corner(grid_obj, mn):
-    if len(_recent_corners) > 16:
-        _recent_corners.clear()
-    _recent_corners[(grid_obj.data_ptr(), tuple(grid_obj.shape))] = [float(v) for v in mn]
+    # kept on the tensor OBJECT (like _scalar's host value): a cache keyed by address would hand a grid that was
+    # not produced by forward() (a loaded / golden grid on a recycled allocation of the same shape) a stale origin
+    grid_obj._cv_corner = [float(v) for v in mn]
 
 
 def recent_corner(grid_obj):
-    """grid origin of a grid_obj returned by forward() (None if it is not one of the last few)"""
-    return _recent_corners.get((grid_obj.data_ptr(), tuple(grid_obj.shape)))
+    """grid origin of a grid_obj returned by forward() (None for any other tensor)"""
+    return getattr(grid_obj, "_cv_corner", None)
 
 
 def _check_input(x, name):
@@ -98,7 +95,14 @@ def prefetch_geometry(points):
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
     if len(_prefetched) > 8:
-        _prefetched.clear()
+        # drop the oldest entries, but only once their copy into the pinned buffer has landed: torch's pinned
+        # allocator does not know about the raw hipMemcpyAsync, so a buffer released earlier could be reissued
+        # and overwritten by the copy still in flight
+        for key in list(_prefetched)[:-8]:
+            old = _prefetched.pop(key)
+            old[3].synchronize()
+            if len(_pinned_pool) < 32:
+                _pinned_pool.append(old[2])
     # the entry keeps `points` (and the workspace) alive, so the address cannot be recycled while it is cached
     _prefetched[points.data_ptr()] = (points, points._version, host, ev, ws)
 
@@ -187,14 +191,19 @@ def forward(points, xyz_labels, scale_labels, obj_labels, res, num_rots, corners
     return [grid_obj, grid_rot, grid_scale]
 
 
-def backward(grad_grid, points, xyz_labels, scale_labels, obj_labels, res, num_rots):
+def backward(grad_grid, points, xyz_labels, scale_labels, obj_labels, res, num_rots, corners=None):
+    """``corners`` (optional, not in the reference's 7-positional signature): the [2,3] box the forward was
+    given; the grid origin is then corners[0] as in forward() instead of the minimum of the points."""
     _check_input(grad_grid, "grad_grid")
     n, res_v, nrot = _checked_inputs(points, xyz_labels, scale_labels, obj_labels, res, num_rots)
     if grad_grid.dtype != torch.float32 or grad_grid.dim() != 3:
         raise RuntimeError("grad_grid must be a float32 [X,Y,Z] tensor")
     L = _lib.lib()
     dev = points.device
-    mn, _, _ = grid_geometry(points, res_v)          # hv_cuda_kernel.cu:274-276
+    if corners is None:
+        mn, _, _ = grid_geometry(points, res_v)      # hv_cuda_kernel.cu:274-276
+    else:
+        mn = [float(v) for v in corners.detach().to("cpu", torch.float32)[0]]
     cdims = (ctypes.c_int * 3)(*grad_grid.shape)     # :200 sizes come from grad_grid
     d_xyz = torch.empty_like(xyz_labels)
     d_scale = torch.empty_like(scale_labels)
