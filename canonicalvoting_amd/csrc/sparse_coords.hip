@@ -74,6 +74,11 @@ __global__ __launch_bounds__(256) void insert_rows(const int* __restrict__ coord
     const int n = *n_ptr;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        // pack_key keeps 16 bits per field: a coordinate whose neighbour lookups (up to +-2 * 16 at the coarsest
+        // level, rounded up to 64) leave the window, or a batch index beyond 16 bits, would alias another voxel
+        const int lo = -32768 + 64, hi = 32767 - 64;
+        if ((unsigned)c.x > 0xffffu || c.y < lo || c.y > hi || c.z < lo || c.z > hi || c.w < lo || c.w > hi)
+            atomicAdd(dup_count + 1, 1);
         const long long slot = table_insert_min(keys, vals, mask, pack_key(c.x, c.y, c.z, c.w), i);
         (void)slot;
     }
@@ -259,7 +264,8 @@ size_t cv_sp_levels_workspace_bytes(long long n) {
 // Builds the coordinate sets of tensor strides 1,2,4,8,16 and their hash tables.
 //   d_coords[L]   : int32 [cap_rows][4] (L = 0 is the caller's input set, rows n)
 //   d_keys/vals[L]: hash tables of cv_sp_table_capacity(n) slots each
-//   d_counts      : int32[8] device; [L] = rows at level L, [5] = duplicate count at level 0
+//   d_counts      : int32[8] device; [L] = rows at level L, [5] = duplicate count at level 0, [6] = rows whose
+//                   coordinates are outside the 16-bit key window (|c| <= 32703, batch < 65536)
 // h_counts receives the same 8 ints (one synchronisation).
 int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_keys,
                        int32_t* const* d_vals, long long n, long long cap, int num_levels,

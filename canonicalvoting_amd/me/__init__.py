@@ -75,7 +75,7 @@ class CoordinateManager:
                        "cv_sp_build_levels")
         self._verified = sync
         if sync:
-            self._raise_on_dups(counts_h[5])
+            self._raise_on_dups(counts_h[5], counts_h[6])
             self.counts = [int(counts_h[i]) for i in range(num_levels)]
         else:
             self.counts = [n]
@@ -84,7 +84,10 @@ class CoordinateManager:
         self._maps = {}
 
     @staticmethod
-    def _raise_on_dups(count):
+    def _raise_on_dups(count, out_of_range=0):
+        if out_of_range != 0:
+            raise RuntimeError("SparseTensor: %d coordinates outside the supported window (spatial coordinates in "
+                               "[-32704, 32703], batch index < 65536)" % out_of_range)
         if count != 0:
             raise RuntimeError("SparseTensor: %d duplicate coordinates (quantise with "
                                "utils.sparse_quantize first, as utils/dataloader.py:197 does)" % count)
@@ -92,7 +95,8 @@ class CoordinateManager:
     def _verify(self):
         """deferred duplicate check of a set built without a host sync (first map request pays it)"""
         if not self._verified:
-            self._raise_on_dups(int(self._counts_d[5].item()))
+            c = self._counts_d[5:7].tolist()
+            self._raise_on_dups(int(c[0]), int(c[1]))
             self._verified = True
 
     def ensure_levels(self, num_levels=NUM_LEVELS):
@@ -822,6 +826,78 @@ class MinkowskiBatchNorm(nn.Module):
             return x._like(torch.relu(y) if relu else y)
         scale, shift = bn_affine(self.bn)
         return x._like(affine_forward(x.F.contiguous(), scale, shift, relu, residual=residual))
+
+
+class _SyncBNFn(torch.autograd.Function):
+    """Training-mode BatchNorm over the rows of ALL ranks (scene-parallel DDP gives every rank its own scenes; the
+    reference's statistics are over the batch of 3 scans on one GPU, config/config.yaml:15, train_joint.py:244-251).
+    One all-reduce of [2C + 1] sums (count, sum x, sum x^2) in the forward, one of [2C] (sum dy, sum dy * xhat) in the
+    backward; everything else is row-local.  Plain torch ops on purpose: the same code runs over gloo on CPU (the
+    2-rank test) and over RCCL on the GPUs, and it is an option next to the per-GPU HIP BatchNorm, not the default."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, group):
+        import torch.distributed as dist
+        n, c = x.shape
+        xd = x.double()
+        pack = torch.cat([xd.new_full((1,), float(n)), xd.sum(0), (xd * xd).sum(0)])
+        dist.all_reduce(pack, group=group)
+        total = pack[0]
+        mean = pack[1:1 + c] / total
+        var = (pack[1 + c:] / total - mean * mean).clamp_(min=0.0)           # biased (normalisation) variance
+        with torch.no_grad():
+            running_mean.mul_(1 - momentum).add_(momentum * mean.to(running_mean.dtype))
+            unbiased = var * (total / (total - 1).clamp(min=1.0))
+            running_var.mul_(1 - momentum).add_(momentum * unbiased.to(running_var.dtype))
+        invstd = torch.rsqrt(var + eps)
+        xhat = ((xd - mean) * invstd).to(x.dtype)
+        ctx.save_for_backward(xhat, gamma, invstd.to(x.dtype))
+        ctx.total = total
+        ctx.group = group
+        return xhat * gamma + beta
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        xhat, gamma, invstd = ctx.saved_tensors
+        c = dy.shape[1]
+        dyd = dy.double()
+        sums = torch.cat([dyd.sum(0), (dyd * xhat.double()).sum(0)])
+        dgamma, dbeta = sums[c:].to(dy.dtype), sums[:c].to(dy.dtype)          # local: DDP averages parameter grads
+        dist.all_reduce(sums, group=ctx.group)
+        m_dy = (sums[:c] / ctx.total).to(dy.dtype)
+        m_dyx = (sums[c:] / ctx.total).to(dy.dtype)
+        dx = (dy - m_dy - xhat * m_dyx) * (gamma * invstd)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
+    """MinkowskiBatchNorm whose training-mode statistics span all ranks (ME.MinkowskiSyncBatchNorm); same ``bn``
+    sub-module, same state-dict keys.  Eval mode and single-process runs are the base class."""
+    process_group = None
+
+    def forward_fused(self, x, residual=None, relu=False):
+        import torch.distributed as dist
+        bn = self.bn
+        if not (self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1):
+            return super().forward_fused(x, residual, relu)
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+        y = _SyncBNFn.apply(x.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                            self.process_group)
+        if residual is not None:
+            y = y + residual
+        return x._like(torch.relu(y) if relu else y)
+
+
+def convert_sync_batchnorm(module, process_group=None):
+    """every MinkowskiBatchNorm of ``module`` becomes a MinkowskiSyncBatchNorm in place (parameters, buffers and
+    state-dict names untouched) - the counterpart of ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm"""
+    for m in module.modules():
+        if type(m) is MinkowskiBatchNorm:
+            m.__class__ = MinkowskiSyncBatchNorm
+            m.process_group = process_group
+    return module
 
 
 class MinkowskiReLU(nn.Module):

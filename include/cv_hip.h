@@ -140,7 +140,8 @@ size_t cv_sp_levels_workspace_bytes(long long n);
  * unique(floor(c / 2ts) * 2ts), ordered by first appearance) and one hash table per level.
  * d_coords[0] is the caller's input (n rows); d_coords[1..], d_keys[L], d_vals[L] are caller
  * allocated (n rows / `cap` slots each).  h_counts[0..4] = rows per level, h_counts[5] = number
- * of duplicate input coordinates (must be 0).  Synchronises `stream` once, or not at all when
+ * of duplicate input coordinates (must be 0), h_counts[6] = rows outside the 16-bit key window (spatial
+ * coordinates in [-32704, 32703], batch index < 65536; must be 0).  Synchronises `stream` once, or not at all when
  * h_counts is NULL (the counts then stay in d_counts only). */
 int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_keys,
                        int32_t* const* d_vals, long long n, long long cap, int num_levels,

@@ -79,3 +79,36 @@ def hv_forward(points, xyz, scale, obj, res, num_rots, acc_dtype=np.float64):
     g_scale = (g_scale.astype(f32).astype(np.float64) / d[:, None]).astype(f32)
     return (w32.reshape(X, Y, Z), g_rot.reshape(X, Y, Z, 2), g_scale.reshape(X, Y, Z, 3),
             int(ok.sum()))
+
+
+def contribution_counts(points, xyz, scale, res, num_rots, corner=None, dims=None, chunk=20000):
+    """int32 [X,Y,Z]: how many (vote, corner) contributions each cell receives (hv_cuda_kernel.cu:41-96: eight per
+    in-bounds vote).  Tests use it to state the accumulated-rounding bound of a cell's sums; same fp32 geometry as
+    hv_forward above, chunked over points so that a 300k-point scene stays within a few hundred MB."""
+    pts = np.asarray(points, f32)
+    xyz = np.asarray(xyz, f32)
+    scale = np.asarray(scale, f32)
+    res = f32(res)
+    if corner is None:
+        corner, _, dims = grid_dims(pts, res)
+    corner = np.asarray(corner, f32)
+    X, Y, Z = dims
+    ct, st = rot_table(num_rots)
+    counts = np.zeros(X * Y * Z, np.int64)
+    for a in range(0, len(pts), chunk):
+        p = pts[a:a + chunk]
+        corr = (xyz[a:a + chunk] * scale[a:a + chunk]).astype(f32)
+        cx, cy, cz = corr[:, 0:1], corr[:, 1:2], corr[:, 2:3]
+        ox = ((-ct)[None] * cx).astype(f32) + (st[None] * cz).astype(f32)
+        oy = np.broadcast_to(-cy, ox.shape)
+        oz = ((-st)[None] * cx).astype(f32) - (ct[None] * cz).astype(f32)
+        g = [(((p[:, k:k + 1] + o).astype(f32) - corner[k]).astype(f32) / res).astype(f32)
+             for k, o in enumerate((ox, oy, oz))]
+        ok = (g[0] >= 0) & (g[1] >= 0) & (g[2] >= 0) & (g[0] < f32(X - 1)) & (g[1] < f32(Y - 1)) & (g[2] < f32(Z - 1))
+        fl = [np.trunc(v[ok]).astype(np.int64) for v in g]
+        base = (fl[0] * Y + fl[1]) * Z + fl[2]
+        for bx in (0, 1):
+            for by in (0, 1):
+                for bz in (0, 1):
+                    counts += np.bincount(base + (bx * Y + by) * Z + bz, minlength=X * Y * Z)
+    return counts.reshape(X, Y, Z).astype(np.int32)

@@ -30,7 +30,8 @@ def evaluate(model, dataset, res=0.03, teacher=False, nclasses=9, device="cuda")
     loader = torch.utils.data.DataLoader(dataset, collate_fn=collate_fn, batch_size=1, shuffle=False)
     for index, (ids, coords, feats, _, _, _) in enumerate(loader):
         id_scan = ids[0]
-        feats = feats.to(device) * 2.0 - 1.0                                  # eval_joint.py:167-168
+        feats = feats.to(device)
+        feats[:, -3:] = feats[:, -3:] * 2.0 - 1.0                             # eval_joint.py:167-168: colour columns only
         coords = coords.to(device)
         with torch.no_grad():
             out = model(ME.SparseTensor(feats, coords, device=device))

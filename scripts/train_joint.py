@@ -38,7 +38,15 @@ def main():
     torch.manual_seed(0)
     model = MinkUNet34C(6 if (cfg and cfg.use_xyz) else 3, 6 * 9 + 9 + 1).to(dev)
     net = train.make_ddp(model, dev) if world > 1 else model
-    opt = train.make_optimizer(model, lr=a.lr)
+    base_lr, wd, steps, rates = a.lr, 0.0, (80, 120, 160), (0.1, 0.1, 0.1)
+    first_epoch, last_epoch = 0, a.epochs - 1
+    if cfg:
+        # train_joint.py:204-206,219-223,235: the optimizer and the schedule come from the config
+        base_lr, wd = float(cfg.opt.learning_rate), float(cfg.weight_decay)
+        steps = [int(x) for x in str(cfg.opt.lr_decay_steps).split(",")]
+        rates = [float(x) for x in str(cfg.opt.lr_decay_rates).split(",")]
+        first_epoch, last_epoch = int(cfg.start_epoch), int(cfg.max_epoch)      # range(start_epoch, max_epoch + 1)
+    opt = train.make_optimizer(model, lr=base_lr, weight_decay=wd)
     if cfg:
         # train_joint.py:205-211; every rank reads its own slice of the scans (DistributedSampler)
         ds = ScanNetXYZProbMultiDataset(cfg, training=True, augment=cfg.augment)
@@ -48,19 +56,20 @@ def main():
     else:
         ds = SyntheticScanDataset(a.scenes, a.points, seed0=1000 * rank)      # every rank owns its scenes
         loader = torch.utils.data.DataLoader(ds, batch_size=a.batch, shuffle=True, collate_fn=collate_fn, drop_last=True)
-    for epoch in range(a.epochs):
-        train.adjust_learning_rate(opt, epoch, a.lr)
+    for epoch in range(first_epoch, last_epoch + 1):
+        train.adjust_learning_rate(opt, epoch, base_lr, steps, rates)
         net.train()
         t0, tot, n = time.perf_counter(), 0.0, 0
         for _, coords, feats, xyz, scale, cls in loader:
-            loss, _ = train.train_step(net, opt, coords.to(dev), feats.to(dev) * 2.0 - 1.0, xyz.to(dev),
-                                       scale.to(dev), cls.to(dev))
+            feats = feats.to(dev)
+            feats[:, -3:] = feats[:, -3:] * 2.0 - 1.0                         # train_joint.py:248-249: colour columns only
+            loss, _ = train.train_step(net, opt, coords.to(dev), feats, xyz.to(dev), scale.to(dev), cls.to(dev))
             tot += float(loss)
             n += 1
         if rank == 0:
             print("epoch %d  loss %.4f  %.1f s" % (epoch, tot / max(n, 1), time.perf_counter() - t0), flush=True)
-    if a.save and rank == 0:
-        torch.save(model.state_dict(), a.save)                                # train_joint.py:290-291
+        if a.save and rank == 0 and (epoch % 10 == 0 or epoch == last_epoch):
+            torch.save(model.state_dict(), a.save)                            # train_joint.py:290-291 (every 10 epochs)
     cvd.finalize()
 
 

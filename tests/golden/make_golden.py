@@ -51,4 +51,4 @@ if __name__ == "__main__":
     vote_case("vote_512", seed=3, n=512, room=(1.5, 0.9, 1.5), n_boxes=2, num_rots=24, res=0.06,
               margin=0.5, box_scale=0.4, thresh=8.0)
     vote_case("vote_2k", seed=5, n=2048, room=(2.0, 1.0, 2.0), n_boxes=3, num_rots=120, res=0.05,
-              margin=0.6, box_scale=0.5, thresh=60.0, full=False)
+              margin=0.6, box_scale=0.5, thresh=60.0)

@@ -58,3 +58,98 @@ def test_single_process_is_identity():
     os.environ.pop("WORLD_SIZE", None)
     assert cvd.reduce_scalar(3.5, "max") == 3.5 and cvd.throughput(10, 1, 2.0) == 5.0
     assert cvd.scene_seeds(3, 2) == [3000, 3001]
+
+
+class _TinyNet(torch.nn.Module):
+    """Linear -> BatchNorm over rows -> ReLU -> Linear: enough to push gradients through the statistics"""
+
+    def __init__(self, sync):
+        super().__init__()
+        from canonicalvoting_amd import me as ME
+        self.a = torch.nn.Linear(5, 16)
+        self.norm = (ME.MinkowskiSyncBatchNorm if sync else ME.MinkowskiBatchNorm)(16)
+        self.b = torch.nn.Linear(16, 3)
+        self.sync = sync
+
+    def forward(self, x):
+        from canonicalvoting_amd import me as ME
+        h = self.a(x)
+        if self.sync:
+            bn = self.norm.bn
+            h = ME._SyncBNFn.apply(h, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, None)
+        else:
+            h = self.norm.bn(h)
+        return self.b(torch.relu(h))
+
+
+def _syncbn_batch():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1000, 5, generator=g) * torch.tensor([1.0, 3.0, 0.2, 1.0, 5.0]) + torch.tensor([0.0, 2.0, -1.0, 0.5, 0.0])
+    t = torch.randn(1000, 3, generator=g)
+    return x, t
+
+
+def _syncbn_worker(rank, world_size, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world_size),
+                      RANK=str(rank), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from canonicalvoting_amd import dist as cvd
+    cvd.init("gloo")
+    torch.manual_seed(0)
+    net = _TinyNet(sync=True).train()
+    ddp = DDP(net)
+    x, t = _syncbn_batch()
+    rows = slice(0, 700) if rank == 0 else slice(700, 1000)        # two scans on rank 0, one on rank 1
+    xr = x[rows].clone().requires_grad_(True)
+    # DDP averages parameter gradients over ranks: world * (sum over my rows) / N_total sums to the batch mean
+    loss = world_size * ((ddp(xr) - t[rows]) ** 2).sum() / 1000.0
+    loss.backward()
+    # numpy, not tensors: a tensor in a queue is a shared-memory handle that dies with this process
+    q.put((rank, {k: v.grad.numpy().copy() for k, v in net.named_parameters()}, xr.grad.numpy().copy(),
+           net.norm.bn.running_mean.numpy().copy(), net.norm.bn.running_var.numpy().copy(), float(loss.detach())))
+    cvd.finalize()
+
+
+def test_sync_batchnorm_two_ranks_reproduce_the_single_process_batch_of_three():
+    """train_joint.py:244-251 computes BatchNorm statistics over the 3 scans of a batch on one GPU; under
+    scene-parallel DDP with --sync-bn two ranks holding 2 + 1 scans must give the same statistics, the same running
+    buffers and - after DDP's gradient averaging - the same parameter and input gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted((q.get(timeout=180) for _ in procs), key=lambda o: o[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    ref = _TinyNet(sync=False).train()
+    x, t = _syncbn_batch()
+    x = x.clone().requires_grad_(True)
+    loss = ((ref(x) - t) ** 2).sum() / 1000.0
+    loss.backward()
+    T = torch.from_numpy
+    (_, g0, dx0, rm0, rv0, l0), (_, g1, dx1, rm1, rv1, l1) = [
+        (o[0], {k: T(v) for k, v in o[1].items()}, T(o[2]), T(o[3]), T(o[4]), o[5]) for o in out]
+    assert abs((l0 + l1) / 2 - float(loss)) < 1e-5 * abs(float(loss))
+    for k, p in ref.named_parameters():
+        torch.testing.assert_close(g0[k], p.grad, rtol=1e-4, atol=1e-6)      # DDP left the same averaged gradient
+        torch.testing.assert_close(g1[k], g0[k], rtol=0, atol=0)              # on both ranks
+    torch.testing.assert_close(torch.cat([dx0, dx1]) / 2, x.grad, rtol=1e-4, atol=1e-7)
+    for rm, rv in ((rm0, rv0), (rm1, rv1)):
+        torch.testing.assert_close(rm, ref.norm.bn.running_mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(rv, ref.norm.bn.running_var, rtol=1e-5, atol=1e-6)
+
+
+def test_convert_sync_batchnorm_keeps_the_state_dict():
+    from canonicalvoting_amd import me as ME
+    from canonicalvoting_amd.minkunet import MinkUNet34C
+    m = MinkUNet34C(3, 8)
+    keys = list(m.state_dict())
+    ME.convert_sync_batchnorm(m)
+    assert list(m.state_dict()) == keys
+    bns = [x for x in m.modules() if isinstance(x, ME.MinkowskiBatchNorm)]
+    assert len(bns) == 62 and all(type(x) is ME.MinkowskiSyncBatchNorm for x in bns)

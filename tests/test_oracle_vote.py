@@ -201,3 +201,15 @@ def test_proposal_oracle_matches_reference_lines_executed_on_cpu():
     np.testing.assert_allclose(cand, z["candidates"], rtol=0, atol=1e-6)
     np.testing.assert_array_equal(scales, z["scales"])
     assert float(np.abs(z["probs"]).max()) == 0.0
+
+
+def test_contribution_counts_agree_with_the_c_oracle():
+    """hv_numpy.contribution_counts (the n_c of the quotient-grid bound in tests/test_vote_gpu.py): eight per in-bounds
+    vote of the C oracle, every touched cell has some, chunking does not change it"""
+    sc = make_scene(4, n_points=1500, res=0.06, room=(1.5, 0.9, 1.5), n_boxes=2, margin=0.5, box_scale=0.4)
+    xyz, scale, prob, _ = synth_predictions(sc)
+    g = oracle.hv_forward(sc.points, xyz, scale, prob, sc.res, 36, return_vin=True)
+    cnt = hv_numpy.contribution_counts(sc.points, xyz, scale, sc.res, 36)
+    assert cnt.shape == g[0].shape and int(cnt.sum()) == 8 * g[3]
+    assert (cnt[g[0] != 0] > 0).all()
+    assert np.array_equal(cnt, hv_numpy.contribution_counts(sc.points, xyz, scale, sc.res, 36, chunk=97))

@@ -1,0 +1,169 @@
+"""Parity at the sizes BASELINE.json quotes, on the exact launch path bench.py times.
+
+  config 2   one 80 000-point scene: the C-program MinkUNet34C forward (4 mask groups, split-K sizing for 256 CUs,
+             one-arena scene maps, C executor - everything rows >= 16 384 switches on) against the CPU oracle,
+             head classes, vote + decode of the network's own predictions
+  config 5   one 300 000-point SUN RGB-D shaped scene (9 x 3 x 9 m room, 40 boxes, grid ~302 x 102 x 302):
+             coordinate sets / kernel maps exact at that hash occupancy, vote grid exact integer outputs,
+             two separate 8-channel models on ONE SparseTensor (eval_separate.py:162-186)
+
+Bars: integer outputs (coordinate sets, kernel maps, classes, grid shape, in-bounds vote count, touched-cell set,
+candidates, verdicts, box count) exact; floats within 1e-4 (north_star), with the per-cell bound of the quotient grids
+of tests/test_vote_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import sparse_oracle as so
+from canonicalvoting_amd import decode, hv_cuda, pipeline
+from canonicalvoting_amd import me as ME
+from canonicalvoting_amd.hough import HoughVoting
+from canonicalvoting_amd.minkunet import MinkUNet34C
+from canonicalvoting_amd.synth import make_scene, synth_predictions
+from tests.test_vote_gpu import assert_grids_close
+
+pytestmark = pytest.mark.gpu
+RES, R = 0.03, 120
+
+
+def dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def decided_points(class_logits_ref, err):
+    """points whose two argmaxes (over the 9 classes + background for the head select, over the 9 classes for the
+    label: eval_joint.py:176-190) have a top-2 margin in the ORACLE's logits above twice the float error between the
+    two networks - a tie inside the float tolerance has no defined winner"""
+    ok = np.ones(len(class_logits_ref), bool)
+    for logits in (class_logits_ref, class_logits_ref[:, :-1]):
+        top2 = np.sort(logits, 1)[:, -2:]
+        ok &= (top2[:, 1] - top2[:, 0]) > 2 * err
+    return ok
+
+
+def test_config2_80k_network_program_matches_oracle(cuda, built_lib):
+    sc = make_scene(0, n_points=80000)
+    coords4 = np.concatenate([np.zeros((80000, 1), np.int64), sc.coords], 1)
+    feats = (sc.feats * 2 - 1).astype(np.float32)
+    torch.manual_seed(0)
+    model = MinkUNet34C(3, 6 * 9 + 9 + 1).cuda().eval()          # bench.py's network (eval_joint.py:151)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    x = ME.SparseTensor(dev(feats, cuda), dev(coords4, cuda).int(), device=cuda)
+    with torch.no_grad():
+        y = model(x, defer_check=True)                           # the call bench.py's run_step makes
+        assert model.check_range(x, y) is y                      # no fp16-range fallback on this scene
+        pred = pipeline.head_joint(y.F)
+    plan = x.coordinate_manager.fused_plan()
+    assert plan is not None and x.coordinate_manager.num_rows(1) == 80000 >= 16384      # the mask-group regime
+    ref = so.minkunet34c_forward(sd, coords4, feats).numpy()
+    got = y.F.cpu().numpy()
+    err = float(np.abs(got - ref).max())
+    assert err < 1e-4 * max(1.0, float(np.abs(ref).max())), err
+    rx, rs, rp, rc = [t.numpy() for t in so.head_joint_eval(torch.from_numpy(ref))]
+    xyz, scale, prob, cls = [t.cpu().numpy() for t in pred]
+    ok = decided_points(ref[:, 6 * 9:], err)
+    assert (~ok).sum() < 80                                      # < 0.1 % of the points sit on a float-level tie
+    assert np.array_equal(cls[ok], rc[ok])                       # head classes exact
+    np.testing.assert_allclose(prob, rp, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(scale[ok], rs[ok], rtol=1e-4)
+    np.testing.assert_allclose(xyz[ok], rx[ok], rtol=0, atol=1e-4)
+    # vote + decode on the network's own (HIP) predictions vs the oracle on the same predictions
+    pts = (sc.coords * RES).astype(np.float32)
+    hv = HoughVoting(RES, R)
+    with torch.no_grad():
+        grids = hv(dev(pts, cuda), *pred[:3])
+    refg = oracle.hv_forward(pts, xyz, scale, prob, RES, R, return_vin=True)
+    assert_grids_close([g.cpu().numpy() for g in grids], refg[:3], "80k network predictions",
+                       inputs=(pts, xyz, scale, RES, R))
+    corner, _, dims = oracle.grid_geometry(pts, RES)
+    assert hv_cuda.count_votes(dev(pts, cuda), pred[0], pred[1], RES, R, corner, dims) == refg[3]
+
+
+def test_config2_80k_teacher_scene_end_to_end_matches_oracle(cuda, built_lib):
+    """the workload of bench.py's default line: vote + decode + NMS on teacher predictions of an 80k scene"""
+    sc = make_scene(0, n_points=80000)
+    xyz, scale, prob, cls = synth_predictions(sc)
+    pts = sc.points
+    hv = HoughVoting(RES, R)
+    p, x, s, o, c = [dev(a, cuda) for a in (pts, xyz, scale, prob, cls)]
+    with torch.no_grad():
+        grids = hv(p, x, s, o)
+    raw = decode.decode_boxes(*grids, p, x, o, c, RES)
+    g = [t.cpu().numpy() for t in hv(p, x, s, o)]
+    corner, _, _ = oracle.grid_geometry(pts, RES)
+    d = oracle.decode(g[0], g[1], g[2], corner, RES, pts, xyz, prob, cls)
+    assert np.array_equal(raw["cand_idx"], d["cand_idx"]) and np.array_equal(raw["verdict"], d["verdict"])
+    assert len(raw["boxes"]) == len(d["boxes"]) >= 8 and list(raw["classes"]) == list(d["classes"])
+    np.testing.assert_allclose(raw["boxes"], d["boxes"], rtol=0, atol=1e-5)
+    dets = decode.nms_per_class(raw["boxes"], raw["scores"], raw["classes"])
+    rdet = oracle.nms_per_class(d["boxes"], d["scores"], d["classes"])
+    assert len(dets) == len(rdet)
+
+
+@pytest.fixture(scope="module")
+def scene300k():
+    sc = make_scene(3, n_points=300000, room=(9.0, 3.0, 9.0), n_boxes=40)
+    assert len(sc.coords) == 300000
+    return sc
+
+
+def test_config5_300k_coordinate_sets_and_kernel_maps_exact(cuda, built_lib, scene300k):
+    sc = scene300k
+    coords4 = np.concatenate([np.zeros((len(sc.coords), 1), np.int64), sc.coords], 1)
+    cm = ME.CoordinateManager(dev(coords4, cuda).int())
+    ocm = so.CoordinateManager(coords4)
+    for ts in (1, 2, 4, 8, 16):
+        assert np.array_equal(cm.coords[ts].cpu().numpy(), ocm.coords[ts]), ts
+    for k, ts, stride in ((5, 1, 1), (3, 1, 1), (3, 2, 1), (3, 4, 1), (3, 8, 1), (3, 16, 1), (2, 1, 2), (2, 2, 2),
+                          (2, 4, 2), (2, 8, 2)):
+        assert np.array_equal(cm.kernel_map(k, ts, stride).cpu().numpy(), ocm.map(k, ts, stride)), (k, ts, stride)
+
+
+def test_config5_300k_vote_grid_matches_oracle(cuda, built_lib, scene300k):
+    sc = scene300k
+    xyz, scale, prob, cls = synth_predictions(sc)
+    pts = sc.points
+    ref = oracle.hv_forward(pts, xyz, scale, prob, RES, R, return_vin=True)
+    assert ref[0].shape[0] > 290 and ref[0].shape[2] > 290          # the ~302 x 102 x 302 grid of config 5
+    hv = HoughVoting(RES, R)
+    p, x, s, o, c = [dev(a, cuda) for a in (pts, xyz, scale, prob, cls)]
+    with torch.no_grad():
+        grids = hv(p, x, s, o)
+    assert_grids_close([g.cpu().numpy() for g in grids], ref[:3], "300k", inputs=(pts, xyz, scale, RES, R))
+    corner, _, dims = oracle.grid_geometry(pts, RES)
+    assert hv_cuda.count_votes(p, x, s, RES, R, corner, dims) == ref[3]
+    raw = decode.decode_boxes(*grids, p, x, o, c, RES)
+    g = [t.cpu().numpy() for t in hv(p, x, s, o)]
+    d = oracle.decode(g[0], g[1], g[2], corner, RES, pts, xyz, prob, cls)
+    assert np.array_equal(raw["cand_idx"], d["cand_idx"]) and np.array_equal(raw["verdict"], d["verdict"])
+    assert len(raw["boxes"]) == len(d["boxes"]) and list(raw["classes"]) == list(d["classes"])
+    assert len(d["boxes"]) >= 20                                      # most of the 40 planted boxes come back
+
+
+def test_config5_300k_separate_heads_on_one_sparse_tensor(cuda, built_lib, scene300k):
+    """eval_separate.py:162-186 at config-5 size: two 8-channel models share one SparseTensor / coordinate manager;
+    the first is compared with the oracle network at full size"""
+    sc = scene300k
+    coords4 = np.concatenate([np.zeros((len(sc.coords), 1), np.int64), sc.coords], 1)
+    feats = (sc.feats * 2 - 1).astype(np.float32)
+    sds = [so.make_state_dict(3, 8, seed=50 + i) for i in range(2)]
+    models = []
+    for sd in sds:
+        m = MinkUNet34C(3, 8)
+        m.load_state_dict(sd)
+        models.append(m.cuda().eval())
+    x = ME.SparseTensor(dev(feats, cuda), dev(coords4, cuda).int(), device=cuda)
+    with torch.no_grad():
+        ys = [m(x).F for m in models]
+    plan = x.coordinate_manager.fused_plan()
+    assert x.coordinate_manager.fused_plan() is plan                   # maps built once for both models
+    ref = so.minkunet34c_forward(sds[0], coords4, feats)
+    err = float((ys[0].cpu() - ref).abs().max())
+    assert err < 1e-4 * max(1.0, float(ref.abs().max())), err
+    xyz, scale, prob = pipeline.head_separate(ys[0])
+    rx, rs, rp = so.head_separate_eval(ys[0].cpu())
+    np.testing.assert_allclose(xyz.cpu().numpy(), rx.numpy(), rtol=0, atol=0)
+    np.testing.assert_allclose(scale.cpu().numpy(), rs.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(prob.cpu().numpy(), rp.numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.isfinite(ys[1]).all() and not torch.equal(ys[0], ys[1])

@@ -54,6 +54,16 @@ def test_duplicate_coordinates_rejected(cuda, built_lib):
         model(ME.SparseTensor(torch.zeros(3, 3, device=cuda), c))
 
 
+def test_coordinates_outside_the_key_window_rejected(cuda, built_lib):
+    """the coordinate hash packs 16 bits per field: anything that could alias is refused, not mis-mapped"""
+    for bad in ([0, 40000, 0, 0], [0, 0, -32768, 0], [70000, 1, 2, 3]):
+        c = torch.tensor([[0, 1, 2, 3], bad], dtype=torch.int32, device=cuda)
+        with pytest.raises(RuntimeError, match="outside the supported window"):
+            ME.MinkowskiConvolution(3, 8, kernel_size=3, dimension=3).cuda()(ME.SparseTensor(torch.zeros(2, 3, device=cuda), c))
+    ok = torch.tensor([[0, 32703, -32704, 3], [65535, 1, 2, 3]], dtype=torch.int32, device=cuda)
+    ME.MinkowskiConvolution(3, 8, kernel_size=3, dimension=3).cuda()(ME.SparseTensor(torch.zeros(2, 3, device=cuda), ok))
+
+
 def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1e-6, np.abs(b).max()))
 
@@ -530,3 +540,35 @@ def test_hip_network_matches_reference_class_executed_on_cpu(cuda, built_lib):
         model.train()
         y = model(x).F.cpu().numpy()
     assert np.abs(y - z["out_train"]).max() < 1e-4 * max(1.0, np.abs(z["out_train"]).max())
+
+
+@pytest.mark.parametrize("wrapper", [None, "model_state_dict"])
+def test_reference_checkpoint_in_z_fastest_offset_order_loads_and_matches_oracle(cuda, built_lib, tmp_path, wrapper):
+    """SURVEY 8 f-3 (eval_joint.py:152 torch.load + load_state_dict; sunrgbd/brnetcanon.py:167 the
+    ``model_state_dict`` wrapper): a checkpoint file whose [K^3, Cin, Cout] kernels enumerate the offsets with the LAST
+    spatial axis fastest, written to disk, goes through load_reference_checkpoint(offset_order="z_fastest") into the
+    HIP network; its output equals the oracle's run with the same file's weights under a z-fastest offset table, and
+    the oracle's run with the un-permuted (x-fastest) weights.  Loading it as if it were x-fastest must NOT match."""
+    from canonicalvoting_amd.minkunet import convert_kernel_offset_order, load_reference_checkpoint
+    coords, feats = scene_coords(31, 1500, small=True)
+    sd_x = so.make_state_dict(3, 64, seed=7)                                   # this engine's order
+    sd_z = convert_kernel_offset_order(sd_x, "x_fastest", "z_fastest")          # what such a checkpoint would hold
+    assert not torch.equal(sd_z["conv0p1s1.kernel"], sd_x["conv0p1s1.kernel"])
+    path = str(tmp_path / "joint.pth")
+    torch.save({wrapper: sd_z, "epoch": 3} if wrapper else sd_z, path)
+    model = load_reference_checkpoint(MinkUNet34C(3, 64), path, offset_order="z_fastest", key=wrapper).cuda().eval()
+    x = ME.SparseTensor(torch.from_numpy(feats), torch.from_numpy(coords).int(), device="cuda")
+    with torch.no_grad():
+        y = model(x).F.cpu().numpy()
+    ref = so.minkunet34c_forward(sd_x, coords, feats).numpy()
+    assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    old = so.KERNEL_OFFSET_ORDER
+    try:
+        so.KERNEL_OFFSET_ORDER = "z_fastest"                                    # the file's weights as they are
+        ref_z = so.minkunet34c_forward(sd_z, coords, feats).numpy()
+    finally:
+        so.KERNEL_OFFSET_ORDER = old
+    assert np.abs(y - ref_z).max() < 1e-4 * max(1.0, np.abs(ref_z).max())
+    wrong = load_reference_checkpoint(MinkUNet34C(3, 64), path, offset_order="x_fastest", key=wrapper).cuda().eval()
+    with torch.no_grad():
+        assert np.abs(wrong(x).F.cpu().numpy() - ref).max() > 1e-2 * np.abs(ref).max()
