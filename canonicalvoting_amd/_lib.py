@@ -84,7 +84,7 @@ SIGNATURES = {
     "cv_decode_f32": (ctypes.c_int, [vp, vp, vp, c_int_p, c_float_p, ctypes.c_float, vp, vp, vp, vp,
                                      ctypes.c_int64, ctypes.POINTER(DecodeParams), ctypes.c_int, vp,
                                      ctypes.c_size_t, c_int_p, c_i64_p, c_i32_p, c_int_p, c_float_p,
-                                     c_float_p, c_i32_p, vp]),
+                                     c_float_p, c_i32_p, c_int_p, vp]),
     "cv_sp_table_capacity": (ctypes.c_longlong, [ctypes.c_longlong]),
     "cv_sp_levels_workspace_bytes": (ctypes.c_size_t, [ctypes.c_longlong]),
     "cv_sp_build_levels": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),

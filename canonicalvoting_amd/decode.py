@@ -26,14 +26,18 @@ def _ptr(t):
 def decode_boxes(grid_obj, grid_rot, grid_scale, scan_points, xyz_pred, prob_pred, class_pred, res,
                  corner=None, thresh_high=thresh_high, thresh_low=thresh_low,
                  valid_ratio=valid_ratio, elimination=elimination, prob_thresh=0.3, err_thresh=0.3,
-                 separate_variant=False, max_candidates=512, mutate_grid=False):
+                 separate_variant=False, max_candidates=512, mutate_grid=False, allow_truncation=False):
     """Greedy decode on the device, one host sync.
 
     scan_points [N,3] f32 world points (``curr_points * res``, eval_joint.py:200), ``corner``
     defaults to their minimum (``corners[0]``, :201).  Returns a dict with ``boxes`` [K,8,3],
     ``scores`` [K], ``classes`` [K] (numpy, acceptance order) plus the examined candidate cells
     and verdicts (0 accepted, 1 too few confident points :246-247, 2 LCC error :252-253).
-    ``separate_variant`` selects eval_separate.py:209's elimination slice (no ``+1``)."""
+    ``separate_variant`` selects eval_separate.py:209's elimination slice (no ``+1``).
+    ``max_candidates`` is the first capacity of the walk, not a limit on the result: the reference's ``while True``
+    (:204-209) runs until the grid maximum drops below ``thresh_high``, so a walk that fills its capacity with a cell
+    >= thresh_high still live is redone with eight times the room (up to 65536, then RuntimeError).
+    ``allow_truncation=True`` returns the capped walk instead, marked ``truncated=True`` in the dict."""
     L = _lib.lib()
     dev = grid_obj.device
     for t, name in ((grid_obj, "grid_obj"), (grid_rot, "grid_rot"), (grid_scale, "grid_scale"),
@@ -51,27 +55,36 @@ def decode_boxes(grid_obj, grid_rot, grid_scale, scan_points, xyz_pred, prob_pre
                           int(elimination), float(prob_thresh), 0 if separate_variant else 1,
                           int(max_candidates), float(err_thresh))
     M = int(max_candidates)
-    ws = torch.empty(int(L.cv_decode_workspace_bytes(dims, n, M)), dtype=torch.uint8, device=dev)
-    n_cand, n_boxes = ctypes.c_int(0), ctypes.c_int(0)
-    cand = np.zeros(M, np.int64)
-    verdict = np.zeros(M, np.int32)
-    boxes = np.zeros((M, 8, 3), np.float32)
-    scores = np.zeros(M, np.float32)
-    classes = np.zeros(M, np.int32)
-    with torch.cuda.device(dev):
-        rc = L.cv_decode_f32(
-            _ptr(grid_obj), _ptr(grid_rot), _ptr(grid_scale), dims,
-            (ctypes.c_float * 3)(*[float(v) for v in corner]), ctypes.c_float(float(res)),
-            _ptr(scan_points), _ptr(xyz_pred), _ptr(prob_pred), _ptr(cls), n, ctypes.byref(p),
-            1 if mutate_grid else 0, _ptr(ws), ws.numel(), ctypes.byref(n_cand),
-            cand.ctypes.data_as(_lib.c_i64_p), verdict.ctypes.data_as(_lib.c_i32_p),
-            ctypes.byref(n_boxes), boxes.ctypes.data_as(_lib.c_float_p),
-            scores.ctypes.data_as(_lib.c_float_p), classes.ctypes.data_as(_lib.c_i32_p),
-            ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
-    _lib.check(rc, "cv_decode_f32")
+    while True:
+        p.max_iters = M
+        ws = torch.empty(int(L.cv_decode_workspace_bytes(dims, n, M)), dtype=torch.uint8, device=dev)
+        n_cand, n_boxes, truncated = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        cand = np.zeros(M, np.int64)
+        verdict = np.zeros(M, np.int32)
+        boxes = np.zeros((M, 8, 3), np.float32)
+        scores = np.zeros(M, np.float32)
+        classes = np.zeros(M, np.int32)
+        with torch.cuda.device(dev):
+            rc = L.cv_decode_f32(
+                _ptr(grid_obj), _ptr(grid_rot), _ptr(grid_scale), dims,
+                (ctypes.c_float * 3)(*[float(v) for v in corner]), ctypes.c_float(float(res)),
+                _ptr(scan_points), _ptr(xyz_pred), _ptr(prob_pred), _ptr(cls), n, ctypes.byref(p),
+                1 if mutate_grid else 0, _ptr(ws), ws.numel(), ctypes.byref(n_cand),
+                cand.ctypes.data_as(_lib.c_i64_p), verdict.ctypes.data_as(_lib.c_i32_p),
+                ctypes.byref(n_boxes), boxes.ctypes.data_as(_lib.c_float_p),
+                scores.ctypes.data_as(_lib.c_float_p), classes.ctypes.data_as(_lib.c_i32_p),
+                ctypes.byref(truncated), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(rc, "cv_decode_f32")
+        if not truncated.value or allow_truncation:
+            break
+        # the reference's `while True` (eval_joint.py:204-209) runs until the grid maximum drops below thresh_high:
+        # a capped walk that stopped early is redone with more room, never returned as if it were complete
+        if M >= 65536 or mutate_grid:
+            raise RuntimeError("decode_boxes: more than %d candidate cells >= thresh_high (max_candidates)" % M)
+        M = min(M * 8, 65536)
     k, m = n_boxes.value, n_cand.value
     return dict(boxes=boxes[:k].copy(), scores=scores[:k].copy(), classes=classes[:k].copy(),
-                cand_idx=cand[:m].copy(), verdict=verdict[:m].copy())
+                cand_idx=cand[:m].copy(), verdict=verdict[:m].copy(), truncated=bool(truncated.value))
 
 
 def get_iou_obb(bbox1, bbox2):

@@ -110,13 +110,15 @@ size_t cv_decode_workspace_bytes(const int dims[3], int64_t n, int max_iters);
  * receives the same zeroing the reference applies in place (:211,:243).
  * Host outputs: h_n_cand candidates examined (cell index + verdict 0 accept /
  * 1 too few confident points / 2 LCC error), h_n_boxes accepted boxes in
- * acceptance order (corners [8][3], score, class).  Synchronises `stream` once. */
+ * acceptance order (corners [8][3], score, class).  *h_truncated (may be NULL) is set to 1 when max_iters candidates
+ * were examined and a cell >= thresh_high is still live - the reference's `while True` loop (:204-209) would have gone
+ * on, so the caller must re-run with a larger max_iters rather than use the result.  Synchronises `stream` once. */
 int cv_decode_f32(float* d_grid_obj, const float* d_grid_rot, const float* d_grid_scale,
                   const int dims[3], const float h_corner3[3], float res, const float* d_points,
                   const float* d_xyz, const float* d_prob, const int32_t* d_class, int64_t n,
                   const cv_decode_params* params, int mutate_grid, void* d_ws, size_t ws_bytes,
                   int* h_n_cand, int64_t* h_cand_idx, int32_t* h_verdict, int* h_n_boxes,
-                  float* h_boxes, float* h_scores, int32_t* h_classes, void* stream);
+                  float* h_boxes, float* h_scores, int32_t* h_classes, int* h_truncated, void* stream);
 
 /* utils/calc_map.py:6-21 on two [8][3] corner sets (host). */
 double cv_iou_obb(const float* h_box1, const float* h_box2);

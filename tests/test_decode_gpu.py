@@ -24,6 +24,7 @@ def compare(cuda, g_obj, g_rot, g_scale, corner, res, pts, xyz, prob, cls, **kw)
         okw["elim_hi_plus1"] = 0 if okw.pop("separate_variant") else 1
     if "max_candidates" in okw:
         okw["max_iters"] = okw.pop("max_candidates")
+    okw.pop("allow_truncation", None)
     ref = oracle.decode(g_obj, g_rot, g_scale, corner, res, pts, xyz, prob, cls,
                         oracle.DecodeParams.default(**okw))
     dg = t(cuda, g_obj).clone()
@@ -84,8 +85,17 @@ def test_decode_nothing_above_threshold_and_iteration_cap(cuda, built_lib):
     g_scale[...] = 0.001
     g_obj[::6, ::6, ::6] = 77                          # many isolated peaks, cap at 5 candidates
     ref, hip = compare(cuda, g_obj, g_rot, g_scale, z, 0.05, pts, pts, np.zeros(4, np.float32),
-                       np.zeros(4, np.int32), max_candidates=5)
-    assert len(hip["cand_idx"]) == 5
+                       np.zeros(4, np.int32), max_candidates=5, allow_truncation=True)
+    assert len(hip["cand_idx"]) == 5 and hip["truncated"]
+    # without allow_truncation the capped walk is never returned: it is redone with more room until the grid
+    # maximum is below thresh_high, as the reference's `while True` does (eval_joint.py:204-209)
+    ref = oracle.decode(g_obj, g_rot, g_scale, z, 0.05, pts, pts, np.zeros(4, np.float32), np.zeros(4, np.int32),
+                        oracle.DecodeParams.default(max_iters=4096))
+    full = decode.decode_boxes(t(cuda, g_obj), t(cuda, g_rot), t(cuda, g_scale), t(cuda, pts), t(cuda, pts),
+                               t(cuda, np.zeros(4, np.float32)), t(cuda, np.zeros(4, np.int32)), 0.05, corner=z,
+                               max_candidates=5)
+    assert not full["truncated"] and len(full["cand_idx"]) == len(ref["cand_idx"]) > 5 * 8
+    assert list(full["cand_idx"]) == list(ref["cand_idx"])
 
 
 def test_detect_end_to_end_80k(cuda, built_lib):
