@@ -91,6 +91,8 @@ SIGNATURES = {
                                           ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int, vp,
                                           c_i32_p, vp, ctypes.c_size_t, vp]),
     "cv_sp_morton_keys": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp]),
+    "cv_sp_sort_workspace_bytes": (ctypes.c_size_t, [ctypes.c_longlong]),
+    "cv_sp_sort_rows": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp, vp, vp, ctypes.c_size_t, vp]),
     "cv_sp_kernel_map": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp, ctypes.c_longlong, ctypes.c_int,
                                         ctypes.c_int, vp, vp]),
     "cv_sp_up_map": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_longlong, vp, vp]),
@@ -106,7 +108,7 @@ SIGNATURES = {
     "cv_sp_scene_maps_words": (ctypes.c_size_t, [c_i64_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_longlong, ctypes.POINTER(SceneMaps)]),
     "cv_sp_scene_maps": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_longlong,
-                                        c_i64_p, vp, vp, vp, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int,
+                                        c_i64_p, vp, ctypes.c_longlong, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_longlong, vp, ctypes.c_size_t, vp]),
     "cv_net_arena_bytes": (ctypes.c_size_t, [ctypes.POINTER(NetBuf), ctypes.c_int, c_i64_p, ctypes.c_int]),
     "cv_net_run_f32": (ctypes.c_int, [ctypes.POINTER(NetOp), ctypes.c_int, ctypes.POINTER(NetBuf), ctypes.c_int,

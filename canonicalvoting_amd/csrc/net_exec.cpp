@@ -25,7 +25,8 @@ static void scene_maps_layout(const long long* rows, long long n_orig, int stem_
     auto take = [&](size_t words) { const size_t at = off; off += cv_align_up(words, 64); return (long long)at; };
     const size_t K5 = (size_t)stem_k * stem_k * stem_k;
     o->stem = take((size_t)rows[0] * K5);
-    o->out = take((size_t)n_orig);
+    o->out = -1;                       // (the sort's inverse permutation is the final map)
+    (void)n_orig;
     for (int i = 0; i < 4; ++i) o->down[i] = take((size_t)rows[i + 1] * 8);
     for (int i = 0; i < 5; ++i) o->k3[i] = take((size_t)rows[i] * 27);
     for (int i = 0; i < 4; ++i) o->up[i] = take((size_t)rows[3 - i] * 8);            // up[i]: level 4-i -> 3-i
@@ -33,7 +34,7 @@ static void scene_maps_layout(const long long* rows, long long n_orig, int stem_
         o->mask_perm[i] = (mask_groups > 1 && rows[i] >= masked_min_rows)
                               ? take((size_t)mask_groups * rows[i] * (1 + (27 + mask_groups - 1) / mask_groups)) : -1;
     for (int i = 0; i < 4; ++i) o->up_perm[i] = take((size_t)rows[3 - i]);
-    o->scratch = take((size_t)std::max(mask_groups, 1) * 1024);
+    o->scratch = take((size_t)(5 * std::max(mask_groups, 1) + 4) * 1024);
     *total = off;
 }
 
@@ -46,38 +47,50 @@ size_t cv_sp_scene_maps_words(const long long* level_rows, long long n_orig, int
 }
 
 int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
-                     long long cap, const long long* level_rows, const int32_t* d_orig_coords,
-                     const unsigned long long* d_orig_keys, const int32_t* d_orig_vals, long long orig_cap,
-                     long long n_orig, int stem_k, int mask_groups, long long masked_min_rows, int32_t* d_arena,
-                     size_t arena_words, void* stream) {
-    CV_REQUIRE(d_coords && d_keys && d_vals && level_rows && d_orig_coords && d_orig_keys && d_orig_vals && d_arena,
-               CV_EINVAL, "null pointer argument");
+                     long long cap, const long long* level_rows, const int32_t* d_perm, long long n_orig, int stem_k,
+                     int mask_groups, long long masked_min_rows, int32_t* d_arena, size_t arena_words, void* stream) {
+    CV_REQUIRE(d_coords && d_keys && d_vals && level_rows && d_perm && d_arena, CV_EINVAL, "null pointer argument");
+    CV_REQUIRE(n_orig == level_rows[0], CV_EINVAL, "the sorted set must hold the caller's %lld rows", n_orig);
     cv_scene_maps o;
     size_t total = 0;
     scene_maps_layout(level_rows, n_orig, stem_k, mask_groups, masked_min_rows, &o, &total);
     CV_REQUIRE(arena_words >= total, CV_ENOMEM, "scene map arena too small");
-    int rc;
-#define CV_TRY(call) do { rc = (call); if (rc != CV_OK) return rc; } while (0)
-    // stem: sorted rows <- rows of the ORIGINAL order; final: original rows <- sorted rows
-    CV_TRY(cv_sp_kernel_map(d_coords[0], level_rows[0], d_orig_keys, d_orig_vals, orig_cap, stem_k, 1,
-                            d_arena + o.stem, stream));
-    CV_TRY(cv_sp_kernel_map(d_orig_coords, n_orig, d_keys[0], d_vals[0], cap, 1, 1, d_arena + o.out, stream));
+    // one launch for the eleven kernel maps, one fill + one launch for the four transposed maps, three launches for
+    // the six processing orders (the per-map calls were ~45 launches of a few microseconds each on the scene's
+    // critical path)
+    CvMapJob mj[CV_MAX_MAP_JOBS];
+    int nm = 0;
+    // stem: sorted rows <- rows of the ORIGINAL order = the sorted set's own map with the permutation folded in
+    // (the caller's set needs no hash table of its own); the final original <- sorted map is the sort's inverse
+    mj[nm++] = {d_coords[0], level_rows[0], d_keys[0], d_vals[0], cap, stem_k, 1, d_arena + o.stem, d_perm};
     for (int i = 0; i < 4; ++i)
-        CV_TRY(cv_sp_kernel_map(d_coords[i + 1], level_rows[i + 1], d_keys[i], d_vals[i], cap, 2, 1 << i,
-                                d_arena + o.down[i], stream));
+        mj[nm++] = {d_coords[i + 1], level_rows[i + 1], d_keys[i], d_vals[i], cap, 2, 1 << i, d_arena + o.down[i], nullptr};
     for (int i = 0; i < 5; ++i)
-        CV_TRY(cv_sp_kernel_map(d_coords[i], level_rows[i], d_keys[i], d_vals[i], cap, 3, 1 << i, d_arena + o.k3[i],
-                                stream));
-    for (int i = 0; i < 4; ++i)
-        CV_TRY(cv_sp_up_map(d_arena + o.down[3 - i], level_rows[4 - i], level_rows[3 - i], d_arena + o.up[i], stream));
+        mj[nm++] = {d_coords[i], level_rows[i], d_keys[i], d_vals[i], cap, 3, 1 << i, d_arena + o.k3[i], nullptr};
+    int rc = cv_sp_kernel_maps_batch(mj, nm, stream);
+    if (rc != CV_OK) return rc;
+    // the four transposed maps are neighbours in the arena: one fill
+    {
+        const long long lo = o.up[0], hi = o.up[3] + level_rows[0] * 8;
+        CV_HIP_CHECK(hipMemsetAsync(d_arena + lo, 0xff, sizeof(int32_t) * (size_t)(hi - lo), static_cast<hipStream_t>(stream)));
+    }
+    CvUpJob uj[4];
+    for (int i = 0; i < 4; ++i) uj[i] = {d_arena + o.down[3 - i], level_rows[4 - i], d_arena + o.up[i]};
+    rc = cv_sp_up_maps_batch(uj, 4, stream);
+    if (rc != CV_OK) return rc;
+    CvPermJob pj[CV_MAX_PERM_JOBS];
+    int np = 0, groups = 0;
     for (int i = 0; i < 5; ++i)
-        if (o.mask_perm[i] >= 0)
-            CV_TRY(cv_sp_mask_perms(d_arena + o.k3[i], level_rows[i], 27, mask_groups, d_arena + o.mask_perm[i],
-                                    d_arena + o.scratch, sizeof(int) * (size_t)mask_groups * 1024, 1, stream));
-    for (int i = 0; i < 4; ++i)
-        CV_TRY(cv_sp_mask_perms(d_arena + o.up[i], level_rows[3 - i], 8, 1, d_arena + o.up_perm[i], d_arena + o.scratch,
-                                sizeof(int) * 1024, 0, stream));
-#undef CV_TRY
+        if (o.mask_perm[i] >= 0) {
+            pj[np++] = {d_arena + o.k3[i], level_rows[i], 27, mask_groups, d_arena + o.mask_perm[i], 1};
+            groups += mask_groups;
+        }
+    for (int i = 0; i < 4; ++i) {
+        pj[np++] = {d_arena + o.up[i], level_rows[3 - i], 8, 1, d_arena + o.up_perm[i], 0};
+        groups += 1;
+    }
+    rc = cv_sp_mask_perms_batch(pj, np, d_arena + o.scratch, sizeof(int) * (size_t)groups * 1024, stream);
+    if (rc != CV_OK) return rc;
     return CV_OK;
 }
 

@@ -2003,6 +2003,63 @@ __global__ __launch_bounds__(MP_THREADS) void mp_scatter(const int* __restrict__
     }
 }
 
+// the same three launches for several maps at once (every processing order of a scene): blockIdx.y = (job, group)
+struct PermJobsDev {
+    CvPermJob j[CV_MAX_PERM_JOBS];
+    int group_begin[CV_MAX_PERM_JOBS + 1];
+    int n;
+};
+
+__device__ __forceinline__ int perm_job_of(const PermJobsDev& jobs, int gy) {
+    int ji = 0;
+    while (ji + 1 < jobs.n && gy >= jobs.group_begin[ji + 1]) ++ji;
+    return ji;
+}
+
+__global__ __launch_bounds__(MP_THREADS) void mp_hist_batch(const PermJobsDev jobs, int* __restrict__ hist) {
+    __shared__ int lh[MP_BINS];
+    const int ji = perm_job_of(jobs, blockIdx.y);
+    const CvPermJob& jb = jobs.j[ji];
+    const long long row = blockIdx.x * (long long)MP_THREADS + threadIdx.x;
+    if (blockIdx.x * (long long)MP_THREADS >= jb.n) return;
+    const int g = blockIdx.y - jobs.group_begin[ji];
+    const int jlo = jb.K * g / jb.groups, jhi = jb.K * (g + 1) / jb.groups;
+    for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS) lh[i] = 0;
+    __syncthreads();
+    if (row < jb.n) atomicAdd(&lh[group_mask(jb.nbr, row, jb.K, jlo, jhi)], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS)
+        if (lh[i]) atomicAdd(&hist[blockIdx.y * MP_BINS + i], lh[i]);
+}
+
+__global__ __launch_bounds__(MP_THREADS) void mp_scatter_batch(const PermJobsDev jobs, int* __restrict__ cursor) {
+    __shared__ int lh[MP_BINS];
+    const int ji = perm_job_of(jobs, blockIdx.y);
+    const CvPermJob& jb = jobs.j[ji];
+    if (blockIdx.x * (long long)MP_THREADS >= jb.n) return;
+    const int g = blockIdx.y - jobs.group_begin[ji];
+    const int K = jb.K, jlo = K * g / jb.groups, jhi = K * (g + 1) / jb.groups, W = (K + jb.groups - 1) / jb.groups;
+    int* nbrp = jb.with_map ? jb.perm + (long long)jb.groups * jb.n : nullptr;
+    for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS) lh[i] = 0;
+    __syncthreads();
+    const long long row = blockIdx.x * (long long)MP_THREADS + threadIdx.x;
+    int key = 0, rank = 0;
+    if (row < jb.n) {
+        key = group_mask(jb.nbr, row, K, jlo, jhi);
+        rank = atomicAdd(&lh[key], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS)
+        if (lh[i]) lh[i] = atomicAdd(&cursor[blockIdx.y * MP_BINS + i], lh[i]);
+    __syncthreads();
+    if (row < jb.n) {
+        const long long pos = (long long)g * jb.n + lh[key] + rank;
+        jb.perm[pos] = (int)row;
+        if (nbrp)
+            for (int j = jlo; j < jhi; ++j) nbrp[pos * W + (j - jlo)] = jb.nbr[row * K + j];
+    }
+}
+
 // ------------------------------------------------------------------ elementwise helpers
 // y = x*scale + shift (+relu)   (MinkowskiBatchNorm in eval mode, MinkowskiReLU)
 __global__ __launch_bounds__(256) void affine_rows(const float* __restrict__ x, long long n, int c,
@@ -2479,6 +2536,37 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
 }
 
 }  // namespace
+
+int cv_sp_mask_perms_batch(const CvPermJob* jobs, int n_jobs, void* d_ws, size_t ws_bytes, void* stream) {
+    CV_REQUIRE(jobs && d_ws && n_jobs > 0 && n_jobs <= CV_MAX_PERM_JOBS, CV_EINVAL, "bad mask perm batch");
+    PermJobsDev d;
+    d.n = n_jobs;
+    int groups = 0;
+    long long max_n = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const CvPermJob& j = jobs[i];
+        CV_REQUIRE(j.nbr && j.perm && j.n > 0 && j.K > 0 && j.groups >= 1 && j.groups <= j.K, CV_EINVAL,
+                   "bad mask perm job %d", i);
+        CV_REQUIRE((j.K + j.groups - 1) / j.groups <= 10, CV_EINVAL, "at most 10 kernel offsets per group");
+        d.j[i] = j;
+        d.group_begin[i] = groups;
+        groups += j.groups;
+        max_n = std::max(max_n, j.n);
+    }
+    d.group_begin[n_jobs] = groups;
+    CV_REQUIRE(ws_bytes >= sizeof(int) * (size_t)groups * MP_BINS, CV_ENOMEM, "workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int* hist = static_cast<int*>(d_ws);
+    CV_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * (size_t)groups * MP_BINS, st));
+    dim3 grid((unsigned)((max_n + MP_THREADS - 1) / MP_THREADS), (unsigned)groups);
+    mp_hist_batch<<<grid, MP_THREADS, 0, st>>>(d, hist);
+    CV_LAUNCH_CHECK();
+    mp_scan<<<groups, MP_BINS, 0, st>>>(hist);
+    CV_LAUNCH_CHECK();
+    mp_scatter_batch<<<grid, MP_THREADS, 0, st>>>(d, hist);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
 
 extern "C" {
 

@@ -108,16 +108,10 @@ __global__ __launch_bounds__(256) void insert_coarse(const int* __restrict__ coo
     }
 }
 
-__global__ __launch_bounds__(256) void flag_first(const int* n_ptr, const int* vals,
-                                                  const long long* slot_of_row, int* flag) {
-    const int n = *n_ptr;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-        flag[i] = vals[slot_of_row[i]] == i ? 1 : 0;
-}
-
 // exclusive scan of the 0/1 flags in three short launches (a single-workgroup scan of 80k flags took
 // 37 us): per-block sums -> scan of the block sums -> per-block scan + offset.
-constexpr int SCAN_PER = 8, SCAN_BLOCK = 1024 * SCAN_PER;
+// rows per thread: 1 up to 1M rows (an 80k-row level then runs on 79 workgroups instead of 10: the passes read
+// vals[slot_of_row[i]] at random, latency-bound on few workgroups), 8 beyond
 
 __device__ __forceinline__ int block_exclusive_scan(int v, int* s /*[1024]*/) {
     s[threadIdx.x] = v;
@@ -131,14 +125,22 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* s /*[1024]*/) {
     return s[threadIdx.x] - v;
 }
 
-__global__ __launch_bounds__(1024) void scan_block_sums(const int* __restrict__ flag, const int* n_ptr,
-                                                        int* __restrict__ bsum) {
+// flag_first + scan_block_sums in one launch: flag[i] = (row i is the first row of its coarse voxel)
+template <int SCAN_PER>
+__global__ __launch_bounds__(1024) void flag_and_block_sums(const int* n_ptr, const int* __restrict__ vals,
+                                                            const long long* __restrict__ slot_of_row,
+                                                            int* __restrict__ flag, int* __restrict__ bsum) {
     __shared__ int s[1024];
     const int n = *n_ptr;
-    const int b0 = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER;
+    const int b0 = (blockIdx.x * 1024 + threadIdx.x) * SCAN_PER;
     int sum = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_PER; ++j) sum += (b0 + j < n) ? flag[b0 + j] : 0;
+    for (int j = 0; j < SCAN_PER; ++j)
+        if (b0 + j < n) {
+            const int f = vals[slot_of_row[b0 + j]] == b0 + j ? 1 : 0;
+            flag[b0 + j] = f;
+            sum += f;
+        }
     s[threadIdx.x] = sum;
     __syncthreads();
     for (int st = 512; st > 0; st >>= 1) {
@@ -148,47 +150,55 @@ __global__ __launch_bounds__(1024) void scan_block_sums(const int* __restrict__ 
     if (threadIdx.x == 0) bsum[blockIdx.x] = s[0];
 }
 
-__global__ __launch_bounds__(1024) void scan_block_offsets(int* __restrict__ bsum, int nblocks, int* total_out) {
-    __shared__ int s[1024];
-    const int v = threadIdx.x < nblocks ? bsum[threadIdx.x] : 0;
-    const int ex = block_exclusive_scan(v, s);
-    if (threadIdx.x < nblocks) bsum[threadIdx.x] = ex;
-    if (threadIdx.x == 1023) *total_out = ex + v;
-}
-
-__global__ __launch_bounds__(1024) void scan_apply(const int* __restrict__ flag, const int* n_ptr,
-                                                   const int* __restrict__ boff, int* __restrict__ rank) {
+// scan_apply + emit_coarse in one launch: the rank of a flagged row is its coarse row
+template <int SCAN_PER>
+__global__ __launch_bounds__(1024) void scan_apply_emit(const int* __restrict__ coords, const int* n_ptr, int stride2,
+                                                        const int* __restrict__ flag, const int* __restrict__ boff,
+                                                        const long long* __restrict__ slot_of_row, int* vals,
+                                                        int* __restrict__ out_coords) {
     __shared__ int s[1024];
     const int n = *n_ptr;
-    const int b0 = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_PER;
+    const int b0 = (blockIdx.x * 1024 + threadIdx.x) * SCAN_PER;
     int v[SCAN_PER], sum = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_PER; ++j) { v[j] = (b0 + j < n) ? flag[b0 + j] : 0; sum += v[j]; }
     int run = block_exclusive_scan(sum, s) + boff[blockIdx.x];
 #pragma unroll
     for (int j = 0; j < SCAN_PER; ++j) {
-        if (b0 + j < n) rank[b0 + j] = run;
+        if (v[j]) {
+            const int i = b0 + j;
+            const int4 c = reinterpret_cast<const int4*>(coords)[i];
+            int4 o;
+            o.x = c.x;
+            o.y = floor_div(c.y, stride2) * stride2;
+            o.z = floor_div(c.z, stride2) * stride2;
+            o.w = floor_div(c.w, stride2) * stride2;
+            reinterpret_cast<int4*>(out_coords)[run] = o;
+            vals[slot_of_row[i]] = run;     // table now maps coarse key -> compact coarse row
+        }
         run += v[j];
     }
 }
 
-__global__ __launch_bounds__(256) void emit_coarse(const int* __restrict__ coords, const int* n_ptr,
-                                                   int stride2, const int* flag, const int* rank,
-                                                   const long long* slot_of_row, int* vals,
-                                                   int* __restrict__ out_coords) {
-    const int n = *n_ptr;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        if (!flag[i]) continue;
-        const int4 c = reinterpret_cast<const int4*>(coords)[i];
-        int4 o;
-        o.x = c.x;
-        o.y = floor_div(c.y, stride2) * stride2;
-        o.z = floor_div(c.z, stride2) * stride2;
-        o.w = floor_div(c.w, stride2) * stride2;
-        const int r = rank[i];
-        reinterpret_cast<int4*>(out_coords)[r] = o;
-        vals[slot_of_row[i]] = r;     // table now maps coarse key -> compact coarse row
+struct TablesDev { unsigned long long* keys[5]; int* vals[5]; int n; };
+
+// every level's table cleared by one launch; also the counters: counts[0] = n, the rest 0
+__global__ __launch_bounds__(256) void table_clear_all(const TablesDev t, long long cap, int* counts, int n_rows) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < cap * t.n; i += (long long)gridDim.x * 256) {
+        const int L = (int)(i / cap);
+        const long long k = i - (long long)L * cap;
+        t.keys[L][k] = EMPTY_KEY;
+        t.vals[L][k] = 0x7fffffff;
     }
+    if (blockIdx.x == 0 && threadIdx.x < 8) counts[threadIdx.x] = threadIdx.x == 0 ? n_rows : 0;
+}
+
+__global__ __launch_bounds__(1024) void scan_block_offsets(int* __restrict__ bsum, int nblocks, int* total_out) {
+    __shared__ int s[1024];
+    const int v = threadIdx.x < nblocks ? bsum[threadIdx.x] : 0;
+    const int ex = block_exclusive_scan(v, s);
+    if (threadIdx.x < nblocks) bsum[threadIdx.x] = ex;
+    if (threadIdx.x == 1023) *total_out = ex + v;
 }
 
 // nbr[u][j] = row of (out_coord[u] + offset_j * ts) in the input set, or -1.  Offset index j runs
@@ -221,6 +231,51 @@ __global__ __launch_bounds__(256) void build_up_map(const int* __restrict__ nbr_
     }
 }
 
+// all kernel maps of a scene in one launch: blockIdx.x ranges per job
+struct MapJobsDev {
+    CvMapJob j[CV_MAX_MAP_JOBS];
+    int block_begin[CV_MAX_MAP_JOBS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void build_kernel_maps(const MapJobsDev jobs) {
+    int ji = 0;
+    while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.block_begin[ji + 1]) ++ji;
+    const CvMapJob& jb = jobs.j[ji];
+    const int nblk = jobs.block_begin[ji + 1] - jobs.block_begin[ji], blk = blockIdx.x - jobs.block_begin[ji];
+    const int k = jb.k, K = k * k * k, ts = jb.ts;
+    const int lo = (k & 1) ? -(k / 2) : 0;
+    const long long mask = jb.cap - 1;
+    for (long long t = blk * 256ll + threadIdx.x; t < jb.n_out * K; t += (long long)nblk * 256) {
+        const long long u = t / K;
+        const int j = (int)(t - u * K);
+        const int ox = lo + j % k, oy = lo + (j / k) % k, oz = lo + j / (k * k);
+        const int4 c = reinterpret_cast<const int4*>(jb.out_coords)[u];
+        const long long slot = table_find(jb.keys, mask, pack_key(c.x, c.y + ox * ts, c.z + oy * ts, c.w + oz * ts));
+        int r = slot >= 0 ? jb.vals[slot] : -1;
+        if (jb.compose && r >= 0) r = jb.compose[r];
+        jb.nbr[t] = r;
+    }
+}
+
+struct UpJobsDev {
+    CvUpJob j[4];
+    int block_begin[5];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void build_up_maps(const UpJobsDev jobs) {
+    int ji = 0;
+    while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.block_begin[ji + 1]) ++ji;
+    const CvUpJob& jb = jobs.j[ji];
+    const int nblk = jobs.block_begin[ji + 1] - jobs.block_begin[ji], blk = blockIdx.x - jobs.block_begin[ji];
+    const long long n = jb.n_coarse * 8;
+    for (long long t = blk * 256ll + threadIdx.x; t < n; t += (long long)nblk * 256) {
+        const int f = jb.nbr_down[t];
+        if (f >= 0) jb.up[(long long)f * 8 + (t & 7)] = (int)(t >> 3);
+    }
+}
+
 __global__ void set_int(int* p, int v) { *p = v; }
 
 __device__ __forceinline__ unsigned long long spread3(unsigned long long v) {   // 16 bits -> every 3rd bit
@@ -244,9 +299,187 @@ __global__ __launch_bounds__(256) void morton_keys(const int* __restrict__ coord
     keys[i] = (long long)(((unsigned long long)(c.x & 0x7fff) << 48) | m);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Spatial row order of a scene: stable LSD radix sort (three 9-bit digits) on
+//   key = batch (9 bits) | Morton code of ((c - min) >> shift) (6 bits per axis),
+// shift = the smallest that brings every axis' extent under 64.  Rows of one 2^shift cube stay in the caller's order,
+// cubes run in Z-order, scenes of a batch one after the other: what the gathers and the 32-row MFMA tiles need (and
+// deterministic: the sort is stable).  Replaces a 64-bit device-wide sort + gathers (13 launches, ~170 us per scene).
+constexpr int SORT_BITS = 9, SORT_BINS = 1 << SORT_BITS, SORT_ROWS = 2048, SORT_T = 256;
+
+// mm[0..2] = min c, mm[3..5] = min(-c) (i.e. -max), mm[6] = min(-batch); initialised to 0x7f7f7f7f by a fill
+__global__ __launch_bounds__(256) void sort_minmax(const int* __restrict__ coords, long long n, int* __restrict__ mm) {
+    __shared__ int s[7];
+    if (threadIdx.x < 7) s[threadIdx.x] = 0x7f7f7f7f;
+    __syncthreads();
+    int v[7] = {0x7f7f7f7f, 0x7f7f7f7f, 0x7f7f7f7f, 0x7f7f7f7f, 0x7f7f7f7f, 0x7f7f7f7f, 0x7f7f7f7f};
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        v[0] = min(v[0], c.y); v[1] = min(v[1], c.z); v[2] = min(v[2], c.w);
+        v[3] = min(v[3], -c.y); v[4] = min(v[4], -c.z); v[5] = min(v[5], -c.w);
+        v[6] = min(v[6], -c.x);
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        int x = v[k];
+        for (int off = 32; off > 0; off >>= 1) x = min(x, __shfl_xor(x, off));
+        if ((threadIdx.x & 63) == 0) atomicMin(&s[k], x);
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) atomicMin(&mm[threadIdx.x], s[threadIdx.x]);
+}
+
+__device__ __forceinline__ unsigned sort_key_of(int4 c, const int* __restrict__ mm) {
+    const int ex = max(max(-mm[3] - mm[0], -mm[4] - mm[1]), -mm[5] - mm[2]);      // largest extent
+    int shift = 0;
+    while ((ex >> shift) >= 64) ++shift;
+    const unsigned x = (unsigned)((c.y - mm[0]) >> shift) & 63u, y = (unsigned)((c.z - mm[1]) >> shift) & 63u,
+                   z = (unsigned)((c.w - mm[2]) >> shift) & 63u;
+    const unsigned m = (unsigned)(spread3(x) | (spread3(y) << 1) | (spread3(z) << 2));    // 18 bits
+    const unsigned b = (unsigned)min(max(c.x, 0), SORT_BINS - 1);                        // batch index, clamped
+    return (b << 18) | m;
+}
+
+// pass 0: keys + the per-block histogram of digit 0; later passes: histogram of digit `pass` of keys_in
+__global__ __launch_bounds__(SORT_T) void sort_hist(const int* __restrict__ coords, const int* __restrict__ mm,
+                                                    unsigned* __restrict__ keys, long long n, int pass,
+                                                    int* __restrict__ hist /*[nblk][SORT_BINS]*/) {
+    __shared__ int lh[SORT_BINS];
+    for (int i = threadIdx.x; i < SORT_BINS; i += SORT_T) lh[i] = 0;
+    __syncthreads();
+    const long long base = blockIdx.x * (long long)SORT_ROWS;
+    for (int r = 0; r < SORT_ROWS / SORT_T; ++r) {
+        const long long i = base + r * SORT_T + threadIdx.x;
+        if (i < n) {
+            unsigned k;
+            if (coords) { k = sort_key_of(reinterpret_cast<const int4*>(coords)[i], mm); keys[i] = k; }
+            else k = keys[i];
+            atomicAdd(&lh[(k >> (SORT_BITS * pass)) & (SORT_BINS - 1)], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SORT_BINS; i += SORT_T) hist[(long long)blockIdx.x * SORT_BINS + i] = lh[i];
+}
+
+// stable scatter of one digit.  vals_in == nullptr: the value of row i is i (first pass).
+// Last pass (coords != nullptr): instead of keys_out / vals_out it writes perm[pos] = original row,
+// inv[original row] = pos and sorted[pos] = coords[original row].
+__global__ __launch_bounds__(SORT_T) void sort_scatter(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in,
+                                                       long long n, int pass, const int* __restrict__ hist, int nblk,
+                                                       unsigned* __restrict__ keys_out, int* __restrict__ vals_out,
+                                                       const int* __restrict__ coords, int* __restrict__ perm,
+                                                       int* __restrict__ inv, int* __restrict__ sorted) {
+    __shared__ int start[SORT_BINS];      // first output slot of (this block, bin); then the running slot
+    __shared__ int scan[SORT_T];
+    // totals and this block's prefix per bin (two bins per thread, coalesced over the block-major histogram)
+    int tot[SORT_BINS / SORT_T], pre[SORT_BINS / SORT_T];
+#pragma unroll
+    for (int q = 0; q < SORT_BINS / SORT_T; ++q) { tot[q] = 0; pre[q] = 0; }
+    for (int b = 0; b < nblk; ++b) {
+#pragma unroll
+        for (int q = 0; q < SORT_BINS / SORT_T; ++q) {
+            const int h = hist[(long long)b * SORT_BINS + threadIdx.x * (SORT_BINS / SORT_T) + q];
+            tot[q] += h;
+            if (b < (int)blockIdx.x) pre[q] += h;
+        }
+    }
+    // exclusive scan of the bin totals (bins threadIdx.x * 2 + q, in bin order)
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < SORT_BINS / SORT_T; ++q) mine += tot[q];
+    scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < SORT_T; off <<= 1) {
+        const int t = (int)threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+        __syncthreads();
+        scan[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = scan[threadIdx.x] - mine;
+#pragma unroll
+    for (int q = 0; q < SORT_BINS / SORT_T; ++q) {
+        start[threadIdx.x * (SORT_BINS / SORT_T) + q] = run + pre[q];
+        run += tot[q];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long base = blockIdx.x * (long long)SORT_ROWS;
+    for (int r = 0; r < SORT_ROWS / SORT_T; ++r) {
+        const long long i = base + r * SORT_T + threadIdx.x;
+        const bool have = i < n;
+        unsigned k = 0;
+        int d = 0;
+        if (have) { k = keys_in[i]; d = (int)((k >> (SORT_BITS * pass)) & (SORT_BINS - 1)); }
+        // lanes of this wave with the same digit
+        uint64_t peers = __ballot(have);
+#pragma unroll
+        for (int bit = 0; bit < SORT_BITS; ++bit) {
+            const uint64_t bm = __ballot(have && ((d >> bit) & 1));
+            peers &= ((d >> bit) & 1) ? bm : ~bm;
+        }
+        const int rank_w = __popcll(peers & ((1ull << lane) - 1ull)), cnt_w = __popcll(peers);
+        const int leader = have ? (int)__ffsll((unsigned long long)peers) - 1 : lane;
+        int slot = 0;
+        // waves take their turn on the running slots (rows of wave w precede those of wave w + 1)
+        for (int w = 0; w < SORT_T / 64; ++w) {
+            if (wave == w && have && lane == leader) { slot = start[d]; start[d] = slot + cnt_w; }
+            __syncthreads();
+        }
+        slot = __shfl(slot, leader);
+        if (have) {
+            const long long pos = slot + rank_w;
+            const int v = vals_in ? vals_in[i] : (int)i;
+            if (coords) {
+                perm[pos] = v;
+                inv[v] = (int)pos;
+                reinterpret_cast<int4*>(sorted)[pos] = reinterpret_cast<const int4*>(coords)[v];
+            } else {
+                keys_out[pos] = k;
+                vals_out[pos] = v;
+            }
+        }
+    }
+}
+
 int grid_for(long long n) { return (int)std::min<long long>((n + 255) / 256, 4096); }
 
 }  // namespace
+
+int cv_sp_kernel_maps_batch(const CvMapJob* jobs, int n_jobs, void* stream) {
+    CV_REQUIRE(jobs && n_jobs > 0 && n_jobs <= CV_MAX_MAP_JOBS, CV_EINVAL, "bad kernel map batch");
+    MapJobsDev d;
+    d.n = n_jobs;
+    int total = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const CvMapJob& j = jobs[i];
+        CV_REQUIRE(j.out_coords && j.keys && j.vals && j.nbr && j.n_out > 0 && j.k >= 1 && j.k <= 7 && j.ts >= 1,
+                   CV_EINVAL, "bad kernel map job %d", i);
+        d.j[i] = j;
+        d.block_begin[i] = total;
+        total += grid_for(j.n_out * j.k * j.k * j.k);
+    }
+    d.block_begin[n_jobs] = total;
+    build_kernel_maps<<<total, 256, 0, static_cast<hipStream_t>(stream)>>>(d);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+int cv_sp_up_maps_batch(const CvUpJob* jobs, int n_jobs, void* stream) {
+    CV_REQUIRE(jobs && n_jobs > 0 && n_jobs <= 4, CV_EINVAL, "bad up map batch");
+    UpJobsDev d;
+    d.n = n_jobs;
+    int total = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        CV_REQUIRE(jobs[i].nbr_down && jobs[i].up && jobs[i].n_coarse > 0, CV_EINVAL, "bad up map job %d", i);
+        d.j[i] = jobs[i];
+        d.block_begin[i] = total;
+        total += grid_for(jobs[i].n_coarse * 8);
+    }
+    d.block_begin[n_jobs] = total;
+    build_up_maps<<<total, 256, 0, static_cast<hipStream_t>(stream)>>>(d);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
 
 extern "C" {
 
@@ -279,15 +512,21 @@ int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_ke
     CvCarver cv(d_ws);
     long long* slot_of_row = cv.take<long long>(n);
     int* flag = cv.take<int>(n);
-    int* rank = cv.take<int>(n);
+    (void)cv.take<int>(n);      // (formerly the rank array; the workspace size is part of the C ABI)
     int* bsum = cv.take<int>(1024);
-    const int nsb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    const int scan_per = n <= (1ll << 20) ? 1 : 8;
+    const int nsb = (int)((n + 1024ll * scan_per - 1) / (1024ll * scan_per));
     CV_REQUIRE(nsb <= 1024, CV_EINVAL, "coordinate set too large for the scan (%lld rows)", n);
     const int g = grid_for(n);
-    CV_HIP_CHECK(hipMemsetAsync(d_counts, 0, sizeof(int) * 8, st));
-    set_int<<<1, 1, 0, st>>>(d_counts, (int)n);
-    CV_LAUNCH_CHECK();
-    table_clear<<<grid_for(cap), 256, 0, st>>>(d_keys[0], d_vals[0], cap);
+    // 4 launches per coarse level + 3 for level 0 (the first version took 7 per level + 5: the flag / emit passes are
+    // folded into the scan's two passes, all tables and the counters are cleared by one launch)
+    TablesDev tabs;
+    tabs.n = num_levels;
+    for (int L = 0; L < 5; ++L) {
+        tabs.keys[L] = L < num_levels ? d_keys[L] : nullptr;
+        tabs.vals[L] = L < num_levels ? d_vals[L] : nullptr;
+    }
+    table_clear_all<<<grid_for(cap * num_levels), 256, 0, st>>>(tabs, cap, d_counts, (int)n);
     CV_LAUNCH_CHECK();
     insert_rows<<<g, 256, 0, st>>>(d_coords[0], d_counts, d_keys[0], d_vals[0], cap - 1, d_counts + 5);
     CV_LAUNCH_CHECK();
@@ -295,21 +534,20 @@ int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_ke
     CV_LAUNCH_CHECK();
     for (int L = 1; L < num_levels; ++L) {
         const int stride2 = 1 << L;
-        table_clear<<<grid_for(cap), 256, 0, st>>>(d_keys[L], d_vals[L], cap);
-        CV_LAUNCH_CHECK();
         insert_coarse<<<g, 256, 0, st>>>(d_coords[L - 1], d_counts + L - 1, stride2, d_keys[L], d_vals[L],
                                          cap - 1, slot_of_row);
         CV_LAUNCH_CHECK();
-        flag_first<<<g, 256, 0, st>>>(d_counts + L - 1, d_vals[L], slot_of_row, flag);
-        CV_LAUNCH_CHECK();
-        scan_block_sums<<<nsb, 1024, 0, st>>>(flag, d_counts + L - 1, bsum);
+        if (scan_per == 1) flag_and_block_sums<1><<<nsb, 1024, 0, st>>>(d_counts + L - 1, d_vals[L], slot_of_row, flag, bsum);
+        else flag_and_block_sums<8><<<nsb, 1024, 0, st>>>(d_counts + L - 1, d_vals[L], slot_of_row, flag, bsum);
         CV_LAUNCH_CHECK();
         scan_block_offsets<<<1, 1024, 0, st>>>(bsum, nsb, d_counts + L);
         CV_LAUNCH_CHECK();
-        scan_apply<<<nsb, 1024, 0, st>>>(flag, d_counts + L - 1, bsum, rank);
-        CV_LAUNCH_CHECK();
-        emit_coarse<<<g, 256, 0, st>>>(d_coords[L - 1], d_counts + L - 1, stride2, flag, rank,
-                                       slot_of_row, d_vals[L], d_coords[L]);
+        if (scan_per == 1)
+            scan_apply_emit<1><<<nsb, 1024, 0, st>>>(d_coords[L - 1], d_counts + L - 1, stride2, flag, bsum, slot_of_row,
+                                                     d_vals[L], d_coords[L]);
+        else
+            scan_apply_emit<8><<<nsb, 1024, 0, st>>>(d_coords[L - 1], d_counts + L - 1, stride2, flag, bsum, slot_of_row,
+                                                     d_vals[L], d_coords[L]);
         CV_LAUNCH_CHECK();
     }
     if (h_counts) {
@@ -325,6 +563,50 @@ int cv_sp_morton_keys(const int32_t* d_coords, long long n, long long* d_keys, v
     CV_REQUIRE(d_coords && d_keys && n > 0, CV_EINVAL, "bad morton arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     morton_keys<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(d_coords, n, d_keys);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+size_t cv_sp_sort_workspace_bytes(long long n) {
+    if (n <= 0) return 0;
+    const size_t nblk = (size_t)((n + SORT_ROWS - 1) / SORT_ROWS);
+    return 256 + 4 * cv_align_up(sizeof(int) * (size_t)n, 256) + cv_align_up(sizeof(int) * nblk * SORT_BINS, 256);
+}
+
+// Spatial (batch, Z-order of coarse cubes, caller order inside a cube) row order of a coordinate set, stable.
+//   d_sorted [n][4] = the rows in that order, d_perm[n] = original row of sorted row, d_inv[n] = sorted row of
+//   original row.  Asynchronous, 8 launches, no host synchronisation.
+int cv_sp_sort_rows(const int32_t* d_coords, long long n, int32_t* d_sorted, int32_t* d_perm, int32_t* d_inv,
+                    void* d_ws, size_t ws_bytes, void* stream) {
+    CV_REQUIRE(d_coords && d_sorted && d_perm && d_inv && d_ws, CV_EINVAL, "null pointer argument");
+    CV_REQUIRE(n > 0 && n < (1ll << 30), CV_EINVAL, "bad row count %lld", n);
+    CV_REQUIRE(ws_bytes >= cv_sp_sort_workspace_bytes(n), CV_ENOMEM, "workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CvCarver cv(d_ws);
+    int* mm = cv.take<int>(8);
+    unsigned* keys_a = cv.take<unsigned>(n);
+    unsigned* keys_b = cv.take<unsigned>(n);
+    int* vals_a = cv.take<int>(n);
+    int* vals_b = cv.take<int>(n);
+    const int nblk = (int)((n + SORT_ROWS - 1) / SORT_ROWS);
+    int* hist = cv.take<int>((size_t)nblk * SORT_BINS);
+    CV_HIP_CHECK(hipMemsetAsync(mm, 0x7f, sizeof(int) * 8, st));
+    sort_minmax<<<(unsigned)std::min<long long>((n + 255) / 256, 256), 256, 0, st>>>(d_coords, n, mm);
+    CV_LAUNCH_CHECK();
+    sort_hist<<<nblk, SORT_T, 0, st>>>(d_coords, mm, keys_a, n, 0, hist);
+    CV_LAUNCH_CHECK();
+    sort_scatter<<<nblk, SORT_T, 0, st>>>(keys_a, nullptr, n, 0, hist, nblk, keys_b, vals_b, nullptr, nullptr, nullptr,
+                                          nullptr);
+    CV_LAUNCH_CHECK();
+    sort_hist<<<nblk, SORT_T, 0, st>>>(nullptr, mm, keys_b, n, 1, hist);
+    CV_LAUNCH_CHECK();
+    sort_scatter<<<nblk, SORT_T, 0, st>>>(keys_b, vals_b, n, 1, hist, nblk, keys_a, vals_a, nullptr, nullptr, nullptr,
+                                          nullptr);
+    CV_LAUNCH_CHECK();
+    sort_hist<<<nblk, SORT_T, 0, st>>>(nullptr, mm, keys_a, n, 2, hist);
+    CV_LAUNCH_CHECK();
+    sort_scatter<<<nblk, SORT_T, 0, st>>>(keys_a, vals_a, n, 2, hist, nblk, nullptr, nullptr, d_coords, d_perm, d_inv,
+                                          d_sorted);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

@@ -42,9 +42,11 @@ class CoordinateManager:
 
     NUM_LEVELS = 5
 
-    def __init__(self, coords, num_levels=NUM_LEVELS, check=True):
+    def __init__(self, coords, num_levels=NUM_LEVELS, check=True, lazy=False):
         """check=False with num_levels=1 builds the level-0 hash without any host sync (the
-        duplicate count stays on the device); used for the boundary maps of the fused network."""
+        duplicate count stays on the device).  lazy=True (what SparseTensor passes): nothing is built until a map,
+        a coarser level or the coordinates of this (caller-order) set are asked for - the fused network never does,
+        it runs on the spatially sorted twin from fused_plan()."""
         assert coords.is_cuda and coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
         self.device = coords.device
         if coords.shape[0] == 0:
@@ -52,7 +54,18 @@ class CoordinateManager:
         self.cap = int(_lib.lib().cv_sp_table_capacity(coords.shape[0]))
         self._input = coords.contiguous()
         self._fused = None
-        self._build(num_levels, check)
+        self._lazy = (num_levels, check) if lazy else None
+        if not lazy:
+            self._build(num_levels, check)
+
+    def __getattr__(self, name):
+        # attributes created by _build(): a lazy manager builds on first use
+        if name in ("coords", "counts", "_level", "_keys", "_vals", "_coords_buf", "_counts_d", "_verified", "_maps",
+                    "num_levels") and self.__dict__.get("_lazy") is not None:
+            lazy, self._lazy = self._lazy, None
+            self._build(*lazy)
+            return self.__dict__[name]
+        raise AttributeError(name)
 
     def _build(self, num_levels, check):
         L = _lib.lib()
@@ -166,11 +179,16 @@ class CoordinateManager:
             L = _lib.lib()
             dev = self.device
             n = self._input.shape[0]
-            keys = torch.empty(n, dtype=torch.int64, device=dev)
+            # spatial row order (stable radix sort on the device, no host synchronisation): sorted rows, sorted <- original
+            # and original <- sorted row indices
+            sorted_c = torch.empty((n, 4), dtype=torch.int32, device=dev)
+            perm = torch.empty(n, dtype=torch.int32, device=dev)
+            inv = torch.empty(n, dtype=torch.int32, device=dev)
+            sws = torch.empty(int(L.cv_sp_sort_workspace_bytes(n)), dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
-                _lib.check(L.cv_sp_morton_keys(_ptr(self._input), n, _ptr(keys), _stream(dev)), "cv_sp_morton_keys")
-            perm = torch.argsort(keys)                      # device radix sort (plumbing, 80k keys)
-            cm_s = CoordinateManager(self._input[perm].contiguous(), CoordinateManager.NUM_LEVELS, True)
+                _lib.check(L.cv_sp_sort_rows(_ptr(self._input), n, _ptr(sorted_c), _ptr(perm), _ptr(inv), _ptr(sws),
+                                             sws.numel(), _stream(dev)), "cv_sp_sort_rows")
+            cm_s = CoordinateManager(sorted_c, CoordinateManager.NUM_LEVELS, True)
             rows = (ctypes.c_int64 * 5)(*cm_s.counts)
             off = _lib.SceneMaps()
             G = self.MASK_GROUPS if (27 + self.MASK_GROUPS - 1) // self.MASK_GROUPS <= 10 else 0   # wide groups: lazily
@@ -179,13 +197,12 @@ class CoordinateManager:
             arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
             with torch.cuda.device(dev):
                 _lib.check(L.cv_sp_scene_maps(arr(cm_s._coords_buf), arr(cm_s._keys), arr(cm_s._vals), cm_s.cap, rows,
-                                              _ptr(self._input), _ptr(self._keys[0]), _ptr(self._vals[0]), self.cap, n,
-                                              stem_k, G, self.MASKED_MIN_ROWS, _ptr(arena), words, _stream(dev)),
-                           "cv_sp_scene_maps")
+                                              _ptr(perm), n, stem_k, G, self.MASKED_MIN_ROWS, _ptr(arena), words,
+                                              _stream(dev)), "cv_sp_scene_maps")
             c = cm_s.counts
             view = lambda o, r, k: arena[o:o + r * k].view(r, k)
             stem_map = view(off.stem, c[0], stem_k ** 3)
-            out_map = view(off.out, n, 1)
+            out_map = inv.view(n, 1)                # original row <- sorted row: the final 1x1 conv's "kernel map"
             for i in range(4):
                 cm_s._maps[("k", 2, 1 << i, 2)] = view(off.down[i], c[i + 1], 8)
                 cm_s._maps[("up", 16 >> i)] = view(off.up[i], c[3 - i], 8)
@@ -202,6 +219,8 @@ class CoordinateManager:
         return self._fused
 
     def num_rows(self, ts):
+        if ts == 1:
+            return self._input.shape[0]
         if ts not in self._level:
             self.ensure_levels()
         return self.counts[self._level[ts]]
@@ -261,7 +280,7 @@ class SparseTensor:
             if c.is_floating_point():
                 c = torch.floor(c)
             coordinate_manager = CoordinateManager(c.to(device=device, dtype=torch.int32).contiguous(),
-                                                   num_levels=1, check=False)
+                                                   num_levels=1, check=False, lazy=True)
         self.coordinate_manager = coordinate_manager
         self.tensor_stride = tensor_stride if isinstance(tensor_stride, int) else int(tensor_stride[0])
         if self.F.shape[0] != coordinate_manager.num_rows(self.tensor_stride):

@@ -149,6 +149,14 @@ int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_ke
                        int32_t* const* d_vals, long long n, long long cap, int num_levels,
                        int32_t* d_counts, int32_t* h_counts, void* d_ws, size_t ws_bytes, void* stream);
 
+/* Spatial row order of a coordinate set (what the fused network runs on; replaces the sort of Morton keys by the
+ * caller): stable sort on (batch index, Z-order of the 2^shift cubes), rows of one cube in the caller's order.
+ * d_sorted[n][4] = rows in that order, d_perm[n] = original row of each sorted row, d_inv[n] = sorted row of each
+ * original row.  d_ws: cv_sp_sort_workspace_bytes(n).  Asynchronous, no host synchronisation. */
+size_t cv_sp_sort_workspace_bytes(long long n);
+int cv_sp_sort_rows(const int32_t* d_coords, long long n, int32_t* d_sorted, int32_t* d_perm, int32_t* d_inv,
+                    void* d_ws, size_t ws_bytes, void* stream);
+
 /* Z-order (Morton) sort keys, batch index in the top bits: d_keys[n] int64.  Asynchronous. */
 int cv_sp_morton_keys(const int32_t* d_coords, long long n, long long* d_keys, void* stream);
 
@@ -247,8 +255,9 @@ int cv_sp_conv_f32(const cv_conv_desc* desc, void* stream);
 
 /* Every kernel map and processing order the fused MinkUNet forward needs, built by ONE call per scene into one
  * int32 arena (offsets in int32 words; -1 = absent):
- *   stem  [rows0][stem_k^3]  sorted rows <- rows of the caller's order (table of the caller's coordinate set)
- *   out   [n_orig][1]        caller's rows <- sorted rows
+ *   stem  [rows0][stem_k^3]  sorted rows <- rows of the caller's order (the sorted set's own map with d_perm, the
+ *                            sorted <- original permutation of cv_sp_sort_rows, folded in)
+ *   out                      always -1: the caller's rows <- sorted rows map is cv_sp_sort_rows' d_inv
  *   down[i] [rows(i+1)][8]   k2s2 conv level i -> i+1;   k3[i] [rows(i)][27];   up[i] [rows(3-i)][8] level 4-i -> 3-i
  *   mask_perm[i] [groups][rows(i)] for levels with >= masked_min_rows rows;  up_perm[i] [rows(3-i)] octant order
  * d_coords / d_keys / d_vals: the five levels of the (Z-order sorted) coordinate set from cv_sp_build_levels. */
@@ -258,10 +267,8 @@ typedef struct cv_scene_maps {
 size_t cv_sp_scene_maps_words(const long long* level_rows, long long n_orig, int stem_k, int mask_groups,
                               long long masked_min_rows, cv_scene_maps* offsets);
 int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
-                     long long cap, const long long* level_rows, const int32_t* d_orig_coords,
-                     const unsigned long long* d_orig_keys, const int32_t* d_orig_vals, long long orig_cap,
-                     long long n_orig, int stem_k, int mask_groups, long long masked_min_rows, int32_t* d_arena,
-                     size_t arena_words, void* stream);
+                     long long cap, const long long* level_rows, const int32_t* d_perm, long long n_orig, int stem_k,
+                     int mask_groups, long long masked_min_rows, int32_t* d_arena, size_t arena_words, void* stream);
 
 /* Fused eval-mode network as ONE call per scene (host-side executor over cv_sp_conv_f32; replaces the reference's
  * module-by-module MinkUNet34C.forward, utils/minkunet.py:122-180, for inference).  The program is symbolic and built

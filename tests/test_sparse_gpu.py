@@ -45,6 +45,41 @@ def test_coordinate_sets_and_kernel_maps_exact(cuda, built_lib, seed, n, batch):
         assert np.array_equal(down[up[f, j], j], f)
 
 
+@pytest.mark.parametrize("seed,n,batch", [(3, 1, 1), (0, 700, 1), (1, 3000, 3), (2, 80000, 1)])
+def test_spatial_row_sort_is_the_stable_sort_of_its_key(cuda, built_lib, seed, n, batch):
+    """cv_sp_sort_rows (the row order the fused network runs on): key = batch | Z-order of the coarse cube,
+    stable, so perm equals numpy's stable argsort of the same key bit for bit; inv is its inverse."""
+    import ctypes
+    from canonicalvoting_amd import _lib
+    L = _lib.lib()
+    coords, _ = scene_coords(seed, n, batch, small=n < 10000)
+    rng = np.random.default_rng(seed)
+    coords = coords[rng.permutation(len(coords))]             # scenes of the batch interleaved, rows shuffled
+    coords[:, 1:] -= 7                                        # negative coordinates too
+    N = len(coords)
+    c = torch.from_numpy(coords).to(cuda, torch.int32).contiguous()
+    srt = torch.empty((N, 4), dtype=torch.int32, device=cuda)
+    perm = torch.empty(N, dtype=torch.int32, device=cuda)
+    inv = torch.empty(N, dtype=torch.int32, device=cuda)
+    ws = torch.empty(int(L.cv_sp_sort_workspace_bytes(N)), dtype=torch.uint8, device=cuda)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(L.cv_sp_sort_rows(c.data_ptr(), N, srt.data_ptr(), perm.data_ptr(), inv.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), st), "cv_sp_sort_rows")
+    mn, mx = coords[:, 1:].min(0), coords[:, 1:].max(0)
+    shift = 0
+    while (int((mx - mn).max()) >> shift) >= 64:
+        shift += 1
+    q = ((coords[:, 1:] - mn) >> shift).astype(np.uint64)
+    key = coords[:, 0].astype(np.uint64) << np.uint64(18)
+    for bit in range(6):
+        for ax in range(3):
+            key |= ((q[:, ax] >> np.uint64(bit)) & np.uint64(1)) << np.uint64(3 * bit + ax)
+    ref = np.argsort(key, kind="stable")
+    assert np.array_equal(perm.cpu().numpy(), ref)
+    assert np.array_equal(srt.cpu().numpy(), coords[ref])
+    assert np.array_equal(inv.cpu().numpy()[ref], np.arange(N))
+
+
 def test_duplicate_coordinates_rejected(cuda, built_lib):
     c = torch.tensor([[0, 1, 2, 3], [0, 1, 2, 3], [0, 4, 5, 6]], dtype=torch.int32, device=cuda)
     with pytest.raises(RuntimeError, match="duplicate"):      # reported at the first map request
