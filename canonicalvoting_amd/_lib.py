@@ -39,7 +39,8 @@ class ConvDesc(ctypes.Structure):
                 ("perm_groups", ctypes.c_int), ("plan_ent", vp), ("plan_cnt", vp),
                 ("weight_packed", vp), ("weight_x6", vp), ("in2", vp), ("in2_ld", ctypes.c_int), ("cin2", ctypes.c_int),
                 ("weight2_x6", vp), ("perm_has_map", ctypes.c_int), ("weight_pieces", ctypes.c_int),
-                ("acc_scale", ctypes.c_float), ("range_flag", vp)]
+                ("acc_scale", ctypes.c_float), ("range_flag", vp), ("in_hl", ctypes.c_int), ("out_hl", ctypes.c_int),
+                ("res_hl", ctypes.c_int)]
 
 
 class SceneMaps(ctypes.Structure):
@@ -51,7 +52,7 @@ class SceneMaps(ctypes.Structure):
 
 class NetBuf(ctypes.Structure):
     """struct cv_net_buf (include/cv_hip.h)"""
-    _fields_ = [("level", ctypes.c_int), ("channels", ctypes.c_int), ("rows_level", ctypes.c_int)]
+    _fields_ = [("level", ctypes.c_int), ("channels", ctypes.c_int), ("rows_level", ctypes.c_int), ("hl", ctypes.c_int)]
 
 
 class NetOp(ctypes.Structure):
@@ -93,6 +94,8 @@ SIGNATURES = {
     "cv_sp_morton_keys": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp]),
     "cv_sp_sort_workspace_bytes": (ctypes.c_size_t, [ctypes.c_longlong]),
     "cv_sp_sort_rows": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp, vp, vp, ctypes.c_size_t, vp]),
+    "cv_sp_to_hl_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
+    "cv_sp_from_hl_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp]),
     "cv_sp_kernel_map": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp, ctypes.c_longlong, ctypes.c_int,
                                         ctypes.c_int, vp, vp]),
     "cv_sp_up_map": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_longlong, vp, vp]),

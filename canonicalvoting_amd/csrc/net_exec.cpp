@@ -135,6 +135,10 @@ int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int 
         const Slot& in = slot[o.in_buf];
         const Slot& out = slot[o.out_buf];
         cv_conv_desc d = {};
+        d.in_hl = bufs[o.in_buf].hl;
+        d.out_hl = bufs[o.out_buf].hl;
+        d.res_hl = o.res_buf >= 0 ? bufs[o.res_buf].hl : 0;
+        CV_REQUIRE(o.in2_buf < 0 || bufs[o.in2_buf].hl == d.in_hl, CV_EINVAL, "op %d: both sources must share a format", k);
         d.in = reinterpret_cast<const float*>(in.ptr) + o.in_col;
         d.n_in = in.rows;
         d.in_ld = in.ld;
@@ -143,7 +147,7 @@ int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int 
         d.weight_x6 = o.weight_x6;
         d.weight_pieces = o.weight_pieces;
         d.acc_scale = o.acc_scale;
-        d.range_flag = o.weight_pieces == 2 ? range_flag : nullptr;
+        d.range_flag = (o.weight_pieces == 2 || d.out_hl) ? range_flag : nullptr;
         if (o.in2_buf >= 0) {
             CV_REQUIRE(o.in2_buf < n_bufs, CV_EINVAL, "op %d: bad second-source slot", k);
             d.in2 = reinterpret_cast<const float*>(slot[o.in2_buf].ptr) + o.in2_col;

@@ -27,6 +27,9 @@
 // 90 %, and dead waves / tiles skip their MFMAs / staging.
 #include "cv_common.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -65,7 +68,38 @@ struct ConvArgs {
     int pieces;                  // 3: wp6 holds bf16 triples (six piece products), 2: fp16 pairs (three piece products)
     float acc_scale;             // fp16 pairs: the packed weights carry a power-of-two factor; accumulators *= acc_scale
     int* range_flag;             // fp16 pairs: set to 1 when a staged input magnitude does not fit fp16
+    int in_hl, out_hl, res_hl;   // 1: the operand is in the hl format (fp16 pairs in place, see below) instead of fp32
+    int xcd_tiles;               // conv_rows_wp / conv_hl: XCD-aware tile numbering (xcd_tile)
 };
+
+// ---- hl format: activations stored as the fp16 pairs the matrix cores multiply --------------------------------------
+// A row of C channels (C % 32 == 0) keeps its 4*C bytes: 32-channel chunk q occupies bytes [128 q, 128 q + 128) =
+// 32 fp16 high pieces h = RNE16(x), then the 32 low pieces l = RNE16(x - h) (split2h below).  A convolution that reads
+// the format loads its MFMA operand fragments straight from global memory (no split, no LDS staging of the gathered
+// rows: a lane's 16-byte pieces are contiguous), the producing epilogue splits every value ONCE instead of once per
+// gather (27 x for a 3x3x3 kernel).  Column windows that start at a multiple of 32 channels keep the plain pointer
+// arithmetic (32 channels = 32 floats = 128 bytes).  h + l reproduces x to 2^-24 relative (|x| < 65504).
+__device__ __forceinline__ void hl_split2(float x0, float x1, unsigned& h, unsigned& l);
+__device__ __forceinline__ float4 hl_load4(const float* row, int col) {          // col % 4 == 0
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(row) + (col >> 5) * 128 + (col & 31) * 2;
+    const uint2 h = *reinterpret_cast<const uint2*>(p), l = *reinterpret_cast<const uint2*>(p + 64);
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 h0 = __builtin_bit_cast(h2, h.x), h1 = __builtin_bit_cast(h2, h.y), l0 = __builtin_bit_cast(h2, l.x),
+             l1 = __builtin_bit_cast(h2, l.y);
+    return make_float4((float)h0[0] + (float)l0[0], (float)h0[1] + (float)l0[1], (float)h1[0] + (float)l1[0],
+                       (float)h1[1] + (float)l1[1]);
+}
+__device__ __forceinline__ void hl_store4(float* row, int col, float4 v) {
+    unsigned h0, l0, h1, l1;
+    hl_split2(v.x, v.y, h0, l0);
+    hl_split2(v.z, v.w, h1, l1);
+    unsigned char* p = reinterpret_cast<unsigned char*>(row) + (col >> 5) * 128 + (col & 31) * 2;
+    *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(p + 64) = make_uint2(l0, l1);
+}
+__device__ __forceinline__ bool hl_out_of_range(float4 v) {
+    return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) > 65000.f;
+}
 
 __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& acc, const int* rows,
                                                int col, int lane) {
@@ -127,11 +161,17 @@ __device__ __forceinline__ void epilogue_store_wide(const ConvArgs& a, const f32
             const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
             v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
             if (a.res) {
-                const float4 p = *reinterpret_cast<const float4*>(a.res + (long long)row * a.res_ld + col);
+                const float4 p = a.res_hl ? hl_load4(a.res + (long long)row * a.res_ld, col)
+                                          : *reinterpret_cast<const float4*>(a.res + (long long)row * a.res_ld + col);
                 v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
             }
             if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<float4*>(a.out + (long long)row * a.out_ld + col) = v;
+            if (a.out_hl) {
+                if (a.range_flag && hl_out_of_range(v)) *a.range_flag = 1;
+                hl_store4(a.out + (long long)row * a.out_ld, col, v);
+            } else {
+                *reinterpret_cast<float4*>(a.out + (long long)row * a.out_ld + col) = v;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();       // the tile is rewritten by the next column block
@@ -356,6 +396,8 @@ __device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigne
     const f16x2 lv = {(_Float16)r0, (_Float16)r1};
     l = __builtin_bit_cast(unsigned, lv);
 }
+
+__device__ __forceinline__ void hl_split2(float x0, float x1, unsigned& h, unsigned& l) { split2h(x0, x1, h, l); }
 
 // wp layout of the fp16 pairs (unsigned short): ((((j*nch + c)*2 + plane)*cout + col)*32 + k); values are
 // w * col_scale * mult (mult = 2^scale_log2 keeps the low pieces of small weights out of the fp16 subnormals)
@@ -667,6 +709,16 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
     }
 }
 
+// Tile of a workgroup.  a.xcd_tiles (CV_XCD_TILES=1, an experiment that is off by default; gridDim.x a multiple of 8): workgroups are dealt to the eight XCDs round-robin by
+// their linear id, so blockIdx.x % 8 is the XCD; XCD r takes the r-th eighth of the tiles.  Rows are in spatial order (or
+// in mask order INSIDE the same eighths, see group_mask), so the rows a tile gathers were mostly fetched by its
+// neighbours on the same XCD: the mask-sorted ts1 conv missed that XCD's L2 on 52 % of its requests and fetched 192 MB
+// per launch from the memory side for 31 MB of input when consecutive tiles went to consecutive XCDs.
+__device__ __forceinline__ long long xcd_tile(const ConvArgs& a) {
+    if (a.xcd_tiles) return (long long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    return a.row_perm ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
+}
+
 // conv_rows_x6 with ONE workgroup barrier per (offset, 32-channel) unit instead of two plus two per offset.  The ablations
 // of conv_rows_x6 (profiles/r1/conv_ablate_h2.txt) left ~38 us of the 94 us ts1 96 -> 96 conv to the skeleton: ~56
 // workgroup barriers per workgroup at three workgroups per CU.  Two observations remove most of them:
@@ -678,7 +730,13 @@ __global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
 // The map entries of all the workgroup's offsets (<= WP_NPRE = 10; the host falls back to conv_rows_x6 otherwise) come in
 // with one round of loads, a bit mask of the offsets that exist for the tile is reduced once, and dead offsets are
 // skipped without a barrier.  Same MFMA sequence per accumulator as conv_rows_x6: bit-identical results.
-constexpr int WP_NPRE = 10;          // the traffic cap of pick_splits leaves 9 offsets per workgroup on the training ts8 level
+#ifndef CV_WP_ABL
+#define CV_WP_ABL 0       // timing ablations of conv_rows_wp (wrong results): 1 no fp16 split, 2 no MFMA, 4 no weight tile, 8 no gathers
+#endif
+#ifndef CV_WP_NPRE
+#define CV_WP_NPRE 10
+#endif
+constexpr int WP_NPRE = CV_WP_NPRE;          // the traffic cap of pick_splits leaves 9 offsets per workgroup on the training ts8 level
 template <int NB, int P>
 __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : NB == 2 ? 4 : 5)) void conv_rows_wp(ConvArgs a) {
     constexpr int A_BYTES = P * TM * 64, B_BYTES = P * NB * 32 * 64, EP_BYTES = 4 * 32 * EP_LD * 4;
@@ -692,8 +750,9 @@ __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : NB == 2 ? 4 : 5)) void conv
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.y * (NB * 32);
 
+    const long long tile_id = xcd_tile(a);
+    if (tile_id * TM >= a.n_out) return;             // padding of the XCD-aware grid
     if (tid < TM) {
-        const long long tile_id = a.row_perm ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
         const long long t = tile_id * TM + tid;
         const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)blockIdx.z * a.n_out : 0) : nullptr;
         rows_s[tid] = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
@@ -765,7 +824,6 @@ __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : NB == 2 ? 4 : 5)) void conv
         const int row = rows_s[t];
         if (row < 0) return -1;
         if (a.nbr_perm) {
-            const long long tile_id = (long long)gridDim.x - 1 - blockIdx.x;
             return a.nbr_perm[((long long)blockIdx.z * a.n_out + tile_id * TM + t) * a.nbr_perm_w +
                               (j - (a.j_begin + (int)((long long)nj * blockIdx.z / a.splits)))];
         }
@@ -819,11 +877,16 @@ __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : NB == 2 ? 4 : 5)) void conv
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int src = nb_j[a_row + 8 * i];
+#if (CV_WP_ABL & 8)
+            ra[i] = make_float4((float)src, 0.f, 0.f, 0.f);
+#else
             ra[i] = src >= 0 ? *reinterpret_cast<const float4*>(src_base + (long long)src * src_ld + kc + a_col)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         }
         const unsigned short* slab = second ? a.wp6_2 + (long long)c * P * a.cout * 32
                                             : a.wp6 + (long long)(j * nch + c) * P * a.cout * 32;
+#if !(CV_WP_ABL & 4)
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int f = tid + i * THREADS;
@@ -835,6 +898,7 @@ __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : NB == 2 ? 4 : 5)) void conv
                             : make_uint4(0u, 0u, 0u, 0u);
             }
         }
+#endif
     };
     auto stage = [&](unsigned char* Bb) {
 #pragma unroll
@@ -851,13 +915,18 @@ __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : NB == 2 ? 4 : 5)) void conv
                 *reinterpret_cast<uint2*>(dst + TM * 64) = make_uint2(m0, m1);
                 *reinterpret_cast<uint2*>(dst + 2 * TM * 64) = make_uint2(l0, l1);
             } else {
+#if (CV_WP_ABL & 1)
+                h0 = __float_as_uint(ra[i].x); l0 = __float_as_uint(ra[i].y); h1 = __float_as_uint(ra[i].z); l1 = __float_as_uint(ra[i].w);
+#else
                 in_max = fmaxf(fmaxf(in_max, fmaxf(fabsf(ra[i].x), fabsf(ra[i].y))), fmaxf(fabsf(ra[i].z), fabsf(ra[i].w)));
                 split2h(ra[i].x, ra[i].y, h0, l0);
                 split2h(ra[i].z, ra[i].w, h1, l1);
+#endif
                 *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
                 *reinterpret_cast<uint2*>(dst + TM * 64) = make_uint2(l0, l1);
             }
         }
+#if !(CV_WP_ABL & 4)
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             const int f = tid + i * THREADS;
@@ -867,6 +936,7 @@ __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : NB == 2 ? 4 : 5)) void conv
                 *reinterpret_cast<uint4*>(Bb + (p * NB * 32 + col) * 64 + ((ch ^ ((col >> 2) & 3)) << 4)) = rb[i];
             }
         }
+#endif
     };
     int j = j_first, c = c_first, buf = 0;
     if (njl > 0) skip_dead(j, c); else j = j_last + 1;
@@ -880,7 +950,11 @@ __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : NB == 2 ? 4 : 5)) void conv
         const bool wave_live = __any(nbr_all[j - j_first][wave * 32 + l31] >= 0);
         advance(j, c);
         if (j < j_done) load(j, c);                  // in flight while the matrix cores run
+#if !(CV_WP_ABL & 2)
         if (wave_live) compute(Bb);
+#else
+        if (wave_live && in_max == 12345.f) compute(Bb);
+#endif
         buf ^= 1;
     }
     __syncthreads();                                 // operand tiles are dead: the epilogue tile reuses their LDS
@@ -901,6 +975,219 @@ __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : NB == 2 ? 4 : 5)) void conv
         for (int nb = 0; nb < NB; ++nb)
             epilogue_store(a, acc[nb], rows_s + wave * 32, n0 + nb * 32 + (lane & 31), lane);
     }
+}
+
+// ------------------------------------------------------------------ fp16-pair convolution on hl-format activations
+// conv_rows_wp's tiling (128 rows x NB*32 columns, a wave owns 32 rows, weight tile shared through LDS, one workgroup
+// barrier per (offset, 32-channel) unit) with the gathered operand taken straight from global memory: in the hl format
+// a lane's MFMA A fragments of a unit are four contiguous 16-byte pieces of its row's 128-byte chunk, so the gather IS
+// the fragment load - no fp16 split (it was 2/3 of the VALU work of conv_rows_wp: 17.8 VALU instructions per MFMA,
+// profiles/r1/conv_pmc_wp.txt), no LDS staging of A, no in_max scan.  That frees the registers for a three-deep
+// software pipeline: the fragments of unit u + 2 are requested before the MFMAs of unit u run (conv_rows_wp: u + 1,
+// and the wave-time ablations of profiles/wp_ablate_trace.sh put most of the small layers' 20 us in that dependent
+// chain of load round trips).  Same units, same MFMA sequence per accumulator as conv_rows_wp on the same h / l
+// pieces: bit-identical accumulators.
+#ifndef CV_HL_ABL
+#define CV_HL_ABL 0       // timing ablations of conv_hl (wrong results): 1 no gathers, 2 no MFMA, 4 no weight tile, 8 no epilogue, 16 no map reads
+#endif
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// NS = unit slots (registers for the A fragments and this thread's share of the weight tile, one LDS weight tile each):
+// the loads of unit u + NS - 1 are requested while unit u multiplies.  Workgroups of the split coarse levels have no more
+// than NS units: all their loads are in flight after the prologue (two dependent round trips - map entries, fragments -
+// instead of one per unit).
+template <int NB, int NS>
+__global__ __launch_bounds__(THREADS, (NS > 3 ? 2 : 3)) void conv_hl(ConvArgs a) {
+    constexpr int B_BYTES = 2 * NB * 32 * 64, EP_BYTES = 4 * 32 * EP_LD * 4;
+    constexpr int SM_BYTES = NS * B_BYTES > EP_BYTES ? NS * B_BYTES : EP_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[SM_BYTES];     // NS x weight tile [plane][col][64 B]; then the epilogue tile
+    __shared__ int rows_s[TM];
+    __shared__ int nbr_all[WP_NPRE + 1][TM];
+    __shared__ unsigned live_mask;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.y * (NB * 32);
+
+    const long long tile_id = xcd_tile(a);
+    if (tile_id * TM >= a.n_out) return;             // padding of the XCD-aware grid
+    if (tid < TM) {
+        const long long t = tile_id * TM + tid;
+        const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)blockIdx.z * a.n_out : 0) : nullptr;
+        rows_s[tid] = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
+    }
+    if (tid == 0) live_mask = 0u;
+    __syncthreads();
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nj = a.j_end - a.j_begin;
+    constexpr int B_U4 = 2 * NB * 32 * 4;            // 16-byte pieces of one unit's weight tile
+    constexpr int B_PER = (B_U4 + THREADS - 1) / THREADS;
+    const int nch = a.cin / KC;
+    int u_lo, u_hi;
+    if (a.perm_per_split) {
+        u_lo = (int)((long long)nj * blockIdx.z / a.splits) * nch;
+        u_hi = (int)((long long)nj * (blockIdx.z + 1) / a.splits) * nch;
+    } else {
+        u_lo = (int)((long long)nj * nch * blockIdx.z / a.splits);
+        u_hi = (int)((long long)nj * nch * (blockIdx.z + 1) / a.splits);
+    }
+    const int j_first = a.j_begin + u_lo / nch, j_last = a.j_begin + (u_hi - 1) / nch;
+    const int njl = u_hi > u_lo ? j_last - j_first + 1 : 0;       // <= WP_NPRE (host)
+    auto map_entry = [&](int t, int j) {
+        const int row = rows_s[t];
+        if (row < 0) return -1;
+        if (a.nbr_perm) {
+            return a.nbr_perm[((long long)blockIdx.z * a.n_out + tile_id * TM + t) * a.nbr_perm_w +
+                              (j - (a.j_begin + (int)((long long)nj * blockIdx.z / a.splits)))];
+        }
+        return a.nbr ? a.nbr[(long long)row * a.K + j] : row;
+    };
+    {
+        unsigned m = 0u;
+        for (int e = tid; e < njl * TM; e += THREADS) {
+            const int jj = e / TM, t = e - jj * TM;
+            const int v = (CV_HL_ABL & 16) ? rows_s[t] : map_entry(t, j_first + jj);
+            nbr_all[jj][t] = v;
+            if (v >= 0) m |= 1u << jj;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m |= __shfl_xor(m, off);
+        if (lane == 0 && m) atomicOr(&live_mask, m);
+        if (a.in2 && tid < TM) nbr_all[njl][tid] = rows_s[tid];
+    }
+    __syncthreads();
+    const unsigned lm = live_mask;
+
+    const int c_first = u_lo - (u_lo / nch) * nch, c_last = u_hi > u_lo ? (u_hi - 1) - ((u_hi - 1) / nch) * nch + 1 : 0;
+    auto skip_dead = [&](int& j, int& c) {
+#pragma unroll 1
+        while (j <= j_last && !((lm >> (j - j_first)) & 1u)) { ++j; c = 0; }
+    };
+    const int nch2 = a.in2 ? a.cin2 / KC : 0;
+    const int j_second = j_last + 1, j_done = j_last + 2;
+    auto advance = [&](int& j, int& c) {
+        if (j <= j_last) {
+            if (++c >= (j == j_last ? c_last : nch)) { ++j; c = 0; skip_dead(j, c); }
+            if (j > j_last) { j = j_second; c = blockIdx.z; }
+        } else {
+            c += a.splits;
+        }
+        if (j == j_second && c >= nch2) j = j_done;
+    };
+
+    // NS units in flight: A fragments (h ks0, h ks1, l ks0, l ks1) and this thread's share of the weight tile
+    uint4 ra[NS][4], rb[NS][B_PER];
+    bool live[NS], valid[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { live[q] = false; valid[q] = false; }
+    const int my_row = wave * 32 + l31;
+    auto load = [&](auto S, int j, int c) {
+        constexpr int s = decltype(S)::value;
+        const bool second = j == j_second;
+        const int src = nbr_all[j - j_first][my_row];
+        const float* src_base = second ? a.in2 : a.in;
+        const int src_ld = second ? a.in2_ld : a.in_ld;
+        live[s] = __any(src >= 0);
+        valid[s] = true;
+        if (src >= 0 && !(CV_HL_ABL & 1)) {
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(src_base + (long long)src * src_ld) + c * 128 + half * 16;
+            ra[s][0] = *reinterpret_cast<const uint4*>(p);
+            ra[s][1] = *reinterpret_cast<const uint4*>(p + 32);
+            ra[s][2] = *reinterpret_cast<const uint4*>(p + 64);
+            ra[s][3] = *reinterpret_cast<const uint4*>(p + 96);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[s][i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        const unsigned short* slab = second ? a.wp6_2 + (long long)c * 2 * a.cout * 32
+                                            : a.wp6 + (long long)(j * nch + c) * 2 * a.cout * 32;
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int f = tid + i * THREADS;
+            if (f < B_U4 && !(CV_HL_ABL & 4)) {
+                const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
+                const int col = rem >> 2, ch = rem & 3;
+                rb[s][i] = (n0 + col < a.cout)
+                               ? *reinterpret_cast<const uint4*>(slab + ((long long)p * a.cout + n0 + col) * 32 + ch * 8)
+                               : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+    auto stage_b = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        unsigned char* Bb = sm + s * B_BYTES;
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int f = tid + i * THREADS;
+            if (f < B_U4 && !(CV_HL_ABL & 4)) {
+                const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
+                const int col = rem >> 2, ch = rem & 3;
+                *reinterpret_cast<uint4*>(Bb + (p * NB * 32 + col) * 64 + ((ch ^ ((col >> 2) & 3)) << 4)) = rb[s][i];
+            }
+        }
+    };
+    auto compute = [&](auto S) {
+        constexpr int s = decltype(S)::value;
+        const unsigned char* Bb = sm + s * B_BYTES;
+        const int bswz = (l31 >> 2) & 3;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = 2 * ks + half;
+            const f16x8 a0 = __builtin_bit_cast(f16x8, ra[s][ks]), a1 = __builtin_bit_cast(f16x8, ra[s][2 + ks]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const f16x8 b0 = *reinterpret_cast<const f16x8*>(Bb + (nb * 32 + l31) * 64 + ((chunk ^ bswz) << 4));
+                const f16x8 b1 = *reinterpret_cast<const f16x8*>(Bb + (NB * 32 + nb * 32 + l31) * 64 + ((chunk ^ bswz) << 4));
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[nb], 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[nb], 0, 0, 0);
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> S0;
+    int j = j_first, c = c_first;                     // the loader's cursor (NS - 1 units ahead of the matrix cores)
+    if (njl > 0) skip_dead(j, c); else j = j_last + 1;
+    if (j > j_last) { j = j_second; c = blockIdx.z; if (c >= nch2) j = j_done; }
+    static_for<NS - 1>([&](auto S) { if (j < j_done) { load(S, j, c); advance(j, c); } });
+    if (valid[0]) stage_b(S0{});
+    // step<s>: unit u in slot s.  barrier: tile u visible, tile u - 1 consumed by everyone (its slot takes the loads of
+    // unit u + NS - 1); the tile of unit u + 1 goes to LDS; MFMAs of unit u
+    bool done = false;
+#pragma unroll 1
+    while (!done) {
+        static_for<NS>([&](auto S) {
+            constexpr int s = decltype(S)::value, sn = (s + 1) % NS, sp = (s + NS - 1) % NS;
+            if (done) return;
+            if (!valid[s]) { done = true; return; }
+            __syncthreads();
+            if (valid[sn]) stage_b(std::integral_constant<int, sn>{});
+            valid[sp] = false;
+            if (j < j_done) { load(std::integral_constant<int, sp>{}, j, c); advance(j, c); }
+            if (live[s] && (!(CV_HL_ABL & 2) || a.acc_scale == 12345.f)) compute(S);
+        });
+    }
+    __syncthreads();                                 // weight tiles are dead: the epilogue tile reuses their LDS
+    {
+        const float k = a.acc_scale;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] *= k;
+    }
+    float (*ep)[EP_LD] = reinterpret_cast<float (*)[EP_LD]>(sm + wave * 32 * EP_LD * 4);
+    if ((CV_HL_ABL & 8) && a.acc_scale != 12345.f) return;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) epilogue_store_wide(a, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep);
 }
 
 // Instrumented twin of conv_rows (CV_CONV_PROF=1): shader-clock ticks per phase, summed over waves into prof[16].
@@ -1169,7 +1456,16 @@ __global__ __launch_bounds__(STEM_ROWS) void conv_stem(ConvArgs a, int JC) {
         acc[co] = v;
     }
     float* o = a.out + row * a.out_ld;
-    if ((a.out_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
+    if (a.out_hl) {                        // one 128-byte chunk: 32 high pieces, 32 low pieces (host: aligned, out_ld % 32 == 0)
+        bool big = false;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            big |= hl_out_of_range(v);
+            hl_store4(o, 4 * q, v);
+        }
+        if (big && a.range_flag) *a.range_flag = 1;
+    } else if ((a.out_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             reinterpret_cast<float4*>(o)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -1833,11 +2129,17 @@ __global__ __launch_bounds__(256) void conv_finish(ConvArgs a) {
                 const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
                 x.x = x.x * sc.x + sh.x; x.y = x.y * sc.y + sh.y; x.z = x.z * sc.z + sh.z; x.w = x.w * sc.w + sh.w;
                 if (a.res) {
-                    const float4 p = *reinterpret_cast<const float4*>(a.res + row * a.res_ld + col);
+                    const float4 p = a.res_hl ? hl_load4(a.res + row * a.res_ld, col)
+                                              : *reinterpret_cast<const float4*>(a.res + row * a.res_ld + col);
                     x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
                 }
                 if (a.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
-                *reinterpret_cast<float4*>(a.out + row * a.out_ld + col) = x;
+                if (a.out_hl) {
+                    if (a.range_flag && hl_out_of_range(x)) *a.range_flag = 1;
+                    hl_store4(a.out + row * a.out_ld, col, x);
+                } else {
+                    *reinterpret_cast<float4*>(a.out + row * a.out_ld + col) = x;
+                }
             } else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1885,11 +2187,17 @@ __global__ __launch_bounds__(256) void conv_finish_small(ConvArgs a) {
         const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
         x.x = x.x * sc.x + sh.x; x.y = x.y * sc.y + sh.y; x.z = x.z * sc.z + sh.z; x.w = x.w * sc.w + sh.w;
         if (a.res) {
-            const float4 q = *reinterpret_cast<const float4*>(a.res + row * a.res_ld + col);
+            const float4 q = a.res_hl ? hl_load4(a.res + row * a.res_ld, col)
+                                      : *reinterpret_cast<const float4*>(a.res + row * a.res_ld + col);
             x.x += q.x; x.y += q.y; x.z += q.z; x.w += q.w;
         }
         if (a.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
-        *reinterpret_cast<float4*>(a.out + row * a.out_ld + col) = x;
+        if (a.out_hl) {
+            if (a.range_flag && hl_out_of_range(x)) *a.range_flag = 1;
+            hl_store4(a.out + row * a.out_ld, col, x);
+        } else {
+            *reinterpret_cast<float4*>(a.out + row * a.out_ld + col) = x;
+        }
     }
 }
 
@@ -1938,13 +2246,18 @@ __global__ __launch_bounds__(256) void mask_keys(const int* __restrict__ nbr, lo
 constexpr int MP_BINS = 1024;
 constexpr int MP_THREADS = 1024;
 
-__device__ __forceinline__ int group_mask(const int* __restrict__ nbr, long long row, int K, int jb, int je) {
+__device__ __forceinline__ int group_mask(const int* __restrict__ nbr, long long row, long long n, int K, int jb, int je) {
     int m = 0;
     for (int j = jb; j < je; ++j)
         if (nbr[row * K + j] >= 0) m |= 1 << (j - jb);
     // sort key: rows with equal masks adjacent, and (when it fits the 1024 bins) ordered by the NUMBER of
-    // offsets they need, so the tiles at the end of the order are the most expensive ones
+    // offsets they need, so the tiles at the end of the order are the most expensive ones.
+    // (Measured and dropped, profiles/r2/xcd_tiles.txt: masks sorted inside the eighths of the spatial row order with
+    // tile t run on XCD t / (tiles / 8) - L2 hit rate of the ts1 conv 48 -> 63 %, memory-side fetch 192 -> 120 MB per
+    // launch, and the launch 14 % SLOWER: the kernel is bound by its dependent round trips, not by fetch bandwidth,
+    // and the cost ordering of the tiles is worth more than the hits.)
     if (je - jb <= 7) m |= __popc(m) << 7;
+    (void)n;
     return m;
 }
 
@@ -1956,7 +2269,7 @@ __global__ __launch_bounds__(MP_THREADS) void mp_hist(const int* __restrict__ nb
     for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS) lh[i] = 0;
     __syncthreads();
     const long long row = blockIdx.x * (long long)MP_THREADS + threadIdx.x;
-    if (row < n) atomicAdd(&lh[group_mask(nbr, row, K, jb, je)], 1);
+    if (row < n) atomicAdd(&lh[group_mask(nbr, row, n, K, jb, je)], 1);
     __syncthreads();
     for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS)
         if (lh[i]) atomicAdd(&hist[g * MP_BINS + i], lh[i]);
@@ -1988,7 +2301,7 @@ __global__ __launch_bounds__(MP_THREADS) void mp_scatter(const int* __restrict__
     const long long row = blockIdx.x * (long long)MP_THREADS + threadIdx.x;
     int key = 0, rank = 0;
     if (row < n) {
-        key = group_mask(nbr, row, K, jb, je);
+        key = group_mask(nbr, row, n, K, jb, je);
         rank = atomicAdd(&lh[key], 1);
     }
     __syncthreads();
@@ -2026,7 +2339,7 @@ __global__ __launch_bounds__(MP_THREADS) void mp_hist_batch(const PermJobsDev jo
     const int jlo = jb.K * g / jb.groups, jhi = jb.K * (g + 1) / jb.groups;
     for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS) lh[i] = 0;
     __syncthreads();
-    if (row < jb.n) atomicAdd(&lh[group_mask(jb.nbr, row, jb.K, jlo, jhi)], 1);
+    if (row < jb.n) atomicAdd(&lh[group_mask(jb.nbr, row, jb.n, jb.K, jlo, jhi)], 1);
     __syncthreads();
     for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS)
         if (lh[i]) atomicAdd(&hist[blockIdx.y * MP_BINS + i], lh[i]);
@@ -2045,7 +2358,7 @@ __global__ __launch_bounds__(MP_THREADS) void mp_scatter_batch(const PermJobsDev
     const long long row = blockIdx.x * (long long)MP_THREADS + threadIdx.x;
     int key = 0, rank = 0;
     if (row < jb.n) {
-        key = group_mask(jb.nbr, row, K, jlo, jhi);
+        key = group_mask(jb.nbr, row, jb.n, K, jlo, jhi);
         rank = atomicAdd(&lh[key], 1);
     }
     __syncthreads();
@@ -2113,6 +2426,33 @@ __global__ void bn_fold(const float* gamma, const float* beta, const float* mean
     const float s = gamma[k] / sqrtf(var[k] + eps);
     scale[k] = s;
     shift[k] = beta[k] - mean[k] * s + (bias ? bias[k] * s : 0.f);
+}
+
+// fp32 rows <-> hl format (boundary of the format: tests, modular callers)
+__global__ __launch_bounds__(256) void to_hl(const float* __restrict__ x, long long n, int c, int x_ld, float* __restrict__ y,
+                                             int y_ld, int* __restrict__ range_flag) {
+    const int cq = c >> 2;
+    const long long total = n * cq;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long row = e / cq;
+        const int col = (int)(e - row * cq) * 4;
+        const float* p = x + row * x_ld + col;
+        const float4 v = make_float4(p[0], p[1], p[2], p[3]);
+        if (range_flag && hl_out_of_range(v)) *range_flag = 1;
+        hl_store4(y + row * y_ld, col, v);
+    }
+}
+__global__ __launch_bounds__(256) void from_hl(const float* __restrict__ x, long long n, int c, int x_ld, float* __restrict__ y,
+                                               int y_ld) {
+    const int cq = c >> 2;
+    const long long total = n * cq;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long row = e / cq;
+        const int col = (int)(e - row * cq) * 4;
+        const float4 v = hl_load4(x + row * x_ld, col);
+        float* p = y + row * y_ld + col;
+        p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+    }
 }
 
 // ------------------------------------------------------------------ BatchNorm in training mode
@@ -2398,10 +2738,30 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
             if (hi > lo) per_wg = std::max(per_wg, (int)((hi - 1) / nch_wp - lo / nch_wp + 1));
         }
     }
+    static const bool xcd_on = getenv("CV_XCD_TILES") && atoi(getenv("CV_XCD_TILES")) != 0;      // experiment, off
+    ConvArgs ax = a;
+    dim3 gridx = grid;
+    if (xcd_on && grid.x >= 64) {                    // a few tiles per XCD at least; below that the input fits every L2
+        ax.xcd_tiles = 1;
+        gridx.x = (grid.x + 7) / 8 * 8;
+    }
+    if (a.in_hl) {
+        CV_REQUIRE(vec && a.wp6 && a.pieces == 2 && a.wide && per_wg <= WP_NPRE && NB <= 3, CV_EINVAL,
+                   "hl-format input needs the fp16-pair weights, Cin %% 32 == 0, 16-byte aligned operands and at most %d "
+                   "kernel offsets per workgroup", WP_NPRE);
+        // (measured and dropped, profiles/r2/hl_burst.txt: a variant for workgroups of <= 8 units with every weight tile
+        // requested at once through global_load_lds and two dependent round trips instead of 3 + units - no faster)
+        // (NS = 8 / 6 / 4 slots for NB = 1 / 2 / 3 measured: every layer 25-45 % slower - two workgroups per CU
+        // instead of three or four cost more than the deeper prefetch gains, profiles/r2/hl_slots.txt)
+        if constexpr (NB <= 3) conv_hl<NB, 3><<<gridx, THREADS, 0, st>>>(ax);
+        CV_LAUNCH_CHECK();
+        if (a.splits > 1) return launch_finish(a, st);
+        return CV_OK;
+    }
     if (vec && a.wp6 && !prof_on && wp_on && !a.dbg && per_wg <= WP_NPRE) {
-        if (a.pieces == 2) conv_rows_wp<NB, 2><<<grid, THREADS, 0, st>>>(a);
-        else if (a.pieces == 1) conv_rows_wp<NB, 1><<<grid, THREADS, 0, st>>>(a);
-        else conv_rows_wp<NB, 3><<<grid, THREADS, 0, st>>>(a);
+        if (a.pieces == 2) conv_rows_wp<NB, 2><<<gridx, THREADS, 0, st>>>(ax);
+        else if (a.pieces == 1) conv_rows_wp<NB, 1><<<gridx, THREADS, 0, st>>>(ax);
+        else conv_rows_wp<NB, 3><<<gridx, THREADS, 0, st>>>(ax);
         CV_LAUNCH_CHECK();
         if (a.splits > 1) return launch_finish(a, st);
         return CV_OK;
@@ -2593,7 +2953,19 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
                reinterpret_cast<const float4*>(d->weight_packed), 0, nullptr, 0, 0,
                static_cast<const unsigned short*>(d->weight_x6), d->in2, d->in2_ld, d->cin2,
                static_cast<const unsigned short*>(d->weight2_x6), d->weight_pieces == 2 ? 2 : d->weight_pieces == 1 ? 1 : 3,
-               d->acc_scale != 0.f ? d->acc_scale : 1.f, d->range_flag};
+               d->acc_scale != 0.f ? d->acc_scale : 1.f, d->range_flag, d->in_hl, d->out_hl, d->res_hl};
+    if (d->in_hl || d->out_hl || d->res_hl) {
+        CV_REQUIRE(!d->in_hl || (d->weight_pieces == 2 && d->cin % 32 == 0 && d->in_ld % 32 == 0 &&
+                                 (reinterpret_cast<uintptr_t>(d->in) & 127) == 0 &&
+                                 (!d->in2 || (d->cin2 % 32 == 0 && d->in2_ld % 32 == 0 &&
+                                              (reinterpret_cast<uintptr_t>(d->in2) & 127) == 0))),
+                   CV_EINVAL, "hl-format input: fp16-pair weights, channels and leading dimensions %% 32 == 0, 128-byte aligned rows");
+        CV_REQUIRE(!d->out_hl || (d->cout % 32 == 0 && d->out_ld % 32 == 0 && (reinterpret_cast<uintptr_t>(d->out) & 127) == 0),
+                   CV_EINVAL, "hl-format output: Cout and leading dimension %% 32 == 0, 128-byte aligned rows");
+        CV_REQUIRE(!d->res_hl || !d->residual || (d->res_ld % 32 == 0 && (reinterpret_cast<uintptr_t>(d->residual) & 127) == 0),
+                   CV_EINVAL, "hl-format residual: leading dimension %% 32 == 0, 128-byte aligned rows");
+        CV_REQUIRE(d->flavour == 0 && !d->plan_ent, CV_EINVAL, "the hl format runs on the rows flavour only");
+    }
     CV_REQUIRE(d->weight_pieces >= 0 && d->weight_pieces <= 3, CV_EINVAL,
                "weight_pieces is 0/3 (bf16 triples), 2 (fp16 pairs) or 1 (single bf16 product)");
     CV_REQUIRE(d->weight_pieces != 1 || (d->weight_x6 && d->cin % KC == 0), CV_EINVAL,
@@ -2664,7 +3036,7 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         CV_REQUIRE(false, CV_EINVAL, "flavour 4 needs Cin %% 32 == 0, Cout %% 32 == 0, K <= 27, 16-byte aligned "
                                      "operands, packed weights (cv_sp_pack_weights_f32) and a tile plan "
                                      "(cv_sp_tile_plan) for the kernel map");
-    } else if ((d->flavour == 0 || d->flavour == 4) && !d->in2 && tile_ok(a, vec)) {
+    } else if ((d->flavour == 0 || d->flavour == 4) && !d->in2 && !d->in_hl && !d->out_hl && !d->res_hl && tile_ok(a, vec)) {
         const int sp = tile_splits(d->n_out, d->cout, je - jb);
         const size_t need = sizeof(float) * (size_t)sp * (size_t)d->n_out * (size_t)d->cout;
         if (sp > 1 && d->ws && d->ws_bytes >= need) {
@@ -2966,6 +3338,26 @@ int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float
     else
         affine_rows<<<(unsigned)std::min<long long>((n * c + 255) / 256, 8192), 256, 0, st>>>(
             d_x, n, c, x_ld, d_scale, d_shift, d_residual, res_ld, relu, d_y, y_ld);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+int cv_sp_to_hl_f32(const float* d_x, long long n, int c, int x_ld, float* d_y, int y_ld, int32_t* range_flag, void* stream) {
+    CV_REQUIRE(d_x && d_y && n > 0 && c > 0 && c % 32 == 0 && x_ld >= c && y_ld >= c && y_ld % 32 == 0 &&
+                   (reinterpret_cast<uintptr_t>(d_y) & 127) == 0, CV_EINVAL,
+               "hl format: channels and leading dimension %% 32 == 0, 128-byte aligned rows");
+    to_hl<<<(unsigned)std::min<long long>((n * (c / 4) + 255) / 256, 8192), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        d_x, n, c, x_ld, d_y, y_ld, range_flag);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+int cv_sp_from_hl_f32(const float* d_x, long long n, int c, int x_ld, float* d_y, int y_ld, void* stream) {
+    CV_REQUIRE(d_x && d_y && n > 0 && c > 0 && c % 32 == 0 && x_ld >= c && y_ld >= c && x_ld % 32 == 0 &&
+                   (reinterpret_cast<uintptr_t>(d_x) & 127) == 0, CV_EINVAL,
+               "hl format: channels and leading dimension %% 32 == 0, 128-byte aligned rows");
+    from_hl<<<(unsigned)std::min<long long>((n * (c / 4) + 255) / 256, 8192), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        d_x, n, c, x_ld, d_y, y_ld);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

@@ -359,8 +359,9 @@ def range_flag(dev):
 
 def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=None, relu=False,
                  out=None, flavour=0, row_perm=None, j_begin=0, j_end=0, acc_in=None, perm_groups=0,
-                 cache_weights=True, pieces=None):
+                 cache_weights=True, pieces=None, in_hl=False, out_hl=False, res_hl=False):
     """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout].
+    in_hl / out_hl / res_hl: the operand is in the hl format (to_hl / from_hl; cv_conv_desc.in_hl), pieces=2 only.
     pieces=2: fp16-pair products (weights packed per call; the caller reads range_flag(dev) after synchronising);
     pieces=1: single bf16 products (the opt-in bf16 compute mode); None: 1 under COMPUTE_DTYPE == "bf16", else 3."""
     if pieces is None:
@@ -417,10 +418,28 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
                       plan[0].data_ptr() if plan is not None else None,
                       plan[0].data_ptr() + 4 * plan[1] if plan is not None else None, p(wp), p(wp6), None, 0, 0, None,
                       1 if (perm_groups > 1 and getattr(row_perm, "_cv_has_map", False)) else 0,
-                      2 if flag is not None else (1 if (pieces == 1 and wp6 is not None) else 0), acc_scale, p(flag))
+                      2 if flag is not None else (1 if (pieces == 1 and wp6 is not None) else 0), acc_scale, p(flag),
+                      1 if in_hl else 0, 1 if out_hl else 0, 1 if res_hl else 0)
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
     return out
+
+
+def to_hl(x):
+    """fp32 rows [n, C] (C % 32 == 0) -> the hl format (same shape and dtype, the bytes hold the fp16 pairs)"""
+    y = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().cv_sp_to_hl_f32(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), y.data_ptr(), y.stride(0),
+                                              range_flag(x.device).data_ptr(), _stream(x.device)), "cv_sp_to_hl_f32")
+    return y
+
+
+def from_hl(x):
+    y = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().cv_sp_from_hl_f32(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), y.data_ptr(),
+                                                y.stride(0), _stream(x.device)), "cv_sp_from_hl_f32")
+    return y
 
 
 # conv_forward applies mask-sorted offset groups to big 3x3x3 maps on its own (0 = off)

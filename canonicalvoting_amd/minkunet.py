@@ -149,6 +149,8 @@ class MinkUNetBase(ResNetBase):
     # the sign of l) instead of six bf16 ones.  fp16 has a range: a convolution whose input holds a magnitude above
     # 65000 raises a flag in pinned host memory and the forward is redone on the bf16 triples (check_range).
     PIECES = 2 if os.environ.get("CV_CONV_H2", "1") != "0" else 3
+    # fp16-pair program: activations between the convolutions in the hl format (cv_conv_desc.in_hl)
+    HL_BUFFERS = os.environ.get("CV_NET_HL", "1") != "0"
     # False: forward() waits for the launches and checks the range flag itself; True: the caller does it after its
     # own synchronisation point (pipeline.detect_scene: no extra wait per scene)
     defer_range_check = False
@@ -231,16 +233,19 @@ class MinkUNetBase(ResNetBase):
         ver = ((tensors, (sum(t._version for t in tensors), tensors[0].data_ptr(), str(dev), self.training)))
         exp = self.BLOCK.expansion
         bufs, ops, keep, free = [], [], [], {}
+        # fp16-pair program: every arena buffer holds the hl format (the pair of each value stored in place by the
+        # producing epilogue; consumers load matrix-core fragments straight from it) - the caller's tensors stay fp32
+        hl = 1 if (pieces == 2 and self.HL_BUFFERS and ME.CONV_X6) else 0
 
         def alloc(level, ch):
             pool = free.get((level, ch))
             if pool:
                 return pool.pop()
-            bufs.append((level, ch, level))
+            bufs.append((level, ch, level, hl))
             return len(bufs) - 1
 
         def release(slot):
-            level, ch, _ = bufs[slot]
+            level, ch = bufs[slot][:2]
             if level >= 0:
                 free.setdefault((level, ch), []).append(slot)
 
@@ -323,13 +328,13 @@ class MinkUNetBase(ResNetBase):
                 x = y
             return x
 
-        bufs.append((-1, self.conv0p1s1.in_channels, 0))          # slot 0: caller's features (original row order)
-        bufs.append((-1, self.final.out_channels, 0))             # slot 1: caller's output
+        bufs.append((-1, self.conv0p1s1.in_channels, 0, 0))       # slot 0: caller's features (original row order)
+        bufs.append((-1, self.final.out_channels, 0, 0))          # slot 1: caller's output
         up_c = [self.PLANES[4 + i] for i in range(4)]
         skip_c = (self.PLANES[2] * exp, self.PLANES[1] * exp, self.PLANES[0] * exp, self.INIT_DIM)
         cat = []
         for i in range(4):
-            bufs.append((3 - i, up_c[i] + skip_c[i], 3 - i))
+            bufs.append((3 - i, up_c[i] + skip_c[i], 3 - i, hl))
             cat.append(len(bufs) - 1)
         s, b = self._fold(self.bn0)
         out = (cat[3], up_c[3])

@@ -220,7 +220,19 @@ typedef struct cv_conv_desc {
     float acc_scale;        /* fp16 pairs: 2^-scale_log2 of the pack call (0 = 1): multiplies the accumulators        */
     int32_t* range_flag;    /* fp16 pairs: optional device-visible word, set to 1 when an input magnitude > 65000 was
                                staged (the result is then invalid: redo the convolution with the bf16 triples)        */
+    int in_hl, out_hl, res_hl; /* 1: in (and in2) / out / residual are in the hl format instead of fp32 - the fp16 pair
+                               (h, l) of every value stored in place: a row of C channels (C % 32 == 0) keeps its 4*C
+                               bytes, each 32-channel chunk = 64 bytes of high pieces then 64 bytes of low pieces
+                               (cv_sp_to_hl_f32 / cv_sp_from_hl_f32).  The consumer then loads its matrix-core operand
+                               fragments straight from global memory and nothing is split per gather; the producer
+                               raises range_flag when an OUTPUT magnitude exceeds 65000.  Needs weight_pieces = 2 for
+                               in_hl, channel counts and leading dimensions % 32 == 0, 128-byte aligned rows.        */
 } cv_conv_desc;
+
+/* fp32 rows -> hl format and back (d_x and d_y may not alias; c % 32 == 0; the hl side 128-byte aligned with a leading
+ * dimension % 32 == 0; leading dimensions in 4-byte units on both sides).  range_flag (optional) as in cv_conv_desc. */
+int cv_sp_to_hl_f32(const float* d_x, long long n, int c, int x_ld, float* d_y, int y_ld, int32_t* range_flag, void* stream);
+int cv_sp_from_hl_f32(const float* d_x, long long n, int c, int x_ld, float* d_y, int y_ld, void* stream);
 
 /* Pair lists for the tile kernel, built once per kernel map and processing order and shared by every convolution
  * on that map: d_plan holds cv_sp_tile_plan_ints(n_out, K, &cnt_offset) int32 words; pass plan_ent = d_plan and
@@ -281,6 +293,8 @@ int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* 
  *               perms[perm] (perm < 0 or a NULL table entry: natural order; perm_groups > 1: mask-sorted groups). */
 typedef struct cv_net_buf {
     int level, channels, rows_level;
+    int hl;                    /* 1: the buffer holds the hl format (cv_conv_desc.in_hl): every op reading / writing it runs
+                                  with the matching flag; arena buffers only */
 } cv_net_buf;
 typedef struct cv_net_op {
     int in_buf, in_col, cin;

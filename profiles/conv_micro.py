@@ -12,7 +12,11 @@ x = torch.randn(80000, 96, device=dev)
 w = torch.randn(27, 96, 96, device=dev) * 0.02
 nbr = cm.kernel_map(3, 1)
 perms = cm.mask_perms(3, 1, 4)
+HL = os.environ.get('MICRO_HL', '0') == '1'          # hl-format operands (conv_hl)
+if HL:
+    x = ME.to_hl(x)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
-    y = ME.conv_forward_masked(x, w, nbr, perms, 80000, relu=True, pieces=int(os.environ.get('MICRO_PIECES', '2')))
+    y = ME.conv_forward_masked(x, w, nbr, perms, 80000, relu=True, pieces=int(os.environ.get('MICRO_PIECES', '2')),
+                               in_hl=HL, out_hl=HL)
 torch.cuda.synchronize()
 print(float(y.abs().mean()))

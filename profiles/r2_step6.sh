@@ -1,0 +1,19 @@
+# round 2, step 6: hl-format activations (fp16 pairs stored in place) + conv_hl (fragments straight from global, 3 units in flight)
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r2s6
+mkdir -p $O
+timeout 1500 python -m pytest tests/test_sparse_gpu.py tests/test_production_size_gpu.py -m gpu -x -q > $O/pytest.log 2>&1; tail -15 $O/pytest.log
+CV_NET_HL=0 python bench.py --streams 1 --cpu-scenes 0 2>/dev/null | tail -1 > $O/bench_streams1_nohl.json
+python bench.py --streams 1 --cpu-scenes 0 2>/dev/null | tail -1 > $O/bench_streams1.json
+python bench.py --cpu-scenes 0 2>/dev/null | tail -1 > $O/bench.json
+bash profiles/trace_one.sh r2s6 > /dev/null 2>&1
+python - <<'PY'
+import json
+for f in ("bench_streams1_nohl", "bench_streams1","bench"):
+    try:
+        d=json.load(open("gpurun_out/r2s6/%s.json"%f))
+        print(f, round(d["value"],1), {k:round(v,3) for k,v in d["stage_ms"].items()}, d.get("parity"))
+    except Exception as e: print(f, "ERR", e)
+PY

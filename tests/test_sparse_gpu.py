@@ -142,6 +142,65 @@ def test_conv_matches_oracle(cuda, built_lib, cin, cout, k, flavour):
     assert float(obuf[:, :32].min()) == -7.0 and float(obuf[:, 32 + cout:].max()) == -7.0   # no stray writes
 
 
+@pytest.mark.parametrize("cin,cout,k,n,masked", [(32, 32, 3, 1500, False), (64, 96, 3, 1500, False), (96, 64, 1, 1500, False),
+                                                 (128, 128, 3, 600, False), (256, 256, 3, 300, False),
+                                                 (32, 32, 2, 1500, False), (96, 96, 3, 20000, True),
+                                                 (128, 96, 3, 20000, True)])
+def test_hl_format_conv_matches_fp32_operand_conv(cuda, built_lib, cin, cout, k, n, masked):
+    """activations in the hl format (the fp16 pair of every value stored in place, cv_conv_desc.in_hl): the format
+    round-trips to 2^-24, a convolution reading it has the SAME accumulators as the fp16-pair kernel splitting fp32
+    rows on the fly (bit-identical fp32 outputs), and the hl epilogue (residual read, output split) stays at fp32 level"""
+    coords, _ = scene_coords(2, n, small=n < 10000)
+    N = len(coords)
+    rng = np.random.default_rng(cin * 7 + cout)
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    x = t(rng.normal(0, 1, (N, cin)).astype(np.float32))
+    x[::7] *= 1e-3
+    x[::11] *= 300.0
+    w = t((rng.normal(0, 1, (k ** 3, cin, cout)) / np.sqrt(cin * k ** 3)).astype(np.float32))
+    scale = t(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = t(rng.normal(0, 0.2, cout).astype(np.float32))
+    res = t(rng.normal(0, 1, (N, cout)).astype(np.float32))
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(cuda, torch.int32))
+    if k == 2:
+        nbr, n_out = cm.kernel_map(2, 1, 2), cm.num_rows(2)
+        res = res[:n_out].contiguous()
+    else:
+        nbr, n_out = (cm.kernel_map(k, 1) if k > 1 else None), N
+    xh = ME.to_hl(x)
+    back = ME.from_hl(xh)
+    assert bool(((back - x).abs() <= x.abs() * 2.0 ** -23 + 2.0 ** -24).all())     # low pieces below 2^-14 are fp16 subnormals
+    kw = dict(pieces=2)
+    if masked:
+        perms = cm.mask_perms(3, 1, 4)
+        conv = lambda xin, **e: ME.conv_forward_masked(xin, w, nbr, perms, n_out, **kw, **e)
+    else:
+        conv = lambda xin, **e: ME.conv_forward(xin, w, nbr, n_out, **kw, **e)
+    ref0 = conv(x)
+    got0 = conv(xh, in_hl=True)
+    assert torch.equal(got0, ref0)
+    ref1 = conv(x, scale=scale, shift=shift, residual=res, relu=True)
+    # hl in / residual / out inside wider buffers (column windows at multiples of 32 channels)
+    xin = torch.zeros((N, cin + 64), device=cuda); xin[:, 32:32 + cin] = x
+    xin_h = ME.to_hl(xin)
+    rbuf = torch.zeros((n_out, cout + 32), device=cuda); rbuf[:, 32:] = res
+    rbuf_h = ME.to_hl(rbuf)
+    obuf = ME.to_hl(torch.full((n_out, cout + 64), -7.0, device=cuda))
+    ME.conv_forward(xin_h[:, 32:32 + cin], w, nbr, n_out, scale=scale, shift=shift, residual=rbuf_h[:, 32:], relu=True,
+                    out=obuf[:, 32:32 + cout], in_hl=True, out_hl=True, res_hl=True,
+                    **(dict(row_perm=perms, perm_groups=4, pieces=2) if masked else kw))
+    got1 = ME.from_hl(obuf)
+    assert rel_err(got1[:, 32:32 + cout].cpu().numpy(), ref1.cpu().numpy()) < 1e-6
+    assert float(got1[:, :32].min()) == -7.0 and float(got1[:, :32].max()) == -7.0       # no stray writes
+    assert float(got1[:, 32 + cout:].min()) == -7.0 and float(got1[:, 32 + cout:].max()) == -7.0
+    assert int(ME.range_flag(cuda)[0]) == 0
+    # an output beyond the fp16 range raises the flag (the caller then falls back to fp32 buffers)
+    ME.conv_forward(xh, w * 1e6, nbr, n_out, out=obuf[:, 32:32 + cout], in_hl=True, out_hl=True, **kw)
+    torch.cuda.synchronize()
+    assert int(ME.range_flag(cuda)[0]) == 1
+    ME.range_flag(cuda).zero_()
+
+
 def test_tile_conv_single_launch_and_row_perm(cuda, built_lib):
     """pair-compacted tile kernel on a coordinate set large enough to run without offset splits, in natural and
     permuted processing order, with the fused epilogue"""
