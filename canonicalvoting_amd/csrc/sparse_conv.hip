@@ -1001,37 +1001,29 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 // the loads of unit u + NS - 1 are requested while unit u multiplies.  Workgroups of the split coarse levels have no more
 // than NS units: all their loads are in flight after the prologue (two dependent round trips - map entries, fragments -
 // instead of one per unit).
-template <int NB, int NS>
-__global__ __launch_bounds__(THREADS, (NS > 3 ? 2 : 3)) void conv_hl(ConvArgs a) {
-    constexpr int B_BYTES = 2 * NB * 32 * 64, EP_BYTES = 4 * 32 * EP_LD * 4;
+// NW = waves per workgroup (4: 128 rows; 8: 256 rows, measured slower - profiles/r2/hl_nw8.txt).
+// The unit walk is resolved once, before the loop: wave 0 compacts the workgroup's live (offset, chunk) units into a
+// list in LDS, the loop is a counted loop over that list with per-thread invariants (weight-tile source / LDS offsets,
+// 32-bit row offsets) hoisted - the first version spent ~150 vector and ~250 scalar instructions per unit on the walk
+// (advance / skip_dead, 64-bit address arithmetic, spilled scalars) around 18 MFMAs.
+constexpr int HL_MAX_UNITS = 160;
+template <int NB, int NS, int NW>
+__global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS > 3 ? 2 : 3)) void conv_hl(ConvArgs a) {
+    static_assert(NS == 3, "three unit slots");
+    constexpr int TMv = NW * 32, THv = NW * 64;
+    constexpr int B_BYTES = 2 * NB * 32 * 64, EP_BYTES = NW * 32 * EP_LD * 4;
     constexpr int SM_BYTES = NS * B_BYTES > EP_BYTES ? NS * B_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char sm[SM_BYTES];     // NS x weight tile [plane][col][64 B]; then the epilogue tile
-    __shared__ int rows_s[TM];
-    __shared__ int nbr_all[WP_NPRE + 1][TM];
-    __shared__ unsigned live_mask;
+    __shared__ int rows_s[TMv];
+    __shared__ int nbr_all[WP_NPRE + 1][TMv];
+    __shared__ unsigned wave_mask[NW];
+    __shared__ int units_s[HL_MAX_UNITS + 4];        // (jj << 8) | chunk of every live unit, in processing order; [HL_MAX_UNITS] = count
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.y * (NB * 32);
-
     const long long tile_id = xcd_tile(a);
-    if (tile_id * TM >= a.n_out) return;             // padding of the XCD-aware grid
-    if (tid < TM) {
-        const long long t = tile_id * TM + tid;
-        const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)blockIdx.z * a.n_out : 0) : nullptr;
-        rows_s[tid] = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
-    }
-    if (tid == 0) live_mask = 0u;
-    __syncthreads();
-
-    f32x16 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-
+    if (tile_id * TMv >= a.n_out) return;             // padding of the XCD-aware grid
     const int half = lane >> 5, l31 = lane & 31;
     const int nj = a.j_end - a.j_begin;
-    constexpr int B_U4 = 2 * NB * 32 * 4;            // 16-byte pieces of one unit's weight tile
-    constexpr int B_PER = (B_U4 + THREADS - 1) / THREADS;
     const int nch = a.cin / KC;
     int u_lo, u_hi;
     if (a.perm_per_split) {
@@ -1043,111 +1035,137 @@ __global__ __launch_bounds__(THREADS, (NS > 3 ? 2 : 3)) void conv_hl(ConvArgs a)
     }
     const int j_first = a.j_begin + u_lo / nch, j_last = a.j_begin + (u_hi - 1) / nch;
     const int njl = u_hi > u_lo ? j_last - j_first + 1 : 0;       // <= WP_NPRE (host)
-    auto map_entry = [&](int t, int j) {
-        const int row = rows_s[t];
-        if (row < 0) return -1;
-        if (a.nbr_perm) {
-            return a.nbr_perm[((long long)blockIdx.z * a.n_out + tile_id * TM + t) * a.nbr_perm_w +
-                              (j - (a.j_begin + (int)((long long)nj * blockIdx.z / a.splits)))];
-        }
-        return a.nbr ? a.nbr[(long long)row * a.K + j] : row;
-    };
+    const int nch2 = a.in2 ? a.cin2 / KC : 0;
+
+    // order and map entries in one phase (independent unless a single order comes without its map rows), one barrier
+    const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)blockIdx.z * a.n_out : 0) : nullptr;
+    if (tid < TMv) {
+        const long long t = tile_id * TMv + tid;
+        const int row = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
+        rows_s[tid] = row;
+        if (a.in2) nbr_all[njl][tid] = row;
+    }
     {
         unsigned m = 0u;
-        for (int e = tid; e < njl * TM; e += THREADS) {
-            const int jj = e / TM, t = e - jj * TM;
-            const int v = (CV_HL_ABL & 16) ? rows_s[t] : map_entry(t, j_first + jj);
+        const int jg0 = a.j_begin + (int)((long long)nj * blockIdx.z / a.splits);      // first offset of this mask group
+        for (int e = tid; e < njl * TMv; e += THv) {
+            const int jj = e / TMv, t = e - jj * TMv;
+            const long long pos = tile_id * TMv + t;
+            int v = -1;
+            if (pos < a.n_out) {
+                if (a.nbr_perm) {
+                    v = a.nbr_perm[((long long)blockIdx.z * a.n_out + pos) * a.nbr_perm_w + (j_first + jj - jg0)];
+                } else {
+                    const int row = perm ? perm[pos] : (int)pos;
+                    v = a.nbr ? a.nbr[(long long)row * a.K + j_first + jj] : row;
+                }
+                if (CV_HL_ABL & 16) v = (int)pos;
+            }
             nbr_all[jj][t] = v;
             if (v >= 0) m |= 1u << jj;
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m |= __shfl_xor(m, off);
-        if (lane == 0 && m) atomicOr(&live_mask, m);
-        if (a.in2 && tid < TM) nbr_all[njl][tid] = rows_s[tid];
+        if (lane == 0) wave_mask[wave] = m;
     }
     __syncthreads();
-    const unsigned lm = live_mask;
-
-    const int c_first = u_lo - (u_lo / nch) * nch, c_last = u_hi > u_lo ? (u_hi - 1) - ((u_hi - 1) / nch) * nch + 1 : 0;
-    auto skip_dead = [&](int& j, int& c) {
-#pragma unroll 1
-        while (j <= j_last && !((lm >> (j - j_first)) & 1u)) { ++j; c = 0; }
-    };
-    const int nch2 = a.in2 ? a.cin2 / KC : 0;
-    const int j_second = j_last + 1, j_done = j_last + 2;
-    auto advance = [&](int& j, int& c) {
-        if (j <= j_last) {
-            if (++c >= (j == j_last ? c_last : nch)) { ++j; c = 0; skip_dead(j, c); }
-            if (j > j_last) { j = j_second; c = blockIdx.z; }
-        } else {
-            c += a.splits;
-        }
-        if (j == j_second && c >= nch2) j = j_done;
-    };
-
-    // NS units in flight: A fragments (h ks0, h ks1, l ks0, l ks1) and this thread's share of the weight tile
-    uint4 ra[NS][4], rb[NS][B_PER];
-    bool live[NS], valid[NS];
+    unsigned lm = 0u;
 #pragma unroll
-    for (int q = 0; q < NS; ++q) { live[q] = false; valid[q] = false; }
-    const int my_row = wave * 32 + l31;
-    auto load = [&](auto S, int j, int c) {
-        constexpr int s = decltype(S)::value;
-        const bool second = j == j_second;
-        const int src = nbr_all[j - j_first][my_row];
-        const float* src_base = second ? a.in2 : a.in;
-        const int src_ld = second ? a.in2_ld : a.in_ld;
-        live[s] = __any(src >= 0);
-        valid[s] = true;
-        if (src >= 0 && !(CV_HL_ABL & 1)) {
-            const unsigned char* p = reinterpret_cast<const unsigned char*>(src_base + (long long)src * src_ld) + c * 128 + half * 16;
-            ra[s][0] = *reinterpret_cast<const uint4*>(p);
-            ra[s][1] = *reinterpret_cast<const uint4*>(p + 32);
-            ra[s][2] = *reinterpret_cast<const uint4*>(p + 64);
-            ra[s][3] = *reinterpret_cast<const uint4*>(p + 96);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ra[s][i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        const unsigned short* slab = second ? a.wp6_2 + (long long)c * 2 * a.cout * 32
-                                            : a.wp6 + (long long)(j * nch + c) * 2 * a.cout * 32;
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int f = tid + i * THREADS;
-            if (f < B_U4 && !(CV_HL_ABL & 4)) {
-                const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
-                const int col = rem >> 2, ch = rem & 3;
-                rb[s][i] = (n0 + col < a.cout)
-                               ? *reinterpret_cast<const uint4*>(slab + ((long long)p * a.cout + n0 + col) * 32 + ch * 8)
-                               : make_uint4(0u, 0u, 0u, 0u);
+    for (int w = 0; w < NW; ++w) lm |= wave_mask[w];
+    if (wave == 0) {
+        // live units of the map in order, then the chunks of the second source dealt to this split
+        const int n_first = u_hi - u_lo, n_second = nch2 > (int)blockIdx.z ? (nch2 - (int)blockIdx.z + a.splits - 1) / a.splits : 0;
+        int cnt = 0;
+        for (int base = 0; base < n_first + n_second; base += 64) {
+            const int e = base + lane;
+            int code = -1;
+            if (e < n_first) {
+                const int u = u_lo + e, q = u / nch;
+                const int jj = a.j_begin + q - j_first;
+                if ((lm >> jj) & 1u) code = (jj << 8) | (u - q * nch);
+            } else if (e < n_first + n_second) {
+                code = (njl << 8) | ((int)blockIdx.z + (e - n_first) * a.splits);
             }
+            const unsigned long long bal = __ballot(code >= 0);
+            if (code >= 0) units_s[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = code;
+            cnt += __popcll(bal);
         }
+        if (lane == 0) units_s[HL_MAX_UNITS] = cnt;
+    }
+    __syncthreads();
+    const int n_units = __builtin_amdgcn_readfirstlane(units_s[HL_MAX_UNITS]);
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    // per-thread invariants of the weight tile: this thread's 16-byte pieces (source offset inside a unit's slab in 16-bit
+    // words, or -1 beyond Cout; LDS offset with the XOR swizzle)
+    constexpr int B_U4 = 2 * NB * 32 * 4;
+    constexpr int B_PER = (B_U4 + THv - 1) / THv;
+    int b_src[B_PER], b_dst[B_PER];
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int f = tid + i * THv;
+        const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
+        const int col = rem >> 2, ch = rem & 3;
+        b_src[i] = (f < B_U4 && n0 + col < a.cout) ? (p * a.cout + n0 + col) * 32 + ch * 8 : -1;
+        b_dst[i] = f < B_U4 ? (p * NB * 32 + col) * 64 + ((ch ^ ((col >> 2) & 3)) << 4) : -1;
+    }
+    const unsigned slab_words = 2u * (unsigned)a.cout * 32u;       // one unit's slab: [plane][cout][32] 16-bit words
+    const int my_row = wave * 32 + l31;
+    const unsigned in_row_bytes = (unsigned)a.in_ld * 4u, in2_row_bytes = (unsigned)a.in2_ld * 4u;
+    const unsigned char* const in_b = reinterpret_cast<const unsigned char*>(a.in);
+    const unsigned char* const in2_b = reinterpret_cast<const unsigned char*>(a.in2);
+
+    uint4 ra[3][4], rb[3][B_PER];
+    bool live[3] = {false, false, false};
+    auto load = [&](auto S, int k) {                  // unit k of the list -> slot S
+        constexpr int sl = decltype(S)::value;
+        const int code = __builtin_amdgcn_readfirstlane(units_s[k]);
+        const int jj = code >> 8, c = code & 255;
+        const bool second = jj == njl;
+        const int src = nbr_all[jj][my_row];
+        live[sl] = __any(src >= 0);
+        if (src >= 0 && !(CV_HL_ABL & 1)) {
+            const unsigned off = (unsigned)src * (second ? in2_row_bytes : in_row_bytes) + (unsigned)(c * 128 + half * 16);
+            const unsigned char* p = (second ? in2_b : in_b) + off;
+            ra[sl][0] = *reinterpret_cast<const uint4*>(p);
+            ra[sl][1] = *reinterpret_cast<const uint4*>(p + 32);
+            ra[sl][2] = *reinterpret_cast<const uint4*>(p + 64);
+            ra[sl][3] = *reinterpret_cast<const uint4*>(p + 96);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ra[sl][q] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        const unsigned short* slab = second ? a.wp6_2 + (size_t)c * slab_words
+                                            : a.wp6 + (size_t)((j_first + jj) * nch + c) * slab_words;
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i)
+            rb[sl][i] = (b_src[i] >= 0 && !(CV_HL_ABL & 4)) ? *reinterpret_cast<const uint4*>(slab + b_src[i])
+                                                            : make_uint4(0u, 0u, 0u, 0u);
     };
     auto stage_b = [&](auto S) {
-        constexpr int s = decltype(S)::value;
-        unsigned char* Bb = sm + s * B_BYTES;
+        constexpr int sl = decltype(S)::value;
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int f = tid + i * THREADS;
-            if (f < B_U4 && !(CV_HL_ABL & 4)) {
-                const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
-                const int col = rem >> 2, ch = rem & 3;
-                *reinterpret_cast<uint4*>(Bb + (p * NB * 32 + col) * 64 + ((ch ^ ((col >> 2) & 3)) << 4)) = rb[s][i];
-            }
-        }
+        for (int i = 0; i < B_PER; ++i)
+            if (b_dst[i] >= 0 && !(CV_HL_ABL & 4)) *reinterpret_cast<uint4*>(sm + sl * B_BYTES + b_dst[i]) = rb[sl][i];
     };
+    const int b_rd = l31 * 64;
+    const int bswz = (l31 >> 2) & 3;
     auto compute = [&](auto S) {
-        constexpr int s = decltype(S)::value;
-        const unsigned char* Bb = sm + s * B_BYTES;
-        const int bswz = (l31 >> 2) & 3;
+        constexpr int sl = decltype(S)::value;
+        const unsigned char* Bb = sm + sl * B_BYTES + b_rd;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = 2 * ks + half;
-            const f16x8 a0 = __builtin_bit_cast(f16x8, ra[s][ks]), a1 = __builtin_bit_cast(f16x8, ra[s][2 + ks]);
+            const int piece = ((2 * ks + half) ^ bswz) << 4;
+            const f16x8 a0 = __builtin_bit_cast(f16x8, ra[sl][ks]), a1 = __builtin_bit_cast(f16x8, ra[sl][2 + ks]);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const f16x8 b0 = *reinterpret_cast<const f16x8*>(Bb + (nb * 32 + l31) * 64 + ((chunk ^ bswz) << 4));
-                const f16x8 b1 = *reinterpret_cast<const f16x8*>(Bb + (NB * 32 + nb * 32 + l31) * 64 + ((chunk ^ bswz) << 4));
+                const f16x8 b0 = *reinterpret_cast<const f16x8*>(Bb + nb * 32 * 64 + piece);
+                const f16x8 b1 = *reinterpret_cast<const f16x8*>(Bb + (NB * 32 + nb * 32) * 64 + piece);
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[nb], 0, 0, 0);
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[nb], 0, 0, 0);
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[nb], 0, 0, 0);
@@ -1155,34 +1173,35 @@ __global__ __launch_bounds__(THREADS, (NS > 3 ? 2 : 3)) void conv_hl(ConvArgs a)
         }
     };
     typedef std::integral_constant<int, 0> S0;
-    int j = j_first, c = c_first;                     // the loader's cursor (NS - 1 units ahead of the matrix cores)
-    if (njl > 0) skip_dead(j, c); else j = j_last + 1;
-    if (j > j_last) { j = j_second; c = blockIdx.z; if (c >= nch2) j = j_done; }
-    static_for<NS - 1>([&](auto S) { if (j < j_done) { load(S, j, c); advance(j, c); } });
-    if (valid[0]) stage_b(S0{});
-    // step<s>: unit u in slot s.  barrier: tile u visible, tile u - 1 consumed by everyone (its slot takes the loads of
-    // unit u + NS - 1); the tile of unit u + 1 goes to LDS; MFMAs of unit u
-    bool done = false;
+    typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, 2> S2;
+    if (n_units > 0) load(S0{}, 0);
+    if (n_units > 1) load(S1{}, 1);
+    if (n_units > 0) stage_b(S0{});
+    // step: unit k in slot s.  barrier: tile k visible, tile k - 1 consumed by everyone (its slot takes the loads of unit
+    // k + 2); the tile of unit k + 1 goes to LDS; MFMAs of unit k
+    auto step = [&](auto S, auto SN, auto SP, int k) {
+        constexpr int sl = decltype(S)::value;
+        __syncthreads();
+        if (k + 1 < n_units) stage_b(SN);
+        if (k + 2 < n_units) load(SP, k + 2);
+        if (live[sl] && (!(CV_HL_ABL & 2) || a.acc_scale == 12345.f)) compute(S);
+    };
 #pragma unroll 1
-    while (!done) {
-        static_for<NS>([&](auto S) {
-            constexpr int s = decltype(S)::value, sn = (s + 1) % NS, sp = (s + NS - 1) % NS;
-            if (done) return;
-            if (!valid[s]) { done = true; return; }
-            __syncthreads();
-            if (valid[sn]) stage_b(std::integral_constant<int, sn>{});
-            valid[sp] = false;
-            if (j < j_done) { load(std::integral_constant<int, sp>{}, j, c); advance(j, c); }
-            if (live[s] && (!(CV_HL_ABL & 2) || a.acc_scale == 12345.f)) compute(S);
-        });
+    for (int k = 0; k < n_units; k += 3) {
+        step(S0{}, S1{}, S2{}, k);
+        if (k + 1 >= n_units) break;
+        step(S1{}, S2{}, S0{}, k + 1);
+        if (k + 2 >= n_units) break;
+        step(S2{}, S0{}, S1{}, k + 2);
     }
     __syncthreads();                                 // weight tiles are dead: the epilogue tile reuses their LDS
     {
-        const float k = a.acc_scale;
+        const float sc = a.acc_scale;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] *= k;
+            for (int r = 0; r < 16; ++r) acc[nb][r] *= sc;
     }
     float (*ep)[EP_LD] = reinterpret_cast<float (*)[EP_LD]>(sm + wave * 32 * EP_LD * 4);
     if ((CV_HL_ABL & 8) && a.acc_scale != 12345.f) return;
@@ -2753,7 +2772,16 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         // requested at once through global_load_lds and two dependent round trips instead of 3 + units - no faster)
         // (NS = 8 / 6 / 4 slots for NB = 1 / 2 / 3 measured: every layer 25-45 % slower - two workgroups per CU
         // instead of three or four cost more than the deeper prefetch gains, profiles/r2/hl_slots.txt)
-        if constexpr (NB <= 3) conv_hl<NB, 3><<<gridx, THREADS, 0, st>>>(ax);
+        // 256-row workgroups where the launch has plenty of tiles and no split-K
+        static const bool nw8_on = !(getenv("CV_HL_NW8") && atoi(getenv("CV_HL_NW8")) == 0);
+        if constexpr (NB <= 3) {
+            if (nw8_on && !ax.xcd_tiles && a.n_out >= 16384 && (a.splits == 1 || a.perm_per_split)) {
+                dim3 g8((unsigned)((a.n_out + 255) / 256), grid.y, grid.z);
+                conv_hl<NB, 3, 8><<<g8, 512, 0, st>>>(ax);
+            } else {
+                conv_hl<NB, 3, 4><<<gridx, THREADS, 0, st>>>(ax);
+            }
+        }
         CV_LAUNCH_CHECK();
         if (a.splits > 1) return launch_finish(a, st);
         return CV_OK;
