@@ -113,6 +113,11 @@ SIGNATURES = {
     "cv_sp_scene_maps": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_longlong,
                                         c_i64_p, vp, ctypes.c_longlong, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_longlong, vp, ctypes.c_size_t, vp]),
+    "cv_sp_scene_plan_words": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_longlong]),
+    "cv_sp_scene_plan": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                        ctypes.POINTER(vp), ctypes.c_longlong, vp, c_i32_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_longlong, vp, ctypes.c_size_t, ctypes.POINTER(SceneMaps), vp,
+                                        ctypes.c_size_t, vp, ctypes.c_size_t, vp]),
     "cv_net_arena_bytes": (ctypes.c_size_t, [ctypes.POINTER(NetBuf), ctypes.c_int, c_i64_p, ctypes.c_int]),
     "cv_net_run_f32": (ctypes.c_int, [ctypes.POINTER(NetOp), ctypes.c_int, ctypes.POINTER(NetBuf), ctypes.c_int,
                                       c_i64_p, ctypes.c_int, vp, ctypes.c_size_t, ctypes.POINTER(vp), c_int_p,

@@ -5,6 +5,8 @@
 // C call per scene issues every launch: the Python layer's per-conv overhead (descriptor marshalling, tensor
 // allocation, ~35 us x 63) is what bounded the scene rate once several scenes were in flight.
 #include <algorithm>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "cv_common.h"
@@ -24,17 +26,20 @@ static void scene_maps_layout(const long long* rows, long long n_orig, int stem_
     size_t off = 0;
     auto take = [&](size_t words) { const size_t at = off; off += cv_align_up(words, 64); return (long long)at; };
     const size_t K5 = (size_t)stem_k * stem_k * stem_k;
+    const size_t mp_w = mask_groups > 1 ? (size_t)mask_groups * (1 + (27 + mask_groups - 1) / mask_groups) : 0;
+    // what depends on the caller's row count only comes first: cv_sp_scene_plan builds it before the coarse counts are known
     o->stem = take((size_t)rows[0] * K5);
+    o->k3[0] = take((size_t)rows[0] * 27);
+    o->mask_perm[0] = (mask_groups > 1 && rows[0] >= masked_min_rows) ? take(mp_w * rows[0]) : -1;
+    o->scratch = take((size_t)(5 * std::max(mask_groups, 1) + 4) * 1024);
     o->out = -1;                       // (the sort's inverse permutation is the final map)
     (void)n_orig;
     for (int i = 0; i < 4; ++i) o->down[i] = take((size_t)rows[i + 1] * 8);
-    for (int i = 0; i < 5; ++i) o->k3[i] = take((size_t)rows[i] * 27);
+    for (int i = 1; i < 5; ++i) o->k3[i] = take((size_t)rows[i] * 27);
     for (int i = 0; i < 4; ++i) o->up[i] = take((size_t)rows[3 - i] * 8);            // up[i]: level 4-i -> 3-i
-    for (int i = 0; i < 5; ++i)
-        o->mask_perm[i] = (mask_groups > 1 && rows[i] >= masked_min_rows)
-                              ? take((size_t)mask_groups * rows[i] * (1 + (27 + mask_groups - 1) / mask_groups)) : -1;
+    for (int i = 1; i < 5; ++i)
+        o->mask_perm[i] = (mask_groups > 1 && rows[i] >= masked_min_rows) ? take(mp_w * rows[i]) : -1;
     for (int i = 0; i < 4; ++i) o->up_perm[i] = take((size_t)rows[3 - i]);
-    o->scratch = take((size_t)(5 * std::max(mask_groups, 1) + 4) * 1024);
     *total = off;
 }
 
@@ -46,31 +51,40 @@ size_t cv_sp_scene_maps_words(const long long* level_rows, long long n_orig, int
     return total;
 }
 
-int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
-                     long long cap, const long long* level_rows, const int32_t* d_perm, long long n_orig, int stem_k,
-                     int mask_groups, long long masked_min_rows, int32_t* d_arena, size_t arena_words, void* stream) {
-    CV_REQUIRE(d_coords && d_keys && d_vals && level_rows && d_perm && d_arena, CV_EINVAL, "null pointer argument");
-    CV_REQUIRE(n_orig == level_rows[0], CV_EINVAL, "the sorted set must hold the caller's %lld rows", n_orig);
-    cv_scene_maps o;
-    size_t total = 0;
-    scene_maps_layout(level_rows, n_orig, stem_k, mask_groups, masked_min_rows, &o, &total);
-    CV_REQUIRE(arena_words >= total, CV_ENOMEM, "scene map arena too small");
-    // one launch for the eleven kernel maps, one fill + one launch for the four transposed maps, three launches for
-    // the six processing orders (the per-map calls were ~45 launches of a few microseconds each on the scene's
-    // critical path)
-    CvMapJob mj[CV_MAX_MAP_JOBS];
-    int nm = 0;
+// level-0 part (needs the caller's row count only): the stem map with the sort permutation folded in, the 3x3x3 map of
+// the finest level and its mask-sorted orders
+static int scene_maps_level0(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
+                             long long cap, long long n, const int32_t* d_perm, int stem_k, int mask_groups,
+                             const cv_scene_maps& o, int32_t* d_arena, void* stream) {
+    CvMapJob mj[2];
     // stem: sorted rows <- rows of the ORIGINAL order = the sorted set's own map with the permutation folded in
     // (the caller's set needs no hash table of its own); the final original <- sorted map is the sort's inverse
-    mj[nm++] = {d_coords[0], level_rows[0], d_keys[0], d_vals[0], cap, stem_k, 1, d_arena + o.stem, d_perm};
+    mj[0] = {d_coords[0], n, d_keys[0], d_vals[0], cap, stem_k, 1, d_arena + o.stem, d_perm};
+    mj[1] = {d_coords[0], n, d_keys[0], d_vals[0], cap, 3, 1, d_arena + o.k3[0], nullptr};
+    int rc = cv_sp_kernel_maps_batch(mj, 2, stream);
+    if (rc != CV_OK) return rc;
+    if (o.mask_perm[0] >= 0) {
+        CvPermJob pj = {d_arena + o.k3[0], n, 27, mask_groups, d_arena + o.mask_perm[0], 1};
+        rc = cv_sp_mask_perms_batch(&pj, 1, d_arena + o.scratch, sizeof(int) * (size_t)mask_groups * 1024, stream);
+        if (rc != CV_OK) return rc;
+    }
+    return CV_OK;
+}
+
+// the coarse levels: one launch for the eight remaining kernel maps, one fill + one launch for the four transposed
+// maps, three launches for the remaining processing orders
+static int scene_maps_coarse(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
+                             long long cap, const long long* level_rows, int mask_groups, const cv_scene_maps& o,
+                             int32_t* d_arena, void* stream) {
+    CvMapJob mj[CV_MAX_MAP_JOBS];
+    int nm = 0;
     for (int i = 0; i < 4; ++i)
         mj[nm++] = {d_coords[i + 1], level_rows[i + 1], d_keys[i], d_vals[i], cap, 2, 1 << i, d_arena + o.down[i], nullptr};
-    for (int i = 0; i < 5; ++i)
+    for (int i = 1; i < 5; ++i)
         mj[nm++] = {d_coords[i], level_rows[i], d_keys[i], d_vals[i], cap, 3, 1 << i, d_arena + o.k3[i], nullptr};
     int rc = cv_sp_kernel_maps_batch(mj, nm, stream);
     if (rc != CV_OK) return rc;
-    // the four transposed maps are neighbours in the arena: one fill
-    {
+    {   // the four transposed maps are neighbours in the arena: one fill
         const long long lo = o.up[0], hi = o.up[3] + level_rows[0] * 8;
         CV_HIP_CHECK(hipMemsetAsync(d_arena + lo, 0xff, sizeof(int32_t) * (size_t)(hi - lo), static_cast<hipStream_t>(stream)));
     }
@@ -80,7 +94,7 @@ int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* 
     if (rc != CV_OK) return rc;
     CvPermJob pj[CV_MAX_PERM_JOBS];
     int np = 0, groups = 0;
-    for (int i = 0; i < 5; ++i)
+    for (int i = 1; i < 5; ++i)
         if (o.mask_perm[i] >= 0) {
             pj[np++] = {d_arena + o.k3[i], level_rows[i], 27, mask_groups, d_arena + o.mask_perm[i], 1};
             groups += mask_groups;
@@ -89,9 +103,91 @@ int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* 
         pj[np++] = {d_arena + o.up[i], level_rows[3 - i], 8, 1, d_arena + o.up_perm[i], 0};
         groups += 1;
     }
-    rc = cv_sp_mask_perms_batch(pj, np, d_arena + o.scratch, sizeof(int) * (size_t)groups * 1024, stream);
+    return cv_sp_mask_perms_batch(pj, np, d_arena + o.scratch + (size_t)std::max(mask_groups, 1) * 1024,
+                                  sizeof(int) * (size_t)groups * 1024, stream);
+}
+
+int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
+                     long long cap, const long long* level_rows, const int32_t* d_perm, long long n_orig, int stem_k,
+                     int mask_groups, long long masked_min_rows, int32_t* d_arena, size_t arena_words, void* stream) {
+    CV_REQUIRE(d_coords && d_keys && d_vals && level_rows && d_perm && d_arena, CV_EINVAL, "null pointer argument");
+    CV_REQUIRE(n_orig == level_rows[0], CV_EINVAL, "the sorted set must hold the caller's %lld rows", n_orig);
+    cv_scene_maps o;
+    size_t total = 0;
+    scene_maps_layout(level_rows, n_orig, stem_k, mask_groups, masked_min_rows, &o, &total);
+    CV_REQUIRE(arena_words >= total, CV_ENOMEM, "scene map arena too small");
+    int rc = scene_maps_level0(d_coords, d_keys, d_vals, cap, n_orig, d_perm, stem_k, mask_groups, o, d_arena, stream);
     if (rc != CV_OK) return rc;
+    return scene_maps_coarse(d_coords, d_keys, d_vals, cap, level_rows, mask_groups, o, d_arena, stream);
+}
+
+// ---- the whole coordinate plan of a scene in ONE call: spatial row sort, the five coordinate levels with their hash
+// tables, every kernel map and processing order.  The level counts have to reach the host (grid sizes, arena layout):
+// they are copied into pinned memory as soon as the levels exist and the host waits for THAT copy (an event), while the
+// stream already builds the level-0 maps queued behind it (the 5x5x5 stem map is 3/4 of all lookups) - the host wait,
+// which used to leave the GPU idle for ~80 us between cv_sp_build_levels and cv_sp_scene_maps, now overlaps with them.
+namespace {
+struct PlanSide { hipEvent_t ev; int32_t* h_pinned; };
+std::mutex g_plan_mu;
+std::unordered_map<void*, PlanSide> g_plan_side;        // per main stream (scene threads own their streams)
+int plan_side(void* stream, PlanSide* out) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plan_side.find(stream);
+    if (it == g_plan_side.end()) {
+        PlanSide p{};
+        CV_HIP_CHECK(hipEventCreateWithFlags(&p.ev, hipEventDisableTiming));
+        CV_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p.h_pinned), 64, hipHostMallocDefault));
+        it = g_plan_side.emplace(stream, p).first;
+    }
+    *out = it->second;
     return CV_OK;
+}
+}  // namespace
+
+size_t cv_sp_scene_plan_words(long long n, int stem_k, int mask_groups, long long masked_min_rows) {
+    if (n <= 0 || stem_k < 1) return 0;
+    const long long rows[5] = {n, n, n, n, n};          // a coarser level never has more rows than a finer one
+    cv_scene_maps o;
+    size_t total = 0;
+    scene_maps_layout(rows, n, stem_k, mask_groups, masked_min_rows, &o, &total);
+    return total;
+}
+
+int cv_sp_scene_plan(const int32_t* d_input, long long n, int32_t* d_perm, int32_t* d_inv, int32_t* const* d_coords,
+                     unsigned long long* const* d_keys, int32_t* const* d_vals, long long cap, int32_t* d_counts,
+                     int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int32_t* d_arena,
+                     size_t arena_words, cv_scene_maps* offsets, void* d_sort_ws, size_t sort_ws_bytes, void* d_levels_ws,
+                     size_t levels_ws_bytes, void* stream) {
+    CV_REQUIRE(d_input && d_perm && d_inv && d_coords && d_keys && d_vals && d_counts && h_counts && d_arena && offsets &&
+                   d_sort_ws && d_levels_ws, CV_EINVAL, "null pointer argument");
+    CV_REQUIRE(arena_words >= cv_sp_scene_plan_words(n, stem_k, mask_groups, masked_min_rows), CV_ENOMEM,
+               "scene map arena too small (cv_sp_scene_plan_words)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = cv_sp_sort_rows(d_input, n, d_coords[0], d_perm, d_inv, d_sort_ws, sort_ws_bytes, stream);
+    if (rc != CV_OK) return rc;
+    rc = cv_sp_build_levels(d_coords, d_keys, d_vals, n, cap, 5, d_counts, nullptr, d_levels_ws, levels_ws_bytes, stream);
+    if (rc != CV_OK) return rc;
+    PlanSide ps;
+    rc = plan_side(stream, &ps);
+    if (rc != CV_OK) return rc;
+    CV_HIP_CHECK(hipMemcpyAsync(ps.h_pinned, d_counts, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, st));
+    CV_HIP_CHECK(hipEventRecord(ps.ev, st));
+    // level-0 maps: their arena offsets depend on n only
+    long long rows[5] = {n, 1, 1, 1, 1};
+    cv_scene_maps o;
+    size_t total = 0;
+    scene_maps_layout(rows, n, stem_k, mask_groups, masked_min_rows, &o, &total);
+    rc = scene_maps_level0(d_coords, d_keys, d_vals, cap, n, d_perm, stem_k, mask_groups, o, d_arena, stream);
+    if (rc != CV_OK) return rc;
+    CV_HIP_CHECK(hipEventSynchronize(ps.ev));          // the counts have landed; the level-0 maps are still being built
+    for (int i = 0; i < 8; ++i) h_counts[i] = ps.h_pinned[i];
+    if (h_counts[5] != 0 || h_counts[6] != 0) return CV_OK;      // duplicates / out-of-window rows: the caller reports them
+    for (int i = 0; i < 5; ++i) rows[i] = h_counts[i];
+    CV_REQUIRE(rows[0] == n, CV_EINVAL, "level 0 lost rows (%lld of %lld)", rows[0], n);
+    scene_maps_layout(rows, n, stem_k, mask_groups, masked_min_rows, &o, &total);
+    CV_REQUIRE(arena_words >= total, CV_ENOMEM, "scene map arena too small");
+    *offsets = o;
+    return scene_maps_coarse(d_coords, d_keys, d_vals, cap, rows, mask_groups, o, d_arena, stream);
 }
 
 size_t cv_net_arena_bytes(const cv_net_buf* bufs, int n_bufs, const long long* level_rows, int n_levels) {

@@ -345,6 +345,7 @@ __global__ __launch_bounds__(SORT_T) void sort_hist(const int* __restrict__ coor
                                                     unsigned* __restrict__ keys, long long n, int pass,
                                                     int* __restrict__ hist /*[nblk][SORT_BINS]*/) {
     __shared__ int lh[SORT_BINS];
+    if (pass == 2 && mm[6] == 0) return;              // one scene (batch index 0 everywhere): the third digit is constant
     for (int i = threadIdx.x; i < SORT_BINS; i += SORT_T) lh[i] = 0;
     __syncthreads();
     const long long base = blockIdx.x * (long long)SORT_ROWS;
@@ -367,9 +368,15 @@ __global__ __launch_bounds__(SORT_T) void sort_hist(const int* __restrict__ coor
 __global__ __launch_bounds__(SORT_T) void sort_scatter(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in,
                                                        long long n, int pass, const int* __restrict__ hist, int nblk,
                                                        unsigned* __restrict__ keys_out, int* __restrict__ vals_out,
-                                                       const int* __restrict__ coords, int* __restrict__ perm,
-                                                       int* __restrict__ inv, int* __restrict__ sorted) {
-    __shared__ int start[SORT_BINS];      // first output slot of (this block, bin); then the running slot
+                                                       const int* __restrict__ coords_in, int* __restrict__ perm,
+                                                       int* __restrict__ inv, int* __restrict__ sorted,
+                                                       const int* __restrict__ mm) {
+    __shared__ int start[SORT_BINS];
+    // a single scene (largest batch index 0) is sorted after two digits: pass 1 then writes the final outputs and
+    // pass 2 has nothing to do (two launches that exit at once instead of 30 us of histogram + scatter)
+    const bool single = mm[6] == 0;
+    if (pass == 2 && single) return;
+    const int* coords = (pass == 2 || (pass == 1 && single)) ? coords_in : nullptr;      // first output slot of (this block, bin); then the running slot
     __shared__ int scan[SORT_T];
     // totals and this block's prefix per bin (two bins per thread, coalesced over the block-major histogram)
     int tot[SORT_BINS / SORT_T], pre[SORT_BINS / SORT_T];
@@ -596,17 +603,17 @@ int cv_sp_sort_rows(const int32_t* d_coords, long long n, int32_t* d_sorted, int
     sort_hist<<<nblk, SORT_T, 0, st>>>(d_coords, mm, keys_a, n, 0, hist);
     CV_LAUNCH_CHECK();
     sort_scatter<<<nblk, SORT_T, 0, st>>>(keys_a, nullptr, n, 0, hist, nblk, keys_b, vals_b, nullptr, nullptr, nullptr,
-                                          nullptr);
+                                          nullptr, mm);
     CV_LAUNCH_CHECK();
     sort_hist<<<nblk, SORT_T, 0, st>>>(nullptr, mm, keys_b, n, 1, hist);
     CV_LAUNCH_CHECK();
-    sort_scatter<<<nblk, SORT_T, 0, st>>>(keys_b, vals_b, n, 1, hist, nblk, keys_a, vals_a, nullptr, nullptr, nullptr,
-                                          nullptr);
+    sort_scatter<<<nblk, SORT_T, 0, st>>>(keys_b, vals_b, n, 1, hist, nblk, keys_a, vals_a, d_coords, d_perm, d_inv,
+                                          d_sorted, mm);
     CV_LAUNCH_CHECK();
     sort_hist<<<nblk, SORT_T, 0, st>>>(nullptr, mm, keys_a, n, 2, hist);
     CV_LAUNCH_CHECK();
     sort_scatter<<<nblk, SORT_T, 0, st>>>(keys_a, vals_a, n, 2, hist, nblk, nullptr, nullptr, d_coords, d_perm, d_inv,
-                                          d_sorted);
+                                          d_sorted, mm);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

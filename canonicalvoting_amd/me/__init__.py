@@ -37,6 +37,11 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+class _FusedPlan:
+    """what CoordinateManager.fused_fast() returns"""
+    __slots__ = ("keep", "counts", "cap", "stem_k", "groups", "off", "layout", "map_ptrs", "perm_ptrs", "views")
+
+
 class CoordinateManager:
     """Coordinate sets per tensor stride, their hash tables and the cached kernel maps."""
 
@@ -66,6 +71,24 @@ class CoordinateManager:
             self._build(*lazy)
             return self.__dict__[name]
         raise AttributeError(name)
+
+    @classmethod
+    def _from_levels(cls, coords_buf, keys, vals, counts_d, counts, cap):
+        """manager over levels built elsewhere (cv_sp_scene_plan)"""
+        self = object.__new__(cls)
+        self.device = coords_buf[0].device
+        self.cap = cap
+        self._input = coords_buf[0]
+        self._fused = None
+        self._lazy = None
+        self.num_levels = len(coords_buf)
+        self._coords_buf, self._keys, self._vals, self._counts_d = coords_buf, keys, vals, counts_d
+        self._verified = True
+        self.counts = counts
+        self.coords = {1 << i: coords_buf[i][:counts[i]] for i in range(self.num_levels)}
+        self._level = {1 << i: i for i in range(self.num_levels)}
+        self._maps = {}
+        return self
 
     def _build(self, num_levels, check):
         L = _lib.lib()
@@ -170,39 +193,81 @@ class CoordinateManager:
     MASK_GROUPS = int(os.environ.get("CV_NET_MASK_GROUPS", "4"))
     MASKED_MIN_ROWS = int(os.environ.get("CV_MASKED_MIN_ROWS", "16384"))
 
+    def fused_fast(self, stem_k=5):
+        """The coordinate plan of the fused network as raw device pointers (what MinkUNet.program_forward hands to the
+        C executor): .counts rows per level, .map_ptrs [stem, down 0-3, k3 0-4, up 0-3, out], .perm_ptrs [mask orders of
+        levels 0-4 (None where a level is not mask-sorted), octant orders of the four transposed convs].
+        ONE C call (cv_sp_scene_plan: spatial row sort, the five levels of the sorted set, every map and order) into
+        three allocations; the tensor views of the plan (fused_plan) are only made when somebody asks for them."""
+        if self._fused is not None and self._fused_k == stem_k:
+            return self._fused
+        L = _lib.lib()
+        dev = self.device
+        n = self._input.shape[0]
+        NL = CoordinateManager.NUM_LEVELS
+        G = self.MASK_GROUPS if (27 + self.MASK_GROUPS - 1) // self.MASK_GROUPS <= 10 else 0   # wide groups: lazily
+        cap = int(L.cv_sp_table_capacity(n))
+        words = int(L.cv_sp_scene_plan_words(n, stem_k, G, self.MASKED_MIN_ROWS))
+        up64 = lambda v: (v + 63) // 64 * 64
+        # int32 buffer: perm | inv | coords of the 5 levels | table values of the 5 levels | counts | arena (sized for
+        # the worst case, every coarse level bounded by n: the call does not come back between the levels and the maps)
+        o_perm, o_inv = 0, up64(n)
+        o_coords = [o_inv + up64(n) + i * up64(4 * n) for i in range(NL)]
+        o_vals = [o_coords[-1] + up64(4 * n) + i * up64(cap) for i in range(NL)]
+        o_counts = o_vals[-1] + up64(cap)
+        o_arena = o_counts + 64
+        ibuf = torch.empty(o_arena + words, dtype=torch.int32, device=dev)
+        kbuf = torch.empty(NL * cap, dtype=torch.int64, device=dev)
+        sws_b, lws_b = int(L.cv_sp_sort_workspace_bytes(n)), int(L.cv_sp_levels_workspace_bytes(n))
+        wbuf = torch.empty(up64(sws_b) + lws_b, dtype=torch.uint8, device=dev)
+        ib, kb, wb = ibuf.data_ptr(), kbuf.data_ptr(), wbuf.data_ptr()
+        vp = ctypes.c_void_p
+        c_coords = (vp * NL)(*[ib + 4 * o for o in o_coords])
+        c_keys = (vp * NL)(*[kb + 8 * cap * i for i in range(NL)])
+        c_vals = (vp * NL)(*[ib + 4 * o for o in o_vals])
+        counts_h = (ctypes.c_int32 * 8)()
+        off = _lib.SceneMaps()
+        with torch.cuda.device(dev):
+            _lib.check(L.cv_sp_scene_plan(_ptr(self._input), n, vp(ib + 4 * o_perm), vp(ib + 4 * o_inv), c_coords, c_keys,
+                                          c_vals, cap, vp(ib + 4 * o_counts), counts_h, stem_k, G, self.MASKED_MIN_ROWS,
+                                          vp(ib + 4 * o_arena), words, ctypes.byref(off), vp(wb), sws_b, vp(wb + up64(sws_b)),
+                                          lws_b, _stream(dev)), "cv_sp_scene_plan")
+        self._raise_on_dups(counts_h[5], counts_h[6])
+        plan = _FusedPlan()
+        plan.keep = (ibuf, kbuf, wbuf)
+        plan.counts = [int(counts_h[i]) for i in range(NL)]
+        plan.cap, plan.stem_k, plan.groups, plan.off = cap, stem_k, G, off
+        plan.layout = (o_perm, o_inv, o_coords, o_vals, o_counts, o_arena)
+        ap = lambda o: ib + 4 * (o_arena + o)
+        plan.map_ptrs = [ap(off.stem)] + [ap(off.down[i]) for i in range(4)] + [ap(off.k3[i]) for i in range(5)] + \
+                        [ap(off.up[i]) for i in range(4)] + [ib + 4 * o_inv]
+        plan.perm_ptrs = [ap(off.mask_perm[i]) if off.mask_perm[i] >= 0 else None for i in range(5)] + \
+                         [ap(off.up_perm[i]) for i in range(4)]
+        plan.views = None
+        self._fused = plan
+        self._fused_k = stem_k
+        return plan
+
     def fused_plan(self, stem_k=5):
         """Spatially sorted twin of this coordinate set for the fused network:
-        (sorted manager with all levels, stem map sorted<-original rows, final map original<-sorted).
-        Every kernel map / processing order the network asks the sorted manager for is built here by ONE C call
-        (cv_sp_scene_maps) into one arena and pre-seeded into its cache."""
-        if self._fused is None or self._fused_k != stem_k:
-            L = _lib.lib()
-            dev = self.device
-            n = self._input.shape[0]
-            # spatial row order (stable radix sort on the device, no host synchronisation): sorted rows, sorted <- original
-            # and original <- sorted row indices
-            sorted_c = torch.empty((n, 4), dtype=torch.int32, device=dev)
-            perm = torch.empty(n, dtype=torch.int32, device=dev)
-            inv = torch.empty(n, dtype=torch.int32, device=dev)
-            sws = torch.empty(int(L.cv_sp_sort_workspace_bytes(n)), dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
-                _lib.check(L.cv_sp_sort_rows(_ptr(self._input), n, _ptr(sorted_c), _ptr(perm), _ptr(inv), _ptr(sws),
-                                             sws.numel(), _stream(dev)), "cv_sp_sort_rows")
-            cm_s = CoordinateManager(sorted_c, CoordinateManager.NUM_LEVELS, True)
-            rows = (ctypes.c_int64 * 5)(*cm_s.counts)
-            off = _lib.SceneMaps()
-            G = self.MASK_GROUPS if (27 + self.MASK_GROUPS - 1) // self.MASK_GROUPS <= 10 else 0   # wide groups: lazily
-            words = int(L.cv_sp_scene_maps_words(rows, n, stem_k, G, self.MASKED_MIN_ROWS, ctypes.byref(off)))
-            arena = torch.empty(words, dtype=torch.int32, device=dev)
-            arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-            with torch.cuda.device(dev):
-                _lib.check(L.cv_sp_scene_maps(arr(cm_s._coords_buf), arr(cm_s._keys), arr(cm_s._vals), cm_s.cap, rows,
-                                              _ptr(perm), n, stem_k, G, self.MASKED_MIN_ROWS, _ptr(arena), words,
-                                              _stream(dev)), "cv_sp_scene_maps")
-            c = cm_s.counts
+        (sorted manager with all levels, stem map sorted<-original rows, final map original<-sorted) as tensors -
+        views of the buffers fused_fast() filled, every kernel map / processing order pre-seeded into the sorted
+        manager's cache."""
+        plan = self.fused_fast(stem_k)
+        if plan.views is None:
+            ibuf, kbuf, _ = plan.keep
+            n, cap, G, off = self._input.shape[0], plan.cap, plan.groups, plan.off
+            o_perm, o_inv, o_coords, o_vals, o_counts, o_arena = plan.layout
+            c = plan.counts
+            NL = len(c)
+            coords_buf = [ibuf[o:o + 4 * n].view(n, 4) for o in o_coords]
+            keys = [kbuf[i * cap:(i + 1) * cap] for i in range(NL)]
+            vals = [ibuf[o:o + cap] for o in o_vals]
+            cm_s = CoordinateManager._from_levels(coords_buf, keys, vals, ibuf[o_counts:o_counts + 8], c, cap)
+            arena = ibuf[o_arena:]
             view = lambda o, r, k: arena[o:o + r * k].view(r, k)
             stem_map = view(off.stem, c[0], stem_k ** 3)
-            out_map = inv.view(n, 1)                # original row <- sorted row: the final 1x1 conv's "kernel map"
+            out_map = ibuf[o_inv:o_inv + n].view(n, 1)   # original row <- sorted row: the final 1x1 conv's "kernel map"
             for i in range(4):
                 cm_s._maps[("k", 2, 1 << i, 2)] = view(off.down[i], c[i + 1], 8)
                 cm_s._maps[("up", 16 >> i)] = view(off.up[i], c[3 - i], 8)
@@ -213,10 +278,8 @@ class CoordinateManager:
                     mp = view(off.mask_perm[i], G, c[i])
                     mp._cv_has_map = True              # the map rows in processing order follow in the arena
                     cm_s._maps[("mp", 3, 1 << i, G)] = mp
-            cm_s._verified = True
-            self._fused = (cm_s, stem_map, out_map)
-            self._fused_k = stem_k
-        return self._fused
+            plan.views = (cm_s, stem_map, out_map)
+        return plan.views
 
     def num_rows(self, ts):
         if ts == 1:

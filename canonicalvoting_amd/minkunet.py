@@ -377,33 +377,38 @@ class MinkUNetBase(ResNetBase):
         import ctypes
         from . import _lib
         L = _lib.lib()
-        cm, stem_map, out_map = x.coordinate_manager.fused_plan(self.conv0p1s1.kernel_size)
+        plan = x.coordinate_manager.fused_fast(self.conv0p1s1.kernel_size)
         dev = x.F.device
         if pieces is None:
             pieces = 1 if ME.COMPUTE_DTYPE == "bf16" else self.PIECES
         c_ops, c_bufs, _ = self._program(dev, pieces)
         flag = ME.range_flag(dev) if pieces == 2 else None
-        n = [cm.num_rows(1 << i) for i in range(5)]
-        maps = [stem_map] + [cm.kernel_map(2, 1 << i, 2) for i in range(4)] + [cm.kernel_map(3, 1 << i) for i in range(5)] \
-            + [cm.up_map(16 >> i) for i in range(4)] + [out_map]
-        perms = [cm.mask_perms(3, 1 << i, self.MASK_GROUPS) if n[i] >= self.MASKED_MIN_ROWS else None
-                 for i in range(5)] + [cm.up_perm(16 >> i) for i in range(4)]
+        n = plan.counts
+        masked = [n[i] >= self.MASKED_MIN_ROWS for i in range(5)]
+        if any(m and plan.perm_ptrs[i] is None for i, m in enumerate(masked)):
+            # mask groups too wide for the plan's counting sort: orders from the generic path
+            cm = x.coordinate_manager.fused_plan(self.conv0p1s1.kernel_size)[0]
+            wide = [cm.mask_perms(3, 1 << i, self.MASK_GROUPS) if masked[i] else None for i in range(5)]
+            perm_ptrs = [w.data_ptr() if w is not None else None for w in wide] + plan.perm_ptrs[5:]
+        else:
+            perm_ptrs = [p if masked[i] else None for i, p in enumerate(plan.perm_ptrs[:5])] + plan.perm_ptrs[5:]
+        map_ptrs = plan.map_ptrs
         feats = x.F.contiguous()
         y = torch.empty((n[0], self.final.out_channels), dtype=torch.float32, device=dev)
         rows = (ctypes.c_int64 * 5)(*n)
         arena = torch.empty(int(L.cv_net_arena_bytes(c_bufs, len(c_bufs), rows, 5)), dtype=torch.uint8, device=dev)
         cmax = max(self.PLANES)
-        ws_bytes = max([4 * self.MASK_GROUPS * n[i] * cmax + 256 for i in range(5) if perms[i] is not None] +
+        ws_bytes = max([4 * self.MASK_GROUPS * n[i] * cmax + 256 for i in range(5) if perm_ptrs[i] is not None] +
                        [int(L.cv_sp_conv_workspace_bytes(min(n[i], 128 * 384 - 1), cmax, 27)) for i in range(5)])
         ws = ME._workspace(dev, ws_bytes)
         vp = ctypes.c_void_p
         ext_ptr = (vp * 2)(feats.data_ptr(), y.data_ptr())
         ext_ld = (ctypes.c_int * 2)(feats.stride(0), y.stride(0))
-        c_maps = (vp * len(maps))(*[m.data_ptr() for m in maps])
-        c_perms = (vp * len(perms))(*[p.data_ptr() if p is not None else None for p in perms])
+        c_maps = (vp * len(map_ptrs))(*map_ptrs)
+        c_perms = (vp * len(perm_ptrs))(*perm_ptrs)
         with torch.cuda.device(dev):
             _lib.check(L.cv_net_run_f32(c_ops, len(c_ops), c_bufs, len(c_bufs), rows, 5, vp(arena.data_ptr()),
-                                        arena.numel(), ext_ptr, ext_ld, c_maps, len(maps), c_perms, len(perms),
+                                        arena.numel(), ext_ptr, ext_ld, c_maps, len(map_ptrs), c_perms, len(perm_ptrs),
                                         vp(ws.data_ptr()), ws.numel(), vp(flag.data_ptr()) if flag is not None else None,
                                         vp(torch.cuda.current_stream(dev).cuda_stream)), "cv_net_run_f32")
         out = x._like(y, 1)

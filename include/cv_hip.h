@@ -267,6 +267,7 @@ int cv_sp_conv_f32(const cv_conv_desc* desc, void* stream);
 
 /* Every kernel map and processing order the fused MinkUNet forward needs, built by ONE call per scene into one
  * int32 arena (offsets in int32 words; -1 = absent):
+ * (level-0 items first - stem, k3[0], mask_perm[0], scratch - then the coarse levels)
  *   stem  [rows0][stem_k^3]  sorted rows <- rows of the caller's order (the sorted set's own map with d_perm, the
  *                            sorted <- original permutation of cv_sp_sort_rows, folded in)
  *   out                      always -1: the caller's rows <- sorted rows map is cv_sp_sort_rows' d_inv
@@ -281,6 +282,20 @@ size_t cv_sp_scene_maps_words(const long long* level_rows, long long n_orig, int
 int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
                      long long cap, const long long* level_rows, const int32_t* d_perm, long long n_orig, int stem_k,
                      int mask_groups, long long masked_min_rows, int32_t* d_arena, size_t arena_words, void* stream);
+
+/* The whole coordinate plan of a scene in ONE call (replaces cv_sp_sort_rows + cv_sp_build_levels + cv_sp_scene_maps
+ * issued by the caller): spatial row sort of d_input[n][4] into d_coords[0], the five levels with their tables, every
+ * kernel map and processing order of the fused network into d_arena.  The arena is sized before the coarse row counts are
+ * known (cv_sp_scene_plan_words: every level bounded by n); *offsets and h_counts[8] (cv_sp_build_levels' counts) are
+ * filled on return.  The level counts are copied to pinned host memory behind the levels and the call waits for that copy
+ * only (an event), while `stream` goes on with the level-0 maps queued behind it.  When h_counts[5] (duplicates) or h_counts[6] (rows
+ * outside the key window) is non-zero nothing beyond the level-0 maps is built and the caller must reject the input. */
+size_t cv_sp_scene_plan_words(long long n, int stem_k, int mask_groups, long long masked_min_rows);
+int cv_sp_scene_plan(const int32_t* d_input, long long n, int32_t* d_perm, int32_t* d_inv, int32_t* const* d_coords,
+                     unsigned long long* const* d_keys, int32_t* const* d_vals, long long cap, int32_t* d_counts,
+                     int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int32_t* d_arena,
+                     size_t arena_words, cv_scene_maps* offsets, void* d_sort_ws, size_t sort_ws_bytes, void* d_levels_ws,
+                     size_t levels_ws_bytes, void* stream);
 
 /* Fused eval-mode network as ONE call per scene (host-side executor over cv_sp_conv_f32; replaces the reference's
  * module-by-module MinkUNet34C.forward, utils/minkunet.py:122-180, for inference).  The program is symbolic and built
