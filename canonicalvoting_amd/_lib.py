@@ -94,6 +94,7 @@ SIGNATURES = {
     "cv_sp_morton_keys": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp]),
     "cv_sp_sort_workspace_bytes": (ctypes.c_size_t, [ctypes.c_longlong]),
     "cv_sp_sort_rows": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp, vp, vp, ctypes.c_size_t, vp]),
+    "cv_sp_pack_weights_stem_h2_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
     "cv_sp_to_hl_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
     "cv_sp_from_hl_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp]),
     "cv_sp_kernel_map": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp, ctypes.c_longlong, ctypes.c_int,

@@ -1494,6 +1494,130 @@ __global__ __launch_bounds__(STEM_ROWS) void conv_stem(ConvArgs a, int JC) {
     }
 }
 
+// ------------------------------------------------------------------ stem on the matrix cores (fp16 pairs)
+// The lane-per-row stem above executes 32*CIN FMAs for every offset ANY of a wave's 64 rows has (~90 % of the 125) while
+// 13 % of the (row, offset) pairs exist: 93 us for 0.25 GFLOP.  As a GEMM over the gathered operand
+// [rows][CIN * 128] (offsets padded to 128, dead entries zero) it is 1.97 GFLOP dense - nothing for the matrix cores -
+// and what remains is what the stem really is: 125 map entries and ~16 gathers of CIN floats per row.
+// A wave owns 32 rows; per group of 16 offsets a lane (row = lane % 32, half = lane / 32) reads its row's 8 map
+// entries, gathers the CIN floats of the existing ones, splits them into fp16 pairs (split2h) and feeds CIN x 3
+// v_mfma_f32_32x32x16_f16 (k = the 16 offsets of the group, one MFMA triple per input channel).  The weights
+// (cv_sp_pack_weights_stem_h2_f32: BatchNorm scale and a power of two folded in, fp16 pairs in B-operand order,
+// 16 KB per input channel) sit in LDS for the whole workgroup.  Same products as the fp32 chain to 2^-22, fp32 accumulation.
+template <int CIN>
+__global__ __launch_bounds__(THREADS, (CIN <= 3 ? 3 : 1)) void conv_stem_mfma(ConvArgs a) {
+    constexpr int G = 8;                              // groups of 16 kernel offsets (K <= 128)
+    constexpr int W_BYTES = G * CIN * 2 * 1024;       // [group][channel][plane][col][half][8] fp16
+    constexpr int EP_BYTES = 4 * 32 * EP_LD * 4;
+    constexpr int SM_BYTES = W_BYTES > EP_BYTES ? W_BYTES : EP_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char w_s[SM_BYTES];    // the weights; then the epilogue tile
+    __shared__ int rows_s[TM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const long long r0 = (long long)blockIdx.x * TM;
+    for (int f = tid; f < W_BYTES / 16; f += THREADS)
+        reinterpret_cast<uint4*>(w_s)[f] = reinterpret_cast<const uint4*>(a.wp6)[f];
+    if (tid < TM) rows_s[tid] = r0 + tid < a.n_out ? (int)(r0 + tid) : -1;
+    const long long row = r0 + wave * 32 + l31;
+    const bool have = row < a.n_out;
+    const int K = a.K;
+    const int* __restrict__ mrow = a.nbr + (have ? row : 0) * (long long)K;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float in_max = 0.f;
+    // every map entry of the lane's row half first (64 independent loads in flight: the map is streamed from HBM / the
+    // Infinity Cache once), then the groups with the gathers one group ahead of the MFMAs
+    int m[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = g * 16 + half * 8 + i;
+            m[g][i] = (have && j < K) ? mrow[j] : -1;
+        }
+    float x0[8][CIN], x1[8][CIN];
+    auto gather = [&](const int* mg, float (*x)[CIN]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (mg[i] >= 0) {
+                const float* p = a.in + (long long)mg[i] * a.in_ld;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) x[i][ci] = p[ci];
+            } else {
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) x[i][ci] = 0.f;
+            }
+        }
+    };
+    gather(m[0], x1);
+    __syncthreads();                                  // weights in LDS
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) x0[i][ci] = x1[i][ci];
+            any |= m[g][i] >= 0;
+        }
+        if (g + 1 < G) gather(m[g + 1], x1);
+        if (__any(any)) {
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                unsigned h[4], l[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    in_max = fmaxf(in_max, fmaxf(fabsf(x0[2 * q][ci]), fabsf(x0[2 * q + 1][ci])));
+                    split2h(x0[2 * q][ci], x0[2 * q + 1][ci], h[q], l[q]);
+                }
+                const f16x8 a0 = __builtin_bit_cast(f16x8, make_uint4(h[0], h[1], h[2], h[3]));
+                const f16x8 a1 = __builtin_bit_cast(f16x8, make_uint4(l[0], l[1], l[2], l[3]));
+                const unsigned char* wb = w_s + ((g * CIN + ci) * 2) * 1024 + (l31 * 2 + half) * 16;
+                const f16x8 b0 = *reinterpret_cast<const f16x8*>(wb);
+                const f16x8 b1 = *reinterpret_cast<const f16x8*>(wb + 1024);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
+            }
+        }
+    }
+    if (in_max > 65000.f && a.range_flag) *a.range_flag = 1;
+    {
+        const float sc = a.acc_scale;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] *= sc;
+    }
+    __syncthreads();                                  // the weights are dead: the epilogue tile reuses their LDS
+    float (*ep)[EP_LD] = reinterpret_cast<float (*)[EP_LD]>(w_s + wave * 32 * EP_LD * 4);
+    epilogue_store_wide(a, acc, rows_s + wave * 32, 0, lane, ep);
+}
+
+// weights of conv_stem_mfma: [K][cin][32] fp32 -> per (group of 16 offsets, input channel): two planes (h, l) of
+// [col][half][8] fp16 = the B operand of v_mfma_f32_32x32x16_f16 with k = offset inside the group; offsets >= K are zero
+__global__ __launch_bounds__(256) void pack_weights_stem_h2(const float* __restrict__ w, int K, int cin,
+                                                            const float* __restrict__ col_scale, float mult,
+                                                            unsigned short* __restrict__ wp) {
+    const int total = 8 * cin * 32 * 2 * 4;           // (group, channel, col, half, pair of offsets)
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+        int r = t;
+        const int q = r % 4; r /= 4;
+        const int hf = r % 2; r /= 2;
+        const int col = r % 32; r /= 32;
+        const int ci = r % cin; r /= cin;
+        const int g = r;
+        const int j0 = g * 16 + hf * 8 + 2 * q;
+        const float sc = (col_scale ? col_scale[col] : 1.f) * mult;
+        const float v0 = j0 < K ? w[((long long)j0 * cin + ci) * 32 + col] * sc : 0.f;
+        const float v1 = j0 + 1 < K ? w[((long long)(j0 + 1) * cin + ci) * 32 + col] * sc : 0.f;
+        unsigned h, l;
+        split2h(v0, v1, h, l);
+        const long long base = ((((long long)(g * cin + ci) * 2) * 32 + col) * 2 + hf) * 8 + 2 * q;
+        *reinterpret_cast<unsigned*>(wp + base) = h;
+        *reinterpret_cast<unsigned*>(wp + base + 512) = l;
+    }
+}
+
 // ------------------------------------------------------------------ wave-independent flavour
 // For the big fine levels.  One wave owns 32 output rows (taken in mask-sorted order) and walks ONLY the
 // kernel offsets that at least one of its rows needs: no workgroup barriers, no LDS staging, no
@@ -2998,8 +3122,10 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
                "weight_pieces is 0/3 (bf16 triples), 2 (fp16 pairs) or 1 (single bf16 product)");
     CV_REQUIRE(d->weight_pieces != 1 || (d->weight_x6 && d->cin % KC == 0), CV_EINVAL,
                "weight_pieces = 1 needs weight_x6 from cv_sp_pack_weights_bf16_f32 and Cin %% 32 == 0");
-    CV_REQUIRE(d->weight_pieces != 2 || (d->weight_x6 && d->cin % KC == 0), CV_EINVAL,
-               "weight_pieces = 2 needs weight_x6 from cv_sp_pack_weights_h2_f32 and Cin %% 32 == 0");
+    const bool stem_h2 = d->weight_pieces == 2 && d->weight_x6 && d->cout == 32 && (d->cin == 3 || d->cin == 6) && d->K <= 128;
+    CV_REQUIRE(d->weight_pieces != 2 || stem_h2 || (d->weight_x6 && d->cin % KC == 0), CV_EINVAL,
+               "weight_pieces = 2 needs weight_x6 from cv_sp_pack_weights_h2_f32 and Cin %% 32 == 0 (or the stem shape with "
+               "cv_sp_pack_weights_stem_h2_f32)");
 
     {
         static const int dbg = getenv("CV_CONV_DBG") ? atoi(getenv("CV_CONV_DBG")) : 0;
@@ -3022,6 +3148,15 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
     }
     if (!vec && d->cout == 32 && (d->cin == 3 || d->cin == 6) && d->nbr && !d->row_perm && d->perm_groups <= 1 &&
         d->flavour == 0) {
+        if (d->weight_x6 && d->weight_pieces == 2 && d->K <= 128 && a.wide && !d->acc_in && d->j_begin == 0 &&
+            (d->j_end == 0 || d->j_end == d->K)) {
+            // matrix-core stem (weights from cv_sp_pack_weights_stem_h2_f32, BatchNorm scale folded in)
+            const unsigned gm = (unsigned)((d->n_out + TM - 1) / TM);
+            if (d->cin == 3) conv_stem_mfma<3><<<gm, THREADS, 0, st>>>(a);
+            else conv_stem_mfma<6><<<gm, THREADS, 0, st>>>(a);
+            CV_LAUNCH_CHECK();
+            return CV_OK;
+        }
         const unsigned grid = (unsigned)((d->n_out + STEM_ROWS - 1) / STEM_ROWS);
         static const int jc_env = getenv("CV_STEM_JC") ? atoi(getenv("CV_STEM_JC")) : 32;
         const int JC = std::max(1, std::min(jc_env, 160));
@@ -3366,6 +3501,17 @@ int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float
     else
         affine_rows<<<(unsigned)std::min<long long>((n * c + 255) / 256, 8192), 256, 0, st>>>(
             d_x, n, c, x_ld, d_scale, d_shift, d_residual, res_ld, relu, d_y, y_ld);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+int cv_sp_pack_weights_stem_h2_f32(const float* d_w, int K, int cin, const float* d_col_scale, int scale_log2, void* d_wp,
+                                   void* stream) {
+    CV_REQUIRE(d_w && d_wp && K > 0 && K <= 128 && (cin == 3 || cin == 6), CV_EINVAL,
+               "stem weights: K <= 128, Cin 3 or 6, 32 output channels");
+    CV_REQUIRE(scale_log2 >= -100 && scale_log2 <= 100, CV_EINVAL, "bad scale exponent");
+    pack_weights_stem_h2<<<64, 256, 0, static_cast<hipStream_t>(stream)>>>(d_w, K, cin, d_col_scale, ldexpf(1.f, scale_log2),
+                                                                           static_cast<unsigned short*>(d_wp));
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

@@ -422,7 +422,7 @@ def range_flag(dev):
 
 def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=None, relu=False,
                  out=None, flavour=0, row_perm=None, j_begin=0, j_end=0, acc_in=None, perm_groups=0,
-                 cache_weights=True, pieces=None, in_hl=False, out_hl=False, res_hl=False):
+                 cache_weights=True, pieces=None, in_hl=False, out_hl=False, res_hl=False, stem_mfma=False):
     """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout].
     in_hl / out_hl / res_hl: the operand is in the hl format (to_hl / from_hl; cv_conv_desc.in_hl), pieces=2 only.
     pieces=2: fp16-pair products (weights packed per call; the caller reads range_flag(dev) after synchronising);
@@ -467,6 +467,10 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
             wp6 = packed_weights_bf16(w)
         else:
             wp6 = packed_weights_x6(weight, w, cache_weights)
+    if stem_mfma and pieces == 2 and cin in (3, 6) and cout == 32 and K <= 128 and nbr is not None and flavour == 0:
+        # the matrix-core stem (conv_stem_mfma): BatchNorm scale folded into the fp16-pair weights
+        k = h2_scale_log2((w, scale))
+        wp6, acc_scale, flag, scale = packed_weights_stem_h2(w, scale, k), 2.0 ** -k, range_flag(dev), None
     ws = None
     if perm_groups > 1:
         ws = _workspace(dev, 4 * perm_groups * n_out * cout + 256)
@@ -615,6 +619,19 @@ def packed_weights_h2(w3, col_scale, scale_log2):
     with torch.cuda.device(w3.device):
         _lib.check(L.cv_sp_pack_weights_h2_f32(_ptr(w3), K, cin, cout, _ptr(col_scale), int(scale_log2), _ptr(wp),
                                                _stream(w3.device)), "cv_sp_pack_weights_h2_f32")
+    return wp
+
+
+def packed_weights_stem_h2(w3, col_scale, scale_log2):
+    """uncached: stem weights [K, 3|6, 32] (times an optional column scale and 2^scale_log2) as fp16 pairs in the
+    B-operand order of conv_stem_mfma (cv_sp_pack_weights_stem_h2_f32)"""
+    L = _lib.lib()
+    K, cin, cout = w3.shape
+    assert cout == 32
+    wp = torch.empty(8 * cin * 1024, dtype=torch.int16, device=w3.device)
+    with torch.cuda.device(w3.device):
+        _lib.check(L.cv_sp_pack_weights_stem_h2_f32(_ptr(w3), K, cin, _ptr(col_scale), int(scale_log2), _ptr(wp),
+                                                    _stream(w3.device)), "cv_sp_pack_weights_stem_h2_f32")
     return wp
 
 

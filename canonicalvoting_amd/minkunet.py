@@ -151,6 +151,8 @@ class MinkUNetBase(ResNetBase):
     PIECES = 2 if os.environ.get("CV_CONV_H2", "1") != "0" else 3
     # fp16-pair program: activations between the convolutions in the hl format (cv_conv_desc.in_hl)
     HL_BUFFERS = os.environ.get("CV_NET_HL", "1") != "0"
+    # fp16-pair program: the 5x5x5 stem as a GEMM over the gathered operand on the matrix cores (conv_stem_mfma)
+    STEM_MFMA = os.environ.get("CV_STEM_MFMA", "1") != "0"
     # False: forward() waits for the launches and checks the range flag itself; True: the caller does it after its
     # own synchronisation point (pipeline.detect_scene: no extra wait per scene)
     defer_range_check = False
@@ -272,6 +274,12 @@ class MinkUNetBase(ResNetBase):
                     w6 = ME.packed_weights_x6_scaled(w, scale)
                     w6_2 = ME.packed_weights_x6_scaled(w2, scale2)
                 in2, cin2, scale = src2, w2.shape[1], None
+            elif (pieces == 2 and hl and not vec and self.STEM_MFMA and w.shape[2] == 32 and w.shape[1] in (3, 6)
+                  and w.shape[0] <= 128):
+                # stem on the matrix cores: BatchNorm scale folded into the fp16-pair weights
+                k = ME.h2_scale_log2((w, scale))
+                w6 = ME.packed_weights_stem_h2(w, scale, k)
+                op_pieces, acc_scale, scale = 2, 2.0 ** -k, None
             elif vec and pieces == 1:
                 w6, op_pieces = ME.packed_weights_bf16(w), 1
             elif vec and pieces == 2:

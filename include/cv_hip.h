@@ -259,6 +259,11 @@ int cv_sp_pack_weights_h2_f32(const float* d_w, int K, int cin, int cout, const 
  * bits); the reference trains and evaluates in fp32 (train_joint.py:218), BASELINE config 3 asks for bf16. */
 int cv_sp_pack_weights_bf16_f32(const float* d_w, int K, int cin, int cout, const float* d_col_scale, void* d_wp,
                                 void* stream);
+/* Weights of the matrix-core stem (Cin 3 or 6 -> 32 channels, K <= 128 offsets; cv_conv_desc with weight_pieces = 2 and
+ * this buffer in weight_x6): (w * d_col_scale * 2^scale_log2) as fp16 pairs in MFMA B-operand order, 8 * cin * 2048 bytes;
+ * pass acc_scale = 2^-scale_log2 and no `scale` in the descriptor. */
+int cv_sp_pack_weights_stem_h2_f32(const float* d_w, int K, int cin, const float* d_col_scale, int scale_log2, void* d_wp,
+                                   void* stream);
 int cv_sp_tile_kw(int cin, int cout);
 int cv_sp_pack_weights_f32(const float* d_w, int K, int cin, int cout, float* d_wp, void* stream);
 

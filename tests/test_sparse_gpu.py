@@ -201,6 +201,39 @@ def test_hl_format_conv_matches_fp32_operand_conv(cuda, built_lib, cin, cout, k,
     ME.range_flag(cuda).zero_()
 
 
+@pytest.mark.parametrize("cin,n,hl", [(3, 1500, False), (3, 20000, True), (6, 1500, True)])
+def test_matrix_core_stem_matches_oracle(cuda, built_lib, cin, n, hl):
+    """5x5x5 stem as a GEMM over the gathered operand on the matrix cores (conv_stem_mfma, fp16 pairs, BatchNorm scale
+    folded into the packed weights) against the oracle's fp32 convolution, fp32 and hl-format output"""
+    coords, _ = scene_coords(4, n, small=n < 10000)
+    N = len(coords)
+    rng = np.random.default_rng(cin + n)
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    x = rng.uniform(-1, 1, (N, cin)).astype(np.float32)
+    w = (rng.normal(0, 1, (125, cin, 32)) / np.sqrt(cin * 16)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, 32).astype(np.float32)
+    shift = rng.normal(0, 0.2, 32).astype(np.float32)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(cuda, torch.int32))
+    nbr = cm.kernel_map(5, 1)
+    ref = so.conv(torch.from_numpy(x), torch.from_numpy(w), so.kernel_map(coords, coords, 5, 1, 1)).numpy()
+    ref = np.maximum(ref * scale + shift, 0)
+    out = torch.full((N, 64), -7.0, device=cuda)
+    if hl:
+        out = ME.to_hl(out)
+    ME.conv_forward(t(x), t(w), nbr, N, scale=t(scale), shift=t(shift), relu=True, out=out[:, 32:], pieces=2,
+                    stem_mfma=True, out_hl=hl)
+    got = (ME.from_hl(out) if hl else out).cpu().numpy()
+    assert rel_err(got[:, 32:], ref) < 2e-6
+    assert float(got[:, :32].min()) == -7.0 and float(got[:, :32].max()) == -7.0
+    assert int(ME.range_flag(cuda)[0]) == 0
+    # an input beyond the fp16 range raises the flag
+    xb = t(x).clone(); xb[5, 0] = 1e5
+    ME.conv_forward(xb, t(w), nbr, N, out=out[:, 32:], pieces=2, stem_mfma=True, out_hl=hl)
+    torch.cuda.synchronize()
+    assert int(ME.range_flag(cuda)[0]) == 1
+    ME.range_flag(cuda).zero_()
+
+
 def test_tile_conv_single_launch_and_row_perm(cuda, built_lib):
     """pair-compacted tile kernel on a coordinate set large enough to run without offset splits, in natural and
     permuted processing order, with the fused epilogue"""
