@@ -2896,8 +2896,9 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         // requested at once through global_load_lds and two dependent round trips instead of 3 + units - no faster)
         // (NS = 8 / 6 / 4 slots for NB = 1 / 2 / 3 measured: every layer 25-45 % slower - two workgroups per CU
         // instead of three or four cost more than the deeper prefetch gains, profiles/r2/hl_slots.txt)
-        // 256-row workgroups where the launch has plenty of tiles and no split-K
-        static const bool nw8_on = !(getenv("CV_HL_NW8") && atoi(getenv("CV_HL_NW8")) == 0);
+        // 256-row workgroups where the launch has plenty of tiles and no split-K: an experiment (CV_HL_NW8=1), off by
+        // default - measured slower, profiles/r2/hl_nw8.txt
+        static const bool nw8_on = getenv("CV_HL_NW8") && atoi(getenv("CV_HL_NW8")) != 0;
         if constexpr (NB <= 3) {
             if (nw8_on && !ax.xcd_tiles && a.n_out >= 16384 && (a.splits == 1 || a.perm_per_split)) {
                 dim3 g8((unsigned)((a.n_out + 255) / 256), grid.y, grid.z);

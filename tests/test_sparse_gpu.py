@@ -80,6 +80,56 @@ def test_spatial_row_sort_is_the_stable_sort_of_its_key(cuda, built_lib, seed, n
     assert np.array_equal(inv.cpu().numpy()[ref], np.arange(N))
 
 
+@pytest.mark.parametrize("n,batch", [(3000, 1), (2000, 2), (40000, 1)])
+def test_scene_plan_in_one_call_equals_the_step_by_step_plan(cuda, built_lib, n, batch):
+    """cv_sp_scene_plan (sort + levels + every map and order in one call, counts through pinned memory) against the
+    same plan built call by call (cv_sp_sort_rows, cv_sp_build_levels, cv_sp_kernel_map / up maps of a
+    CoordinateManager over the sorted rows): coordinate sets, kernel maps and transposed maps exact; the mask-sorted
+    orders are permutations that group equal masks (their order inside a class is not defined)"""
+    import ctypes
+    from canonicalvoting_amd import _lib
+    L = _lib.lib()
+    coords, _ = scene_coords(7, n, batch, small=n < 10000)
+    rng = np.random.default_rng(n)
+    coords = coords[rng.permutation(len(coords))]
+    N = len(coords)
+    c = torch.from_numpy(coords).to(cuda, torch.int32).contiguous()
+    cm = ME.CoordinateManager(c, num_levels=1, check=False, lazy=True)
+    cm_s, stem_map, out_map = cm.fused_plan(5)
+    # step by step
+    srt = torch.empty((N, 4), dtype=torch.int32, device=cuda)
+    perm = torch.empty(N, dtype=torch.int32, device=cuda)
+    inv = torch.empty(N, dtype=torch.int32, device=cuda)
+    ws = torch.empty(int(L.cv_sp_sort_workspace_bytes(N)), dtype=torch.uint8, device=cuda)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(L.cv_sp_sort_rows(c.data_ptr(), N, srt.data_ptr(), perm.data_ptr(), inv.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), st), "cv_sp_sort_rows")
+    ref = ME.CoordinateManager(srt)
+    assert torch.equal(out_map.view(-1), inv)
+    for ts in (1, 2, 4, 8, 16):
+        assert cm_s.num_rows(ts) == ref.num_rows(ts)
+        assert torch.equal(cm_s.coords[ts], ref.coords[ts])
+        assert torch.equal(cm_s.kernel_map(3, ts), ref.kernel_map(3, ts))
+    for ts in (1, 2, 4, 8):
+        assert torch.equal(cm_s.kernel_map(2, ts, 2), ref.kernel_map(2, ts, 2))
+        assert torch.equal(cm_s.up_map(2 * ts), ref.up_map(2 * ts))
+    # stem map: the sorted set's own 5x5x5 map with the sort permutation folded in
+    k5 = ref.kernel_map(5, 1)
+    expect = torch.where(k5 >= 0, perm[k5.clamp_min(0).long()], k5)
+    assert torch.equal(stem_map, expect)
+    G = ME.CoordinateManager.MASK_GROUPS
+    for ts in (1, 2):
+        if cm_s.num_rows(ts) >= ME.CoordinateManager.MASKED_MIN_ROWS:
+            mp = cm_s.mask_perms(3, ts, G).cpu().numpy()
+            nbr = cm_s.kernel_map(3, ts).cpu().numpy()
+            for g in range(G):
+                jb, je = 27 * g // G, 27 * (g + 1) // G
+                assert np.array_equal(np.sort(mp[g]), np.arange(nbr.shape[0]))
+                key = ((nbr[mp[g], jb:je] >= 0) * (1 << np.arange(je - jb))).sum(1)
+                change = np.nonzero(np.diff(key))[0]
+                assert len(np.unique(key)) == len(change) + 1           # every mask value is one contiguous run
+
+
 def test_duplicate_coordinates_rejected(cuda, built_lib):
     c = torch.tensor([[0, 1, 2, 3], [0, 1, 2, 3], [0, 4, 5, 6]], dtype=torch.int32, device=cuda)
     with pytest.raises(RuntimeError, match="duplicate"):      # reported at the first map request
