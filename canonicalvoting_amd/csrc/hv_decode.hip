@@ -181,12 +181,17 @@ __device__ __forceinline__ int wave_min_i32(int x) {
                min(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
 }
 
-template <bool IN_LDS>
+// MODE 1: the thread's entries in registers, the rare by-index reads from an LDS copy (lists <= 16 * T = 4096 at T = 256);
+// MODE 2: the same walk with the by-index reads from the global arrays (L2) - no 128 KB LDS copy, so 1024 threads take lists
+//         up to 16384 cells (300k-point scenes); MODE 0: everything from the global arrays (any length)
+template <int MODE, int T>
 __device__ __forceinline__ void dec_greedy(Geo geo, cv_decode_params prm, List L,
                                            const unsigned* __restrict__ list_n, Cand* __restrict__ cands,
                                            Stats* __restrict__ stats, int* __restrict__ n_cand_out) {
-    constexpr int CAP = IN_LDS ? GREEDY_CAP : 1;
-    constexpr int GREEDY_E = GREEDY_CAP / GREEDY_T;      // entries per thread of the register-resident walk
+    constexpr bool IN_REG = MODE != 0, IN_LDS = MODE == 1;
+    constexpr int GREEDY_E = 16;                         // entries per thread of the register-resident walk
+    constexpr int CAP = IN_LDS ? GREEDY_E * T : 1;
+    constexpr int GREEDY_T = T, GREEDY_W = T / 64;
     __shared__ unsigned l_xy[CAP];
     __shared__ int l_z[CAP];
     __shared__ float l_geo[5][CAP];
@@ -196,7 +201,7 @@ __device__ __forceinline__ void dec_greedy(Geo geo, cv_decode_params prm, List L
     float r_val[GREEDY_E];
     unsigned r_xy[GREEDY_E], dead = 0;
     int r_z[GREEDY_E], r_id[GREEDY_E];
-    if (IN_LDS) {
+    if (IN_REG) {
 #pragma unroll
         for (int j = 0; j < GREEDY_E; ++j) {
             const int k = (int)threadIdx.x + j * GREEDY_T;
@@ -206,7 +211,7 @@ __device__ __forceinline__ void dec_greedy(Geo geo, cv_decode_params prm, List L
             r_z[j] = ok ? L.z[k] : 0;
             r_id[j] = ((int)(r_xy[j] & 0xffffu) * geo.Y + (int)(r_xy[j] >> 16)) * geo.Z + r_z[j];
             dead |= ok ? 0u : (1u << j);
-            if (ok) {
+            if (ok && IN_LDS) {
                 l_xy[k] = r_xy[j];
                 l_z[k] = r_z[j];
                 for (int q = 0; q < 5; ++q) l_geo[q][k] = L.geo[q * L.cap + k];
@@ -237,7 +242,7 @@ __device__ __forceinline__ void dec_greedy(Geo geo, cv_decode_params prm, List L
         //      what is left (largest value, lowest flat index on ties: eval_joint.py:205)
         float bv = -1.f;
         int bpos = -1, bid = 0x7fffffff;
-        if constexpr (IN_LDS) {
+        if constexpr (IN_REG) {
             // the thread's entries live in registers (r_*; loaded once): a pass is VALU work only.  The first version
             // walked them in LDS - two dependent LDS round trips per entry with one wave per SIMD and nothing to
             // overlap them with: 10k cycles per pass for 13 entries per thread.
@@ -255,8 +260,8 @@ __device__ __forceinline__ void dec_greedy(Geo geo, cv_decode_params prm, List L
                     const int j = __ffs(near) - 1;
                     near &= near - 1;
                     const int k = (int)threadIdx.x + j * GREEDY_T;
-                    const unsigned xy = l_xy[k];
-                    const int z = l_z[k];
+                    const unsigned xy = IN_LDS ? l_xy[k] : L.xy[k];
+                    const int z = IN_LDS ? l_z[k] : L.z[k];
                     const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
                     bool kill = x >= cx - e && x < cx + hp && y >= cy - e && y < cy + hp && z >= cz - e && z < cz + hp;
                     if (!kill && x >= clo0 && x <= chi0 && y >= clo1 && y <= chi1 && z >= clo2 && z <= chi2) {
@@ -361,14 +366,23 @@ __device__ __forceinline__ void dec_greedy(Geo geo, cv_decode_params prm, List L
     if (threadIdx.x == 0) { n_cand_out[0] = it; n_cand_out[1] = truncated ? 1 : 0; }
 }
 
-// the list length is only known on the device: lists up to GREEDY_CAP entries are walked in LDS, longer ones by
+// the list length is only known on the device: lists up to GREEDY_CAP entries are walked in registers + LDS, longer ones by
 // the same code over the global arrays (L2-resident)
 __global__ __launch_bounds__(GREEDY_T) void dec_greedy_dispatch(Geo geo, cv_decode_params prm, List L,
                                                                 const unsigned* __restrict__ list_n,
                                                                 Cand* __restrict__ cands, Stats* __restrict__ stats,
                                                                 int* __restrict__ n_cand_out) {
-    if (*list_n <= (unsigned)GREEDY_CAP) dec_greedy<true>(geo, prm, L, list_n, cands, stats, n_cand_out);
-    else dec_greedy<false>(geo, prm, L, list_n, cands, stats, n_cand_out);
+    if (*list_n <= (unsigned)GREEDY_CAP) dec_greedy<1, GREEDY_T>(geo, prm, L, list_n, cands, stats, n_cand_out);
+    else dec_greedy<0, GREEDY_T>(geo, prm, L, list_n, cands, stats, n_cand_out);
+}
+// big grids (the host picks this launch from the cell count): 1024 threads, lists up to 16384 cells in registers
+constexpr int GREEDY_T_BIG = 1024;
+__global__ __launch_bounds__(GREEDY_T_BIG) void dec_greedy_dispatch_big(Geo geo, cv_decode_params prm, List L,
+                                                                        const unsigned* __restrict__ list_n,
+                                                                        Cand* __restrict__ cands, Stats* __restrict__ stats,
+                                                                        int* __restrict__ n_cand_out) {
+    if (*list_n <= 16u * GREEDY_T_BIG) dec_greedy<2, GREEDY_T_BIG>(geo, prm, L, list_n, cands, stats, n_cand_out);
+    else dec_greedy<0, GREEDY_T_BIG>(geo, prm, L, list_n, cands, stats, n_cand_out);
 }
 
 // packed host result: [0]=n_cand [1]=n_boxes [2]=truncated, then arrays sized by max_iters
@@ -669,7 +683,10 @@ int cv_decode_f32(float* d_grid_obj, const float* d_grid_rot, const float* d_gri
     CV_LAUNCH_CHECK();
     // the list length is only known on the device: the LDS-resident walker takes lists up to GREEDY_CAP, longer ones
     // the same code over the global arrays - both are launched, the one that does not apply returns at once
-    dec_greedy_dispatch<<<1, GREEDY_T, 0, st>>>(geo, *params, L, list_n, cands, stats, n_cand);
+    // (grids beyond 4 M cells - 300k-point scenes - list more cells than the 256-thread walker keeps in registers)
+    static const long long big_cells = getenv("CV_DEC_BIG_CELLS") ? atoll(getenv("CV_DEC_BIG_CELLS")) : (4ll << 20);
+    if (G > big_cells) dec_greedy_dispatch_big<<<1, GREEDY_T_BIG, 0, st>>>(geo, *params, L, list_n, cands, stats, n_cand);
+    else dec_greedy_dispatch<<<1, GREEDY_T, 0, st>>>(geo, *params, L, list_n, cands, stats, n_cand);
     CV_LAUNCH_CHECK();
     // candidate groups of 8 over blockIdx.y (the count is only known on the device: groups beyond it return at once)
     const dim3 bgrid((unsigned)((n + 255) / 256), (unsigned)std::min((M + 7) / 8, 8));
