@@ -3042,7 +3042,8 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
     // (measured without gain: sizing by the chip's resident workgroup slots, floor(256 x waves-per-SIMD / tiles), so that
     // no second round of workgroups starts: 257 vs 265 scenes/s one scene in flight, 401-409 vs 410-412 with six)
     s = std::min(s, units);
-    const long long by_traffic = (24ll << 20) / std::max<long long>(1, n_out * cout * 4);   // <= 24 MB of partials
+    static const long long traffic_mb = getenv("CV_SPLIT_TRAFFIC_MB") ? atoll(getenv("CV_SPLIT_TRAFFIC_MB")) : 24;
+    const long long by_traffic = (traffic_mb << 20) / std::max<long long>(1, n_out * cout * 4);   // <= 24 MB of partials
     s = std::min(s, std::max<long long>(by_traffic, 2));
     s = std::min<long long>(s, 64);
     return (int)std::max<long long>(s, 1);
@@ -3086,7 +3087,8 @@ extern "C" {
 size_t cv_sp_conv_workspace_bytes(long long n_out, int cout, int K) {
     if (n_out <= 0 || cout <= 0 || K <= 0) return 0;
     const size_t one = sizeof(float) * (size_t)n_out * (size_t)cout;
-    return 256 + std::min<size_t>(64 * one, std::max<size_t>((size_t)48 << 20, 2 * one));   // see pick_splits
+    return 256 + std::min<size_t>(64 * one, std::max<size_t>((size_t)48 << 20, 3 * one));   // see pick_splits (and the
+                                                                                            // 3-way split of conv_hl)
 }
 
 int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
@@ -3209,8 +3211,18 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         }
         return launch_tile(a, st);
     } else if (d->flavour == 0) {
-        const int sp = pick_splits(d->n_out, d->cout, je - jb, d->cin, vec);
+        int sp = pick_splits(d->n_out, d->cout, je - jb, d->cin, vec);
+        if (d->in_hl) {
+            // conv_hl keeps the map entries of at most WP_NPRE offsets per workgroup (there is no second kernel for the hl
+            // format): launches that would not be split (>= 384 tiles below the mask-sorting threshold, e.g. 13k rows x
+            // 256 columns) are split over just enough workgroups
+            const int nj = je - jb;
+            const int per_wg = sp <= 1 ? nj : (nj + sp - 1) / sp + 1;
+            if (per_wg > WP_NPRE) sp = std::max(sp, (nj + WP_NPRE - 2) / (WP_NPRE - 1));
+        }
         const size_t need = sizeof(float) * (size_t)sp * (size_t)d->n_out * (size_t)d->cout;
+        CV_REQUIRE(!d->in_hl || sp <= 1 || (d->ws && d->ws_bytes >= need), CV_ENOMEM,
+                   "hl-format convolution needs a workspace of %zu bytes (cv_sp_conv_workspace_bytes)", need);
         if (sp > 1 && d->ws && d->ws_bytes >= need) {
             a.splits = sp;
             a.partial = static_cast<float*>(d->ws);

@@ -193,6 +193,8 @@ def test_conv_matches_oracle(cuda, built_lib, cin, cout, k, flavour):
 
 
 @pytest.mark.parametrize("cin,cout,k,n,masked", [(32, 32, 3, 1500, False), (64, 96, 3, 1500, False), (96, 64, 1, 1500, False),
+                                                 (32, 256, 3, 13000, False),       # >= 384 tiles, not mask-sorted: forced 3-way split
+
                                                  (128, 128, 3, 600, False), (256, 256, 3, 300, False),
                                                  (32, 32, 2, 1500, False), (96, 96, 3, 20000, True),
                                                  (128, 96, 3, 20000, True)])
@@ -228,7 +230,10 @@ def test_hl_format_conv_matches_fp32_operand_conv(cuda, built_lib, cin, cout, k,
         conv = lambda xin, **e: ME.conv_forward(xin, w, nbr, n_out, **kw, **e)
     ref0 = conv(x)
     got0 = conv(xh, in_hl=True)
-    assert torch.equal(got0, ref0)
+    if n == 13000:      # the hl launch is split three ways (conv_hl holds <= 10 offsets per workgroup), the fp32 one is not
+        assert rel_err(got0.cpu().numpy(), ref0.cpu().numpy()) < 1e-6
+    else:
+        assert torch.equal(got0, ref0)
     ref1 = conv(x, scale=scale, shift=shift, residual=res, relu=True)
     # hl in / residual / out inside wider buffers (column windows at multiples of 32 channels)
     xin = torch.zeros((N, cin + 64), device=cuda); xin[:, 32:32 + cin] = x
