@@ -47,7 +47,7 @@ class SceneMaps(ctypes.Structure):
     """struct cv_scene_maps (include/cv_hip.h)"""
     _fields_ = [("stem", ctypes.c_longlong), ("out", ctypes.c_longlong), ("down", ctypes.c_longlong * 4),
                 ("k3", ctypes.c_longlong * 5), ("up", ctypes.c_longlong * 4), ("mask_perm", ctypes.c_longlong * 5),
-                ("up_perm", ctypes.c_longlong * 4), ("scratch", ctypes.c_longlong)]
+                ("up_perm", ctypes.c_longlong * 4), ("scratch", ctypes.c_longlong), ("bitmap", ctypes.c_longlong)]
 
 
 class NetBuf(ctypes.Structure):

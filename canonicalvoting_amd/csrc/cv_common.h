@@ -54,9 +54,18 @@ struct CvMapJob {            // kernel map: out set looked up in an input set's 
     int k, ts;
     int32_t* nbr;
     const int32_t* compose;  // optional: store compose[row] instead of row (a permutation folded into the map)
+    const unsigned* bitmap;  // optional (ts == 1 maps of the set the bitmap was built from): occupancy bits in front of the
+    const int32_t* bbox;     // hash probes, see cv_sp_occupancy_bitmap; bbox = the 8 ints of cv_sp_sort_rows' bounds
 };
 constexpr int CV_MAX_MAP_JOBS = 12;
 int cv_sp_kernel_maps_batch(const CvMapJob* jobs, int n_jobs, void* stream);
+// Occupancy bitmap of a coordinate set over its bounding box (d_bbox: mm[0..2] = min, mm[3..5] = -max per axis, mm[6] =
+// -max batch, as left by cv_sp_sort_rows at the start of its workspace): 87 % of a scene's kernel-map lookups are
+// misses, each ~2 random probes into a 2 MB table; a bit test against ~0.5 MB with neighbouring lookups in the same words
+// answers them.  d_bits: CV_BITMAP_WORDS words; when the box does not fit (or a batch index is negative) the kernels
+// that take the bitmap ignore it (they re-derive the same test from the bounds).  Two launches, asynchronous.
+constexpr long long CV_BITMAP_WORDS = 1ll << 20;
+int cv_sp_occupancy_bitmap(const int32_t* d_coords, long long n, const int32_t* d_bbox, unsigned* d_bits, void* stream);
 
 struct CvUpJob { const int32_t* nbr_down; long long n_coarse; int32_t* up; };
 int cv_sp_up_maps_batch(const CvUpJob* jobs, int n_jobs, void* stream);      // the up arrays must be pre-filled with -1

@@ -5,6 +5,7 @@
 // C call per scene issues every launch: the Python layer's per-conv overhead (descriptor marshalling, tensor
 // allocation, ~35 us x 63) is what bounded the scene rate once several scenes were in flight.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -32,6 +33,7 @@ static void scene_maps_layout(const long long* rows, long long n_orig, int stem_
     o->k3[0] = take((size_t)rows[0] * 27);
     o->mask_perm[0] = (mask_groups > 1 && rows[0] >= masked_min_rows) ? take(mp_w * rows[0]) : -1;
     o->scratch = take((size_t)(5 * std::max(mask_groups, 1) + 4) * 1024);
+    o->bitmap = take((size_t)CV_BITMAP_WORDS);          // occupancy bits of the level-0 set (cv_sp_scene_plan only)
     o->out = -1;                       // (the sort's inverse permutation is the final map)
     (void)n_orig;
     for (int i = 0; i < 4; ++i) o->down[i] = take((size_t)rows[i + 1] * 8);
@@ -55,12 +57,18 @@ size_t cv_sp_scene_maps_words(const long long* level_rows, long long n_orig, int
 // the finest level and its mask-sorted orders
 static int scene_maps_level0(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
                              long long cap, long long n, const int32_t* d_perm, int stem_k, int mask_groups,
-                             const cv_scene_maps& o, int32_t* d_arena, void* stream) {
+                             const cv_scene_maps& o, int32_t* d_arena, const int32_t* d_bbox, void* stream) {
+    const unsigned* bits = nullptr;
+    if (d_bbox) {       // occupancy bitmap in front of the hash probes (bounds from the sort; cv_sp_scene_plan)
+        bits = reinterpret_cast<const unsigned*>(d_arena + o.bitmap);
+        const int rc0 = cv_sp_occupancy_bitmap(d_coords[0], n, d_bbox, reinterpret_cast<unsigned*>(d_arena + o.bitmap), stream);
+        if (rc0 != CV_OK) return rc0;
+    }
     CvMapJob mj[2];
     // stem: sorted rows <- rows of the ORIGINAL order = the sorted set's own map with the permutation folded in
     // (the caller's set needs no hash table of its own); the final original <- sorted map is the sort's inverse
-    mj[0] = {d_coords[0], n, d_keys[0], d_vals[0], cap, stem_k, 1, d_arena + o.stem, d_perm};
-    mj[1] = {d_coords[0], n, d_keys[0], d_vals[0], cap, 3, 1, d_arena + o.k3[0], nullptr};
+    mj[0] = {d_coords[0], n, d_keys[0], d_vals[0], cap, stem_k, 1, d_arena + o.stem, d_perm, bits, d_bbox};
+    mj[1] = {d_coords[0], n, d_keys[0], d_vals[0], cap, 3, 1, d_arena + o.k3[0], nullptr, bits, d_bbox};
     int rc = cv_sp_kernel_maps_batch(mj, 2, stream);
     if (rc != CV_OK) return rc;
     if (o.mask_perm[0] >= 0) {
@@ -79,9 +87,9 @@ static int scene_maps_coarse(int32_t* const* d_coords, const unsigned long long*
     CvMapJob mj[CV_MAX_MAP_JOBS];
     int nm = 0;
     for (int i = 0; i < 4; ++i)
-        mj[nm++] = {d_coords[i + 1], level_rows[i + 1], d_keys[i], d_vals[i], cap, 2, 1 << i, d_arena + o.down[i], nullptr};
+        mj[nm++] = {d_coords[i + 1], level_rows[i + 1], d_keys[i], d_vals[i], cap, 2, 1 << i, d_arena + o.down[i], nullptr, nullptr, nullptr};
     for (int i = 1; i < 5; ++i)
-        mj[nm++] = {d_coords[i], level_rows[i], d_keys[i], d_vals[i], cap, 3, 1 << i, d_arena + o.k3[i], nullptr};
+        mj[nm++] = {d_coords[i], level_rows[i], d_keys[i], d_vals[i], cap, 3, 1 << i, d_arena + o.k3[i], nullptr, nullptr, nullptr};
     int rc = cv_sp_kernel_maps_batch(mj, nm, stream);
     if (rc != CV_OK) return rc;
     {   // the four transposed maps are neighbours in the arena: one fill
@@ -116,7 +124,7 @@ int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* 
     size_t total = 0;
     scene_maps_layout(level_rows, n_orig, stem_k, mask_groups, masked_min_rows, &o, &total);
     CV_REQUIRE(arena_words >= total, CV_ENOMEM, "scene map arena too small");
-    int rc = scene_maps_level0(d_coords, d_keys, d_vals, cap, n_orig, d_perm, stem_k, mask_groups, o, d_arena, stream);
+    int rc = scene_maps_level0(d_coords, d_keys, d_vals, cap, n_orig, d_perm, stem_k, mask_groups, o, d_arena, nullptr, stream);
     if (rc != CV_OK) return rc;
     return scene_maps_coarse(d_coords, d_keys, d_vals, cap, level_rows, mask_groups, o, d_arena, stream);
 }
@@ -177,7 +185,10 @@ int cv_sp_scene_plan(const int32_t* d_input, long long n, int32_t* d_perm, int32
     cv_scene_maps o;
     size_t total = 0;
     scene_maps_layout(rows, n, stem_k, mask_groups, masked_min_rows, &o, &total);
-    rc = scene_maps_level0(d_coords, d_keys, d_vals, cap, n, d_perm, stem_k, mask_groups, o, d_arena, stream);
+    static const bool bitmap_on = !(getenv("CV_MAP_BITMAP") && atoi(getenv("CV_MAP_BITMAP")) == 0);
+    // (the sort leaves its bounds - min, -max per axis, -max batch - in the first 8 ints of its workspace)
+    rc = scene_maps_level0(d_coords, d_keys, d_vals, cap, n, d_perm, stem_k, mask_groups, o, d_arena,
+                           bitmap_on ? static_cast<const int32_t*>(d_sort_ws) : nullptr, stream);
     if (rc != CV_OK) return rc;
     CV_HIP_CHECK(hipEventSynchronize(ps.ev));          // the counts have landed; the level-0 maps are still being built
     for (int i = 0; i < 8; ++i) h_counts[i] = ps.h_pinned[i];

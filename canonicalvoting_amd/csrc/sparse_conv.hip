@@ -1006,7 +1006,7 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 // list in LDS, the loop is a counted loop over that list with per-thread invariants (weight-tile source / LDS offsets,
 // 32-bit row offsets) hoisted - the first version spent ~150 vector and ~250 scalar instructions per unit on the walk
 // (advance / skip_dead, 64-bit address arithmetic, spilled scalars) around 18 MFMAs.
-constexpr int HL_MAX_UNITS = 160;
+constexpr int HL_MAX_UNITS = 512;      // live units of one workgroup: <= 10 offsets x Cin / 32 chunks + the second source's (host-checked)
 template <int NB, int NS, int NW>
 __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS > 3 ? 2 : 3)) void conv_hl(ConvArgs a) {
     static_assert(NS == 3, "three unit slots");
@@ -2889,6 +2889,8 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         gridx.x = (grid.x + 7) / 8 * 8;
     }
     if (a.in_hl) {
+        CV_REQUIRE(per_wg * (a.cin / KC) + (a.in2 ? a.cin2 / KC : 0) <= HL_MAX_UNITS, CV_EINVAL,
+                   "hl-format convolution: more than %d units per workgroup (Cin too wide)", HL_MAX_UNITS);
         CV_REQUIRE(vec && a.wp6 && a.pieces == 2 && a.wide && per_wg <= WP_NPRE && NB <= 3, CV_EINVAL,
                    "hl-format input needs the fp16-pair weights, Cin %% 32 == 0, 16-byte aligned operands and at most %d "
                    "kernel offsets per workgroup", WP_NPRE);

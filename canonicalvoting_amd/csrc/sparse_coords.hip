@@ -231,6 +231,55 @@ __global__ __launch_bounds__(256) void build_up_map(const int* __restrict__ nbr_
     }
 }
 
+// ---- occupancy bitmap over the bounding box (cv_sp_occupancy_bitmap) ----
+struct BitBox { int mn[3], d[3], nb; bool ok; };
+__device__ __forceinline__ BitBox bitbox(const int* __restrict__ mm) {
+    BitBox b;
+    long long cells = 1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        b.mn[k] = mm[k];
+        b.d[k] = -mm[3 + k] - mm[k] + 1;
+        cells *= b.d[k] > 0 ? b.d[k] : 0;
+    }
+    b.nb = -mm[6] + 1;
+    cells *= b.nb > 0 ? b.nb : 0;
+    b.ok = cells > 0 && cells <= CV_BITMAP_WORDS * 32 && mm[7] == 1;      // mm[7] == 1: no negative batch index seen
+    return b;
+}
+// bit of (batch, x, y, z), or -1 outside the box
+__device__ __forceinline__ long long bitbox_index(const BitBox& b, int bi, int x, int y, int z) {
+    const int ux = x - b.mn[0], uy = y - b.mn[1], uz = z - b.mn[2];
+    if ((unsigned)ux >= (unsigned)b.d[0] || (unsigned)uy >= (unsigned)b.d[1] || (unsigned)uz >= (unsigned)b.d[2] ||
+        (unsigned)bi >= (unsigned)b.nb) return -1;
+    return (((long long)bi * b.d[0] + ux) * b.d[1] + uy) * b.d[2] + uz;
+}
+__global__ __launch_bounds__(256) void bitmap_clear(const int* __restrict__ coords, long long n, int* __restrict__ mm,
+                                                    unsigned* __restrict__ bits) {
+    // mm[7] = "the bitmap may be trusted": set here, taken back by bitmap_set when a row falls outside the bounds (a negative
+    // batch index: the sort tracks the largest batch index only and such inputs fail the key-window check anyway)
+    if (blockIdx.x == 0 && threadIdx.x == 0) mm[7] = 1;
+    long long cells = 1;
+    for (int k = 0; k < 3; ++k) { const int d = -mm[3 + k] - mm[k] + 1; cells *= d > 0 ? d : 0; }
+    const int nb = -mm[6] + 1;
+    cells *= nb > 0 ? nb : 0;
+    if (cells <= 0 || cells > CV_BITMAP_WORDS * 32) return;
+    const long long words = (cells + 31) / 32;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < words; i += (long long)gridDim.x * 256) bits[i] = 0u;
+    (void)coords; (void)n;
+}
+__global__ __launch_bounds__(256) void bitmap_set(const int* __restrict__ coords, long long n, int* __restrict__ mm,
+                                                  unsigned* __restrict__ bits) {
+    const BitBox b = bitbox(mm);
+    if (!b.ok) return;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        const long long bit = bitbox_index(b, c.x, c.y, c.z, c.w);
+        if (bit >= 0) atomicOr(&bits[bit >> 5], 1u << (bit & 31));
+        else mm[7] = 0;                    // a row outside its own bounds (negative batch index): do not trust the bitmap
+    }
+}
+
 // all kernel maps of a scene in one launch: blockIdx.x ranges per job
 struct MapJobsDev {
     CvMapJob j[CV_MAX_MAP_JOBS];
@@ -238,23 +287,52 @@ struct MapJobsDev {
     int n;
 };
 
+// one job's lookups; KC = k^3 as a compile-time constant (the index split t -> (row, offset) is a constant division and the
+// 32-bit form is used whenever the map has fewer than 2^31 entries: the generic 64-bit division by a run-time K was most of
+// what a lookup cost once the bitmap answers the misses)
+template <int KK>
+__device__ __forceinline__ void map_job(const CvMapJob& jb, int nblk, int blk) {
+    const int k = KK > 0 ? (KK == 125 ? 5 : KK == 27 ? 3 : 2) : jb.k;
+    const int K = KK > 0 ? KK : k * k * k, ts = jb.ts;
+    const int lo = (k & 1) ? -(k / 2) : 0;
+    const long long mask = jb.cap - 1;
+    BitBox bb;
+    bb.ok = false;
+    if (jb.bitmap && ts == 1) bb = bitbox(jb.bbox);
+    const long long total = jb.n_out * K;
+    const bool small = total < (1ll << 31);
+    for (long long t = blk * 256ll + threadIdx.x; t < total; t += (long long)nblk * 256) {
+        long long u;
+        int j;
+        if (small) { const unsigned tu = (unsigned)t, uu = tu / (unsigned)K; u = uu; j = (int)(tu - uu * (unsigned)K); }
+        else { u = t / K; j = (int)(t - u * K); }
+        const int ox = lo + j % k, oy = lo + (j / k) % k, oz = lo + j / (k * k);
+        const int4 c = reinterpret_cast<const int4*>(jb.out_coords)[u];
+        int r = -1;
+        bool probe = true;
+        if (bb.ok) {                       // most lookups are misses: one bit answers them
+            const long long bit = bitbox_index(bb, c.x, c.y + ox, c.z + oy, c.w + oz);
+            probe = bit >= 0 && ((jb.bitmap[bit >> 5] >> (bit & 31)) & 1u);
+        }
+        if (probe) {
+            const long long slot = table_find(jb.keys, mask, pack_key(c.x, c.y + ox * ts, c.z + oy * ts, c.w + oz * ts));
+            r = slot >= 0 ? jb.vals[slot] : -1;
+            if (jb.compose && r >= 0) r = jb.compose[r];
+        }
+        jb.nbr[t] = r;
+    }
+}
+
 __global__ __launch_bounds__(256) void build_kernel_maps(const MapJobsDev jobs) {
     int ji = 0;
     while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.block_begin[ji + 1]) ++ji;
     const CvMapJob& jb = jobs.j[ji];
     const int nblk = jobs.block_begin[ji + 1] - jobs.block_begin[ji], blk = blockIdx.x - jobs.block_begin[ji];
-    const int k = jb.k, K = k * k * k, ts = jb.ts;
-    const int lo = (k & 1) ? -(k / 2) : 0;
-    const long long mask = jb.cap - 1;
-    for (long long t = blk * 256ll + threadIdx.x; t < jb.n_out * K; t += (long long)nblk * 256) {
-        const long long u = t / K;
-        const int j = (int)(t - u * K);
-        const int ox = lo + j % k, oy = lo + (j / k) % k, oz = lo + j / (k * k);
-        const int4 c = reinterpret_cast<const int4*>(jb.out_coords)[u];
-        const long long slot = table_find(jb.keys, mask, pack_key(c.x, c.y + ox * ts, c.z + oy * ts, c.w + oz * ts));
-        int r = slot >= 0 ? jb.vals[slot] : -1;
-        if (jb.compose && r >= 0) r = jb.compose[r];
-        jb.nbr[t] = r;
+    switch (jb.k) {
+        case 5: map_job<125>(jb, nblk, blk); break;
+        case 3: map_job<27>(jb, nblk, blk); break;
+        case 2: map_job<8>(jb, nblk, blk); break;
+        default: map_job<0>(jb, nblk, blk); break;
     }
 }
 
@@ -467,6 +545,17 @@ int cv_sp_kernel_maps_batch(const CvMapJob* jobs, int n_jobs, void* stream) {
     }
     d.block_begin[n_jobs] = total;
     build_kernel_maps<<<total, 256, 0, static_cast<hipStream_t>(stream)>>>(d);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+int cv_sp_occupancy_bitmap(const int32_t* d_coords, long long n, const int32_t* d_bbox, unsigned* d_bits, void* stream) {
+    CV_REQUIRE(d_coords && d_bbox && d_bits && n > 0, CV_EINVAL, "bad bitmap arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int* mm = const_cast<int*>(d_bbox);
+    bitmap_clear<<<256, 256, 0, st>>>(d_coords, n, mm, d_bits);
+    CV_LAUNCH_CHECK();
+    bitmap_set<<<grid_for(n), 256, 0, st>>>(d_coords, n, mm, d_bits);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }
