@@ -1008,8 +1008,8 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 // (advance / skip_dead, 64-bit address arithmetic, spilled scalars) around 18 MFMAs.
 constexpr int HL_MAX_UNITS = 512;      // live units of one workgroup: <= 10 offsets x Cin / 32 chunks + the second source's (host-checked)
 template <int NB, int NS, int NW>
-__global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS > 3 ? 2 : 3)) void conv_hl(ConvArgs a) {
-    static_assert(NS == 3, "three unit slots");
+__global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS == 2 ? 4 : 3)) void conv_hl(ConvArgs a) {
+    static_assert(NS == 3 || NS == 2, "three unit slots (or two: the loads of unit k + 2 follow the MFMAs of unit k)");
     constexpr int TMv = NW * 32, THv = NW * 64;
     constexpr int B_BYTES = 2 * NB * 32 * 64, EP_BYTES = NW * 32 * EP_LD * 4;
     constexpr int SM_BYTES = NS * B_BYTES > EP_BYTES ? NS * B_BYTES : EP_BYTES;
@@ -1120,8 +1120,10 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS > 3 ? 2 : 3)) void conv_h
     const unsigned char* const in_b = reinterpret_cast<const unsigned char*>(a.in);
     const unsigned char* const in2_b = reinterpret_cast<const unsigned char*>(a.in2);
 
-    uint4 ra[3][4], rb[3][B_PER];
-    bool live[3] = {false, false, false};
+    uint4 ra[NS][4], rb[NS][B_PER];
+    bool live[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) live[q] = false;
     auto load = [&](auto S, int k) {                  // unit k of the list -> slot S
         constexpr int sl = decltype(S)::value;
         const int code = __builtin_amdgcn_readfirstlane(units_s[k]);
@@ -1180,20 +1182,38 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS > 3 ? 2 : 3)) void conv_h
     if (n_units > 0) stage_b(S0{});
     // step: unit k in slot s.  barrier: tile k visible, tile k - 1 consumed by everyone (its slot takes the loads of unit
     // k + 2); the tile of unit k + 1 goes to LDS; MFMAs of unit k
-    auto step = [&](auto S, auto SN, auto SP, int k) {
-        constexpr int sl = decltype(S)::value;
-        __syncthreads();
-        if (k + 1 < n_units) stage_b(SN);
-        if (k + 2 < n_units) load(SP, k + 2);
-        if (live[sl] && (!(CV_HL_ABL & 2) || a.acc_scale == 12345.f)) compute(S);
-    };
+    if constexpr (NS == 3) {
+        auto step = [&](auto S, auto SN, auto SP, int k) {
+            constexpr int sl = decltype(S)::value;
+            __syncthreads();
+            if (k + 1 < n_units) stage_b(SN);
+            if (k + 2 < n_units) load(SP, k + 2);
+            if (live[sl] && (!(CV_HL_ABL & 2) || a.acc_scale == 12345.f)) compute(S);
+        };
 #pragma unroll 1
-    for (int k = 0; k < n_units; k += 3) {
-        step(S0{}, S1{}, S2{}, k);
-        if (k + 1 >= n_units) break;
-        step(S1{}, S2{}, S0{}, k + 1);
-        if (k + 2 >= n_units) break;
-        step(S2{}, S0{}, S1{}, k + 2);
+        for (int k = 0; k < n_units; k += 3) {
+            step(S0{}, S1{}, S2{}, k);
+            if (k + 1 >= n_units) break;
+            step(S1{}, S2{}, S0{}, k + 1);
+            if (k + 2 >= n_units) break;
+            step(S2{}, S0{}, S1{}, k + 2);
+        }
+    } else {
+        // two slots: the registers of unit k take the loads of unit k + 2 once its MFMAs are issued (fewer registers:
+        // four workgroups per CU instead of three)
+        auto step = [&](auto S, auto SN, int k) {
+            constexpr int sl = decltype(S)::value;
+            __syncthreads();
+            if (k + 1 < n_units) stage_b(SN);
+            if (live[sl] && (!(CV_HL_ABL & 2) || a.acc_scale == 12345.f)) compute(S);
+            if (k + 2 < n_units) load(S, k + 2);
+        };
+#pragma unroll 1
+        for (int k = 0; k < n_units; k += 2) {
+            step(S0{}, S1{}, k);
+            if (k + 1 >= n_units) break;
+            step(S1{}, S0{}, k + 1);
+        }
     }
     __syncthreads();                                 // weight tiles are dead: the epilogue tile reuses their LDS
     {
@@ -2906,7 +2926,12 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
                 dim3 g8((unsigned)((a.n_out + 255) / 256), grid.y, grid.z);
                 conv_hl<NB, 3, 8><<<g8, 512, 0, st>>>(ax);
             } else {
-                conv_hl<NB, 3, 4><<<gridx, THREADS, 0, st>>>(ax);
+                // two unit slots for the 32- and 64-column workgroups (85 / 113 VGPRs: five / four workgroups per CU instead
+                // of four / three; net 2.53 -> 2.48 ms, 474 -> 485 scenes/s); three for 96 columns (two slots spill there:
+                // 2.62 ms).  CV_HL_NS2: bit nb-1 = two slots for NB = nb
+                static const int ns2 = getenv("CV_HL_NS2") ? atoi(getenv("CV_HL_NS2")) : 3;
+                if ((ns2 >> (NB - 1)) & 1) conv_hl<NB, 2, 4><<<gridx, THREADS, 0, st>>>(ax);
+                else conv_hl<NB, 3, 4><<<gridx, THREADS, 0, st>>>(ax);
             }
         }
         CV_LAUNCH_CHECK();
