@@ -189,8 +189,11 @@ class CoordinateManager:
             self._maps[key] = m
         return m
 
-    # mask-sorted offset groups of the 3x3x3 convs: levels with at least MASKED_MIN_ROWS rows get MASK_GROUPS orders
-    MASK_GROUPS = int(os.environ.get("CV_NET_MASK_GROUPS", "4"))
+    # mask-sorted offset groups of the 3x3x3 convs: levels with at least MASKED_MIN_ROWS rows get MASK_GROUPS orders.
+    # Three groups since the hl-format kernels (round 2): 3 / 4 / 5 groups = net 2.44 / 2.47 / 2.53 ms, 507 / 486 / 476
+    # scenes/s six in flight - a quarter less partial-sum traffic is worth more than the 4 % more MFMA blocks (four groups
+    # were better with the round-1 kernels: 2.99 vs 3.20 ms)
+    MASK_GROUPS = int(os.environ.get("CV_NET_MASK_GROUPS", "3"))
     MASKED_MIN_ROWS = int(os.environ.get("CV_MASKED_MIN_ROWS", "16384"))
 
     def fused_fast(self, stem_k=5):
