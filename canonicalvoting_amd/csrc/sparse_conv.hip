@@ -3064,7 +3064,10 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
     const long long tiles = ((n_out + TM - 1) / TM) * ((cout + nb * 32 - 1) / (nb * 32));
     const long long units = vec ? (long long)K * (cin / KC) : ((long long)K * cin + KC - 1) / KC;
     if (tiles >= 384 || units <= 1) return 1;
-    static const long long target = getenv("CV_SPLIT_TARGET") ? atoll(getenv("CV_SPLIT_TARGET")) : 1024;
+    // workgroups a split launch aims at.  512 since round 2: 384 / 512 / 768 / 1024 = 513 / 508 / 496 / 491 scenes/s six in
+    // flight, net 2.58 / 2.51 / 2.47 / 2.47 ms one in flight - the partial tiles of the coarse levels are 0.8 GB of the
+    // 1.7 GB a forward writes, and with several scenes in flight the other scenes fill the chip, not the splits
+    static const long long target = getenv("CV_SPLIT_TARGET") ? atoll(getenv("CV_SPLIT_TARGET")) : 512;
     long long s = (target + tiles - 1) / tiles;
     // (measured without gain: sizing by the chip's resident workgroup slots, floor(256 x waves-per-SIMD / tiles), so that
     // no second round of workgroups starts: 257 vs 265 scenes/s one scene in flight, 401-409 vs 410-412 with six)
