@@ -1006,9 +1006,15 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 // list in LDS, the loop is a counted loop over that list with per-thread invariants (weight-tile source / LDS offsets,
 // 32-bit row offsets) hoisted - the first version spent ~150 vector and ~250 scalar instructions per unit on the walk
 // (advance / skip_dead, 64-bit address arithmetic, spilled scalars) around 18 MFMAs.
+#ifndef HL_OCC1
+#define HL_OCC1 4
+#endif
+#ifndef HL_OCC2
+#define HL_OCC2 4
+#endif
 constexpr int HL_MAX_UNITS = 512;      // live units of one workgroup: <= 10 offsets x Cin / 32 chunks + the second source's (host-checked)
 template <int NB, int NS, int NW>
-__global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS == 2 ? 4 : 3)) void conv_hl(ConvArgs a) {
+__global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS == 2 ? (NB == 1 ? HL_OCC1 : NB == 2 ? HL_OCC2 : 4) : 3)) void conv_hl(ConvArgs a) {
     static_assert(NS == 3 || NS == 2, "three unit slots (or two: the loads of unit k + 2 follow the MFMAs of unit k)");
     constexpr int TMv = NW * 32, THv = NW * 64;
     constexpr int B_BYTES = 2 * NB * 32 * 64, EP_BYTES = NW * 32 * EP_LD * 4;
