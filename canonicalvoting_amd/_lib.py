@@ -40,7 +40,7 @@ class ConvDesc(ctypes.Structure):
                 ("weight_packed", vp), ("weight_x6", vp), ("in2", vp), ("in2_ld", ctypes.c_int), ("cin2", ctypes.c_int),
                 ("weight2_x6", vp), ("perm_has_map", ctypes.c_int), ("weight_pieces", ctypes.c_int),
                 ("acc_scale", ctypes.c_float), ("range_flag", vp), ("in_hl", ctypes.c_int), ("out_hl", ctypes.c_int),
-                ("res_hl", ctypes.c_int)]
+                ("res_hl", ctypes.c_int), ("split_tickets", vp)]
 
 
 class SceneMaps(ctypes.Structure):

@@ -235,6 +235,19 @@ int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int 
             }
         }
     }
+    // split-K tickets of the hl-format convolutions (cv_conv_desc.split_tickets): the last 16 KB of the workspace,
+    // zeroed once per forward (the launches leave them at zero; the fill keeps a failed forward from poisoning the next)
+    int32_t* tickets = nullptr;
+    size_t conv_ws_bytes = ws_bytes;
+    const size_t ticket_bytes = sizeof(int32_t) * CV_SPLIT_TICKETS;
+    // OFF unless CV_HL_FUSE_FINISH=1: measured 2.50 -> 3.79 ms per forward (the per-workgroup agent-scope release writes
+    // the whole L2 of the XCD back), profiles/r2/fused_finish.txt
+    static const bool fuse_on = getenv("CV_HL_FUSE_FINISH") && atoi(getenv("CV_HL_FUSE_FINISH")) != 0;
+    if (fuse_on && d_ws && ws_bytes > ((size_t)1 << 20) + ticket_bytes) {
+        conv_ws_bytes = (ws_bytes - ticket_bytes) & ~(size_t)255;
+        tickets = reinterpret_cast<int32_t*>(static_cast<char*>(d_ws) + conv_ws_bytes);
+        CV_HIP_CHECK(hipMemsetAsync(tickets, 0, ticket_bytes, static_cast<hipStream_t>(stream)));
+    }
     for (int k = 0; k < n_ops; ++k) {
         const cv_net_op& o = ops[k];
         CV_REQUIRE(o.in_buf >= 0 && o.in_buf < n_bufs && o.out_buf >= 0 && o.out_buf < n_bufs &&
@@ -276,7 +289,8 @@ int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int 
         d.out = reinterpret_cast<float*>(out.ptr) + o.out_col;
         d.out_ld = out.ld;
         d.ws = d_ws;
-        d.ws_bytes = ws_bytes;
+        d.ws_bytes = conv_ws_bytes;
+        d.split_tickets = d.in_hl ? tickets : nullptr;
         const int32_t* perm = o.perm >= 0 ? perms[o.perm] : nullptr;
         if (perm) {
             d.row_perm = perm;

@@ -70,6 +70,7 @@ struct ConvArgs {
     int* range_flag;             // fp16 pairs: set to 1 when a staged input magnitude does not fit fp16
     int in_hl, out_hl, res_hl;   // 1: the operand is in the hl format (fp16 pairs in place, see below) instead of fp32
     int xcd_tiles;               // conv_rows_wp / conv_hl: XCD-aware tile numbering (xcd_tile)
+    int* tickets;                // conv_hl split-K: arrival counters per output tile (zero; the last arriver reduces, see there)
 };
 
 // ---- hl format: activations stored as the fp16 pairs the matrix cores multiply --------------------------------------
@@ -128,6 +129,30 @@ __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& 
     }
 }
 
+// the fused epilogue on four consecutive columns of one output row (16-byte aligned operands): partial-sum input, folded
+// BatchNorm affine / bias, residual (fp32 or hl), ReLU, store (fp32 or hl + range flag)
+__device__ __forceinline__ void epilogue_apply4(const ConvArgs& a, long long row, int col, float4 v) {
+    if (a.acc_in) {
+        const float4 p = *reinterpret_cast<const float4*>(a.acc_in + row * a.acc_ld + col);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+    if (a.res) {
+        const float4 p = a.res_hl ? hl_load4(a.res + row * a.res_ld, col)
+                                  : *reinterpret_cast<const float4*>(a.res + row * a.res_ld + col);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (a.out_hl) {
+        if (a.range_flag && hl_out_of_range(v)) *a.range_flag = 1;
+        hl_store4(a.out + row * a.out_ld, col, v);
+    } else {
+        *reinterpret_cast<float4*>(a.out + row * a.out_ld + col) = v;
+    }
+}
+
 // The same epilogue with 16-byte stores: the 32x32 accumulator tile goes through a wave-private LDS tile so that
 // 8 lanes write 128 contiguous bytes of one output row (4 dwordx4 stores per lane instead of 16 dword stores).
 // Measured with the instrumented twin (profiles/conv_phases.py): the dword epilogue was 63 % of the wave time
@@ -153,25 +178,7 @@ __device__ __forceinline__ void epilogue_store_wide(const ConvArgs& a, const f32
                 *reinterpret_cast<float4*>(a.partial + ((long long)blockIdx.z * a.n_out + row) * a.cout + col) = v;
                 continue;
             }
-            if (a.acc_in) {
-                const float4 p = *reinterpret_cast<const float4*>(a.acc_in + (long long)row * a.acc_ld + col);
-                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-            }
-            const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
-            const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-            if (a.res) {
-                const float4 p = a.res_hl ? hl_load4(a.res + (long long)row * a.res_ld, col)
-                                          : *reinterpret_cast<const float4*>(a.res + (long long)row * a.res_ld + col);
-                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-            }
-            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (a.out_hl) {
-                if (a.range_flag && hl_out_of_range(v)) *a.range_flag = 1;
-                hl_store4(a.out + (long long)row * a.out_ld, col, v);
-            } else {
-                *reinterpret_cast<float4*>(a.out + (long long)row * a.out_ld + col) = v;
-            }
+            epilogue_apply4(a, row, col, v);
         }
     }
     __builtin_amdgcn_wave_barrier();       // the tile is rewritten by the next column block
@@ -1233,6 +1240,53 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS == 2 ? (NB == 1 ? HL_OCC1
     if ((CV_HL_ABL & 8) && a.acc_scale != 12345.f) return;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) epilogue_store_wide(a, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep);
+    if (a.splits > 1 && a.tickets) {
+        // split-K without a second launch: every workgroup of an output tile publishes its partial tile, the LAST one to
+        // arrive sums the partial tiles in split order and runs the epilogue (plain stores -> per-wave vmcnt(0) -> barrier
+        // -> one-lane agent release -> ticket; the last arriver's agent acquire -> plain loads: the hot-plane merge of
+        // hv_vote.hip).  Summation order = conv_finish's (four running sums over the splits k % 4, then ((s0 + s1) + s2)
+        // + s3): bit-identical to the two-launch path.  The last arriver leaves the counter at zero for the next launch.
+        __shared__ int last_flag;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* ticket = a.tickets + tile_id * gridDim.y + blockIdx.y;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int old = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = old == a.splits - 1;
+            if (last_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        if (tid == 0) *ticket = 0;
+        const long long plane = a.n_out * (long long)a.cout;       // one split's partial tile set
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = n0 + nb * 32 + (lane & 7) * 4;
+            if (col >= a.cout) continue;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = rows_s[wave * 32 + (lane >> 3) + 8 * it];
+                if (row < 0) continue;
+                const float* p = a.partial + (long long)row * a.cout + col;
+                float4 sq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k0 = 0; k0 < a.splits; k0 += 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (k0 + q < a.splits) {
+                            const float4 v = *reinterpret_cast<const float4*>(p + (long long)(k0 + q) * plane);
+                            sq[q].x += v.x; sq[q].y += v.y; sq[q].z += v.z; sq[q].w += v.w;
+                        }
+                }
+                const float4 x = make_float4(sq[0].x + sq[1].x + sq[2].x + sq[3].x, sq[0].y + sq[1].y + sq[2].y + sq[3].y,
+                                             sq[0].z + sq[1].z + sq[2].z + sq[3].z, sq[0].w + sq[1].w + sq[2].w + sq[3].w);
+                epilogue_apply4(a, row, col, x);
+            }
+        }
+    }
 }
 
 // Instrumented twin of conv_rows (CV_CONV_PROF=1): shader-clock ticks per phase, summed over waves into prof[16].
@@ -2936,8 +2990,18 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
                 // of four / three; net 2.53 -> 2.48 ms, 474 -> 485 scenes/s); three for 96 columns (two slots spill there:
                 // 2.62 ms).  CV_HL_NS2: bit nb-1 = two slots for NB = nb
                 static const int ns2 = getenv("CV_HL_NS2") ? atoi(getenv("CV_HL_NS2")) : 3;
+                // split-K reduced by the last-arriving workgroup (cv_conv_desc.split_tickets): correct and bit-identical
+                // (tests), but every workgroup's agent-scope release writes the XCD's L2 back and the forward takes 3.79
+                // instead of 2.50 ms (profiles/r2/fused_finish.txt) - the executor only hands the tickets over when
+                // CV_HL_FUSE_FINISH=1; direct callers of cv_sp_conv_f32 get what they ask for
+                static const bool fuse_on = !(getenv("CV_HL_FUSE_FINISH") && atoi(getenv("CV_HL_FUSE_FINISH")) == 0);
+                if (!(fuse_on && ax.splits > 1 && !ax.perm_per_split && !ax.xcd_tiles &&
+                      (long long)gridx.x * gridx.y <= CV_SPLIT_TICKETS)) ax.tickets = nullptr;
                 if ((ns2 >> (NB - 1)) & 1) conv_hl<NB, 2, 4><<<gridx, THREADS, 0, st>>>(ax);
                 else conv_hl<NB, 3, 4><<<gridx, THREADS, 0, st>>>(ax);
+                CV_LAUNCH_CHECK();
+                if (a.splits > 1 && !ax.tickets) return launch_finish(a, st);
+                return CV_OK;
             }
         }
         CV_LAUNCH_CHECK();
@@ -3144,7 +3208,7 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
                reinterpret_cast<const float4*>(d->weight_packed), 0, nullptr, 0, 0,
                static_cast<const unsigned short*>(d->weight_x6), d->in2, d->in2_ld, d->cin2,
                static_cast<const unsigned short*>(d->weight2_x6), d->weight_pieces == 2 ? 2 : d->weight_pieces == 1 ? 1 : 3,
-               d->acc_scale != 0.f ? d->acc_scale : 1.f, d->range_flag, d->in_hl, d->out_hl, d->res_hl};
+               d->acc_scale != 0.f ? d->acc_scale : 1.f, d->range_flag, d->in_hl, d->out_hl, d->res_hl, 0, d->split_tickets};
     if (d->in_hl || d->out_hl || d->res_hl) {
         CV_REQUIRE(!d->in_hl || (d->weight_pieces == 2 && d->cin % 32 == 0 && d->in_ld % 32 == 0 &&
                                  (reinterpret_cast<uintptr_t>(d->in) & 127) == 0 &&

@@ -425,7 +425,8 @@ def range_flag(dev):
 
 def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=None, relu=False,
                  out=None, flavour=0, row_perm=None, j_begin=0, j_end=0, acc_in=None, perm_groups=0,
-                 cache_weights=True, pieces=None, in_hl=False, out_hl=False, res_hl=False, stem_mfma=False):
+                 cache_weights=True, pieces=None, in_hl=False, out_hl=False, res_hl=False, stem_mfma=False,
+                 split_tickets=None):
     """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout].
     in_hl / out_hl / res_hl: the operand is in the hl format (to_hl / from_hl; cv_conv_desc.in_hl), pieces=2 only.
     pieces=2: fp16-pair products (weights packed per call; the caller reads range_flag(dev) after synchronising);
@@ -489,7 +490,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
                       plan[0].data_ptr() + 4 * plan[1] if plan is not None else None, p(wp), p(wp6), None, 0, 0, None,
                       1 if (perm_groups > 1 and getattr(row_perm, "_cv_has_map", False)) else 0,
                       2 if flag is not None else (1 if (pieces == 1 and wp6 is not None) else 0), acc_scale, p(flag),
-                      1 if in_hl else 0, 1 if out_hl else 0, 1 if res_hl else 0)
+                      1 if in_hl else 0, 1 if out_hl else 0, 1 if res_hl else 0, p(split_tickets))
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
     return out

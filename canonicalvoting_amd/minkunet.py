@@ -408,7 +408,7 @@ class MinkUNetBase(ResNetBase):
         cmax = max(self.PLANES)
         ws_bytes = max([4 * self.MASK_GROUPS * n[i] * cmax + 256 for i in range(5) if perm_ptrs[i] is not None] +
                        [int(L.cv_sp_conv_workspace_bytes(min(n[i], 128 * 384 - 1), cmax, 27)) for i in range(5)])
-        ws = ME._workspace(dev, ws_bytes)
+        ws = ME._workspace(dev, ws_bytes + 16384 + 256)      # + the split-K tickets the executor keeps at the tail
         vp = ctypes.c_void_p
         ext_ptr = (vp * 2)(feats.data_ptr(), y.data_ptr())
         ext_ld = (ctypes.c_int * 2)(feats.stride(0), y.stride(0))

@@ -227,7 +227,12 @@ typedef struct cv_conv_desc {
                                fragments straight from global memory and nothing is split per gather; the producer
                                raises range_flag when an OUTPUT magnitude exceeds 65000.  Needs weight_pieces = 2 for
                                in_hl, channel counts and leading dimensions % 32 == 0, 128-byte aligned rows.        */
+    int32_t* split_tickets; /* optional, hl-format input only: CV_SPLIT_TICKETS zero-initialised ints owned by the caller's
+                               stream.  A split launch then reduces its partial tiles in the last-arriving workgroup of every
+                               output tile (same summation order as the finish launch: bit-identical) instead of a second
+                               launch; the library leaves the counters at zero.  NULL: two launches. */
 } cv_conv_desc;
+#define CV_SPLIT_TICKETS 4096
 
 /* fp32 rows -> hl format and back (d_x and d_y may not alias; c % 32 == 0; the hl side 128-byte aligned with a leading
  * dimension % 32 == 0; leading dimensions in 4-byte units on both sides).  range_flag (optional) as in cv_conv_desc. */

@@ -235,6 +235,15 @@ def test_hl_format_conv_matches_fp32_operand_conv(cuda, built_lib, cin, cout, k,
     else:
         assert torch.equal(got0, ref0)
     ref1 = conv(x, scale=scale, shift=shift, residual=res, relu=True)
+    if not masked:
+        # split-K reduced by the last-arriving workgroup of every output tile (cv_conv_desc.split_tickets) instead of a
+        # finish launch: same summation order, bit-identical; the counters are left at zero
+        tickets = torch.zeros(4096, dtype=torch.int32, device=cuda)
+        for _ in range(2):
+            got_f = conv(xh, in_hl=True, scale=scale, shift=shift, residual=res, relu=True, split_tickets=tickets)
+            got_u = conv(xh, in_hl=True, scale=scale, shift=shift, residual=res, relu=True)
+            assert torch.equal(got_f, got_u)
+            assert int(tickets.abs().sum()) == 0
     # hl in / residual / out inside wider buffers (column windows at multiples of 32 channels)
     xin = torch.zeros((N, cin + 64), device=cuda); xin[:, 32:32 + cin] = x
     xin_h = ME.to_hl(xin)
