@@ -3070,7 +3070,8 @@ int nb_for(int cout, long long n_out) {
     if (cout <= 32) return 1;
     if (cout <= 64) return 2;
     if (cout <= 96) return 3;
-    return n_out < 1024 ? 1 : 2;
+    static const int nb_wide = getenv("CV_NB_WIDE") ? atoi(getenv("CV_NB_WIDE")) : 2;      // 128 / 256 columns: 64-column workgroups
+    return n_out < 1024 ? 1 : std::max(1, std::min(nb_wide, 2));
 }
 
 // ---- tile flavour dispatch: CS = waves (32-column slices) per workgroup, KW = K chunk width
