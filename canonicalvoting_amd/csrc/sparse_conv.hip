@@ -1184,6 +1184,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS == 2 ? (NB == 1 ? HL_OCC1
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[nb], 0, 0, 0);
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[nb], 0, 0, 0);
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[nb], 0, 0, 0);
+                if constexpr (NB == 3 && NS == 2) asm volatile("" ::: "memory");   // keep the next fragments' reads behind these MFMAs (registers)
             }
         }
     };
@@ -2986,10 +2987,11 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
                 dim3 g8((unsigned)((a.n_out + 255) / 256), grid.y, grid.z);
                 conv_hl<NB, 3, 8><<<g8, 512, 0, st>>>(ax);
             } else {
-                // two unit slots for the 32- and 64-column workgroups (85 / 113 VGPRs: five / four workgroups per CU instead
-                // of four / three; net 2.53 -> 2.48 ms, 474 -> 485 scenes/s); three for 96 columns (two slots spill there:
-                // 2.62 ms).  CV_HL_NS2: bit nb-1 = two slots for NB = nb
-                static const int ns2 = getenv("CV_HL_NS2") ? atoi(getenv("CV_HL_NS2")) : 3;
+                // two unit slots (85 / 113 / 128 VGPRs for 32 / 64 / 96 columns: five / four / four workgroups per CU instead
+                // of four / three / three; net 2.53 -> 2.48 ms for the first two, 2.52 -> 2.48 ms for the third once a compiler
+                // barrier keeps its fragment reads from being hoisted - its remaining spills are outside the unit loop).
+                // CV_HL_NS2: bit nb-1 = two slots for NB = nb
+                static const int ns2 = getenv("CV_HL_NS2") ? atoi(getenv("CV_HL_NS2")) : 7;
                 // split-K reduced by the last-arriving workgroup (cv_conv_desc.split_tickets): correct and bit-identical
                 // (tests), but every workgroup's agent-scope release writes the XCD's L2 back and the forward takes 3.79
                 // instead of 2.50 ms (profiles/r2/fused_finish.txt) - the executor only hands the tickets over when
