@@ -1013,6 +1013,9 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 // list in LDS, the loop is a counted loop over that list with per-thread invariants (weight-tile source / LDS offsets,
 // 32-bit row offsets) hoisted - the first version spent ~150 vector and ~250 scalar instructions per unit on the walk
 // (advance / skip_dead, 64-bit address arithmetic, spilled scalars) around 18 MFMAs.
+#ifndef HL_CB_MIN_NB
+#define HL_CB_MIN_NB 3
+#endif
 #ifndef HL_OCC1
 #define HL_OCC1 4
 #endif
@@ -1184,7 +1187,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS == 2 ? (NB == 1 ? HL_OCC1
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[nb], 0, 0, 0);
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[nb], 0, 0, 0);
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[nb], 0, 0, 0);
-                if constexpr (NB == 3 && NS == 2) asm volatile("" ::: "memory");   // keep the next fragments' reads behind these MFMAs (registers)
+                if constexpr (NB >= HL_CB_MIN_NB && NS == 2) asm volatile("" ::: "memory");   // keep the next fragments' reads behind these MFMAs (registers)
             }
         }
     };
