@@ -5,6 +5,7 @@ op fails loudly with instructions, and every entry point checks its return code.
 """
 import ctypes
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_C", "libcvhip.so")
@@ -175,6 +176,32 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+_scratch_lock = threading.Lock()
+_scratch_bufs = {}
+
+
+def scratch(dev, name, nbytes):
+    """Persistent device scratch of the CURRENT stream of `dev`, grown on demand: ``nbytes`` of uint8 named ``name``.
+
+    Internal workspaces (the executor arena, sort / level / vote / decode workspaces) used to be ``torch.empty`` per
+    call: every scene-thread stream owns a separate caching-allocator pool, so the first scenes of a stream - and any
+    later scene whose sizes differ - paid a hipMalloc inside the timed region.  A workspace is consumed by launches
+    of one stream only and the next call on that stream is ordered behind them, so one buffer per (device, stream,
+    name) is safe; results handed to the caller are never scratch."""
+    import torch
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(dev).cuda_stream, name)
+    nbytes = max(int(nbytes), 256)
+    with _scratch_lock:
+        buf = _scratch_bufs.get(key)
+    if buf is None or buf.numel() < nbytes:
+        # (the old buffer may still be read by queued launches: the caching allocator keeps its block stream-ordered)
+        buf = torch.empty(nbytes + nbytes // 8, dtype=torch.uint8, device=dev)
+        with _scratch_lock:
+            _scratch_bufs[key] = buf
+    return buf
 
 
 def check(rc, what):

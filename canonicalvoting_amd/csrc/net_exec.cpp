@@ -135,21 +135,40 @@ int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* 
 // stream already builds the level-0 maps queued behind it (the 5x5x5 stem map is 3/4 of all lookups) - the host wait,
 // which used to leave the GPU idle for ~80 us between cv_sp_build_levels and cv_sp_scene_maps, now overlaps with them.
 namespace {
-struct PlanSide { hipEvent_t ev; int32_t* h_pinned; };
+// event + 64-byte pinned landing buffer of one cv_sp_scene_plan call, taken from a per-device pool for the duration of
+// the call (a slot keyed by the stream handle was shared by every thread / device that planned on the null stream)
+struct PlanSide { hipEvent_t ev; int32_t* h_pinned; int device; };
 std::mutex g_plan_mu;
-std::unordered_map<void*, PlanSide> g_plan_side;        // per main stream (scene threads own their streams)
-int plan_side(void* stream, PlanSide* out) {
-    std::lock_guard<std::mutex> lk(g_plan_mu);
-    auto it = g_plan_side.find(stream);
-    if (it == g_plan_side.end()) {
-        PlanSide p{};
-        CV_HIP_CHECK(hipEventCreateWithFlags(&p.ev, hipEventDisableTiming));
-        CV_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p.h_pinned), 64, hipHostMallocDefault));
-        it = g_plan_side.emplace(stream, p).first;
+std::unordered_map<int, std::vector<PlanSide>> g_plan_free;
+int plan_side_acquire(PlanSide* out) {
+    int dev = 0;
+    CV_HIP_CHECK(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        auto& pool = g_plan_free[dev];
+        if (!pool.empty()) {
+            *out = pool.back();
+            pool.pop_back();
+            return CV_OK;
+        }
     }
-    *out = it->second;
+    PlanSide p{};
+    p.device = dev;
+    CV_HIP_CHECK(hipEventCreateWithFlags(&p.ev, hipEventDisableTiming));
+    CV_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p.h_pinned), 64, hipHostMallocDefault));
+    *out = p;
     return CV_OK;
 }
+struct PlanSideLease {
+    PlanSide ps{};
+    bool held = false;
+    ~PlanSideLease() {
+        if (!held) return;
+        (void)hipEventSynchronize(ps.ev);       // an early error return must not hand the buffer on with its copy in flight
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        g_plan_free[ps.device].push_back(ps);
+    }
+};
 }  // namespace
 
 size_t cv_sp_scene_plan_words(long long n, int stem_k, int mask_groups, long long masked_min_rows) {
@@ -175,9 +194,11 @@ int cv_sp_scene_plan(const int32_t* d_input, long long n, int32_t* d_perm, int32
     if (rc != CV_OK) return rc;
     rc = cv_sp_build_levels(d_coords, d_keys, d_vals, n, cap, 5, d_counts, nullptr, d_levels_ws, levels_ws_bytes, stream);
     if (rc != CV_OK) return rc;
-    PlanSide ps;
-    rc = plan_side(stream, &ps);
+    PlanSideLease lease;
+    rc = plan_side_acquire(&lease.ps);
     if (rc != CV_OK) return rc;
+    lease.held = true;
+    const PlanSide& ps = lease.ps;
     CV_HIP_CHECK(hipMemcpyAsync(ps.h_pinned, d_counts, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, st));
     CV_HIP_CHECK(hipEventRecord(ps.ev, st));
     // level-0 maps: their arena offsets depend on n only

@@ -3226,6 +3226,10 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         CV_REQUIRE(!d->res_hl || !d->residual || (d->res_ld % 32 == 0 && (reinterpret_cast<uintptr_t>(d->residual) & 127) == 0),
                    CV_EINVAL, "hl-format residual: leading dimension %% 32 == 0, 128-byte aligned rows");
         CV_REQUIRE(d->flavour == 0 && !d->plan_ent, CV_EINVAL, "the hl format runs on the rows flavour only");
+        // conv_hl forms its gather addresses in 32 bits (row * row bytes + chunk offset)
+        CV_REQUIRE(!d->in_hl || ((unsigned long long)d->n_in * (unsigned long long)d->in_ld * 4ull + (unsigned long long)d->cin * 4ull < (1ull << 32) &&
+                                 (!d->in2 || (unsigned long long)d->n_out * (unsigned long long)d->in2_ld * 4ull + (unsigned long long)d->cin2 * 4ull < (1ull << 32))),
+                   CV_EINVAL, "hl-format input larger than 4 GiB (rows x leading dimension x 4): split the batch");
     }
     CV_REQUIRE(d->weight_pieces >= 0 && d->weight_pieces <= 3, CV_EINVAL,
                "weight_pieces is 0/3 (bf16 triples), 2 (fp16 pairs) or 1 (single bf16 product)");

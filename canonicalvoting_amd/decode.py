@@ -57,7 +57,7 @@ def decode_boxes(grid_obj, grid_rot, grid_scale, scan_points, xyz_pred, prob_pre
     M = int(max_candidates)
     while True:
         p.max_iters = M
-        ws = torch.empty(int(L.cv_decode_workspace_bytes(dims, n, M)), dtype=torch.uint8, device=dev)
+        ws = _lib.scratch(dev, "decode", L.cv_decode_workspace_bytes(dims, n, M))
         n_cand, n_boxes, truncated = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         cand = np.zeros(M, np.int64)
         verdict = np.zeros(M, np.int32)

@@ -16,6 +16,7 @@ instead of the legacy default stream, one host sync per forward (the grid shape 
 the host) instead of twelve, zero when ``corners`` is given.
 """
 import ctypes
+import threading
 
 import torch
 
@@ -78,6 +79,28 @@ def _f3(vals):
 
 _prefetched = {}
 _pinned_pool = []
+_prefetch_lock = threading.Lock()      # scene threads share the two containers (bench.py, pipeline.detect_scene)
+
+
+def _pinned6():
+    # pinned landing buffers are recycled: allocating page-locked memory costs about a millisecond per call
+    with _prefetch_lock:
+        if _pinned_pool:
+            return _pinned_pool.pop()
+    return torch.empty(6, dtype=torch.float32).pin_memory()
+
+
+def _recycle(host):
+    with _prefetch_lock:
+        if len(_pinned_pool) < 64:
+            _pinned_pool.append(host)
+
+
+def reserve_pinned(count):
+    """create `count` pinned landing buffers now (bench.py does it before the clock starts)"""
+    bufs = [torch.empty(6, dtype=torch.float32).pin_memory() for _ in range(count)]
+    for b in bufs:
+        _recycle(b)
 
 
 def prefetch_geometry(points):
@@ -86,35 +109,45 @@ def prefetch_geometry(points):
     Call it before the network forward of the scene (pipeline.detect_scene does)."""
     L = _lib.lib()
     dev = points.device
-    ws = torch.empty(L.cv_hv_minmax_workspace_bytes(), dtype=torch.uint8, device=dev)
-    # pinned landing buffers are recycled: allocating page-locked memory costs about a millisecond per call
-    host = _pinned_pool.pop() if _pinned_pool else torch.empty(6, dtype=torch.float32).pin_memory()
+    ws = _lib.scratch(dev, "hv_minmax", L.cv_hv_minmax_workspace_bytes())
+    host = _pinned6()
     with torch.cuda.device(dev):
         _lib.check(L.cv_hv_minmax_async_f32(_ptr(points), points.shape[0], ctypes.c_void_p(host.data_ptr()),
                                             _ptr(ws), ws.numel(), _stream(dev)), "cv_hv_minmax_async_f32")
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    if len(_prefetched) > 8:
-        # drop the oldest entries, but only once their copy into the pinned buffer has landed: torch's pinned
-        # allocator does not know about the raw hipMemcpyAsync, so a buffer released earlier could be reissued
-        # and overwritten by the copy still in flight
-        for key in list(_prefetched)[:-8]:
-            old = _prefetched.pop(key)
-            old[3].synchronize()
-            if len(_pinned_pool) < 32:
-                _pinned_pool.append(old[2])
-    # the entry keeps `points` (and the workspace) alive, so the address cannot be recycled while it is cached
-    _prefetched[points.data_ptr()] = (points, points._version, host, ev, ws)
+    stale = []
+    with _prefetch_lock:
+        # the entry keeps `points` alive, so the address cannot be recycled while it is cached
+        # (keyed per host thread: two scene threads may work on the same resident scene at the same time)
+        key = (threading.get_ident(), points.data_ptr())
+        old = _prefetched.pop(key, None)
+        _prefetched[key] = (points, points._version, host, ev)
+        if old is not None:
+            stale.append(old)
+        if len(_prefetched) > 64:
+            # entries nobody came back for (a prefetch without a vote): drop the oldest ones whose copy has landed -
+            # torch's pinned allocator does not know about the raw hipMemcpyAsync, so a buffer released earlier could
+            # be reissued and overwritten by a copy still in flight; entries of other threads still in flight stay
+            for k in list(_prefetched)[:-32]:
+                if _prefetched[k][3].query():
+                    stale.append(_prefetched.pop(k))
+    for ent in stale:
+        ent[3].synchronize()
+        _recycle(ent[2])
 
 
 def _take_prefetched(points):
-    hit = _prefetched.pop(points.data_ptr(), None)
-    if hit is None or hit[0] is not points or hit[1] != points._version:
+    with _prefetch_lock:
+        hit = _prefetched.pop((threading.get_ident(), points.data_ptr()), None)
+    if hit is None:
         return None
     hit[3].synchronize()
+    if hit[0] is not points or hit[1] != points._version:
+        _recycle(hit[2])
+        return None
     h = hit[2].tolist()
-    if len(_pinned_pool) < 32:
-        _pinned_pool.append(hit[2])
+    _recycle(hit[2])
     return h[:3], h[3:]
 
 
@@ -128,7 +161,7 @@ def grid_geometry(points, res):
         dims = (ctypes.c_int * 3)()
         _lib.check(L.cv_hv_grid_dims_f32(mn, mx, ctypes.c_float(res), dims), "cv_hv_grid_dims_f32")
         return list(mn), list(mx), [int(d) for d in dims]
-    ws = torch.empty(L.cv_hv_minmax_workspace_bytes(), dtype=torch.uint8, device=points.device)
+    ws = _lib.scratch(points.device, "hv_minmax", L.cv_hv_minmax_workspace_bytes())
     mn = (ctypes.c_float * 3)()
     mx = (ctypes.c_float * 3)()
     with torch.cuda.device(points.device):
@@ -179,7 +212,7 @@ def forward(points, xyz_labels, scale_labels, obj_labels, res, num_rots, corners
     grid_scale = torch.empty((X, Y, Z, 3), dtype=torch.float32, device=dev)
     cdims = (ctypes.c_int * 3)(*dims)
     wsb = L.cv_hv_forward_workspace_bytes(n, nrot, cdims, _algo)
-    ws = torch.empty(max(int(wsb), 256), dtype=torch.uint8, device=dev)
+    ws = _lib.scratch(dev, "hv_forward", wsb)
     with torch.cuda.device(dev):
         _lib.check(L.cv_hv_forward_f32(_ptr(points), _ptr(xyz_labels), _ptr(scale_labels),
                                        _ptr(obj_labels), n, ctypes.c_float(res_v), nrot, _f3(mn),
@@ -221,7 +254,7 @@ def count_votes(points, xyz_labels, scale_labels, res, num_rots, corner, dims):
     """Number of in-bounds (point, rotation) votes: V_in of the algorithmic byte count."""
     L = _lib.lib()
     dev = points.device
-    ws = torch.empty(256, dtype=torch.uint8, device=dev)
+    ws = _lib.scratch(dev, "hv_count", 256)
     out = ctypes.c_int64(0)
     with torch.cuda.device(dev):
         _lib.check(L.cv_hv_count_votes_f32(_ptr(points), _ptr(xyz_labels), _ptr(scale_labels),

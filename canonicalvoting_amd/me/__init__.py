@@ -18,6 +18,7 @@ stride-1 output corresponds to row i of the input coordinates.
 import ctypes
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -222,7 +223,7 @@ class CoordinateManager:
         ibuf = torch.empty(o_arena + words, dtype=torch.int32, device=dev)
         kbuf = torch.empty(NL * cap, dtype=torch.int64, device=dev)
         sws_b, lws_b = int(L.cv_sp_sort_workspace_bytes(n)), int(L.cv_sp_levels_workspace_bytes(n))
-        wbuf = torch.empty(up64(sws_b) + lws_b, dtype=torch.uint8, device=dev)
+        wbuf = _lib.scratch(dev, "scene_plan", up64(sws_b) + lws_b)      # sort + level workspaces: dead when the call returns
         ib, kb, wb = ibuf.data_ptr(), kbuf.data_ptr(), wbuf.data_ptr()
         vp = ctypes.c_void_p
         c_coords = (vp * NL)(*[ib + 4 * o for o in o_coords])
@@ -237,7 +238,7 @@ class CoordinateManager:
                                           lws_b, _stream(dev)), "cv_sp_scene_plan")
         self._raise_on_dups(counts_h[5], counts_h[6])
         plan = _FusedPlan()
-        plan.keep = (ibuf, kbuf, wbuf)
+        plan.keep = (ibuf, kbuf)
         plan.counts = [int(counts_h[i]) for i in range(NL)]
         plan.cap, plan.stem_k, plan.groups, plan.off = cap, stem_k, G, off
         plan.layout = (o_perm, o_inv, o_coords, o_vals, o_counts, o_arena)
@@ -258,7 +259,7 @@ class CoordinateManager:
         manager's cache."""
         plan = self.fused_fast(stem_k)
         if plan.views is None:
-            ibuf, kbuf, _ = plan.keep
+            ibuf, kbuf = plan.keep
             n, cap, G, off = self._input.shape[0], plan.cap, plan.groups, plan.off
             o_perm, o_inv, o_coords, o_vals, o_counts, o_arena = plan.layout
             c = plan.counts
@@ -396,30 +397,24 @@ class SparseTensor:
                             tensor_stride=self.tensor_stride if tensor_stride is None else tensor_stride)
 
 
-_conv_ws = {}
-
-
 def _workspace(dev, nbytes):
     """one persistent split-K workspace per (device, stream), grown on demand; stream-ordered reuse is safe
     because every conv of a stream finishes reading it before the next one starts."""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _conv_ws.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-        _conv_ws[key] = ws
-    return ws
+    return _lib.scratch(dev, "conv_ws", nbytes)
 
 
 _range_flags = {}
+_range_lock = threading.Lock()
 
 
 def range_flag(dev):
     """one int32 word of pinned (device-visible) host memory per (device, stream): fp16-pair convolutions set it when
     an input magnitude leaves the fp16 range (cv_conv_desc.range_flag); read it after synchronising the stream"""
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    f = _range_flags.get(key)
-    if f is None:
-        f = _range_flags[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    with _range_lock:
+        f = _range_flags.get(key)
+        if f is None:
+            f = _range_flags[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
     return f
 
 

@@ -404,7 +404,8 @@ class MinkUNetBase(ResNetBase):
         feats = x.F.contiguous()
         y = torch.empty((n[0], self.final.out_channels), dtype=torch.float32, device=dev)
         rows = (ctypes.c_int64 * 5)(*n)
-        arena = torch.empty(int(L.cv_net_arena_bytes(c_bufs, len(c_bufs), rows, 5)), dtype=torch.uint8, device=dev)
+        # activations of the executor: scratch of this stream (dead when `y` is written; sizes differ from scene to scene)
+        arena = _lib.scratch(dev, "net_arena", L.cv_net_arena_bytes(c_bufs, len(c_bufs), rows, 5))
         cmax = max(self.PLANES)
         ws_bytes = max([4 * self.MASK_GROUPS * n[i] * cmax + 256 for i in range(5) if perm_ptrs[i] is not None] +
                        [int(L.cv_sp_conv_workspace_bytes(min(n[i], 128 * 384 - 1), cmax, 27)) for i in range(5)])

@@ -71,6 +71,13 @@ def lib():
         L.hv_oracle_minmax.argtypes = [fp, ctypes.c_int64, fp, fp]
         L.hv_oracle_grid_dims.restype = None
         L.hv_oracle_grid_dims.argtypes = [fp, fp, ctypes.c_float, ip]
+        i64p_ = ctypes.POINTER(ctypes.c_int64)
+        L.hv_oracle_vote_diff.restype = None
+        L.hv_oracle_vote_diff.argtypes = [fp, fp, fp, ctypes.c_int64, ctypes.c_float, ctypes.c_int, fp, ip, fp,
+                                          ctypes.c_int, fp, ctypes.c_int, i64p_]
+        L.hv_oracle_forward_variant.restype = ctypes.c_int64
+        L.hv_oracle_forward_variant.argtypes = [fp, fp, fp, fp, ctypes.c_int64, ctypes.c_float, ctypes.c_int, fp, ip,
+                                                fp, ctypes.c_int, fp, fp, fp]
         L.hv_oracle_rot_table.restype = None
         L.hv_oracle_rot_table.argtypes = [ctypes.c_int, fp]
         i32p = ctypes.POINTER(ctypes.c_int32)
@@ -136,6 +143,51 @@ def hv_forward(points, xyz, scale, obj, res, num_rots, corners=None, return_vin=
     L.hv_oracle_average(_f(g_obj)[1], _f(g_rot)[1], _f(g_scale)[1], X * Y * Z)
     if return_vin:
         return g_obj, g_rot, g_scale, int(vin)
+    return g_obj, g_rot, g_scale
+
+
+def rot_table(num_rots):
+    """the oracle's (cos, sin) table [num_rots, 2]: theta in fp32 (hv_cuda_kernel.cu:35,37), cos/sin correctly rounded"""
+    cs = np.zeros((int(num_rots), 2), np.float32)
+    lib().hv_oracle_rot_table(int(num_rots), _f(cs)[1])
+    return cs
+
+
+def vote_diff(points, xyz, scale, res, num_rots, cs_a=None, mode_a=0, cs_b=None, mode_b=0):
+    """Counts of votes whose in-bounds status / floor cell differs between two variants of the vote geometry
+    (hv_oracle_vote_diff): dict(votes, in_bounds, status_changed, cell_changed, points_changed)."""
+    L = lib()
+    pts, pp = _f(points)
+    xa, xp = _f(xyz)
+    sa, sp = _f(scale)
+    mn, _, dims = grid_geometry(pts, res)
+    out = (ctypes.c_int64 * 5)()
+    null = ctypes.POINTER(ctypes.c_float)()
+    ka = _f(cs_a) if cs_a is not None else (None, null)
+    kb = _f(cs_b) if cs_b is not None else (None, null)
+    L.hv_oracle_vote_diff(pp, xp, sp, pts.shape[0], ctypes.c_float(res), int(num_rots), _f(mn)[1],
+                          (ctypes.c_int * 3)(*dims), ka[1], int(mode_a), kb[1], int(mode_b), out)
+    return dict(zip(("votes", "in_bounds", "status_changed", "cell_changed", "points_changed"), [int(v) for v in out]))
+
+
+def hv_forward_variant(points, xyz, scale, obj, res, num_rots, cs=None, fma_mode=0):
+    """hv_forward under another choice of FMA contraction / cosf table (hv_oracle_forward_variant)."""
+    L = lib()
+    pts, pp = _f(points)
+    xa, xp = _f(xyz)
+    sa, sp = _f(scale)
+    oa, op = _f(obj)
+    mn, _, dims = grid_geometry(pts, res)
+    X, Y, Z = dims
+    g_obj = np.zeros((X, Y, Z), np.float32)
+    g_rot = np.zeros((X, Y, Z, 2), np.float32)
+    g_scale = np.zeros((X, Y, Z, 3), np.float32)
+    null = ctypes.POINTER(ctypes.c_float)()
+    k = _f(cs) if cs is not None else (None, null)
+    L.hv_oracle_forward_variant(pp, xp, sp, op, pts.shape[0], ctypes.c_float(res), int(num_rots), _f(mn)[1],
+                                (ctypes.c_int * 3)(*dims), k[1], int(fma_mode), _f(g_obj)[1], _f(g_rot)[1],
+                                _f(g_scale)[1])
+    L.hv_oracle_average(_f(g_obj)[1], _f(g_rot)[1], _f(g_scale)[1], X * Y * Z)
     return g_obj, g_rot, g_scale
 
 

@@ -228,3 +228,120 @@ void hv_oracle_backward(const float* grad, const float* points, const float* xyz
         }
     }
 }
+
+/* ---- what-if variants of the vote geometry (tests/test_vote_contraction.py) -----------------------------------
+ * The CUDA binary of the reference cannot be produced here, and two of its choices are invisible in the source:
+ * nvcc contracts `-cos*cx + sin*cz` and `-sin*cx - cos*cz` (hv_cuda_kernel.cu:38-39) into FMAs (-fmad=true is its
+ * default) and calls its own cosf/sinf (<= 2 ulp).  The functions below evaluate the SAME statements under those
+ * alternatives so that a CPU test can count how many votes would land in a different cell / change their in-bounds
+ * status, and whether any decode output changes.
+ *   fma_mode 0: no contraction (the oracle's and the HIP kernel's convention)
+ *            1: the SECOND product of each sum is the fused one: fma(s, cz, (-c)*cx), fma(-c, cz, (-s)*cx)
+ *            2: the FIRST product is the fused one (LLVM's (fadd (fmul x, y), z) -> fma x, y, z rule, the likely nvcc
+ *               output): fma(-c, cx, s*cz), fma(-s, cx, -(c*cz))
+ *   cs: [num_rots][2] table of (cos, sin) to use (any <= 2 ulp cosf/sinf), or NULL for the oracle's table. */
+static inline void hv_variant_offset(float ct, float st, float cx, float cz, int fma_mode, float* ox, float* oz) {
+    if (fma_mode == 1) {
+        *ox = fmaf(st, cz, (-ct) * cx);
+        *oz = fmaf(-ct, cz, (-st) * cx);
+    } else if (fma_mode == 2) {
+        *ox = fmaf(-ct, cx, st * cz);
+        *oz = fmaf(-st, cx, -(ct * cz));
+    } else {
+        *ox = (-ct) * cx + st * cz;
+        *oz = (-st) * cx - ct * cz;
+    }
+}
+
+/* out[0] votes examined, out[1] in-bounds under A, out[2] in-bounds status differs, out[3] both in bounds but another
+ * floor cell, out[4] points with at least one changed vote */
+void hv_oracle_vote_diff(const float* points, const float* xyz, const float* scale, int64_t n, float res, int num_rots,
+                         const float corner[3], const int dims[3], const float* cs_a, int mode_a, const float* cs_b,
+                         int mode_b, int64_t out[5]) {
+    float cs0[2 * 4096];
+    const int X = dims[0], Y = dims[1], Z = dims[2];
+    for (int k = 0; k < 5; ++k) out[k] = 0;
+    if (num_rots > 4096) return;
+    hv_oracle_rot_table(num_rots, cs0);
+    if (!cs_a) cs_a = cs0;
+    if (!cs_b) cs_b = cs0;
+    for (int64_t c = 0; c < n; ++c) {
+        const float cx = xyz[c * 3 + 0] * scale[c * 3 + 0];
+        const float cy = xyz[c * 3 + 1] * scale[c * 3 + 1];
+        const float cz = xyz[c * 3 + 2] * scale[c * 3 + 2];
+        const float px = points[c * 3 + 0], py = points[c * 3 + 1], pz = points[c * 3 + 2];
+        int changed = 0;
+        for (int i = 0; i < num_rots; ++i) {
+            float g[2][3];
+            int in[2];
+            for (int v = 0; v < 2; ++v) {
+                const float* cs = v ? cs_b : cs_a;
+                float ox, oz;
+                hv_variant_offset(cs[2 * i], cs[2 * i + 1], cx, cz, v ? mode_b : mode_a, &ox, &oz);
+                g[v][0] = ((px + ox) - corner[0]) / res;
+                g[v][1] = ((py + (-cy)) - corner[1]) / res;
+                g[v][2] = ((pz + oz) - corner[2]) / res;
+                in[v] = !(g[v][0] < 0 || g[v][1] < 0 || g[v][2] < 0 || g[v][0] >= (float)(X - 1) ||
+                          g[v][1] >= (float)(Y - 1) || g[v][2] >= (float)(Z - 1));
+            }
+            ++out[0];
+            out[1] += in[0];
+            if (in[0] != in[1]) { ++out[2]; changed = 1; }
+            else if (in[0] && ((int)g[0][0] != (int)g[1][0] || (int)g[0][1] != (int)g[1][1] || (int)g[0][2] != (int)g[1][2])) {
+                ++out[3];
+                changed = 1;
+            }
+        }
+        out[4] += changed;
+    }
+}
+
+/* hv_oracle_forward with the geometry variant (grids zero-filled by the caller; everything after the offset is the
+ * oracle's own sequence) */
+int64_t hv_oracle_forward_variant(const float* points, const float* xyz, const float* scale, const float* obj, int64_t n,
+                                  float res, int num_rots, const float corner[3], const int dims[3], const float* cs_in,
+                                  int fma_mode, float* g_obj, float* g_rot, float* g_scale) {
+    const int X = dims[0], Y = dims[1], Z = dims[2];
+    float cs0[2 * 4096];
+    if (num_rots > 4096) return -1;
+    hv_oracle_rot_table(num_rots, cs0);
+    const float* cs = cs_in ? cs_in : cs0;
+    int64_t v_in = 0;
+    for (int64_t c = 0; c < n; ++c) {
+        const float objness = obj[c];
+        const float cx = xyz[c * 3 + 0] * scale[c * 3 + 0];
+        const float cy = xyz[c * 3 + 1] * scale[c * 3 + 1];
+        const float cz = xyz[c * 3 + 2] * scale[c * 3 + 2];
+        const float px = points[c * 3 + 0], py = points[c * 3 + 1], pz = points[c * 3 + 2];
+        for (int i = 0; i < num_rots; ++i) {
+            const float ct = cs[2 * i], st = cs[2 * i + 1];
+            float ox, oz;
+            hv_variant_offset(ct, st, cx, cz, fma_mode, &ox, &oz);
+            const float oy = -cy;
+            const float gx = ((px + ox) - corner[0]) / res;
+            const float gy = ((py + oy) - corner[1]) / res;
+            const float gz = ((pz + oz) - corner[2]) / res;
+            if (gx < 0 || gy < 0 || gz < 0 || gx >= (float)(X - 1) || gy >= (float)(Y - 1) || gz >= (float)(Z - 1)) continue;
+            ++v_in;
+            const int fx = (int)gx, fy = (int)gy, fz = (int)gz;
+            const int hx = fx + 1, hy = fy + 1, hz = fz + 1;
+            const float rx = gx - floorf(gx), ry = gy - floorf(gy), rz = gz - floorf(gz);
+            const float w0x = 1.f - rx, w0y = 1.f - ry, w0z = 1.f - rz;
+            const float w[8] = {w0x * w0y * w0z * objness, w0x * w0y * rz * objness, w0x * ry * w0z * objness,
+                                w0x * ry * rz * objness,   rx * w0y * w0z * objness, rx * w0y * rz * objness,
+                                rx * ry * w0z * objness,   rx * ry * rz * objness};
+            const int64_t cell[8] = {IDX3(fx, fy, fz, Y, Z), IDX3(fx, fy, hz, Y, Z), IDX3(fx, hy, fz, Y, Z),
+                                     IDX3(fx, hy, hz, Y, Z), IDX3(hx, fy, fz, Y, Z), IDX3(hx, fy, hz, Y, Z),
+                                     IDX3(hx, hy, fz, Y, Z), IDX3(hx, hy, hz, Y, Z)};
+            for (int k = 0; k < 8; ++k) g_obj[cell[k]] += w[k];
+            const float rot_vec[2] = {ct, st};
+            for (int j = 0; j < 2; ++j)
+                for (int k = 0; k < 8; ++k) g_rot[cell[k] * 2 + j] += w[k] * rot_vec[j];
+            for (int j = 0; j < 3; ++j) {
+                const float s = scale[c * 3 + j];
+                for (int k = 0; k < 8; ++k) g_scale[cell[k] * 3 + j] += w[k] * s;
+            }
+        }
+    }
+    return v_in;
+}
