@@ -56,6 +56,8 @@ struct CvMapJob {            // kernel map: out set looked up in an input set's 
     const int32_t* compose;  // optional: store compose[row] instead of row (a permutation folded into the map)
     const unsigned* bitmap;  // optional (ts == 1 maps of the set the bitmap was built from): occupancy bits in front of the
     const int32_t* bbox;     // hash probes, see cv_sp_occupancy_bitmap; bbox = the 8 ints of cv_sp_sort_rows' bounds
+    int up;                  // 1: transposed k2s2 map instead - out_coords are the FINE rows (tensor stride ts), keys / vals the
+                             // table of the next coarser level, nbr[n_out][8] = parent row in the octant column, -1 elsewhere
 };
 constexpr int CV_MAX_MAP_JOBS = 12;
 int cv_sp_kernel_maps_batch(const CvMapJob* jobs, int n_jobs, void* stream);
@@ -65,12 +67,20 @@ int cv_sp_kernel_maps_batch(const CvMapJob* jobs, int n_jobs, void* stream);
 // answers them.  d_bits: CV_BITMAP_WORDS words; when the box does not fit (or a batch index is negative) the kernels
 // that take the bitmap ignore it (they re-derive the same test from the bounds).  Two launches, asynchronous.
 constexpr long long CV_BITMAP_WORDS = 1ll << 20;
-int cv_sp_occupancy_bitmap(const int32_t* d_coords, long long n, const int32_t* d_bbox, unsigned* d_bits, void* stream);
+// pre_cleared: the words are zero and d_bbox[7] == 1 already (cv_sp_build_levels_zero did it): one launch
+int cv_sp_occupancy_bitmap(const int32_t* d_coords, long long n, const int32_t* d_bbox, unsigned* d_bits, void* stream,
+                           bool pre_cleared = false);
+
+// cv_sp_build_levels with an extra range of words zeroed by its first launch (saves the caller's fill launches)
+int cv_sp_build_levels_zero(int32_t* const* d_coords, unsigned long long* const* d_keys, int32_t* const* d_vals,
+                            long long n, long long cap, int num_levels, int32_t* d_counts, int32_t* h_counts, void* d_ws,
+                            size_t ws_bytes, int32_t* d_zero, long long n_zero, int32_t* d_set_one, void* stream);
 
 struct CvUpJob { const int32_t* nbr_down; long long n_coarse; int32_t* up; };
 int cv_sp_up_maps_batch(const CvUpJob* jobs, int n_jobs, void* stream);      // the up arrays must be pre-filled with -1
 
 struct CvPermJob { const int32_t* nbr; long long n; int K, groups; int32_t* perm; int with_map; };
 constexpr int CV_MAX_PERM_JOBS = 8;
-// d_ws: (sum of groups) * 1024 ints, zero-filled by the call
-int cv_sp_mask_perms_batch(const CvPermJob* jobs, int n_jobs, void* d_ws, size_t ws_bytes, void* stream);
+// d_ws: (sum of groups) * 1024 ints, zero-filled by the call (unless pre_zeroed)
+int cv_sp_mask_perms_batch(const CvPermJob* jobs, int n_jobs, void* d_ws, size_t ws_bytes, void* stream,
+                           bool pre_zeroed = false);

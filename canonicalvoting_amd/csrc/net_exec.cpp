@@ -57,48 +57,47 @@ size_t cv_sp_scene_maps_words(const long long* level_rows, long long n_orig, int
 // the finest level and its mask-sorted orders
 static int scene_maps_level0(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
                              long long cap, long long n, const int32_t* d_perm, int stem_k, int mask_groups,
-                             const cv_scene_maps& o, int32_t* d_arena, const int32_t* d_bbox, void* stream) {
+                             const cv_scene_maps& o, int32_t* d_arena, const int32_t* d_bbox, void* stream,
+                             bool pre_cleared = false) {
     const unsigned* bits = nullptr;
     if (d_bbox) {       // occupancy bitmap in front of the hash probes (bounds from the sort; cv_sp_scene_plan)
         bits = reinterpret_cast<const unsigned*>(d_arena + o.bitmap);
-        const int rc0 = cv_sp_occupancy_bitmap(d_coords[0], n, d_bbox, reinterpret_cast<unsigned*>(d_arena + o.bitmap), stream);
+        const int rc0 = cv_sp_occupancy_bitmap(d_coords[0], n, d_bbox, reinterpret_cast<unsigned*>(d_arena + o.bitmap), stream,
+                                               pre_cleared);
         if (rc0 != CV_OK) return rc0;
     }
     CvMapJob mj[2];
     // stem: sorted rows <- rows of the ORIGINAL order = the sorted set's own map with the permutation folded in
     // (the caller's set needs no hash table of its own); the final original <- sorted map is the sort's inverse
-    mj[0] = {d_coords[0], n, d_keys[0], d_vals[0], cap, stem_k, 1, d_arena + o.stem, d_perm, bits, d_bbox};
-    mj[1] = {d_coords[0], n, d_keys[0], d_vals[0], cap, 3, 1, d_arena + o.k3[0], nullptr, bits, d_bbox};
+    mj[0] = {d_coords[0], n, d_keys[0], d_vals[0], cap, stem_k, 1, d_arena + o.stem, d_perm, bits, d_bbox, 0};
+    mj[1] = {d_coords[0], n, d_keys[0], d_vals[0], cap, 3, 1, d_arena + o.k3[0], nullptr, bits, d_bbox, 0};
     int rc = cv_sp_kernel_maps_batch(mj, 2, stream);
     if (rc != CV_OK) return rc;
     if (o.mask_perm[0] >= 0) {
         CvPermJob pj = {d_arena + o.k3[0], n, 27, mask_groups, d_arena + o.mask_perm[0], 1};
-        rc = cv_sp_mask_perms_batch(&pj, 1, d_arena + o.scratch, sizeof(int) * (size_t)mask_groups * 1024, stream);
+        rc = cv_sp_mask_perms_batch(&pj, 1, d_arena + o.scratch, sizeof(int) * (size_t)mask_groups * 1024, stream, pre_cleared);
         if (rc != CV_OK) return rc;
     }
     return CV_OK;
 }
 
-// the coarse levels: one launch for the eight remaining kernel maps, one fill + one launch for the four transposed
-// maps, three launches for the remaining processing orders
+// the coarse levels: ONE launch for the eight remaining kernel maps and the four transposed maps (by lookup of the
+// parent voxel: no pre-fill, no dependency on the strided maps), three launches for the remaining processing orders
 static int scene_maps_coarse(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
                              long long cap, const long long* level_rows, int mask_groups, const cv_scene_maps& o,
-                             int32_t* d_arena, void* stream) {
+                             int32_t* d_arena, void* stream, bool pre_zeroed = false) {
     CvMapJob mj[CV_MAX_MAP_JOBS];
     int nm = 0;
     for (int i = 0; i < 4; ++i)
-        mj[nm++] = {d_coords[i + 1], level_rows[i + 1], d_keys[i], d_vals[i], cap, 2, 1 << i, d_arena + o.down[i], nullptr, nullptr, nullptr};
+        mj[nm++] = {d_coords[i + 1], level_rows[i + 1], d_keys[i], d_vals[i], cap, 2, 1 << i, d_arena + o.down[i], nullptr, nullptr, nullptr, 0};
     for (int i = 1; i < 5; ++i)
-        mj[nm++] = {d_coords[i], level_rows[i], d_keys[i], d_vals[i], cap, 3, 1 << i, d_arena + o.k3[i], nullptr, nullptr, nullptr};
-    int rc = cv_sp_kernel_maps_batch(mj, nm, stream);
-    if (rc != CV_OK) return rc;
-    {   // the four transposed maps are neighbours in the arena: one fill
-        const long long lo = o.up[0], hi = o.up[3] + level_rows[0] * 8;
-        CV_HIP_CHECK(hipMemsetAsync(d_arena + lo, 0xff, sizeof(int32_t) * (size_t)(hi - lo), static_cast<hipStream_t>(stream)));
+        mj[nm++] = {d_coords[i], level_rows[i], d_keys[i], d_vals[i], cap, 3, 1 << i, d_arena + o.k3[i], nullptr, nullptr, nullptr, 0};
+    for (int i = 0; i < 4; ++i) {       // up[i]: level 4 - i -> 3 - i; the fine rows look their parent up in the coarser table
+        const int fine = 3 - i;
+        mj[nm++] = {d_coords[fine], level_rows[fine], d_keys[fine + 1], d_vals[fine + 1], cap, 2, 1 << fine, d_arena + o.up[i],
+                    nullptr, nullptr, nullptr, 1};
     }
-    CvUpJob uj[4];
-    for (int i = 0; i < 4; ++i) uj[i] = {d_arena + o.down[3 - i], level_rows[4 - i], d_arena + o.up[i]};
-    rc = cv_sp_up_maps_batch(uj, 4, stream);
+    int rc = cv_sp_kernel_maps_batch(mj, nm, stream);
     if (rc != CV_OK) return rc;
     CvPermJob pj[CV_MAX_PERM_JOBS];
     int np = 0, groups = 0;
@@ -112,7 +111,7 @@ static int scene_maps_coarse(int32_t* const* d_coords, const unsigned long long*
         groups += 1;
     }
     return cv_sp_mask_perms_batch(pj, np, d_arena + o.scratch + (size_t)std::max(mask_groups, 1) * 1024,
-                                  sizeof(int) * (size_t)groups * 1024, stream);
+                                  sizeof(int) * (size_t)groups * 1024, stream, pre_zeroed);
 }
 
 int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
@@ -192,7 +191,18 @@ int cv_sp_scene_plan(const int32_t* d_input, long long n, int32_t* d_perm, int32
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc = cv_sp_sort_rows(d_input, n, d_coords[0], d_perm, d_inv, d_sort_ws, sort_ws_bytes, stream);
     if (rc != CV_OK) return rc;
-    rc = cv_sp_build_levels(d_coords, d_keys, d_vals, n, cap, 5, d_counts, nullptr, d_levels_ws, levels_ws_bytes, stream);
+    // level-0 layout of the arena (depends on n only): the histogram scratch of the mask orders and the occupancy bitmap
+    // are neighbours there and are zeroed by the first launch of the level build (no fill launches of their own)
+    long long rows[5] = {n, 1, 1, 1, 1};
+    cv_scene_maps o;
+    size_t total = 0;
+    scene_maps_layout(rows, n, stem_k, mask_groups, masked_min_rows, &o, &total);
+    static const bool bitmap_on = !(getenv("CV_MAP_BITMAP") && atoi(getenv("CV_MAP_BITMAP")) == 0);
+    const long long n_zero = o.bitmap + (bitmap_on ? CV_BITMAP_WORDS : 0) - o.scratch;
+    // (the sort leaves its bounds - min, -max per axis, -max batch - in the first 8 ints of its workspace; [7] = 1 marks
+    // the bitmap as trusted until bitmap_set finds a row outside them)
+    rc = cv_sp_build_levels_zero(d_coords, d_keys, d_vals, n, cap, 5, d_counts, nullptr, d_levels_ws, levels_ws_bytes,
+                                 d_arena + o.scratch, n_zero, bitmap_on ? static_cast<int32_t*>(d_sort_ws) + 7 : nullptr, stream);
     if (rc != CV_OK) return rc;
     PlanSideLease lease;
     rc = plan_side_acquire(&lease.ps);
@@ -202,14 +212,8 @@ int cv_sp_scene_plan(const int32_t* d_input, long long n, int32_t* d_perm, int32
     CV_HIP_CHECK(hipMemcpyAsync(ps.h_pinned, d_counts, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, st));
     CV_HIP_CHECK(hipEventRecord(ps.ev, st));
     // level-0 maps: their arena offsets depend on n only
-    long long rows[5] = {n, 1, 1, 1, 1};
-    cv_scene_maps o;
-    size_t total = 0;
-    scene_maps_layout(rows, n, stem_k, mask_groups, masked_min_rows, &o, &total);
-    static const bool bitmap_on = !(getenv("CV_MAP_BITMAP") && atoi(getenv("CV_MAP_BITMAP")) == 0);
-    // (the sort leaves its bounds - min, -max per axis, -max batch - in the first 8 ints of its workspace)
     rc = scene_maps_level0(d_coords, d_keys, d_vals, cap, n, d_perm, stem_k, mask_groups, o, d_arena,
-                           bitmap_on ? static_cast<const int32_t*>(d_sort_ws) : nullptr, stream);
+                           bitmap_on ? static_cast<const int32_t*>(d_sort_ws) : nullptr, stream, true);
     if (rc != CV_OK) return rc;
     CV_HIP_CHECK(hipEventSynchronize(ps.ev));          // the counts have landed; the level-0 maps are still being built
     for (int i = 0; i < 8; ++i) h_counts[i] = ps.h_pinned[i];
@@ -219,7 +223,7 @@ int cv_sp_scene_plan(const int32_t* d_input, long long n, int32_t* d_perm, int32
     scene_maps_layout(rows, n, stem_k, mask_groups, masked_min_rows, &o, &total);
     CV_REQUIRE(arena_words >= total, CV_ENOMEM, "scene map arena too small");
     *offsets = o;
-    return scene_maps_coarse(d_coords, d_keys, d_vals, cap, rows, mask_groups, o, d_arena, stream);
+    return scene_maps_coarse(d_coords, d_keys, d_vals, cap, rows, mask_groups, o, d_arena, stream, true);
 }
 
 size_t cv_net_arena_bytes(const cv_net_buf* bufs, int n_bufs, const long long* level_rows, int n_levels) {

@@ -3157,7 +3157,7 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
 
 }  // namespace
 
-int cv_sp_mask_perms_batch(const CvPermJob* jobs, int n_jobs, void* d_ws, size_t ws_bytes, void* stream) {
+int cv_sp_mask_perms_batch(const CvPermJob* jobs, int n_jobs, void* d_ws, size_t ws_bytes, void* stream, bool pre_zeroed) {
     CV_REQUIRE(jobs && d_ws && n_jobs > 0 && n_jobs <= CV_MAX_PERM_JOBS, CV_EINVAL, "bad mask perm batch");
     PermJobsDev d;
     d.n = n_jobs;
@@ -3177,7 +3177,7 @@ int cv_sp_mask_perms_batch(const CvPermJob* jobs, int n_jobs, void* d_ws, size_t
     CV_REQUIRE(ws_bytes >= sizeof(int) * (size_t)groups * MP_BINS, CV_ENOMEM, "workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     int* hist = static_cast<int*>(d_ws);
-    CV_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * (size_t)groups * MP_BINS, st));
+    if (!pre_zeroed) CV_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * (size_t)groups * MP_BINS, st));
     dim3 grid((unsigned)((max_n + MP_THREADS - 1) / MP_THREADS), (unsigned)groups);
     mp_hist_batch<<<grid, MP_THREADS, 0, st>>>(d, hist);
     CV_LAUNCH_CHECK();

@@ -66,52 +66,18 @@ __global__ __launch_bounds__(256) void table_clear(unsigned long long* keys, int
     }
 }
 
-// level 1: key(coord i) -> i ; duplicates are counted (the reference feeds unique coordinates,
-// utils/dataloader.py:197-204)
-__global__ __launch_bounds__(256) void insert_rows(const int* __restrict__ coords, const int* n_ptr,
-                                                   unsigned long long* keys, int* vals, long long mask,
-                                                   int* dup_count) {
-    const int n = *n_ptr;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int4 c = reinterpret_cast<const int4*>(coords)[i];
-        // pack_key keeps 16 bits per field: a coordinate whose neighbour lookups (up to +-2 * 16 at the coarsest
-        // level, rounded up to 64) leave the window, or a batch index beyond 16 bits, would alias another voxel
-        const int lo = -32768 + 64, hi = 32767 - 64;
-        if ((unsigned)c.x > 0xffffu || c.y < lo || c.y > hi || c.z < lo || c.z > hi || c.w < lo || c.w > hi)
-            atomicAdd(dup_count + 1, 1);
-        const long long slot = table_insert_min(keys, vals, mask, pack_key(c.x, c.y, c.z, c.w), i);
-        (void)slot;
-    }
-}
-
-__global__ __launch_bounds__(256) void count_dups(const int* __restrict__ coords, const int* n_ptr,
-                                                  const unsigned long long* keys, const int* vals,
-                                                  long long mask, int* dup_count) {
-    const int n = *n_ptr;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int4 c = reinterpret_cast<const int4*>(coords)[i];
-        const long long slot = table_find(keys, mask, pack_key(c.x, c.y, c.z, c.w));
-        if (slot < 0 || vals[slot] != i) atomicAdd(dup_count, 1);
-    }
-}
-
-// coarse key of every fine row inserted with min(fine row)
-__global__ __launch_bounds__(256) void insert_coarse(const int* __restrict__ coords, const int* n_ptr,
-                                                     int stride2, unsigned long long* keys, int* vals,
-                                                     long long mask, long long* slot_of_row) {
-    const int n = *n_ptr;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int4 c = reinterpret_cast<const int4*>(coords)[i];
-        const int x = floor_div(c.y, stride2) * stride2, y = floor_div(c.z, stride2) * stride2,
-                  z = floor_div(c.w, stride2) * stride2;
-        slot_of_row[i] = table_insert_min(keys, vals, mask, pack_key(c.x, x, y, z), i);
-    }
-}
-
-// exclusive scan of the 0/1 flags in three short launches (a single-workgroup scan of 80k flags took
-// 37 us): per-block sums -> scan of the block sums -> per-block scan + offset.
-// rows per thread: 1 up to 1M rows (an 80k-row level then runs on 79 workgroups instead of 10: the passes read
-// vals[slot_of_row[i]] at random, latency-bound on few workgroups), 8 beyond
+// ---- all coordinate levels from the level-0 rows in five launches (round 3; the level-by-level build took 19) -------
+// A coarse set is ordered by the first appearance of a child in the next finer set.  By induction that is the order of
+// the SMALLEST LEVEL-0 ROW among a voxel's descendants (the finer set is itself in that order, so the first child is the
+// one holding the smallest descendant), so every level can be built from the level-0 rows directly:
+//   insert_all       key_L(row i) -> min(i) into the table of every level L (one pass over the rows; a lane whose
+//                    level-L key equals its left neighbour's cannot hold the minimum and skips the atomics - the rows
+//                    of the fused network arrive spatially sorted, so most lanes do)
+//   flag_levels      row i is the first descendant of its level-L voxel iff vals_L[slot] == i (+ the duplicate check
+//                    of level 0 as one more job of the same launch)
+//   scan_levels      block offsets of the flags, the level sizes
+//   emit_levels      rank of a flagged row = its coarse row: coordinates out, table value := coarse row
+struct LevelsDev { unsigned long long* keys[5]; int* vals[5]; int* coords[5]; int n_levels; };
 
 __device__ __forceinline__ int block_exclusive_scan(int v, int* s /*[1024]*/) {
     s[threadIdx.x] = v;
@@ -125,21 +91,63 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* s /*[1024]*/) {
     return s[threadIdx.x] - v;
 }
 
-// flag_first + scan_block_sums in one launch: flag[i] = (row i is the first row of its coarse voxel)
+__global__ __launch_bounds__(256) void insert_all(const int* __restrict__ coords, int n, const LevelsDev t, long long mask,
+                                                  int* __restrict__ slots /*[n_levels - 1][n]*/, int* dup_count) {
+    const int lane = threadIdx.x & 63;
+    const int n_pad = (n + 255) / 256 * 256;           // whole waves stay in the loop (the shuffles need them)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_pad; i += gridDim.x * 256) {
+        const bool have = i < n;
+        int4 c = make_int4(0, 0, 0, 0);
+        if (have) {
+            c = reinterpret_cast<const int4*>(coords)[i];
+            // pack_key keeps 16 bits per field: a coordinate whose neighbour lookups (up to +-2 * 16 at the coarsest
+            // level, rounded up to 64) leave the window, or a batch index beyond 16 bits, would alias another voxel
+            const int lo = -32768 + 64, hi = 32767 - 64;
+            if ((unsigned)c.x > 0xffffu || c.y < lo || c.y > hi || c.z < lo || c.z > hi || c.w < lo || c.w > hi)
+                atomicAdd(dup_count + 1, 1);
+            table_insert_min(t.keys[0], t.vals[0], mask, pack_key(c.x, c.y, c.z, c.w), i);
+        }
+        for (int L = 1; L < t.n_levels; ++L) {
+            const int m = ~((1 << L) - 1);             // floor(c / 2^L) * 2^L in two's complement
+            const unsigned long long key = have ? pack_key(c.x, c.y & m, c.z & m, c.w & m) : EMPTY_KEY;
+            const unsigned long long left = __shfl_up(key, 1);
+            int slot = -1;
+            if (have && (lane == 0 || left != key)) slot = (int)table_insert_min(t.keys[L], t.vals[L], mask, key, i);
+            if (have) slots[(long long)(L - 1) * n + i] = slot;
+        }
+    }
+}
+
+// blockIdx.y < n_levels - 1: flags of level y + 1 (kept as slot >= 0) and their block sums; blockIdx.y == n_levels - 1:
+// every level-0 row must find ITSELF in the level-0 table (duplicates are counted: the reference feeds unique
+// coordinates, utils/dataloader.py:197-204)
 template <int SCAN_PER>
-__global__ __launch_bounds__(1024) void flag_and_block_sums(const int* n_ptr, const int* __restrict__ vals,
-                                                            const long long* __restrict__ slot_of_row,
-                                                            int* __restrict__ flag, int* __restrict__ bsum) {
+__global__ __launch_bounds__(1024) void flag_levels(const int* __restrict__ coords, int n, const LevelsDev t, long long mask,
+                                                    int* __restrict__ slots, int* __restrict__ bsum /*[4][1024]*/,
+                                                    int* dup_count) {
     __shared__ int s[1024];
-    const int n = *n_ptr;
     const int b0 = (blockIdx.x * 1024 + threadIdx.x) * SCAN_PER;
+    if ((int)blockIdx.y == t.n_levels - 1) {
+#pragma unroll
+        for (int j = 0; j < SCAN_PER; ++j)
+            if (b0 + j < n) {
+                const int4 c = reinterpret_cast<const int4*>(coords)[b0 + j];
+                const long long slot = table_find(t.keys[0], mask, pack_key(c.x, c.y, c.z, c.w));
+                if (slot < 0 || t.vals[0][slot] != b0 + j) atomicAdd(dup_count, 1);
+            }
+        return;
+    }
+    const int L = blockIdx.y + 1;
+    int* sl = slots + (long long)blockIdx.y * n;
     int sum = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_PER; ++j)
         if (b0 + j < n) {
-            const int f = vals[slot_of_row[b0 + j]] == b0 + j ? 1 : 0;
-            flag[b0 + j] = f;
-            sum += f;
+            const int slot = sl[b0 + j];
+            if (slot >= 0) {
+                if (t.vals[L][slot] == b0 + j) sum += 1;
+                else sl[b0 + j] = -1;
+            }
         }
     s[threadIdx.x] = sum;
     __syncthreads();
@@ -147,58 +155,57 @@ __global__ __launch_bounds__(1024) void flag_and_block_sums(const int* n_ptr, co
         if (threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) bsum[blockIdx.x] = s[0];
+    if (threadIdx.x == 0) bsum[blockIdx.y * 1024 + blockIdx.x] = s[0];
 }
 
-// scan_apply + emit_coarse in one launch: the rank of a flagged row is its coarse row
-template <int SCAN_PER>
-__global__ __launch_bounds__(1024) void scan_apply_emit(const int* __restrict__ coords, const int* n_ptr, int stride2,
-                                                        const int* __restrict__ flag, const int* __restrict__ boff,
-                                                        const long long* __restrict__ slot_of_row, int* vals,
-                                                        int* __restrict__ out_coords) {
+// one block per coarse level: exclusive scan of its block sums, total -> counts[level]
+__global__ __launch_bounds__(1024) void scan_levels(int* __restrict__ bsum, int nblocks, int* counts) {
     __shared__ int s[1024];
-    const int n = *n_ptr;
+    int* bs = bsum + blockIdx.x * 1024;
+    const int v = (int)threadIdx.x < nblocks ? bs[threadIdx.x] : 0;
+    const int ex = block_exclusive_scan(v, s);
+    if ((int)threadIdx.x < nblocks) bs[threadIdx.x] = ex;
+    if (threadIdx.x == 1023) counts[blockIdx.x + 1] = ex + v;
+}
+
+template <int SCAN_PER>
+__global__ __launch_bounds__(1024) void emit_levels(const int* __restrict__ coords, int n, const LevelsDev t,
+                                                    const int* __restrict__ slots, const int* __restrict__ boff) {
+    __shared__ int s[1024];
+    const int L = blockIdx.y + 1;
+    const int* sl = slots + (long long)blockIdx.y * n;
     const int b0 = (blockIdx.x * 1024 + threadIdx.x) * SCAN_PER;
     int v[SCAN_PER], sum = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_PER; ++j) { v[j] = (b0 + j < n) ? flag[b0 + j] : 0; sum += v[j]; }
-    int run = block_exclusive_scan(sum, s) + boff[blockIdx.x];
+    for (int j = 0; j < SCAN_PER; ++j) { v[j] = (b0 + j < n) ? sl[b0 + j] : -1; sum += v[j] >= 0; }
+    int run = block_exclusive_scan(sum, s) + boff[blockIdx.y * 1024 + blockIdx.x];
+    const int m = ~((1 << L) - 1);
 #pragma unroll
     for (int j = 0; j < SCAN_PER; ++j) {
-        if (v[j]) {
-            const int i = b0 + j;
-            const int4 c = reinterpret_cast<const int4*>(coords)[i];
-            int4 o;
-            o.x = c.x;
-            o.y = floor_div(c.y, stride2) * stride2;
-            o.z = floor_div(c.z, stride2) * stride2;
-            o.w = floor_div(c.w, stride2) * stride2;
-            reinterpret_cast<int4*>(out_coords)[run] = o;
-            vals[slot_of_row[i]] = run;     // table now maps coarse key -> compact coarse row
+        if (v[j] >= 0) {
+            const int4 c = reinterpret_cast<const int4*>(coords)[b0 + j];
+            reinterpret_cast<int4*>(t.coords[L])[run] = make_int4(c.x, c.y & m, c.z & m, c.w & m);
+            t.vals[L][v[j]] = run;          // table now maps coarse key -> compact coarse row
+            ++run;
         }
-        run += v[j];
     }
 }
 
 struct TablesDev { unsigned long long* keys[5]; int* vals[5]; int n; };
 
-// every level's table cleared by one launch; also the counters: counts[0] = n, the rest 0
-__global__ __launch_bounds__(256) void table_clear_all(const TablesDev t, long long cap, int* counts, int n_rows) {
+// every level's table cleared by one launch; also the counters: counts[0] = n, the rest 0; and an optional extra range
+// of words set to zero (cv_sp_scene_plan: the histogram scratch of the mask orders, so that they need no fill launches)
+__global__ __launch_bounds__(256) void table_clear_all(const TablesDev t, long long cap, int* counts, int n_rows,
+                                                       int* __restrict__ zero_words, long long n_zero, int* set_one) {
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < cap * t.n; i += (long long)gridDim.x * 256) {
         const int L = (int)(i / cap);
         const long long k = i - (long long)L * cap;
         t.keys[L][k] = EMPTY_KEY;
         t.vals[L][k] = 0x7fffffff;
     }
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n_zero; i += (long long)gridDim.x * 256) zero_words[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x < 8) counts[threadIdx.x] = threadIdx.x == 0 ? n_rows : 0;
-}
-
-__global__ __launch_bounds__(1024) void scan_block_offsets(int* __restrict__ bsum, int nblocks, int* total_out) {
-    __shared__ int s[1024];
-    const int v = threadIdx.x < nblocks ? bsum[threadIdx.x] : 0;
-    const int ex = block_exclusive_scan(v, s);
-    if (threadIdx.x < nblocks) bsum[threadIdx.x] = ex;
-    if (threadIdx.x == 1023) *total_out = ex + v;
+    if (set_one && blockIdx.x == 0 && threadIdx.x == 0) *set_one = 1;
 }
 
 // nbr[u][j] = row of (out_coord[u] + offset_j * ts) in the input set, or -1.  Offset index j runs
@@ -236,15 +243,21 @@ struct BitBox { int mn[3], d[3], nb; bool ok; };
 __device__ __forceinline__ BitBox bitbox(const int* __restrict__ mm) {
     BitBox b;
     long long cells = 1;
+    bool sane = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
+        // extents in 64 bits: coordinates far outside the key window must not wrap the product into the accepted range
+        const long long d = -(long long)mm[3 + k] - (long long)mm[k] + 1;
+        sane = sane && d > 0 && d <= 65536;
         b.mn[k] = mm[k];
-        b.d[k] = -mm[3 + k] - mm[k] + 1;
-        cells *= b.d[k] > 0 ? b.d[k] : 0;
+        b.d[k] = sane ? (int)d : 0;
+        cells *= sane ? d : 0;
     }
-    b.nb = -mm[6] + 1;
-    cells *= b.nb > 0 ? b.nb : 0;
-    b.ok = cells > 0 && cells <= CV_BITMAP_WORDS * 32 && mm[7] == 1;      // mm[7] == 1: no negative batch index seen
+    const long long nb = -(long long)mm[6] + 1;
+    sane = sane && nb > 0 && nb <= 65536;
+    b.nb = sane ? (int)nb : 0;
+    cells = sane ? cells * nb : 0;
+    b.ok = sane && cells > 0 && cells <= CV_BITMAP_WORDS * 32 && mm[7] == 1;      // mm[7] == 1: no negative batch index seen
     return b;
 }
 // bit of (batch, x, y, z), or -1 outside the box
@@ -260,9 +273,12 @@ __global__ __launch_bounds__(256) void bitmap_clear(const int* __restrict__ coor
     // batch index: the sort tracks the largest batch index only and such inputs fail the key-window check anyway)
     if (blockIdx.x == 0 && threadIdx.x == 0) mm[7] = 1;
     long long cells = 1;
-    for (int k = 0; k < 3; ++k) { const int d = -mm[3 + k] - mm[k] + 1; cells *= d > 0 ? d : 0; }
-    const int nb = -mm[6] + 1;
-    cells *= nb > 0 ? nb : 0;
+    for (int k = 0; k < 3; ++k) {
+        const long long d = -(long long)mm[3 + k] - (long long)mm[k] + 1;
+        cells = (d > 0 && d <= 65536 && cells > 0) ? cells * d : 0;
+    }
+    const long long nb = -(long long)mm[6] + 1;
+    cells = (nb > 0 && nb <= 65536) ? cells * nb : 0;
     if (cells <= 0 || cells > CV_BITMAP_WORDS * 32) return;
     const long long words = (cells + 31) / 32;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < words; i += (long long)gridDim.x * 256) bits[i] = 0u;
@@ -323,11 +339,32 @@ __device__ __forceinline__ void map_job(const CvMapJob& jb, int nblk, int blk) {
     }
 }
 
+// transposed k2s2 map by lookup: fine row f -> its parent's row in the octant column (no pre-fill, no down map needed)
+__device__ __forceinline__ void up_job(const CvMapJob& jb, int nblk, int blk) {
+    const long long mask = jb.cap - 1;
+    const int ts = jb.ts, m = ~(2 * ts - 1);
+    for (long long f = blk * 256ll + threadIdx.x; f < jb.n_out; f += (long long)nblk * 256) {
+        const int4 c = reinterpret_cast<const int4*>(jb.out_coords)[f];
+        const int px = c.y & m, py = c.z & m, pz = c.w & m;
+        const long long slot = table_find(jb.keys, mask, pack_key(c.x, px, py, pz));
+        const int parent = slot >= 0 ? jb.vals[slot] : -1;
+        const int oct = ((c.y - px) / ts) + 2 * ((c.z - py) / ts) + 4 * ((c.w - pz) / ts);
+        int4 lo = make_int4(-1, -1, -1, -1), hi = lo;
+        switch (oct) {
+            case 0: lo.x = parent; break; case 1: lo.y = parent; break; case 2: lo.z = parent; break; case 3: lo.w = parent; break;
+            case 4: hi.x = parent; break; case 5: hi.y = parent; break; case 6: hi.z = parent; break; default: hi.w = parent; break;
+        }
+        reinterpret_cast<int4*>(jb.nbr)[2 * f] = lo;
+        reinterpret_cast<int4*>(jb.nbr)[2 * f + 1] = hi;
+    }
+}
+
 __global__ __launch_bounds__(256) void build_kernel_maps(const MapJobsDev jobs) {
     int ji = 0;
     while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.block_begin[ji + 1]) ++ji;
     const CvMapJob& jb = jobs.j[ji];
     const int nblk = jobs.block_begin[ji + 1] - jobs.block_begin[ji], blk = blockIdx.x - jobs.block_begin[ji];
+    if (jb.up) { up_job(jb, nblk, blk); return; }
     switch (jb.k) {
         case 5: map_job<125>(jb, nblk, blk); break;
         case 3: map_job<27>(jb, nblk, blk); break;
@@ -541,7 +578,7 @@ int cv_sp_kernel_maps_batch(const CvMapJob* jobs, int n_jobs, void* stream) {
                    CV_EINVAL, "bad kernel map job %d", i);
         d.j[i] = j;
         d.block_begin[i] = total;
-        total += grid_for(j.n_out * j.k * j.k * j.k);
+        total += j.up ? grid_for(j.n_out) : grid_for(j.n_out * j.k * j.k * j.k);
     }
     d.block_begin[n_jobs] = total;
     build_kernel_maps<<<total, 256, 0, static_cast<hipStream_t>(stream)>>>(d);
@@ -549,12 +586,15 @@ int cv_sp_kernel_maps_batch(const CvMapJob* jobs, int n_jobs, void* stream) {
     return CV_OK;
 }
 
-int cv_sp_occupancy_bitmap(const int32_t* d_coords, long long n, const int32_t* d_bbox, unsigned* d_bits, void* stream) {
+int cv_sp_occupancy_bitmap(const int32_t* d_coords, long long n, const int32_t* d_bbox, unsigned* d_bits, void* stream,
+                           bool pre_cleared) {
     CV_REQUIRE(d_coords && d_bbox && d_bits && n > 0, CV_EINVAL, "bad bitmap arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
     int* mm = const_cast<int*>(d_bbox);
-    bitmap_clear<<<256, 256, 0, st>>>(d_coords, n, mm, d_bits);
-    CV_LAUNCH_CHECK();
+    if (!pre_cleared) {
+        bitmap_clear<<<256, 256, 0, st>>>(d_coords, n, mm, d_bits);
+        CV_LAUNCH_CHECK();
+    }
     bitmap_set<<<grid_for(n), 256, 0, st>>>(d_coords, n, mm, d_bits);
     CV_LAUNCH_CHECK();
     return CV_OK;
@@ -586,8 +626,8 @@ long long cv_sp_table_capacity(long long n) {
 }
 
 size_t cv_sp_levels_workspace_bytes(long long n) {
-    // slot_of_row (8n) + flag (4n) + rank (4n) + counters
-    return cv_align_up((size_t)n * 8, 256) + 2 * cv_align_up((size_t)n * 4, 256) + 4096 + 1024;
+    // table slot of every (coarse level, level-0 row) + block sums of the four flag scans
+    return 4 * cv_align_up((size_t)n * 4, 256) + 4 * 4096 + 1024;
 }
 
 // Builds the coordinate sets of tensor strides 1,2,4,8,16 and their hash tables.
@@ -596,9 +636,12 @@ size_t cv_sp_levels_workspace_bytes(long long n) {
 //   d_counts      : int32[8] device; [L] = rows at level L, [5] = duplicate count at level 0, [6] = rows whose
 //                   coordinates are outside the 16-bit key window (|c| <= 32703, batch < 65536)
 // h_counts receives the same 8 ints (one synchronisation).
-int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_keys,
-                       int32_t* const* d_vals, long long n, long long cap, int num_levels,
-                       int32_t* d_counts, int32_t* h_counts, void* d_ws, size_t ws_bytes, void* stream) {
+}  // extern "C"
+
+// (C++ linkage, cv_common.h) d_zero / n_zero: an optional range of words the first launch also clears
+int cv_sp_build_levels_zero(int32_t* const* d_coords, unsigned long long* const* d_keys, int32_t* const* d_vals,
+                            long long n, long long cap, int num_levels, int32_t* d_counts, int32_t* h_counts, void* d_ws,
+                            size_t ws_bytes, int32_t* d_zero, long long n_zero, int32_t* d_set_one, void* stream) {
     CV_REQUIRE(d_coords && d_keys && d_vals && d_counts && d_ws, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(n > 0 && n < (1ll << 30), CV_EINVAL, "bad row count %lld", n);
     CV_REQUIRE(num_levels >= 1 && num_levels <= 5, CV_EINVAL, "num_levels must be 1..5");
@@ -606,44 +649,32 @@ int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_ke
     CV_REQUIRE(ws_bytes >= cv_sp_levels_workspace_bytes(n), CV_ENOMEM, "workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     CvCarver cv(d_ws);
-    long long* slot_of_row = cv.take<long long>(n);
-    int* flag = cv.take<int>(n);
-    (void)cv.take<int>(n);      // (formerly the rank array; the workspace size is part of the C ABI)
-    int* bsum = cv.take<int>(1024);
+    int* slots = cv.take<int>((size_t)4 * n);
+    int* bsum = cv.take<int>(4 * 1024);
     const int scan_per = n <= (1ll << 20) ? 1 : 8;
     const int nsb = (int)((n + 1024ll * scan_per - 1) / (1024ll * scan_per));
     CV_REQUIRE(nsb <= 1024, CV_EINVAL, "coordinate set too large for the scan (%lld rows)", n);
     const int g = grid_for(n);
-    // 4 launches per coarse level + 3 for level 0 (the first version took 7 per level + 5: the flag / emit passes are
-    // folded into the scan's two passes, all tables and the counters are cleared by one launch)
     TablesDev tabs;
-    tabs.n = num_levels;
+    LevelsDev lv;
+    tabs.n = lv.n_levels = num_levels;
     for (int L = 0; L < 5; ++L) {
-        tabs.keys[L] = L < num_levels ? d_keys[L] : nullptr;
-        tabs.vals[L] = L < num_levels ? d_vals[L] : nullptr;
+        tabs.keys[L] = lv.keys[L] = L < num_levels ? d_keys[L] : nullptr;
+        tabs.vals[L] = lv.vals[L] = L < num_levels ? d_vals[L] : nullptr;
+        lv.coords[L] = L < num_levels ? d_coords[L] : nullptr;
     }
-    table_clear_all<<<grid_for(cap * num_levels), 256, 0, st>>>(tabs, cap, d_counts, (int)n);
+    table_clear_all<<<grid_for(cap * num_levels), 256, 0, st>>>(tabs, cap, d_counts, (int)n, d_zero, d_zero ? n_zero : 0, d_set_one);
     CV_LAUNCH_CHECK();
-    insert_rows<<<g, 256, 0, st>>>(d_coords[0], d_counts, d_keys[0], d_vals[0], cap - 1, d_counts + 5);
+    insert_all<<<g, 256, 0, st>>>(d_coords[0], (int)n, lv, cap - 1, slots, d_counts + 5);
     CV_LAUNCH_CHECK();
-    count_dups<<<g, 256, 0, st>>>(d_coords[0], d_counts, d_keys[0], d_vals[0], cap - 1, d_counts + 5);
+    if (scan_per == 1) flag_levels<1><<<dim3(nsb, num_levels), 1024, 0, st>>>(d_coords[0], (int)n, lv, cap - 1, slots, bsum, d_counts + 5);
+    else flag_levels<8><<<dim3(nsb, num_levels), 1024, 0, st>>>(d_coords[0], (int)n, lv, cap - 1, slots, bsum, d_counts + 5);
     CV_LAUNCH_CHECK();
-    for (int L = 1; L < num_levels; ++L) {
-        const int stride2 = 1 << L;
-        insert_coarse<<<g, 256, 0, st>>>(d_coords[L - 1], d_counts + L - 1, stride2, d_keys[L], d_vals[L],
-                                         cap - 1, slot_of_row);
+    if (num_levels > 1) {
+        scan_levels<<<num_levels - 1, 1024, 0, st>>>(bsum, nsb, d_counts);
         CV_LAUNCH_CHECK();
-        if (scan_per == 1) flag_and_block_sums<1><<<nsb, 1024, 0, st>>>(d_counts + L - 1, d_vals[L], slot_of_row, flag, bsum);
-        else flag_and_block_sums<8><<<nsb, 1024, 0, st>>>(d_counts + L - 1, d_vals[L], slot_of_row, flag, bsum);
-        CV_LAUNCH_CHECK();
-        scan_block_offsets<<<1, 1024, 0, st>>>(bsum, nsb, d_counts + L);
-        CV_LAUNCH_CHECK();
-        if (scan_per == 1)
-            scan_apply_emit<1><<<nsb, 1024, 0, st>>>(d_coords[L - 1], d_counts + L - 1, stride2, flag, bsum, slot_of_row,
-                                                     d_vals[L], d_coords[L]);
-        else
-            scan_apply_emit<8><<<nsb, 1024, 0, st>>>(d_coords[L - 1], d_counts + L - 1, stride2, flag, bsum, slot_of_row,
-                                                     d_vals[L], d_coords[L]);
+        if (scan_per == 1) emit_levels<1><<<dim3(nsb, num_levels - 1), 1024, 0, st>>>(d_coords[0], (int)n, lv, slots, bsum);
+        else emit_levels<8><<<dim3(nsb, num_levels - 1), 1024, 0, st>>>(d_coords[0], (int)n, lv, slots, bsum);
         CV_LAUNCH_CHECK();
     }
     if (h_counts) {
@@ -651,6 +682,15 @@ int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_ke
         CV_HIP_CHECK(hipStreamSynchronize(st));
     }
     return CV_OK;
+}
+
+extern "C" {
+
+int cv_sp_build_levels(int32_t* const* d_coords, unsigned long long* const* d_keys,
+                       int32_t* const* d_vals, long long n, long long cap, int num_levels,
+                       int32_t* d_counts, int32_t* h_counts, void* d_ws, size_t ws_bytes, void* stream) {
+    return cv_sp_build_levels_zero(d_coords, d_keys, d_vals, n, cap, num_levels, d_counts, h_counts, d_ws, ws_bytes, nullptr,
+                                   0, nullptr, stream);
 }
 
 // Z-order sort keys of a coordinate set (the fused network runs on spatially sorted rows so that
