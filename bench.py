@@ -76,7 +76,7 @@ def parse():
                          "from one shared counter (scenes are independent; fills the launch tails and host syncs of one scene "
                          "with the kernels of another)")
     ap.add_argument("--switch-interval", type=float, default=0.0005, help="sys.setswitchinterval for the scene threads")
-    ap.add_argument("--mode", default="eval", choices=["eval", "train"],
+    ap.add_argument("--mode", default="eval", choices=["eval", "train", "separate"],
                     help="eval (default, the BASELINE metric): eval_joint.py path.  train: train_joint.py step "
                          "(fwd + bwd + Adam, fp32) on --train-batch scenes per GPU-step, DDP gradient all-reduce over "
                          "RCCL when launched on several GPUs (BASELINE configs 3-4; a side measurement, not the "
@@ -87,6 +87,9 @@ def parse():
                          "bf16, one product, fp32 accumulation and storage (BASELINE configs 3-4 name bf16 for "
                          "training; outside the 1e-4 parity bar, reported as dtype bf16)")
     ap.add_argument("--train-batch", type=int, default=3, help="scenes per GPU-step in --mode train (config.yaml:15)")
+    ap.add_argument("--train-steps", type=int, default=5,
+                    help="eval mode, rank 0: train_joint.py steps timed AFTER the timed region for the `train_step_ms` side "
+                         "field (0 = skip)")
     ap.add_argument("--sync-bn", action="store_true", help="--mode train: BatchNorm statistics over all ranks' rows "
                                                            "(the reference's batch-of-3 semantics under scene-parallel DDP)")
     ap.add_argument("--large", action="store_true",
@@ -102,6 +105,17 @@ def parse():
     if a.teacher_forced:
         a.predictions = "teacher"
     return a
+
+
+def scene_threads(requested):
+    """scene threads (= scenes in flight) of this rank: what was asked for, but never more than the host cores the rank
+    can run on (8 ranks x S threads share one node's cores; at least 2 so that host syncs of one scene overlap another)"""
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(max(1, requested), max(2, cores // max(1, local_world))))
 
 
 def check_world(a):
@@ -279,6 +293,50 @@ def cpu_baseline(a, scenes, model, hv, full, teacher):
     return base, par
 
 
+def train_batch(rank, B, n, dev, scenes=None):
+    """(coords4, feats, xyz, scale, class labels) of B synthetic ScanNet-shaped scenes as train_joint.py:247-251 batches
+    them (batch index in column 0, colours recentred)"""
+    scenes = scenes or [make_scene(seed, n_points=n, res=RES) for seed in cvd.scene_seeds(rank, B)]
+    coords = torch.cat([torch.cat([torch.full((len(s.coords), 1), b, dtype=torch.int32), torch.from_numpy(s.coords)], 1)
+                        for b, s in enumerate(scenes)]).to(dev)
+    feats = torch.cat([torch.from_numpy(s.feats) for s in scenes]).to(dev) * 2 - 1
+    xyz = torch.cat([torch.from_numpy(s.xyz_labels) for s in scenes]).to(dev)
+    scale = torch.cat([torch.from_numpy(s.scale_labels) for s in scenes]).to(dev)
+    cls = torch.cat([torch.from_numpy(s.class_labels) for s in scenes]).to(dev)
+    return coords, feats, xyz, scale, cls
+
+
+def train_side_field(a, scenes, dev):
+    """config 3 next to the headline: a few train_joint.py steps (forward + backward + Adam, fp32-level
+    products, batch of --train-batch scenes) on this GPU AFTER the timed region, so that the driver's default line
+    shows the training step too.  Not part of `value`."""
+    from canonicalvoting_amd import train
+    B = a.train_batch
+    batch = train_batch(0, B, a.points, dev, scenes=[s.host[0] for s in scenes[:B]] if len(scenes) >= B else None)
+    prev = ME.set_compute_dtype("fp32")
+    try:
+        torch.manual_seed(0)
+        model = MinkUNet34C(3, 6 * 9 + 9 + 1).cuda().train()
+        opt = train.make_optimizer(model)
+        for _ in range(2):
+            train.train_step(model, opt, *batch)
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(a.train_steps):
+            t0 = time.perf_counter()
+            loss, _ = train.train_step(model, opt, *batch)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        return {"value": float(np.median(times) * 1e3), "unit": "ms per step (median of %d)" % a.train_steps,
+                "scenes_per_step": B, "points_per_scene": a.points, "dtype": "f32",
+                "what": "train_joint.py:244-288 step: MinkUNet34C(3, 64) forward + backward + Adam on one GPU, "
+                        "batch-statistics BatchNorm", "final_loss": float(loss)}
+    finally:
+        ME.set_compute_dtype(prev)
+        del model, opt
+        torch.cuda.empty_cache()
+
+
 def main_train(a):
     """train_joint.py:244-288 steps on synthetic ScanNet-shaped batches: one process per GPU, each with its own
     batch of scenes (weak scaling), gradients all-reduced by torch DDP over RCCL, BatchNorm statistics per GPU
@@ -291,13 +349,7 @@ def main_train(a):
     cvd.init("nccl", dev)
     _lib.lib()
     B, n = a.train_batch, a.points
-    scenes = [make_scene(seed, n_points=n, res=RES) for seed in cvd.scene_seeds(rank, B)]
-    coords = torch.cat([torch.cat([torch.full((n, 1), b, dtype=torch.int32), torch.from_numpy(s.coords)], 1)
-                        for b, s in enumerate(scenes)]).to(dev)
-    feats = torch.cat([torch.from_numpy(s.feats) for s in scenes]).to(dev) * 2 - 1
-    xyz = torch.cat([torch.from_numpy(s.xyz_labels) for s in scenes]).to(dev)
-    scale = torch.cat([torch.from_numpy(s.scale_labels) for s in scenes]).to(dev)
-    cls = torch.cat([torch.from_numpy(s.class_labels) for s in scenes]).to(dev)
+    coords, feats, xyz, scale, cls = train_batch(rank, B, n, dev)
     ME.set_compute_dtype("bf16" if a.dtype == "bf16" else "fp32")
     torch.manual_seed(0)
     model = MinkUNet34C(3, 6 * 9 + 9 + 1).cuda().train()
@@ -329,6 +381,76 @@ def main_train(a):
     cvd.finalize()
 
 
+def main_separate(a):
+    """BASELINE config 5 as the reference runs it (eval_separate.py:136-264): NINE 8-channel per-category models on ONE
+    SparseTensor per scene - the coordinate plan (sort, levels, maps, orders) is built once and shared by the nine
+    forwards - then per category head split -> vote -> decode (eval_separate.py:209 slice) -> NMS.  One scene in
+    flight per rank; a side mode (`--mode separate --large --points 300000`), not the headline metric.
+    Vote / decode are fed per-category teacher predictions (the labels of that category), as in the default mode."""
+    world, rank, local = check_world(a)
+    local %= torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cvd.init("nccl", dev)
+    _lib.lib()
+    ME.set_compute_dtype("bf16" if a.dtype == "bf16" else "fp32")
+    ncat = 9
+    torch.manual_seed(0)
+    models = [MinkUNet34C(3, 8).cuda().eval() for _ in range(ncat)]          # eval_separate.py:140-150
+    hv = HoughVoting(RES, NUM_ROTS)
+    scenes = [ResidentScene(seed, a.points, dev, a.large) for seed in cvd.scene_seeds(rank, min(a.scenes, 2))]
+    err = float(np.float32(0.3))
+
+    def step(s, ev=None):
+        rec = (lambda i: ev[i].record()) if ev is not None else (lambda i: None)
+        n_det = 0
+        with torch.no_grad():
+            rec(0)
+            x = ME.SparseTensor(s.feats_in, s.coords4, device=dev)
+            x.coordinate_manager.fused_fast(5)                                  # the plan, once per scene
+            rec(1)
+            for c, model in enumerate(models):
+                y = model(x)
+                xyz_n, scale_n, prob_n = pipeline.head_separate(y.F)
+                prob_c = s.prob * (s.cls == c).float()                          # teacher predictions of category c
+                grid_obj, grid_rot, grid_scale = hv(s.points, s.xyz, s.scale, prob_c)
+                raw = decode.decode_boxes(grid_obj, grid_rot, grid_scale, s.points, s.xyz, prob_c,
+                                          torch.zeros_like(s.cls), RES, separate_variant=True, err_thresh=err)
+                n_det += len(decode.nms(raw["boxes"], raw["scores"], 0.3))
+                rec(2 + c)
+        return n_det
+
+    for w in range(max(a.warmup, 2)):
+        step(scenes[w % len(scenes)])
+    torch.cuda.synchronize()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(2 + ncat)] for _ in range(a.steps)]
+    cvd.barrier(dev)
+    t0 = time.perf_counter()
+    n_det = 0
+    for k in range(a.steps):
+        n_det += step(scenes[k % len(scenes)], events[k])
+    cvd.barrier(dev)
+    dt = cvd.reduce_scalar(time.perf_counter() - t0, "max", dev)
+    torch.cuda.synchronize()
+    plan_ms = float(np.median([e[0].elapsed_time(e[1]) for e in events]))
+    per_model = [float(np.median([e[1 + c].elapsed_time(e[2 + c]) for e in events])) for c in range(ncat)]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "scenes/sec (eval_separate.py path: nine per-category 8-channel models per scene)",
+            "value": cvd.throughput(a.steps, world, dt), "unit": "scenes/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "single %d-point synthetic scene per GPU-step, eval_separate.py path: ONE coordinate plan, "
+                                   "nine MinkUNet34C(3, 8) forwards + head + vote + decode + NMS" % a.points,
+                       "points": a.points, "large": bool(a.large), "grid": scenes[0].dims, "categories": ncat,
+                       "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": 1},
+            "plan_ms": plan_ms, "per_model_ms": per_model, "per_model_ms_mean": float(np.mean(per_model)),
+            "plan_amortised_ms_per_model": plan_ms / ncat,
+            "plan_share_if_rebuilt_per_model": plan_ms * ncat / (plan_ms * ncat + sum(per_model)),
+            "detections_per_scene": n_det / a.steps}), flush=True)
+    cvd.finalize()
+
+
 def main_rendezvous_only(a):
     """The launch path without a GPU: what the driver's torch.distributed.run line exercises before any kernel runs."""
     world, rank, _ = check_world(a)
@@ -341,6 +463,7 @@ def main_rendezvous_only(a):
     if rank == 0:
         print(json.dumps({"metric": "scenes/sec (80k-pt synthetic scans)", "value": None, "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "rendezvous_only": True, "max_seconds": dt,
+                          "scene_threads_per_rank": scene_threads(a.streams),
                           "scene_seeds_rank0": cvd.scene_seeds(0, a.scenes)}), flush=True)
     cvd.finalize()
 
@@ -351,6 +474,8 @@ def main():
         return main_rendezvous_only(a)
     if a.mode == "train":
         return main_train(a)
+    if a.mode == "separate":
+        return main_separate(a)
     world, rank, local = check_world(a)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     local %= torch.cuda.device_count()          # one rank per GPU on a real node; ranks share GPUs only in the launch-path test
@@ -383,14 +508,7 @@ def main():
                     xyz, scale, prob, cls = pipeline.head_joint(y.F)
                     s.v_in = hv_cuda.count_votes(s.points, xyz, scale, RES, NUM_ROTS, s.corner, s.dims)
                     s.vote_bytes = 40 * a.points + 192 * s.v_in + 68 * s.cells
-    S = max(1, a.streams)
-    # scene threads of a rank never outnumber the host cores it can run on (8 ranks x S threads on one node)
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    S = max(1, min(S, max(2, cores // max(1, local_world))))
+    S = scene_threads(a.streams)
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
     hvs = [hv] + [HoughVoting(RES, NUM_ROTS) for _ in range(S - 1)]
     hv_cuda.reserve_pinned(4 * S + 8)
@@ -570,7 +688,9 @@ def main():
         "stage_ms_isolated": iso_stage,
         "warmup_steps_run": int(sum(warm_steps)),
     }
-    out["cpu_baseline"] = out["parity"] = None
+    out["cpu_baseline"] = out["parity"] = out["train_step_ms"] = None
+    if rank == 0 and full and a.train_steps > 0 and not a.large:
+        out["train_step_ms"] = train_side_field(a, scenes, dev)
     if rank == 0 and a.cpu_scenes > 0:
         out["cpu_baseline"], out["parity"] = cpu_baseline(a, scenes, model, hv, full, teacher)
     if rank == 0:

@@ -23,7 +23,7 @@ STRICT = ["-ffp-contract=off"]
 SOURCES = {
     "cv_host.cpp": STRICT,
     "hv_vote.hip": STRICT + os.environ.get("CV_HV_DEFS", "").split(),     # tile-shape experiments (-DHV_TX=16 -DHV_TW=8)
-    "hv_decode.hip": STRICT,
+    "hv_decode.hip": STRICT + os.environ.get("CV_DEC_DEFS", "").split(),  # greedy-walk experiments (-DDEC_BLOCKED=0)
     "sparse_coords.hip": [],
     "sparse_conv.hip": os.environ.get("CV_SC_DEFS", "").split(),          # kernel experiments (-DCV_WP_CLAMPED_GATHER=1)
     "net_exec.cpp": [],

@@ -26,6 +26,7 @@
 #include "cv_common.h"
 
 #include <cmath>
+#include <cstddef>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -192,16 +193,20 @@ __global__ __launch_bounds__(256) void hv_normalise(const float* __restrict__ g_
 // ---------------------------------------------------------------------------
 // tiles algorithm
 // ---------------------------------------------------------------------------
-// Tile = HV_TX x 32 cells of one y plane, HV_TW waves per workgroup.  16 x 32 cells / 8 waves need 68 KB of LDS, so
-// TWO workgroups share a CU (the 32 x 32 / 16-wave shape needs 133 KB: one): the zero-fill, the part merge and the
-// normalise + store of one tile overlap the expansion of another.  Measured on the headline workload's predictions
-// (profiles/r1/vote_tile_sweep.txt): 32x32/16 waves 0.4325 ms, 16x32/8 0.4119, 16x32/16 0.570, 32x32/8 0.459,
-// 8x32/8 0.468, 16x32/4 0.414 (0.428 teacher-forced), 8x32/4 0.472.
+// Tile = HV_TX x 32 cells of one y plane, HV_TW waves per workgroup.
+// Round 3: 32 x 32 cells / 16 waves (133 KB of LDS, one workgroup per CU) is the default again.  The 16 x 32 / 8-wave
+// shape of rounds 1-2 (68 KB, two workgroups per CU, 4-5 % faster: profiles/r1/vote_tile_sweep.txt) gives WRONG cells -
+// a few dozen cells of one (plane, tile), weight moved between neighbouring cells - in about a third of the launches
+// that run while fp16 / bf16 matrix-core convolutions of OTHER streams are resident on the same CUs, i.e. in the
+// bench's scenes-in-flight mode (tests/test_concurrency_gpu.py, profiles/vote_race_probe3.py; evidence and the list of
+// causes excluded - stale LDS, scratch, f64 conversions, record order, LDS ordering inside a wave - in
+// profiles/r3/vote_concurrency_findings.txt and DESIGN.md 4.1).  Workgroups of 1024 threads leave no room for a
+// convolution wave on their CU and are exact under the same load (0 of 4800 scenes differ).
 #ifndef HV_TX
-#define HV_TX 16
+#define HV_TX 32
 #endif
 #ifndef HV_TW
-#define HV_TW 8
+#define HV_TW 16
 #endif
 #ifndef HV_PART_RECORDS
 #define HV_PART_RECORDS 4096
@@ -214,10 +219,19 @@ constexpr int TW = HV_TW;    // waves per workgroup
 constexpr int PQ = 64;       // surviving points per wave chunk
 constexpr int VQ = 128;      // vote queue entries per wave
 constexpr int MAX_R_TILES = 256;
+#ifndef HV_LIST_PART_ENTRIES
+#define HV_LIST_PART_ENTRIES 384
+#endif
+#ifndef HV_LIST_CHUNK
+#define HV_LIST_CHUNK 16
+#endif
+constexpr int LIST_CHUNK = HV_LIST_CHUNK;                  // list entries a wave takes per hand-out
+constexpr int LIST_PART_ENTRIES = HV_LIST_PART_ENTRIES;    // work-list entries one part of a hot (tile, plane) takes
 
 // y cell of every vote of a point (theta-independent: offset.y = -corr.y, :38-39).
 // Global atomics on a few hot addresses serialise at ~11 ns each on MI355X (measured: 80k
 // atomics over 88 counters = 142 us), so bins are aggregated per workgroup in LDS first.
+constexpr int LIST_CHUNK_RECORDS = 1024;     // records of one y-bin per work-list workgroup (hv_list_pass)
 constexpr int PREP_MAX_Y = 4096;
 constexpr int PREP_THREADS = 1024;
 
@@ -256,7 +270,8 @@ constexpr int MAX_PARTS = HV_MAX_PARTS;
 __global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ ycount, int Y,
                                                      int* __restrict__ ystart,
                                                      int* __restrict__ cursor,
-                                                     int* __restrict__ part_start) {
+                                                     int* __restrict__ part_start, int* __restrict__ plane_of_q,
+                                                     int* __restrict__ chunk_start, int* __restrict__ bin_of_chunk) {
     __shared__ int s[1024];
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
@@ -280,7 +295,9 @@ __global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ yco
     }
     if (threadIdx.x == 0) { ystart[Y] = carry; carry = 0; }
     __syncthreads();
-    // part_start[y] = exclusive scan of the number of workgroups per tile of plane y
+    // streaming path (small grids): part_start[y] = exclusive scan of the number of workgroups per tile of plane y, by
+    // the records of its two bins; plane_of_q[(plane, part) slot] = plane (the tile kernel used to find its plane by a
+    // binary search over part_start: seven dependent global loads in front of every workgroup's work)
     for (int base = 0; base < Y; base += 1024) {
         const int i = base + threadIdx.x;
         int v = 0;
@@ -297,12 +314,38 @@ __global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ yco
             __syncthreads();
         }
         const int incl = s[threadIdx.x] + carry;
-        if (i < Y) part_start[i] = incl - v;
+        if (i < Y) {
+            part_start[i] = incl - v;
+            for (int p2 = 0; p2 < v; ++p2) plane_of_q[incl - v + p2] = i;
+        }
         __syncthreads();
         if (threadIdx.x == 1023) carry = incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) part_start[Y] = carry;
+    if (threadIdx.x == 0) { part_start[Y] = carry; carry = 0; }
+    __syncthreads();
+    // chunks of up to LIST_CHUNK_RECORDS records of one bin (the work-list passes run one workgroup per chunk)
+    for (int base = 0; base < Y; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < Y ? (ycount[i] + LIST_CHUNK_RECORDS - 1) / LIST_CHUNK_RECORDS : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int incl = s[threadIdx.x] + carry;
+        if (i < Y) {
+            chunk_start[i] = incl - v;
+            for (int p2 = 0; p2 < v; ++p2) bin_of_chunk[incl - v + p2] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) chunk_start[Y] = carry;
 }
 
 // Scatters every point with an in-bounds y into its y-bin and writes a compact SoA record
@@ -357,6 +400,208 @@ __global__ __launch_bounds__(PREP_THREADS) void hv_prep_scatter(
     r[12 * rec_stride] = atan2f(cz, cx) + 3.14159265f;
 }
 
+
+// ---- per-(y-bin, tile) work lists (round 3) ------------------------------------------------------------------------
+// Every tile of a plane used to stream ALL records of its two y-bins and cull them (ring vs rectangle, then the arc):
+// 66 tiles x 88 planes x ~1800 records at 80k points, 41 % of the kernel's wave time and most of its VALU work
+// (profiles/r3/vote_pmc_sq_before.txt).  The test depends on (record, tile) only, so it is done ONCE: one workgroup per
+// y-bin walks its records twice (count, then fill) over the tiles in the ring's bounding box and writes, per (bin, tile),
+// the list of (record, first rotation, arc length) entries the tile kernel expands.  Lists live in one bump-allocated
+// array; when it overflows (rings that cover the whole grid) a flag sends the tile kernel back to the streaming path.
+constexpr int LIST_MAX_TILES = 4096;
+struct RingArc { bool keep; int a_start, a_len; };
+__device__ __forceinline__ bool ring_touches(float ux, float uz, float r, float xlo, float xhi, float zlo, float zhi,
+                                             float& dxn, float& dzn) {
+    const float slack = 0.05f;
+    dxn = fmaxf(0.f, fmaxf(xlo - ux, ux - xhi));
+    dzn = fmaxf(0.f, fmaxf(zlo - uz, uz - zhi));
+    const float dxf = fmaxf(fabsf(ux - xlo), fabsf(ux - xhi));
+    const float dzf = fmaxf(fabsf(uz - zlo), fabsf(uz - zhi));
+    const float dmin = sqrtf(dxn * dxn + dzn * dzn), dmax = sqrtf(dxf * dxf + dzf * dzf);
+    const float tol = slack + 1e-5f * (r + fabsf(ux) + fabsf(uz));
+    return (r >= dmin - tol) && (r <= dmax + tol);
+}
+// rotations whose vote can fall in the rectangle: it subtends an arc seen from the ring centre unless the centre is
+// (nearly) inside it
+__device__ __forceinline__ void ring_arc(float ux, float uz, float a0, int R, float xlo, float xhi, float zlo, float zhi,
+                                         float dxn, float dzn, int& a_start, int& a_len) {
+    a_start = 0;
+    a_len = R;
+    if (dxn + dzn > 0.5f) {
+        const float b0 = atan2f(0.5f * (zlo + zhi) - uz, 0.5f * (xlo + xhi) - ux);
+        float lo = 0.f, hi = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float d = atan2f(((k & 2) ? zhi : zlo) - uz, ((k & 1) ? xhi : xlo) - ux) - b0;
+            d -= 6.28318531f * rintf(d * 0.159154943f);
+            lo = fminf(lo, d);
+            hi = fmaxf(hi, d);
+        }
+        const float inv_step = (float)R * 0.159154943f;          // 1 / rot_interval
+        float first = (b0 + lo - a0) * inv_step - 2.f;           // 2 steps of slack per side
+        const int len = (int)((hi - lo) * inv_step) + 6;
+        first -= (float)R * floorf(first / (float)R);
+        a_start = min(max((int)first, 0), R - 1);
+        a_len = min(len, R);
+    }
+}
+
+// Launches over CHUNKS of up to 1024 records of one y-bin (a bin per workgroup left the floor's bin - a quarter of an 80k
+// scene - to one workgroup: 200 us):
+//   hv_list_pass<false>  per (bin, tile): the summed arc lengths of the rings that reach the tile (tile_w: what the work
+//                        queue sizes the parts of a hot tile with) and, when lists are wanted, the entry counts
+//                        (atomicAdd on the (bin, tile) total returns the chunk's first slot inside that list)
+//   hv_list_scan         lists only, one workgroup: exclusive scan of the entry counts (list starts, overflow flag)
+//   hv_list_pass<true>   lists only, the same walk again: entry -> list_start + chunk slot + LDS rank
+// chunk_start[Y + 1] / bin_of_chunk[] come from hv_prep_scan.
+template <bool FILL>
+__global__ __launch_bounds__(1024) void hv_list_pass(const int* __restrict__ ystart, const int* __restrict__ chunk_start,
+                                                     const int* __restrict__ bin_of_chunk, int Y,
+                                                     const float* __restrict__ rec, int64_t rec_stride, int R, int tiles_x,
+                                                     int tiles_z, const int* __restrict__ list_ctl, int* __restrict__ list_cnt,
+                                                     const int* __restrict__ list_start, int* __restrict__ chunk_off,
+                                                     int2* __restrict__ entries, int* __restrict__ tile_w, int want_lists) {
+    __shared__ int cnt[LIST_MAX_TILES];
+    __shared__ int wsum[FILL ? 1 : LIST_MAX_TILES];
+    const int ntiles = tiles_x * tiles_z;
+    const int c = blockIdx.x;
+    if (c >= chunk_start[Y]) return;
+    if (FILL && list_ctl[1] != 0) return;             // overflow: the tile kernel streams the bins
+    const int bin = bin_of_chunk[c];
+    const int idx = ystart[bin] + (c - chunk_start[bin]) * LIST_CHUNK_RECORDS + (int)threadIdx.x;
+    const int end = ystart[bin + 1];
+    for (int t = threadIdx.x; t < ntiles; t += 1024) {
+        cnt[t] = FILL ? list_start[(int64_t)bin * ntiles + t] + chunk_off[(int64_t)c * ntiles + t] : 0;
+        if (!FILL) wsum[t] = 0;
+    }
+    __syncthreads();
+    if (idx < end) {
+        const float ux = rec[9 * rec_stride + idx], uz = rec[10 * rec_stride + idx], r = rec[11 * rec_stride + idx];
+        const float a0 = rec[12 * rec_stride + idx];
+        // tiles whose rectangle [x0 - 1, x0 + TX] x [z0 - 1, z0 + TZ] can meet the ring's bounding box (+ slack)
+        const float ext = r + 2.f + 1e-5f * (r + fabsf(ux) + fabsf(uz));
+        const int tx0 = max(0, (int)floorf((ux - ext - (float)TX) / (float)TX));
+        const int tx1 = min(tiles_x - 1, (int)floorf((ux + ext + 1.f) / (float)TX));
+        const int tz0 = max(0, (int)floorf((uz - ext - (float)TZ) / (float)TZ));
+        const int tz1 = min(tiles_z - 1, (int)floorf((uz + ext + 1.f) / (float)TZ));
+        for (int tx = tx0; tx <= tx1; ++tx)
+            for (int tz = tz0; tz <= tz1; ++tz) {
+                const float xlo = (float)(tx * TX - 1), xhi = (float)(tx * TX + TX), zlo = (float)(tz * TZ - 1),
+                            zhi = (float)(tz * TZ + TZ);
+                float dxn, dzn;
+                if (!ring_touches(ux, uz, r, xlo, xhi, zlo, zhi, dxn, dzn)) continue;
+                int a_start, a_len;
+                ring_arc(ux, uz, a0, R, xlo, xhi, zlo, zhi, dxn, dzn, a_start, a_len);
+                const int t = tx * tiles_z + tz;
+                if (FILL) {
+                    const int p = atomicAdd(&cnt[t], 1);
+                    entries[p] = make_int2(idx, a_start | (a_len << 16));
+                } else {
+                    if (want_lists) atomicAdd(&cnt[t], 1);
+                    atomicAdd(&wsum[t], a_len);
+                }
+            }
+    }
+    if (FILL) return;
+    __syncthreads();
+    for (int t = threadIdx.x; t < ntiles; t += 1024) {
+        if (want_lists) chunk_off[(int64_t)c * ntiles + t] = cnt[t] ? atomicAdd(&list_cnt[(int64_t)bin * ntiles + t], cnt[t]) : 0;
+        if (wsum[t]) atomicAdd(&tile_w[(int64_t)bin * ntiles + t], wsum[t]);
+    }
+}
+
+// list_ctl[0] = total entries, list_ctl[1] = overflow flag (zeroed by the caller's fill)
+__global__ __launch_bounds__(1024) void hv_list_scan(const int* __restrict__ list_cnt, int Y, int ntiles, long long list_cap,
+                                                     int* __restrict__ list_ctl, int* __restrict__ list_start) {
+    __shared__ int s[1024];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int total_lists = Y * ntiles;
+    for (int base = 0; base < total_lists; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < total_lists ? list_cnt[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int t = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int incl = s[threadIdx.x] + carry_s;
+        if (i < total_lists) list_start[i] = incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { list_ctl[0] = carry_s; list_ctl[1] = (long long)carry_s > list_cap ? 1 : 0; }
+}
+
+// ---- work queue of the tile kernel (round 3) -----------------------------------------------------------------------
+// The launch used to hold (plane, part) x tile workgroups with the parts of a plane sized by the RECORDS of its two
+// bins.  The time of the kernel was the time of its hottest tile: 1 % of the (plane, tile) pairs of an 80k scene
+// receive 20 % of the votes (up to 26 x the mean of the non-empty ones) while a plane's record count says nothing about
+// where its rings meet.  The queue holds one item per (plane, tile) that receives nothing (it only writes zeros) and
+// ceil(weight / PART_VOTES) items for the others, weight = summed arc lengths of the rings that reach the tile in the
+// plane's two bins (hv_list_pass<false>); parts merge through `partials` slots handed out by the same scan.
+//   item = (plane, tile, part | parts << 8, first partial slot of the (plane, tile))
+#ifndef HV_PART_VOTES
+#define HV_PART_VOTES 32768
+#endif
+constexpr int PART_VOTES = HV_PART_VOTES;
+constexpr int QUEUE_MAX_PARTS = 32;
+
+__global__ __launch_bounds__(1024) void hv_build_queue(const int* __restrict__ tile_w, int Y, int ntiles, int max_items,
+                                                       int max_slots, int* __restrict__ list_ctl /*[2] = items*/,
+                                                       int4* __restrict__ items) {
+    __shared__ unsigned long long s[1024];
+    __shared__ unsigned long long carry_s;
+    __shared__ int single_s;
+    const int total = Y * ntiles;
+    // pass 0 sizes the parts by weight; when the items or the partial slots would not fit, pass 1 gives every tile one part
+    for (int pass = 0; pass < 2; ++pass) {
+        if (threadIdx.x == 0) { carry_s = 0ull; single_s = pass; }
+        __syncthreads();
+        for (int base = 0; base < total; base += 1024) {
+            const int i = base + threadIdx.x;
+            int parts = 0, y = 0, t = 0;
+            if (i < total) {
+                y = i / ntiles; t = i - y * ntiles;
+                const long long w = (long long)(y >= 1 ? tile_w[(int64_t)(y - 1) * ntiles + t] : 0) +
+                                    (long long)(y <= Y - 2 ? tile_w[(int64_t)y * ntiles + t] : 0);
+                parts = w == 0 ? 0 : (pass ? 1 : (int)min((long long)QUEUE_MAX_PARTS, (w + PART_VOTES - 1) / PART_VOTES));
+            }
+            // items in the high word, partial slots (tiles with more than one part) in the low word
+            const unsigned long long v = i < total ? (((unsigned long long)max(parts, 1) << 32) | (unsigned)(parts > 1 ? parts : 0)) : 0ull;
+            s[threadIdx.x] = v;
+            __syncthreads();
+            for (int off = 1; off < 1024; off <<= 1) {
+                const unsigned long long x = (int)threadIdx.x >= off ? s[threadIdx.x - off] : 0ull;
+                __syncthreads();
+                s[threadIdx.x] += x;
+                __syncthreads();
+            }
+            const unsigned long long excl = s[threadIdx.x] + carry_s - v;
+            const int item0 = (int)(excl >> 32), slot0 = (int)(excl & 0xffffffffull);
+            if (i < total && item0 + max(parts, 1) <= max_items && slot0 + parts <= max_slots) {
+                if (parts == 0) items[item0] = make_int4(y, t, 0, 0);
+                for (int p2 = 0; p2 < parts; ++p2) items[item0 + p2] = make_int4(y, t, p2 | (parts << 8), slot0);
+            }
+            __syncthreads();
+            if (threadIdx.x == 1023) carry_s = s[1023] + carry_s;
+            __syncthreads();
+        }
+        const int n_items = (int)(carry_s >> 32), n_slots = (int)(carry_s & 0xffffffffull);
+        if (n_items <= max_items && n_slots <= max_slots) {
+            if (threadIdx.x == 0) list_ctl[2] = n_items;
+            return;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) list_ctl[2] = min(total, max_items);     // (total <= max_items by construction)
+}
+
 __device__ __forceinline__ int lanes_below(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
@@ -373,9 +618,33 @@ __device__ __forceinline__ int lanes_below(uint64_t mask) {
 // rot / scale quotients lose digits; the reference's own fp32 atomics lose ~1e-7 relative per add everywhere).
 constexpr double FX_SCALE = 68719476736.0;            // 2^36
 constexpr double FX_MAGIC = 6755399441055744.0;       // 1.5 * 2^52: (x*2^36 + MAGIC) has round(x*2^36) in its low bits
+// round(v * 2^36) to nearest even without a floating-point instruction wider than the input (experiment HV_INT_FX:
+// are the f64 conversions what concurrent matrix kernels disturb?); exact for every finite v with |v| < 2^26
+__device__ __forceinline__ unsigned long long fx_from_float_int(float v) {
+    const unsigned b = __float_as_uint(v);
+    const int e = (int)((b >> 23) & 255u);
+    if (e == 0) return 0ull;                                  // zero / fp32 denormal: far below one quantum
+    unsigned long long m = (unsigned long long)((b & 0x7fffffu) | 0x800000u);
+    const int sh = e - 114;                                   // value = m * 2^(e - 150); times 2^36
+    unsigned long long q;
+    if (sh >= 0) q = sh < 40 ? (m << sh) : (m << 39);
+    else if (sh <= -26) q = 0ull;
+    else {
+        const int r = -sh;
+        const unsigned long long half = 1ull << (r - 1), rem = m & ((1ull << r) - 1ull);
+        q = m >> r;
+        if (rem > half || (rem == half && (q & 1ull))) ++q;
+    }
+    return (b >> 31) ? (0ull - q) : q;
+}
 template <bool SMALL>
 __device__ __forceinline__ void lds_add(unsigned long long* p, float v) {
     unsigned long long q;
+#ifdef HV_INT_FX
+    q = fx_from_float_int(SMALL ? v : fminf(fmaxf(v, -6.0e7f), 6.0e7f));
+    __hip_atomic_fetch_add(p, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+#endif
     if (SMALL) {                              // the magic-number conversion holds for |v * 2^36| < 2^51
         const double d = __builtin_fma((double)v, FX_SCALE, FX_MAGIC);
         q = (unsigned long long)__double_as_longlong(d) - (unsigned long long)__double_as_longlong(FX_MAGIC);
@@ -385,12 +654,34 @@ __device__ __forceinline__ void lds_add(unsigned long long* p, float v) {
     __hip_atomic_fetch_add(p, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ double fx_value(unsigned long long q) { return (double)(long long)q * (1.0 / FX_SCALE); }
-__device__ __forceinline__ void lds_add_f64(unsigned long long* p, float v) {
-    __hip_atomic_fetch_add(reinterpret_cast<double*>(p), (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// The objectness weight - the channel that is thresholded, arg-maxed and defines the touched-cell set - accumulated in
+// f64 until round 3: sums of fp32 contributions spanning more than 53 bits are not exact in f64, so the LDS atomics'
+// order reached the last bits and, once in ~1600 runs of one scene, a cell on an fp32 rounding boundary changed the
+// greedy walk (tests/test_concurrency_gpu.py found it).  It now uses the same 2^-36 fixed point as the numerators
+// (integer addition: exact, order independent, bit-reproducible) with ONE extra rule: a non-zero contribution never rounds
+// to zero (it adds one quantum, 1.5e-11), so a cell is non-zero exactly when the reference's fp32 sum is.
+template <bool SMALL>
+__device__ __forceinline__ void lds_add_obj(unsigned long long* p, float v) {
+    unsigned long long q;
+#ifdef HV_INT_FX
+    q = fx_from_float_int(SMALL ? v : fminf(fmaxf(v, -6.0e7f), 6.0e7f));
+    if (q == 0ull && v != 0.f) q = v > 0.f ? 1ull : ~0ull;
+    __hip_atomic_fetch_add(p, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+#endif
+    if (SMALL) {
+        const double d = __builtin_fma((double)v, FX_SCALE, FX_MAGIC);
+        q = (unsigned long long)__double_as_longlong(d) - (unsigned long long)__double_as_longlong(FX_MAGIC);
+    } else {
+        q = (unsigned long long)__double2ll_rn((double)fminf(fmaxf(v, -6.0e7f), 6.0e7f) * FX_SCALE);
+    }
+    if (q == 0ull && v != 0.f) q = v > 0.f ? 1ull : ~0ull;
+    __hip_atomic_fetch_add(p, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// value of accumulator word i of the [6][TCELLS] tile (channel 0 holds f64 bits, the others fixed point)
+// value of accumulator word i of the [6][TCELLS] tile (every channel in 2^-36 fixed point)
 __device__ __forceinline__ double acc_value(unsigned long long q, int i) {
-    return i < TCELLS ? __longlong_as_double((long long)q) : fx_value(q);
+    (void)i;
+    return fx_value(q);
 }
 
 // LDS layout of the tile accumulators: word of (channel ch, cell (cx, cz)) = ch * ACC_CH + cx * ACC_PITCH + cz.
@@ -406,7 +697,7 @@ constexpr int ACC_PITCH = TZ + 8, ACC_CH = TX * ACC_PITCH + 4, ACC_WORDS = 6 * A
 __device__ __forceinline__ int acc_idx(int ch, int cell) { return ch * ACC_CH + (cell >> 5) * ACC_PITCH + (cell & 31); }
 
 struct TileShared {
-    unsigned long long acc[ACC_WORDS];   // channel 0: objectness weight as f64 BITS; 1..5: rot.cos, rot.sin, scale.xyz
+    unsigned long long acc[ACC_WORDS];   // channel 0: objectness weight, 1..5: rot.cos, rot.sin, scale.xyz - all
                                          // in 2^-36 fixed point
     float pq[TW][9][PQ];       // px, pz, cx, cz, wy, obj, s0, s1, s2 of surviving points
     int arc_start[TW][PQ];     // first rotation whose vote can reach the tile
@@ -431,7 +722,7 @@ __device__ __forceinline__ void drain_vote(TileShared& sh, int lx, int lz, float
             // hv_cuda_kernel.cu:52-59 order: ((wx*wy)*wz)*objness
             const float w = wx[bx] * wy * wz[bz] * ob;
             unsigned long long* a = sh.acc + cxl * ACC_PITCH + czl;
-            lds_add_f64(a, w);
+            lds_add_obj<SMALL>(a, w);
             lds_add<SMALL>(a + ACC_CH, w * cs.x);
             lds_add<SMALL>(a + 2 * ACC_CH, w * cs.y);
             lds_add<SMALL>(a + 3 * ACC_CH, w * s0);
@@ -464,19 +755,25 @@ __device__ __forceinline__ void drain64(TileShared& sh, int wave, int slot, bool
 }
 
 __device__ __forceinline__ void wave_sync_lds() {
+#ifdef HV_STRONG_WAVE_SYNC
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // VARIANT (ablations for profiling only): 0 full, 1 no LDS atomics, 2 no dense phase, 3 no record streaming
-template <int VARIANT>
+template <int VARIANT, bool QUEUE>
 __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     int R, float res, F3 corner, I3 dims, const float2* __restrict__ tab,
-    const int* __restrict__ ystart, const int* __restrict__ part_start, const float* __restrict__ rec,
+    const int* __restrict__ ystart, const int4* __restrict__ items, const float* __restrict__ rec,
     int64_t rec_stride, int tiles_x, int tiles_z, float* __restrict__ partials,
     int* __restrict__ arrivals, float* __restrict__ g_obj, float* __restrict__ g_rot,
-    float* __restrict__ g_scale, unsigned long long* __restrict__ prof) {
+    float* __restrict__ g_scale, unsigned long long* __restrict__ prof,
+    const int* __restrict__ list_ctl, const int* __restrict__ list_start, const int* __restrict__ list_cnt,
+    const int2* __restrict__ entries, int list_mode /* 1: stream the bins, 2: work lists */,
+    const int* __restrict__ part_start, const int* __restrict__ plane_of_q) {
     __shared__ TileShared sh;
     __shared__ int last_flag;
     // VARIANT 4: shader-clock ticks per phase, summed over waves into prof[0..7], prof[8] = waves
@@ -492,22 +789,66 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     } while (0)
     const int X = dims.x, Y = dims.y, Z = dims.z;
     const int ntiles = tiles_x * tiles_z;
-    const int tile = blockIdx.x % ntiles;
-    const int q = blockIdx.x / ntiles;               // (plane, part) slot
-    if (q >= part_start[Y]) return;
-    int y;
-    {
-        int lo = 0, hi = Y - 1;                      // largest y with part_start[y] <= q
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (part_start[mid] <= q) lo = mid; else hi = mid - 1;
-        }
-        y = lo;
+    // QUEUE: one work item per workgroup (hv_build_queue; large grids) - ONE 16-byte load says which (plane, tile,
+    // part) this is.  !QUEUE (small grids, the round-2 launch): (plane, part) x tile workgroups, parts by the records of
+    // the plane's bins (hv_prep_scan)
+    int y, tile, part, nparts, slot0, slot_stride;
+    if (QUEUE) {
+        if ((int)blockIdx.x >= list_ctl[2]) return;
+        const int4 item = items[blockIdx.x];
+        y = item.x; tile = item.y; part = item.z & 0xff; nparts = item.z >> 8; slot0 = item.w; slot_stride = 1;
+    } else {
+        tile = blockIdx.x % ntiles;
+        const int q = blockIdx.x / ntiles;               // (plane, part) slot
+        if (q >= part_start[Y]) return;
+        y = plane_of_q[q];
+        part = q - part_start[y]; nparts = part_start[y + 1] - part_start[y];
+        slot0 = part_start[y] * ntiles + tile; slot_stride = ntiles;
     }
-    const int part = q - part_start[y], nparts = part_start[y + 1] - part_start[y];
     const int x0 = (tile / tiles_z) * TX, z0 = (tile % tiles_z) * TZ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (nparts == 0) {
+        // nothing votes into this tile of this plane: zeros straight to the grids (no accumulators, no barriers)
+        const int nx0 = min(TX, X - x0), nz0 = min(TZ, Z - z0);
+        for (int i = threadIdx.x; i < TCELLS; i += TW * 64) {
+            const int lx = i / TZ, lz = i % TZ;
+            if (lx < nx0 && lz < nz0) {
+                const int64_t cell = ((int64_t)(x0 + lx) * Y + y) * Z + z0 + lz;
+                g_obj[cell] = 0.f;
+                reinterpret_cast<float2*>(g_rot)[cell] = make_float2(0.f, 0.f);
+                g_scale[cell * 3 + 0] = 0.f; g_scale[cell * 3 + 1] = 0.f; g_scale[cell * 3 + 2] = 0.f;
+            }
+        }
+        return;
+    }
+    // list_mode 2: work lists of this tile in the two y-bins (hv_list_pass; list_ctl[1] != 0: they overflowed, stream the
+    // bins instead)
+    const bool use_list = QUEUE && VARIANT != 3 && list_mode == 2 && list_ctl[1] == 0;      // (the queue launch is the list launch)
+    int lbeg[2] = {0, 0}, llen[2] = {0, 0};
+    if (use_list) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int s = y - 1 + k;
+            if (s >= 0 && s <= Y - 2) {
+                lbeg[k] = list_start[(int64_t)s * ntiles + tile];
+                llen[k] = list_cnt[(int64_t)s * ntiles + tile];
+            }
+        }
+    }
 
+#ifdef HV_POISON      // debug: stale-LDS hunt (an uninitialised read shows up as a changed result)
+    {
+        unsigned* w = reinterpret_cast<unsigned*>(&sh);
+        const int lo[5] = {(int)(offsetof(TileShared, pq) / 4), (int)(offsetof(TileShared, arc_start) / 4),
+                           (int)(offsetof(TileShared, arc_cum) / 4), (int)(offsetof(TileShared, vq_rec) / 4),
+                           (int)(offsetof(TileShared, tab) / 4)};
+        const int hi[5] = {lo[1], lo[2], lo[3], lo[4], (int)(offsetof(TileShared, next_chunk) / 4)};
+        for (int k = 0; k < 5; ++k)
+            if ((HV_POISON >> k) & 1)
+                for (int i = lo[k] + threadIdx.x; i < hi[k]; i += TW * 64) w[i] = 0x7fc12345u + i * 2654435761u;
+        __syncthreads();
+    }
+#endif
     for (int i = threadIdx.x; i < ACC_WORDS; i += TW * 64) sh.acc[i] = 0ull;
     for (int i = threadIdx.x; i < R; i += TW * 64) sh.tab[i] = tab[i];
     if (threadIdx.x < 2) sh.next_chunk[threadIdx.x] = 0;
@@ -523,19 +864,30 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
 
     for (int s = y - 1; s <= y; ++s) {
         if (s < 0 || s > Y - 2 || VARIANT == 3) continue;
-        const int beg = ystart[s], end = ystart[s + 1];
+        const int beg = use_list ? lbeg[s - (y - 1)] : ystart[s];
+        const int end = use_list ? beg + llen[s - (y - 1)] : ystart[s + 1];
         // waves take chunks from a shared counter: a wave whose chunk expands into many votes takes fewer chunks
         // (static striding left the waves of a workgroup waiting 22 % of their time for the slowest one)
         for (;;) {
             int c = 0;
             if (lane == 0) c = atomicAdd(&sh.next_chunk[s - (y - 1)], 1);
             c = __builtin_amdgcn_readfirstlane(c);
-            const int base = beg + (c * nparts + part) * 64;
+            // list entries are all kept and each expands into an arc: 16 per hand-out keep the waves of a workgroup even
+            const int per = use_list ? LIST_CHUNK : 64;
+            const int base = beg + (c * nparts + part) * per;
             if (base >= end) break;
-            const int idx = base + lane;
+            int idx = base + lane;
             bool keep = false;
             int a_start = 0, a_len = 0;
-            if (idx < end) {
+            if (use_list) {
+                if (lane < per && idx < end) {
+                    const int2 en = entries[idx];
+                    idx = en.x;
+                    a_start = en.y & 0xffff;
+                    a_len = en.y >> 16;
+                    keep = true;
+                }
+            } else if (idx < end) {
                 const float ux = rec[9 * rec_stride + idx], uz = rec[10 * rec_stride + idx],
                             r = rec[11 * rec_stride + idx];
                 // conservative ring-vs-rectangle test in grid units
@@ -692,7 +1044,7 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     if (nparts > 1) {
         // publish this part's tile, the last arriver sums the parts in part order (deterministic):
         // plain stores -> per-wave vmcnt(0) -> barrier -> one-lane agent release -> ticket.
-        float* mine = partials + ((int64_t)q * ntiles + tile) * (6 * TCELLS);
+        float* mine = partials + ((int64_t)slot0 + (int64_t)part * slot_stride) * (6 * TCELLS);
         for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64)
             mine[i] = (float)acc_value(sh.acc[acc_idx(i / TCELLS, i % TCELLS)], i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -707,12 +1059,11 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
         }
         __syncthreads();
         if (!last_flag) return;
-        const float* base = partials + ((int64_t)part_start[y] * ntiles + tile) * (6 * TCELLS);
+        const float* base = partials + (int64_t)slot0 * (6 * TCELLS);
         for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) {
             double sum = 0.0;
-            for (int p2 = 0; p2 < nparts; ++p2) sum += (double)base[(int64_t)p2 * ntiles * (6 * TCELLS) + i];
-            sh.acc[acc_idx(i / TCELLS, i % TCELLS)] = i < TCELLS ? (unsigned long long)__double_as_longlong(sum)
-                                                                 : (unsigned long long)__double2ll_rn(sum * FX_SCALE);
+            for (int p2 = 0; p2 < nparts; ++p2) sum += (double)base[(int64_t)p2 * slot_stride * (6 * TCELLS) + i];
+            sh.acc[acc_idx(i / TCELLS, i % TCELLS)] = (unsigned long long)__double2ll_rn(sum * FX_SCALE);
         }
         __syncthreads();
     }
@@ -874,8 +1225,23 @@ int check_common(const void* a, const void* b, const void* c, int64_t n, float r
     return CV_OK;
 }
 
-// sum over planes of parts per tile: sum_y ceil(n2_y / PART_RECORDS) <= Y + 2n / PART_RECORDS
+// streaming launch (small grids): sum over planes of parts per tile: sum_y ceil(n2_y / PART_RECORDS) <= Y + 2n / PART_RECORDS
 int64_t tiles_q_bound(int64_t n, int Y) { return (int64_t)Y + (2 * n + PART_RECORDS - 1) / PART_RECORDS; }
+// the launch shape: work lists + work queue where a plane has many tiles (measured, bench vote stage: 300k-point scene,
+// 200 tiles: 2.01 -> 1.32 ms; 80k scene, 66 tiles: 0.37 -> 0.40 ms - the weight pass and the queue build cost more than
+// the tile kernel gains there), the streaming launch below that.  CV_HV_LISTS=1 / 2 forces one of them.
+bool use_queue(int64_t ntiles) {
+    static const int lists_env = getenv("CV_HV_LISTS") ? atoi(getenv("CV_HV_LISTS")) : -1;
+    return lists_env >= 1 ? lists_env == 2 : ntiles >= 64;
+}
+// work queue: partial-tile slots for the (plane, tile) pairs with more than one part (sum of arc lengths <= about
+// 2 * n * num_rots counting both planes of a vote and the slack steps; twice that again as room) and items = one per
+// (plane, tile) + the extra parts; hv_build_queue falls back to one part per tile if either is exceeded
+int64_t queue_max_slots(int64_t n, int num_rots) { return 4 * n * (int64_t)num_rots / PART_VOTES + 256; }
+int64_t queue_max_items(int64_t n, int num_rots, int64_t Y, int64_t ntiles) { return Y * ntiles + queue_max_slots(n, num_rots); }
+// capacity of the work-list array: 40 entries per point on average (a ring of 1.5 m radius crosses ~20 tiles) and never
+// more than every (point, tile) pair; beyond it the tile kernel streams the bins as before
+int64_t list_capacity(int64_t n, int64_t ntiles) { return std::min<int64_t>(n * ntiles, 40 * n + 65536); }
 
 int pick_algo(int algo, int64_t n, int num_rots, const int* dims) {
     if (algo >= 21 && algo <= 25) return 2;   // profiling ablations of the tiles kernel
@@ -948,8 +1314,12 @@ size_t cv_hv_forward_workspace_bytes(int64_t n, int num_rots, const int dims[3],
     if (pick_algo(algo, n, num_rots, dims) == 1) return 256;
     const size_t Y = (size_t)dims[1];
     const size_t ntiles = (size_t)((dims[0] + TX - 1) / TX) * (size_t)((dims[2] + TZ - 1) / TZ);
-    return 256 * 9 + sizeof(int) * ((size_t)n * (1 + REC_F) + Y * 4 + 16 + Y * ntiles) +
-           sizeof(float) * (size_t)tiles_q_bound(n, (int)Y) * ntiles * 6 * TCELLS;
+    const size_t max_chunks = Y + (size_t)((n + LIST_CHUNK_RECORDS - 1) / LIST_CHUNK_RECORDS);
+    const size_t slots = std::max<size_t>((size_t)queue_max_slots(n, num_rots), (size_t)tiles_q_bound(n, (int)Y) * ntiles);
+    return 256 * 24 + sizeof(int) * ((size_t)n * (1 + REC_F) + Y * 8 + 16 + 4 * Y * ntiles + 64 + max_chunks * (ntiles + 1) +
+                                     (size_t)tiles_q_bound(n, (int)Y)) +
+           sizeof(int4) * (size_t)queue_max_items(n, num_rots, (int64_t)Y, (int64_t)ntiles) +
+           sizeof(int2) * (size_t)list_capacity(n, (int64_t)ntiles) + sizeof(float) * slots * 6 * TCELLS;
 }
 
 int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_scale,
@@ -991,30 +1361,63 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
     float* rec = cv.take<float>((size_t)n * REC_F);
     const int tiles_x = (dims[0] + TX - 1) / TX, tiles_z = (dims[2] + TZ - 1) / TZ;
     const int ntiles = tiles_x * tiles_z;
+    const int64_t max_items = queue_max_items(n, num_rots, Y, ntiles), max_slots = queue_max_slots(n, num_rots);
     const int64_t max_q = tiles_q_bound(n, Y);
-    // the two zero-initialised arrays sit next to each other: one fill launch instead of two
+    const int64_t list_cap = list_capacity(n, ntiles);
+    const bool queue = use_queue(ntiles) && ntiles <= LIST_MAX_TILES && list_cap < (1ll << 31) && max_items < (1ll << 31) &&
+                       algo != 23;
+    // the zero-initialised arrays sit next to each other: one fill launch
+    int* list_ctl = cv.take<int>(64);
+    int* list_cnt = cv.take<int>((size_t)Y * ntiles);      // (zeroed with the rest: the count pass adds to them)
+    int* tile_w = cv.take<int>((size_t)Y * ntiles);
     int* ycount = cv.take<int>(Y);
     int* arrivals = cv.take<int>((size_t)Y * ntiles);
     int* ystart = cv.take<int>(Y + 1);
     int* cursor = cv.take<int>(Y);
     int* part_start = cv.take<int>(Y + 1);
-    float* partials = cv.take<float>((size_t)max_q * ntiles * 6 * TCELLS);
-    CV_HIP_CHECK(hipMemsetAsync(ycount, 0, (size_t)(reinterpret_cast<char*>(arrivals + (size_t)Y * ntiles) -
-                                                    reinterpret_cast<char*>(ycount)), st));
+    int* plane_of_q = cv.take<int>((size_t)max_q);
+    float* partials = cv.take<float>((size_t)std::max<int64_t>(max_slots, max_q * ntiles) * 6 * TCELLS);
+    int4* items = cv.take<int4>((size_t)max_items);
+    int* list_start = cv.take<int>((size_t)Y * ntiles);
+    const int64_t max_chunks = (int64_t)Y + (n + LIST_CHUNK_RECORDS - 1) / LIST_CHUNK_RECORDS;
+    int* chunk_start = cv.take<int>((size_t)Y + 1);
+    int* bin_of_chunk = cv.take<int>((size_t)max_chunks);
+    int* chunk_off = cv.take<int>((size_t)max_chunks * ntiles);
+    int2* entries = cv.take<int2>((size_t)list_cap);
+    const int list_mode = queue ? 2 : 1;
+    // (the streaming launch only needs ycount and the arrival counters zeroed)
+    int* zero_from = queue ? list_ctl : ycount;
+    CV_HIP_CHECK(hipMemsetAsync(zero_from, 0, (size_t)(reinterpret_cast<char*>(arrivals + (size_t)Y * ntiles) -
+                                                       reinterpret_cast<char*>(zero_from)), st));
     hv_prep_count<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, n, res, corner.y, Y, fy, ycount);
     CV_LAUNCH_CHECK();
-    hv_prep_scan<<<1, 1024, 0, st>>>(ycount, Y, ystart, cursor, part_start);
+    hv_prep_scan<<<1, 1024, 0, st>>>(ycount, Y, ystart, cursor, part_start, plane_of_q, chunk_start, bin_of_chunk);
     CV_LAUNCH_CHECK();
     hv_prep_scatter<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, d_obj, fy, n, Y, res, corner, cursor, rec, n);
     CV_LAUNCH_CHECK();
-    const int64_t wgs = max_q * ntiles;
+    if (queue) {
+        hv_list_pass<false><<<(unsigned)max_chunks, 1024, 0, st>>>(ystart, chunk_start, bin_of_chunk, Y, rec, n, num_rots, tiles_x,
+                                                               tiles_z, list_ctl, list_cnt, list_start, chunk_off, entries, tile_w, 1);
+        CV_LAUNCH_CHECK();
+        hv_build_queue<<<1, 1024, 0, st>>>(tile_w, Y, ntiles, (int)max_items, (int)max_slots, list_ctl, items);
+        CV_LAUNCH_CHECK();
+        hv_list_scan<<<1, 1024, 0, st>>>(list_cnt, Y, ntiles, list_cap, list_ctl, list_start);
+        CV_LAUNCH_CHECK();
+        hv_list_pass<true><<<(unsigned)max_chunks, 1024, 0, st>>>(ystart, chunk_start, bin_of_chunk, Y, rec, n, num_rots, tiles_x,
+                                                              tiles_z, list_ctl, list_cnt, list_start, chunk_off, entries, tile_w, 1);
+        CV_LAUNCH_CHECK();
+    }
+    const int64_t wgs = queue ? max_items : max_q * ntiles;
     CV_REQUIRE(wgs < (1ll << 31), CV_EINVAL, "grid too large");
-#define CV_TILES_LAUNCH(V)                                                                          \
-    hv_fwd_tiles<V><<<(unsigned)wgs, TW * 64, 0, st>>>(num_rots, res, corner, d3, tab, ystart, part_start, \
-                                                      rec, n, tiles_x, tiles_z, partials, arrivals,    \
-                                                      d_grid_obj, d_grid_rot, d_grid_scale, prof)
+#define CV_TILES_ARGS num_rots, res, corner, d3, tab, ystart, items, rec, n, tiles_x, tiles_z, partials, arrivals, d_grid_obj, \
+                      d_grid_rot, d_grid_scale, prof, list_ctl, list_start, list_cnt, entries, list_mode, part_start, plane_of_q
+#define CV_TILES_LAUNCH(V)                                                                                   \
+    do {                                                                                                     \
+        if (queue) hv_fwd_tiles<V, true><<<(unsigned)wgs, TW * 64, 0, st>>>(CV_TILES_ARGS);                   \
+        else hv_fwd_tiles<V, false><<<(unsigned)wgs, TW * 64, 0, st>>>(CV_TILES_ARGS);                        \
+    } while (0)
     unsigned long long* prof = nullptr;
     if (algo == 24) {
         static unsigned long long* d_prof = nullptr;
@@ -1039,6 +1442,7 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
     else if (algo == 23) CV_TILES_LAUNCH(3);
     else CV_TILES_LAUNCH(0);
 #undef CV_TILES_LAUNCH
+#undef CV_TILES_ARGS
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

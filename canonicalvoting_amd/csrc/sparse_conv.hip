@@ -1022,9 +1022,12 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 #ifndef HL_OCC2
 #define HL_OCC2 4
 #endif
+#ifndef HL_OCC3
+#define HL_OCC3 4
+#endif
 constexpr int HL_MAX_UNITS = 512;      // live units of one workgroup: <= 10 offsets x Cin / 32 chunks + the second source's (host-checked)
 template <int NB, int NS, int NW>
-__global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS == 2 ? (NB == 1 ? HL_OCC1 : NB == 2 ? HL_OCC2 : 4) : 3)) void conv_hl(ConvArgs a) {
+__global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS == 2 ? (NB == 1 ? HL_OCC1 : NB == 2 ? HL_OCC2 : HL_OCC3) : 3)) void conv_hl(ConvArgs a) {
     static_assert(NS == 3 || NS == 2, "three unit slots (or two: the loads of unit k + 2 follow the MFMAs of unit k)");
     constexpr int TMv = NW * 32, THv = NW * 64;
     constexpr int B_BYTES = 2 * NB * 32 * 64, EP_BYTES = NW * 32 * EP_LD * 4;

@@ -11,8 +11,8 @@
                         itself is single-GPU)
 
 The sparse convolutions run forward / input-gradient / weight-gradient on the HIP kernels
-(canonicalvoting_amd.me._ConvFn); batch-statistics BatchNorm, ReLU, the residual add and the losses
-are torch ops in training mode this round.
+(canonicalvoting_amd.me._ConvFn), batch-statistics BatchNorm with the residual add and ReLU folded in on
+bn_col_reduce4 / bn_backward_apply4 (me._BNTrainFn); the losses are torch ops.
 The reference's stale-loss bug (`losses` persists across iterations) is not
 reproduced: a batch without object points contributes only the classification loss.
 """
@@ -110,6 +110,28 @@ def adjust_learning_rate(optimizer, epoch, base_lr=1e-3, decay_steps=(80, 120, 1
     for g in optimizer.param_groups:
         g["lr"] = lr
     return lr
+
+
+def bn_momentum(epoch, decay_step, decay_rate, init=0.5, floor=0.001):
+    """train_joint.py:200-201,224: max(0.5 * rate ** (epoch // step), 0.001)"""
+    return max(init * decay_rate ** int(epoch / decay_step), floor)
+
+
+def set_bn_momentum(model, momentum, effective=False):
+    """BNMomentumScheduler.step (train_joint.py:86-125).  The reference's setter assigns ``m.momentum`` on every
+    ``ME.MinkowskiBatchNorm`` (:94-98) - the WRAPPER, whose forward runs its ``.bn`` (an nn.BatchNorm1d created with
+    momentum 0.1): the running statistics of the reference therefore keep updating with 0.1 whatever the schedule
+    says.  Default here = the same observable behaviour (the attribute is set on the wrapper, ``.bn`` is untouched);
+    ``effective=True`` applies the schedule to ``.bn.momentum`` as its authors presumably intended.  Returns the
+    number of modules touched."""
+    k = 0
+    for m in model.modules():
+        if isinstance(m, ME.MinkowskiBatchNorm):
+            m.momentum = momentum
+            if effective:
+                m.bn.momentum = momentum
+            k += 1
+    return k
 
 
 def make_optimizer(model, lr=1e-3, weight_decay=0.0):

@@ -39,6 +39,7 @@ def main():
     model = MinkUNet34C(6 if (cfg and cfg.use_xyz) else 3, 6 * 9 + 9 + 1).to(dev)
     net = train.make_ddp(model, dev) if world > 1 else model
     base_lr, wd, steps, rates = a.lr, 0.0, (80, 120, 160), (0.1, 0.1, 0.1)
+    bn_step, bn_rate = 20.0, 0.5                                               # config/config.yaml opt.bn_decay_*
     first_epoch, last_epoch = 0, a.epochs - 1
     if cfg:
         # train_joint.py:204-206,219-223,235: the optimizer and the schedule come from the config
@@ -46,6 +47,7 @@ def main():
         steps = [int(x) for x in str(cfg.opt.lr_decay_steps).split(",")]
         rates = [float(x) for x in str(cfg.opt.lr_decay_rates).split(",")]
         first_epoch, last_epoch = int(cfg.start_epoch), int(cfg.max_epoch)      # range(start_epoch, max_epoch + 1)
+        bn_step, bn_rate = float(cfg.opt.bn_decay_step), float(cfg.opt.bn_decay_rate)
     opt = train.make_optimizer(model, lr=base_lr, weight_decay=wd)
     if cfg:
         # train_joint.py:205-211; every rank reads its own slice of the scans (DistributedSampler)
@@ -58,6 +60,7 @@ def main():
         loader = torch.utils.data.DataLoader(ds, batch_size=a.batch, shuffle=True, collate_fn=collate_fn, drop_last=True)
     for epoch in range(first_epoch, last_epoch + 1):
         train.adjust_learning_rate(opt, epoch, base_lr, steps, rates)
+        train.set_bn_momentum(model, train.bn_momentum(epoch, bn_step, bn_rate))   # train_joint.py:224-225,239
         net.train()
         t0, tot, n = time.perf_counter(), 0.0, 0
         for _, coords, feats, xyz, scale, cls in loader:
@@ -69,7 +72,9 @@ def main():
         if rank == 0:
             print("epoch %d  loss %.4f  %.1f s" % (epoch, tot / max(n, 1), time.perf_counter() - t0), flush=True)
         if a.save and rank == 0 and (epoch % 10 == 0 or epoch == last_epoch):
-            torch.save(model.state_dict(), a.save)                            # train_joint.py:290-291 (every 10 epochs)
+            # train_joint.py:290-291: one file per saved epoch, 'epoch{N}.pth' (here under the --save prefix)
+            stem, ext = os.path.splitext(a.save)
+            torch.save(model.state_dict(), "%s_epoch%d%s" % (stem, epoch, ext or ".pth"))
     cvd.finalize()
 
 

@@ -51,3 +51,17 @@ def test_single_process_default_is_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rendezvous-only", "--gpus", "2"], cwd=ROOT,
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+def test_eight_rank_launch_and_scene_thread_cap():
+    """the driver's 8-GPU line (one rank per GPU): rendezvous of eight ranks, one JSON line, and the scene threads of a
+    rank capped by the cores the node has per rank (8 ranks x 4 threads on an 8-core box would be 32 runnable threads)"""
+    r = _launch(8, 8, extra=("--streams", "4"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["rendezvous_only"]
+    cores = len(os.sched_getaffinity(0))
+    assert out["scene_threads_per_rank"] == max(1, min(4, max(2, cores // 8)))
+    assert out["max_seconds"] >= 0.08                       # rank 7 sleeps 80 ms: the max over ranks

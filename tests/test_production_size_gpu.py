@@ -167,3 +167,66 @@ def test_config5_300k_separate_heads_on_one_sparse_tensor(cuda, built_lib, scene
     np.testing.assert_allclose(scale.cpu().numpy(), rs.numpy(), rtol=1e-5)
     np.testing.assert_allclose(prob.cpu().numpy(), rp.numpy(), rtol=1e-5, atol=1e-6)
     assert torch.isfinite(ys[1]).all() and not torch.equal(ys[0], ys[1])
+
+
+def _train_batch(cuda, B, n, seed0):
+    scenes = [make_scene(seed0 + b, n_points=n) for b in range(B)]
+    coords = np.concatenate([np.concatenate([np.full((n, 1), b, np.int64), s.coords], 1) for b, s in enumerate(scenes)])
+    feats = np.concatenate([s.feats for s in scenes]).astype(np.float32) * 2 - 1
+    labels = [np.concatenate([getattr(s, k) for s in scenes]) for k in ("xyz_labels", "scale_labels", "class_labels")]
+    return coords, feats, labels
+
+
+def test_config3_training_forward_and_loss_at_three_80k_scenes(cuda, built_lib):
+    """config 3 at the size config/config.yaml:15 trains at (batch of 3 scans, 3 x 80k rows): the
+    TRAINING-mode forward (batch-statistics BatchNorm over the 240k rows, mask-sorted groups, bf16-triple products) and
+    the loss of train_joint.py:253-283 against the oracle's training-mode forward; the backward runs and is finite.
+    (The oracle's autograd does not fit at this size - its gather-matmul-scatter keeps [pairs, C] intermediates of
+    every layer; the gradients are checked at 3 x 20k rows below, where every large-size code path is already on.)"""
+    from canonicalvoting_amd import train
+    coords, feats, (xyz, scale, cls) = _train_batch(cuda, 3, 80000, 40)
+    torch.manual_seed(0)
+    model = MinkUNet34C(3, 6 * 9 + 9 + 1).cuda().train()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    out = model(ME.SparseTensor(dev(feats, cuda), dev(coords, cuda).int(), device=cuda)).F
+    loss = train.joint_loss(out, dev(xyz, cuda), dev(scale, cuda), dev(cls, cuda))[0]
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 for p in model.parameters())
+    with torch.no_grad():
+        ref = so.minkunet34c_forward(sd, coords, feats, training=True)
+        lo = train.joint_loss(ref, torch.from_numpy(xyz), torch.from_numpy(scale), torch.from_numpy(cls))[0]
+    err = float((out.detach().cpu() - ref).abs().max())
+    assert err < 1e-4 * max(1.0, float(ref.abs().max())), err
+    assert abs(float(loss.detach()) - float(lo)) < 1e-4 * max(1.0, abs(float(lo)))
+
+
+def test_config3_training_gradients_at_three_20k_scenes(cuda, built_lib):
+    """every parameter gradient of one train_joint.py step on 3 x 20k rows against autograd through the CPU oracle: at
+    60k rows the finest two levels run the mask-sorted groups (>= 16384 rows), the weight-gradient kernels their
+    chunked plans and the coarse levels their split-K sizing - the code paths of the 3 x 80k step, at a size the
+    oracle's autograd still fits.  (Finite differences of the fp32 forward were tried at 3 x 80k and dropped: they sat
+    6-20 % above the analytic value on the deep layers at every step size, while layer-by-layer checks of BatchNorm /
+    conv dX / dW at 240k rows agree with torch and the oracle to 1e-7, profiles/train_large_probe.py.)"""
+    from canonicalvoting_amd import train
+    coords, feats, (xyz, scale, cls) = _train_batch(cuda, 3, 20000, 60)
+    torch.manual_seed(1)
+    model = MinkUNet34C(3, 6 * 9 + 9 + 1).cuda().train()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    out = model(ME.SparseTensor(dev(feats, cuda), dev(coords, cuda).int(), device=cuda)).F
+    loss = train.joint_loss(out, dev(xyz, cuda), dev(scale, cuda), dev(cls, cuda))[0]
+    loss.backward()
+    pnames = {k for k, _ in model.named_parameters()}
+    sdo = {k: (v.clone().requires_grad_(True) if k in pnames else v.clone()) for k, v in sd.items()}
+    yo = so.minkunet34c_forward(sdo, coords, feats, training=True)
+    lo = train.joint_loss(yo, torch.from_numpy(xyz), torch.from_numpy(scale), torch.from_numpy(cls))[0]
+    lo.backward()
+    assert abs(float(loss.detach()) - float(lo.detach())) < 1e-4 * max(1.0, abs(float(lo.detach())))
+    errs = []
+    for name, p in model.named_parameters():
+        g, go = p.grad.cpu().numpy(), sdo[name].grad.numpy()
+        errs.append((float(np.abs(g - go).max() / max(1e-6, np.abs(go).max())), name))
+    errs.sort(reverse=True)
+    print("largest parameter-gradient errors at 3 x 20k rows (max |d| / max |g|):", [(n, "%.2e" % e) for e, n in errs[:6]],
+          "median %.2e" % errs[len(errs) // 2][0])
+    # tests/test_train_gpu.py holds 2e-3 at 1.4k rows; sums over 40 x the rows are allowed 5e-3
+    assert errs[0][0] < 5e-3, errs[:6]
