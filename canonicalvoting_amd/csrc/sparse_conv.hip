@@ -1025,18 +1025,34 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 #ifndef HL_OCC3
 #define HL_OCC3 4
 #endif
+// HL_COAL (round-3 experiment, OFF: measured slower; bit NB - 1 switches the NB x 32-column kernel): the row gather
+// line-coalesced - 8 lanes fetch the 8 x 16-byte pieces of one row's 128-byte chunk (4 instructions x 8 rows) and a
+// wave-private 4 KB LDS tile turns the [32 rows][128 B] image into the MFMA A layout (lane = row, 4 pieces per lane).
+// Why it was tried (profiles/r3/gather_rate.txt): with lane = row every 16-byte access of a load instruction is its own
+// line look-up in the vector cache and a pure gather tops out at 15 B/clk/CU (9.2 TB/s) even when everything hits the
+// L2; line-coalesced it reaches 36 B/clk/CU (22 TB/s).  The piece a lane fetches is XOR-swizzled with (row >> 1) & 7,
+// so the b128 stores (lane-contiguous) and the b128 reads (row stride 128 B) are conflict-free in the lane groups of
+// ds_read_b128.  Same bytes into the same MFMAs: bit-identical results (82 network tests pass with it).  Measured
+// (profiles/r3/hl_coal_ab.txt): net 2.445 -> 2.54 ms, 506 -> 475 scenes/s six in flight; on the 32 / 64-column kernels
+// alone (occupancy unchanged) 2.56 ms: the vector cache's look-up rate is not what bounds conv_hl - the LDS round trip
+// on every unit's critical path costs more than the faster gather returns.
+#ifndef HL_COAL
+#define HL_COAL 0
+#endif
 constexpr int HL_MAX_UNITS = 512;      // live units of one workgroup: <= 10 offsets x Cin / 32 chunks + the second source's (host-checked)
 template <int NB, int NS, int NW>
-__global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS == 2 ? (NB == 1 ? HL_OCC1 : NB == 2 ? HL_OCC2 : HL_OCC3) : 3)) void conv_hl(ConvArgs a) {
+__global__ __attribute__((amdgpu_waves_per_eu((NW > 4 && NS == 2) ? 4 : 1, 8))) __launch_bounds__(NW * 64, (NW > 4 ? (NS == 2 ? 2 : 1) : NS == 2 ? (NB == 1 ? HL_OCC1 : NB == 2 ? HL_OCC2 : HL_OCC3) : 3)) void conv_hl(ConvArgs a) {
     static_assert(NS == 3 || NS == 2, "three unit slots (or two: the loads of unit k + 2 follow the MFMAs of unit k)");
     constexpr int TMv = NW * 32, THv = NW * 64;
     constexpr int B_BYTES = 2 * NB * 32 * 64, EP_BYTES = NW * 32 * EP_LD * 4;
-    constexpr int SM_BYTES = NS * B_BYTES > EP_BYTES ? NS * B_BYTES : EP_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char sm[SM_BYTES];     // NS x weight tile [plane][col][64 B]; then the epilogue tile
+    constexpr bool COAL = (HL_COAL >> (NB - 1)) & 1;
+    constexpr int A_STAGE = COAL ? NW * 4096 : 0;                           // per wave: [32 rows][8 pieces x 16 B], swizzled
+    constexpr int SM_BYTES = NS * B_BYTES + A_STAGE > EP_BYTES ? NS * B_BYTES + A_STAGE : EP_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[SM_BYTES];     // NS x weight tile [plane][col][64 B], the A tiles; then the epilogue tile
     __shared__ int rows_s[TMv];
     __shared__ int nbr_all[WP_NPRE + 1][TMv];
     __shared__ unsigned wave_mask[NW];
-    __shared__ int units_s[HL_MAX_UNITS + 4];        // (jj << 8) | chunk of every live unit, in processing order; [HL_MAX_UNITS] = count
+    __shared__ unsigned short units_s[HL_MAX_UNITS + 4];      // (jj << 8) | chunk of every live unit, in processing order; [HL_MAX_UNITS] = count
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.y * (NB * 32);
     const long long tile_id = xcd_tile(a);
@@ -1106,13 +1122,13 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS == 2 ? (NB == 1 ? HL_OCC1
                 code = (njl << 8) | ((int)blockIdx.z + (e - n_first) * a.splits);
             }
             const unsigned long long bal = __ballot(code >= 0);
-            if (code >= 0) units_s[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = code;
+            if (code >= 0) units_s[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)code;
             cnt += __popcll(bal);
         }
-        if (lane == 0) units_s[HL_MAX_UNITS] = cnt;
+        if (lane == 0) units_s[HL_MAX_UNITS] = (unsigned short)cnt;
     }
     __syncthreads();
-    const int n_units = __builtin_amdgcn_readfirstlane(units_s[HL_MAX_UNITS]);
+    const int n_units = __builtin_amdgcn_readfirstlane((int)units_s[HL_MAX_UNITS]);
 
     f32x16 acc[NB];
 #pragma unroll
@@ -1145,9 +1161,24 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS == 2 ? (NB == 1 ? HL_OCC1
     for (int q = 0; q < NS; ++q) live[q] = false;
     auto load = [&](auto S, int k) {                  // unit k of the list -> slot S
         constexpr int sl = decltype(S)::value;
-        const int code = __builtin_amdgcn_readfirstlane(units_s[k]);
+        const int code = __builtin_amdgcn_readfirstlane((int)units_s[k]);
         const int jj = code >> 8, c = code & 255;
         const bool second = jj == njl;
+        if constexpr (COAL) {
+            // instruction q: rows (lane >> 3) + 8 q of the wave, lane & 7 = LDS slot of the row, slot ^ ((row >> 1) & 7) = piece
+            const unsigned rb_ = second ? in2_row_bytes : in_row_bytes;
+            const unsigned char* const base = (second ? in2_b : in_b) + (unsigned)(c * 128);
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int src = nbr_all[jj][wave * 32 + (lane >> 3) + 8 * q];
+                any |= src >= 0;
+                if (src >= 0 && !(CV_HL_ABL & 1))
+                    ra[sl][q] = *reinterpret_cast<const uint4*>(base + ((unsigned)src * rb_ + (unsigned)((((lane & 7) ^ (((lane >> 4) + 4 * q) & 7))) << 4)));
+                else ra[sl][q] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            live[sl] = __any(any);
+        } else {
         const int src = nbr_all[jj][my_row];
         live[sl] = __any(src >= 0);
         if (src >= 0 && !(CV_HL_ABL & 1)) {
@@ -1160,6 +1191,7 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS == 2 ? (NB == 1 ? HL_OCC1
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) ra[sl][q] = make_uint4(0u, 0u, 0u, 0u);
+        }
         }
         const unsigned short* slab = second ? a.wp6_2 + (size_t)c * slab_words
                                             : a.wp6 + (size_t)((j_first + jj) * nch + c) * slab_words;
@@ -1179,10 +1211,28 @@ __global__ __launch_bounds__(NW * 64, (NW > 4 ? 1 : NS == 2 ? (NB == 1 ? HL_OCC1
     auto compute = [&](auto S) {
         constexpr int sl = decltype(S)::value;
         const unsigned char* Bb = sm + sl * B_BYTES + b_rd;
+        uint4 (&fa)[4] = ra[sl];
+        if constexpr (COAL) {
+            // [32 rows][128 B] image of the wave's gathered chunk -> lane = row, pieces half, 2 + half, 4 + half, 6 + half,
+            // back into the slot's own registers.  The tile is the wave's own: program order + the in-order LDS pipe are
+            // the only synchronisation needed.
+            unsigned char* st = sm + NS * B_BYTES + wave * 4096;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(st + q * 1024 + lane * 16) = ra[sl][q];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned char* rd = st + l31 * 128;
+            const int g = (l31 >> 1) & 7;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fa[k] = *reinterpret_cast<const uint4*>(rd + (((2 * k + half) ^ g) << 4));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int piece = ((2 * ks + half) ^ bswz) << 4;
-            const f16x8 a0 = __builtin_bit_cast(f16x8, ra[sl][ks]), a1 = __builtin_bit_cast(f16x8, ra[sl][2 + ks]);
+            const f16x8 a0 = __builtin_bit_cast(f16x8, fa[ks]), a1 = __builtin_bit_cast(f16x8, fa[2 + ks]);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const f16x8 b0 = *reinterpret_cast<const f16x8*>(Bb + nb * 32 * 64 + piece);
@@ -2987,11 +3037,12 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         // instead of three or four cost more than the deeper prefetch gains, profiles/r2/hl_slots.txt)
         // 256-row workgroups where the launch has plenty of tiles and no split-K: an experiment (CV_HL_NW8=1), off by
         // default - measured slower, profiles/r2/hl_nw8.txt
-        static const bool nw8_on = getenv("CV_HL_NW8") && atoi(getenv("CV_HL_NW8")) != 0;
+        static const int nw8_mask = getenv("CV_HL_NW8") ? atoi(getenv("CV_HL_NW8")) : 0;        // bit NB - 1
+        const bool nw8_on = (nw8_mask >> (NB - 1)) & 1;
         if constexpr (NB <= 3) {
             if (nw8_on && !ax.xcd_tiles && a.n_out >= 16384 && (a.splits == 1 || a.perm_per_split)) {
                 dim3 g8((unsigned)((a.n_out + 255) / 256), grid.y, grid.z);
-                conv_hl<NB, 3, 8><<<g8, 512, 0, st>>>(ax);
+                conv_hl<NB, 2, 8><<<g8, 512, 0, st>>>(ax);
             } else {
                 // two unit slots (85 / 113 / 128 VGPRs for 32 / 64 / 96 columns: five / four / four workgroups per CU instead
                 // of four / three / three; net 2.53 -> 2.48 ms for the first two, 2.52 -> 2.48 ms for the third once a compiler

@@ -159,13 +159,17 @@ def _layer(x, sd, name, n, cm, ts, training):
     return x
 
 
-def minkunet34c_forward(sd, coords, feats, training=False, return_intermediates=False):
-    """utils/minkunet.py:122-180 on (coords [N,4] int (b,x,y,z), feats [N,Cin]) -> [N, Cout]."""
+def minkunet34c_forward(sd, coords, feats, training=False, return_intermediates=False, dtype=torch.float32):
+    """utils/minkunet.py:122-180 on (coords [N,4] int (b,x,y,z), feats [N,Cin]) -> [N, Cout].
+    dtype=torch.float64 runs the same graph in double precision: the yardstick that says how far ANY fp32 evaluation
+    (this oracle's or the HIP path's) sits from the exact result - ReLU masks of values within rounding of zero flip
+    between two fp32 evaluations, and a flipped mask changes a gradient element by its whole value."""
     # tensors that require grad are used as they are so torch autograd can differentiate the oracle
     sd = {k: (v if (torch.is_tensor(v) and v.requires_grad) else
-              (v.detach().to(torch.float32).cpu().clone() if torch.is_tensor(v) else v)) for k, v in sd.items()}
+              (v.detach().to(dtype if v.dtype.is_floating_point else v.dtype).cpu().clone() if torch.is_tensor(v) else v))
+          for k, v in sd.items()}
     cm = CoordinateManager(coords)
-    x = torch.as_tensor(feats, dtype=torch.float32)
+    x = torch.as_tensor(feats, dtype=dtype)
     inter = {}
 
     def cbr(x, conv_name, bn_name, k, ts, stride=1):

@@ -1,0 +1,6 @@
+#!/bin/bash
+# gradient test with the fp64 yardstick; per-dispatch trace of one scene in flight (default tree)
+O=gpurun_out/r3r; mkdir -p $O
+python -m pytest tests/test_production_size_gpu.py -m gpu -x -q -k "training" -s > $O/pytest.log 2>&1; grep -E "3 x 20k|passed|failed" $O/pytest.log
+bash profiles/trace_one.sh r3r/trace --train-steps 0 > $O/trace.log 2>&1
+tail -3 $O/trace.log
