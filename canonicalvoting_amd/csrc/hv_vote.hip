@@ -270,7 +270,7 @@ constexpr int MAX_PARTS = HV_MAX_PARTS;
 __global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ ycount, int Y,
                                                      int* __restrict__ ystart,
                                                      int* __restrict__ cursor,
-                                                     int* __restrict__ part_start, int* __restrict__ plane_of_q,
+                                                     int* __restrict__ part_start, int4* __restrict__ q_info, int max_q,
                                                      int* __restrict__ chunk_start, int* __restrict__ bin_of_chunk) {
     __shared__ int s[1024];
     __shared__ int carry;
@@ -296,8 +296,10 @@ __global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ yco
     if (threadIdx.x == 0) { ystart[Y] = carry; carry = 0; }
     __syncthreads();
     // streaming path (small grids): part_start[y] = exclusive scan of the number of workgroups per tile of plane y, by
-    // the records of its two bins; plane_of_q[(plane, part) slot] = plane (the tile kernel used to find its plane by a
-    // binary search over part_start: seven dependent global loads in front of every workgroup's work)
+    // the records of its two bins; q_info[(plane, part) slot] = (plane, part, parts of the plane, first slot of the plane),
+    // nparts = -1 on the unused slots behind the last one: ONE 16-byte load in front of a tile workgroup's work (round 1: a
+    // binary search over part_start, seven dependent loads; round 2: three dependent loads part_start[Y] ->
+    // plane_of_q[q] -> part_start[y], part_start[y + 1])
     for (int base = 0; base < Y; base += 1024) {
         const int i = base + threadIdx.x;
         int v = 0;
@@ -316,12 +318,14 @@ __global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ yco
         const int incl = s[threadIdx.x] + carry;
         if (i < Y) {
             part_start[i] = incl - v;
-            for (int p2 = 0; p2 < v; ++p2) plane_of_q[incl - v + p2] = i;
+            for (int p2 = 0; p2 < v; ++p2) q_info[incl - v + p2] = make_int4(i, p2, v, incl - v);
         }
         __syncthreads();
         if (threadIdx.x == 1023) carry = incl;
         __syncthreads();
     }
+    for (int q = carry + (int)threadIdx.x; q < max_q; q += 1024) q_info[q] = make_int4(0, 0, -1, 0);
+    __syncthreads();
     if (threadIdx.x == 0) { part_start[Y] = carry; carry = 0; }
     __syncthreads();
     // chunks of up to LIST_CHUNK_RECORDS records of one bin (the work-list passes run one workgroup per chunk)
@@ -763,6 +767,19 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// atan2 for the arc of rotations a tile can receive from a ring (conservative culling only: every vote is placed by the
+// exact fp32 sequence afterwards).  |error| < 2e-4 rad against 2 rotation steps of slack per side (0.1 rad at 120 rotations,
+// 0.05 at 256): the libm atan2f calls (five per kept record) were a third of the tile kernel's vector instructions.
+__device__ __forceinline__ float arc_atan2(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float a = fminf(ax, ay) * __builtin_amdgcn_rcpf(fmaxf(fmaxf(ax, ay), 1e-30f));
+    const float q = a * a;
+    float r = ((-0.0464964749f * q + 0.15931422f) * q - 0.327622764f) * q * a + a;
+    r = ay > ax ? 1.57079637f - r : r;
+    r = x < 0.f ? 3.14159274f - r : r;
+    return y < 0.f ? -r : r;
+}
+
 // VARIANT (ablations for profiling only): 0 full, 1 no LDS atomics, 2 no dense phase, 3 no record streaming
 template <int VARIANT, bool QUEUE>
 __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
@@ -773,7 +790,7 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     float* __restrict__ g_scale, unsigned long long* __restrict__ prof,
     const int* __restrict__ list_ctl, const int* __restrict__ list_start, const int* __restrict__ list_cnt,
     const int2* __restrict__ entries, int list_mode /* 1: stream the bins, 2: work lists */,
-    const int* __restrict__ part_start, const int* __restrict__ plane_of_q) {
+    const int4* __restrict__ q_info) {
     __shared__ TileShared sh;
     __shared__ int last_flag;
     // VARIANT 4: shader-clock ticks per phase, summed over waves into prof[0..7], prof[8] = waves
@@ -799,11 +816,10 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
         y = item.x; tile = item.y; part = item.z & 0xff; nparts = item.z >> 8; slot0 = item.w; slot_stride = 1;
     } else {
         tile = blockIdx.x % ntiles;
-        const int q = blockIdx.x / ntiles;               // (plane, part) slot
-        if (q >= part_start[Y]) return;
-        y = plane_of_q[q];
-        part = q - part_start[y]; nparts = part_start[y + 1] - part_start[y];
-        slot0 = part_start[y] * ntiles + tile; slot_stride = ntiles;
+        const int4 qi = q_info[blockIdx.x / ntiles];     // (plane, part) slot
+        if (qi.z < 0) return;
+        y = qi.x; part = qi.y; nparts = qi.z;
+        slot0 = qi.w * ntiles + tile; slot_stride = ntiles;
     }
     const int x0 = (tile / tiles_z) * TX, z0 = (tile % tiles_z) * TZ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -904,11 +920,11 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
                     // [b0+lo, b0+hi] seen from the ring centre unless the centre is (nearly) inside it
                     a_len = R;
                     if (dxn + dzn > 0.5f) {
-                        const float b0 = atan2f(0.5f * (zlo + zhi) - uz, 0.5f * (xlo + xhi) - ux);
+                        const float b0 = arc_atan2(0.5f * (zlo + zhi) - uz, 0.5f * (xlo + xhi) - ux);
                         float lo = 0.f, hi = 0.f;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            float d = atan2f(((k & 2) ? zhi : zlo) - uz, ((k & 1) ? xhi : xlo) - ux) - b0;
+                            float d = arc_atan2(((k & 2) ? zhi : zlo) - uz, ((k & 1) ? xhi : xlo) - ux) - b0;
                             d -= 6.28318531f * rintf(d * 0.159154943f);
                             lo = fminf(lo, d);
                             hi = fmaxf(hi, d);
@@ -1317,7 +1333,7 @@ size_t cv_hv_forward_workspace_bytes(int64_t n, int num_rots, const int dims[3],
     const size_t max_chunks = Y + (size_t)((n + LIST_CHUNK_RECORDS - 1) / LIST_CHUNK_RECORDS);
     const size_t slots = std::max<size_t>((size_t)queue_max_slots(n, num_rots), (size_t)tiles_q_bound(n, (int)Y) * ntiles);
     return 256 * 24 + sizeof(int) * ((size_t)n * (1 + REC_F) + Y * 8 + 16 + 4 * Y * ntiles + 64 + max_chunks * (ntiles + 1) +
-                                     (size_t)tiles_q_bound(n, (int)Y)) +
+                                     4 * (size_t)tiles_q_bound(n, (int)Y)) +
            sizeof(int4) * (size_t)queue_max_items(n, num_rots, (int64_t)Y, (int64_t)ntiles) +
            sizeof(int2) * (size_t)list_capacity(n, (int64_t)ntiles) + sizeof(float) * slots * 6 * TCELLS;
 }
@@ -1375,7 +1391,7 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
     int* ystart = cv.take<int>(Y + 1);
     int* cursor = cv.take<int>(Y);
     int* part_start = cv.take<int>(Y + 1);
-    int* plane_of_q = cv.take<int>((size_t)max_q);
+    int4* q_info = cv.take<int4>((size_t)max_q);
     float* partials = cv.take<float>((size_t)std::max<int64_t>(max_slots, max_q * ntiles) * 6 * TCELLS);
     int4* items = cv.take<int4>((size_t)max_items);
     int* list_start = cv.take<int>((size_t)Y * ntiles);
@@ -1392,7 +1408,7 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
     hv_prep_count<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, n, res, corner.y, Y, fy, ycount);
     CV_LAUNCH_CHECK();
-    hv_prep_scan<<<1, 1024, 0, st>>>(ycount, Y, ystart, cursor, part_start, plane_of_q, chunk_start, bin_of_chunk);
+    hv_prep_scan<<<1, 1024, 0, st>>>(ycount, Y, ystart, cursor, part_start, q_info, (int)max_q, chunk_start, bin_of_chunk);
     CV_LAUNCH_CHECK();
     hv_prep_scatter<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, d_obj, fy, n, Y, res, corner, cursor, rec, n);
@@ -1412,7 +1428,7 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
     const int64_t wgs = queue ? max_items : max_q * ntiles;
     CV_REQUIRE(wgs < (1ll << 31), CV_EINVAL, "grid too large");
 #define CV_TILES_ARGS num_rots, res, corner, d3, tab, ystart, items, rec, n, tiles_x, tiles_z, partials, arrivals, d_grid_obj, \
-                      d_grid_rot, d_grid_scale, prof, list_ctl, list_start, list_cnt, entries, list_mode, part_start, plane_of_q
+                      d_grid_rot, d_grid_scale, prof, list_ctl, list_start, list_cnt, entries, list_mode, q_info
 #define CV_TILES_LAUNCH(V)                                                                                   \
     do {                                                                                                     \
         if (queue) hv_fwd_tiles<V, true><<<(unsigned)wgs, TW * 64, 0, st>>>(CV_TILES_ARGS);                   \

@@ -102,6 +102,31 @@ __device__ __forceinline__ bool hl_out_of_range(float4 v) {
     return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) > 65000.f;
 }
 
+// Partial tiles (split-K / mask-group sums) are written once and read once by the finish launch: streamed past the
+// caches with the nontemporal policy (CV_NT_PARTIAL bit 0: the stores, bit 1: the finish launch's loads) so that they do
+// not push the activations and weight slabs, which ARE re-read, out of the 4 MB L2s.  Measured (profiles/r3/nt_partial_ab.txt):
+// net 2.42 -> 2.375 ms one scene in flight, 483 -> 495 scenes/s six in flight with both; the XCD-aware tile numbering on top of
+// either: 2.61-2.64 ms (still slower - the cost ordering of the tiles is worth more than the L2 hits).
+#ifndef CV_NT_PARTIAL
+#define CV_NT_PARTIAL 3
+#endif
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void partial_store4(float* p, float4 v) {
+    if (CV_NT_PARTIAL & 1) {
+        f32x4v t; t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4v*>(p));
+    } else {
+        *reinterpret_cast<float4*>(p) = v;
+    }
+}
+__device__ __forceinline__ float4 partial_load4(const float4* p) {
+    if (CV_NT_PARTIAL & 2) {
+        const f32x4v t = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));
+        return make_float4(t[0], t[1], t[2], t[3]);
+    }
+    return *p;
+}
+
 __device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& acc, const int* rows,
                                                int col, int lane) {
     if (col >= a.cout) return;
@@ -175,7 +200,7 @@ __device__ __forceinline__ void epilogue_store_wide(const ConvArgs& a, const f32
             if (row < 0) continue;
             float4 v = *reinterpret_cast<const float4*>(&T[rl][(lane & 7) * 4]);
             if (a.splits > 1) {
-                *reinterpret_cast<float4*>(a.partial + ((long long)blockIdx.z * a.n_out + row) * a.cout + col) = v;
+                partial_store4(a.partial + ((long long)blockIdx.z * a.n_out + row) * a.cout + col, v);
                 continue;
             }
             epilogue_apply4(a, row, col, v);
@@ -2385,7 +2410,7 @@ __global__ __launch_bounds__(256) void conv_finish(ConvArgs a) {
             const float4* p = reinterpret_cast<const float4*>(a.partial) + e4;
 #pragma unroll 4
             for (int k = q; k < a.splits; k += 4) {
-                const float4 v = p[(long long)k * (total / 4)];
+                const float4 v = partial_load4(p + (long long)k * (total / 4));
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
         }
@@ -2448,7 +2473,7 @@ __global__ __launch_bounds__(256) void conv_finish_small(ConvArgs a) {
         float4 pv[FINISH_SMALL_MAX];
 #pragma unroll
         for (int k = 0; k < FINISH_SMALL_MAX; ++k)
-            pv[k] = k < a.splits ? p[(long long)k * total4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            pv[k] = k < a.splits ? partial_load4(p + (long long)k * total4) : make_float4(0.f, 0.f, 0.f, 0.f);
         const long long row = e4 / cq;
         const int col = (int)(e4 - row * cq) * 4;
         float4 sq[4];
@@ -3352,6 +3377,41 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         if (d->perm_has_map && jb == 0 && je == d->K && d->nbr) {
             a.nbr_perm = d->row_perm + (long long)d->perm_groups * d->n_out;
             a.nbr_perm_w = (d->K + d->perm_groups - 1) / d->perm_groups;
+        }
+        // Chain of group launches (CV_GROUP_CHAIN=1, round-3 experiment): group 0 writes its sums to the workspace, every
+        // later group adds its own to what it reads back (acc_in, same thread, same element: in place), the last one runs
+        // the epilogue - no partial tile per group, no finish launch (w 1 + (r 1 + w 1) (G - 2) + r 1 + w out instead of
+        // w G + r G + w out tile sets); the price is G launches of n_out / 128 workgroups instead of one of G times that.
+        static const bool chain_on = getenv("CV_GROUP_CHAIN") && atoi(getenv("CV_GROUP_CHAIN")) != 0;
+        if (chain_on && d->in_hl && d->flavour == 0 && !d->acc_in && a.wide) {
+            const int G = d->perm_groups, nj = je - jb;
+            float* tmp = static_cast<float*>(d->ws);
+            for (int g = 0; g < G; ++g) {
+                ConvArgs ag = a;
+                ag.splits = 1;
+                ag.perm_per_split = 0;
+                ag.partial = nullptr;
+                ag.tickets = nullptr;
+                ag.j_begin = jb + (int)((long long)nj * g / G);
+                ag.j_end = jb + (int)((long long)nj * (g + 1) / G);
+                ag.row_perm = d->row_perm + (long long)g * d->n_out;
+                if (a.nbr_perm) ag.nbr_perm = a.nbr_perm + (long long)g * d->n_out * a.nbr_perm_w;
+                if (g > 0) { ag.acc_in = tmp; ag.acc_ld = d->cout; ag.in2 = nullptr; ag.cin2 = 0; }
+                if (g < G - 1) {
+                    ag.out = tmp; ag.out_ld = d->cout; ag.out_hl = 0;
+                    ag.scale = nullptr; ag.shift = nullptr; ag.res = nullptr; ag.relu = 0; ag.range_flag = nullptr;
+                }
+                if (ag.j_end <= ag.j_begin) continue;
+                int rc2;
+                switch (nb_for(d->cout, d->n_out)) {
+                    case 1: rc2 = launch_rows<1>(ag, vec, st); break;
+                    case 2: rc2 = launch_rows<2>(ag, vec, st); break;
+                    case 3: rc2 = launch_rows<3>(ag, vec, st); break;
+                    default: rc2 = launch_rows<4>(ag, vec, st); break;
+                }
+                if (rc2) return rc2;
+            }
+            return CV_OK;
         }
         if (d->flavour == 3 && d->in_ld % 4 == 0 && d->cout % nb_full(d->cout) == 0 &&
             (reinterpret_cast<uintptr_t>(d->weight) & 15) == 0) {

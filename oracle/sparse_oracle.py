@@ -115,6 +115,26 @@ def conv_transpose_k2s2(x, kernel, nbr_down):
     return out
 
 
+# Test hook: an iterator of boolean masks, one per ReLU of the forward in call order (or None).  With it the k-th ReLU is
+# x * mask_k instead of max(x, 0): a second evaluation (another precision, the HIP path) can be given the FIRST one's
+# activation pattern, so that gradients are compared on the same piecewise-linear branch - pre-activations within
+# rounding of zero otherwise pick different branches and change a gradient element by its whole value
+# (tests/test_production_size_gpu.py).  relu_trace, when a list, receives every ReLU's mask (x > 0).
+relu_masks = None
+relu_trace = None
+
+
+def _relu(x):
+    if relu_masks is not None:
+        m = next(relu_masks)
+        y = x * torch.as_tensor(m).to(x.dtype)
+    else:
+        y = torch.relu(x)
+    if relu_trace is not None:
+        relu_trace.append((y.detach() > 0))
+    return y
+
+
 def batch_norm(x, sd, prefix, training=False, eps=1e-5):
     return F.batch_norm(x, sd[prefix + ".bn.running_mean"], sd[prefix + ".bn.running_var"],
                         sd[prefix + ".bn.weight"], sd[prefix + ".bn.bias"], training=training,
@@ -142,7 +162,7 @@ def _block(x, sd, name, cm, ts, training):
     """ME BasicBlock (expansion 1) with the optional downsample of resnet.py:126-134."""
     nbr = cm.map(3, ts)
     out = conv(x, sd[name + ".conv1.kernel"], nbr)
-    out = torch.relu(batch_norm(out, sd, name + ".norm1", training))
+    out = _relu(batch_norm(out, sd, name + ".norm1", training))
     out = conv(out, sd[name + ".conv2.kernel"], nbr)
     out = batch_norm(out, sd, name + ".norm2", training)
     if name + ".downsample.0.kernel" in sd:
@@ -150,7 +170,7 @@ def _block(x, sd, name, cm, ts, training):
         res = batch_norm(res, sd, name + ".downsample.1", training)
     else:
         res = x
-    return torch.relu(out + res)
+    return _relu(out + res)
 
 
 def _layer(x, sd, name, n, cm, ts, training):
@@ -174,11 +194,11 @@ def minkunet34c_forward(sd, coords, feats, training=False, return_intermediates=
 
     def cbr(x, conv_name, bn_name, k, ts, stride=1):
         y = conv(x, sd[conv_name + ".kernel"], cm.map(k, ts, stride))
-        return torch.relu(batch_norm(y, sd, bn_name, training))
+        return _relu(batch_norm(y, sd, bn_name, training))
 
     def up(x, conv_name, bn_name, ts_coarse):
         y = conv_transpose_k2s2(x, sd[conv_name + ".kernel"], cm.map(2, ts_coarse // 2, 2))
-        return torch.relu(batch_norm(y, sd, bn_name, training))
+        return _relu(batch_norm(y, sd, bn_name, training))
 
     out_p1 = cbr(x, "conv0p1s1", "bn0", 5, 1)                                    # :123-125
     out = cbr(out_p1, "conv1p1s2", "bn1", 2, 1, 2)                               # :127-129
