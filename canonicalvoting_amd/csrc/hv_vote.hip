@@ -271,8 +271,7 @@ __global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ yco
                                                      int* __restrict__ ystart,
                                                      int* __restrict__ cursor,
                                                      int* __restrict__ part_start, int4* __restrict__ q_info, int max_q,
-                                                     int* __restrict__ chunk_start, int* __restrict__ bin_of_chunk,
-                                                     int* __restrict__ range_start, int n_ranges) {
+                                                     int* __restrict__ chunk_start, int* __restrict__ bin_of_chunk) {
     __shared__ int s[1024];
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
@@ -296,24 +295,6 @@ __global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ yco
     }
     if (threadIdx.x == 0) { ystart[Y] = carry; carry = 0; }
     __syncthreads();
-    // rolling tile kernel (hv_fwd_roll): plane ranges [range_start[k], range_start[k + 1]) that stream about the same
-    // number of records each - range_start[k] = first plane p with ystart[p] >= k * total / n_ranges (a bin that holds
-    // several shares, the floor of a room, leaves empty ranges behind it: their workgroups exit at once)
-    if (range_start && (int)threadIdx.x <= n_ranges) {
-        const int k = (int)threadIdx.x;
-        int pl = k == 0 ? 0 : Y;
-        if (k > 0 && k < n_ranges) {
-            const long long total = __hip_atomic_load(&ystart[Y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const long long target = total * k / n_ranges;
-            int lo = 0, hi = Y;                                   // smallest p in [0, Y] with ystart[p] >= target
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (__hip_atomic_load(&ystart[mid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) hi = mid; else lo = mid + 1;
-            }
-            pl = lo;
-        }
-        range_start[k] = pl;
-    }
     // streaming path (small grids): part_start[y] = exclusive scan of the number of workgroups per tile of plane y, by
     // the records of its two bins; q_info[(plane, part) slot] = (plane, part, parts of the plane, first slot of the plane),
     // nparts = -1 on the unused slots behind the last one: ONE 16-byte load in front of a tile workgroup's work (round 1: a
@@ -1142,287 +1123,13 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
 }
 
 // ---------------------------------------------------------------------------
-// Rolling tile kernel (round 3; small grids, the streaming launch).  hv_fwd_tiles expands every vote TWICE - once in the
-// workgroup of the plane below it, once in the one above (a vote's trilinear weights reach planes floor(gy) and
-// floor(gy) + 1) - and every (plane, tile) workgroup pays the zero-fill, two barriers, the normalise + store and a
-// launch slot for ~2 chunks of records per wave: profiles/r3/vote_ablate.txt puts the fixed part at 0.08 ms, the
-// cull at 0.03, the dense expansion at 0.12 and the LDS atomics at 0.12 of the 0.37 ms op.  Here a workgroup owns a
-// 16 x 32-cell tile over a RANGE of planes [p0, p1) and walks the y-bins p0 - 1 .. p1 - 1 in order with TWO planes
-// in LDS: the votes of bin s are expanded once and accumulated into plane s (weight 1 - ry) and plane s + 1 (weight ry);
-// after bin s plane s is complete - normalised, stored, zeroed - and its buffer becomes plane s + 2.  Per bin: one
-// stream of the records, one expansion, two barriers.  Only the first bin of a range is expanded by two workgroups (the
-// range below owns its lower plane).  Ranges are cut by hv_prep_scan so that every range streams about the same number
-// of records.  Same fixed-point accumulators (integer sums: order independent), same per-vote fp32 sequence, same
-// normalise as hv_fwd_tiles: identical grids except that no plane goes through the float-rounded partial tiles of the
-// hot-plane merge.
-#ifndef HV_RTX
-#define HV_RTX 16
-#endif
-#ifndef HV_RTW
-#define HV_RTW 16
-#endif
-constexpr int RTX = HV_RTX;                               // tile width in x (z: TZ = 32)
-constexpr int RTW = HV_RTW;                               // waves per workgroup
-constexpr int ROLL_MAX_RANGES = 64;                       // plane ranges per tile (hv_prep_scan cuts them)
-#ifndef HV_ROLL_TARGET_WGS
-#define HV_ROLL_TARGET_WGS 1024
-#endif
-constexpr int ROLL_TARGET_WGS = HV_ROLL_TARGET_WGS;       // ranges = target / tiles: four workgroups per CU to balance the hot tiles
-constexpr int RCELLS = RTX * TZ;
-constexpr int R_ACC_CH = RTX * ACC_PITCH + 4;             // words per channel (pitch 40: see ACC_PITCH)
-constexpr int R_ACC_PLANE = 6 * R_ACC_CH;
-struct RollShared {
-    unsigned long long acc[2][R_ACC_PLANE];   // plane y lives in acc[y & 1]
-    float pq[RTW][9][PQ];       // px, pz, cx, cz, ry, obj, s0, s1, s2 of surviving points
-    int arc_start[RTW][PQ];
-    int arc_cum[RTW][PQ];
-    uint32_t vq_rec[RTW][VQ];   // entry | rot<<6 | (lx+1)<<14 | (lz+1)<<20
-    float vq_rx[RTW][VQ];
-    float vq_rz[RTW][VQ];
-    float2 tab[MAX_R_TILES];
-    int next_chunk;
-};
-
-template <bool SMALL>
-__device__ __forceinline__ void roll_drain_vote(RollShared& sh, bool lower, bool upper, int pl_lower, int lx, int lz, float rx,
-                                                float rz, float ry, float ob, float s0, float s1, float s2, float2 cs) {
-    const float wx[2] = {1.f - rx, rx}, wz[2] = {1.f - rz, rz}, wy[2] = {1.f - ry, ry};
-#pragma unroll
-    for (int by = 0; by < 2; ++by) {
-        if (by == 0 ? !lower : !upper) continue;
-        unsigned long long* plane = sh.acc[(pl_lower + by) & 1];
-#pragma unroll
-        for (int bx = 0; bx < 2; ++bx)
-#pragma unroll
-            for (int bz = 0; bz < 2; ++bz) {
-                const int cxl = lx + bx, czl = lz + bz;
-                if (cxl < 0 || cxl >= RTX || czl < 0 || czl >= TZ) continue;
-                // hv_cuda_kernel.cu:52-59 order: ((wx*wy)*wz)*objness
-                const float w = wx[bx] * wy[by] * wz[bz] * ob;
-                unsigned long long* a = plane + cxl * ACC_PITCH + czl;
-                lds_add_obj<SMALL>(a, w);
-                lds_add<SMALL>(a + R_ACC_CH, w * cs.x);
-                lds_add<SMALL>(a + 2 * R_ACC_CH, w * cs.y);
-                lds_add<SMALL>(a + 3 * R_ACC_CH, w * s0);
-                lds_add<SMALL>(a + 4 * R_ACC_CH, w * s1);
-                lds_add<SMALL>(a + 5 * R_ACC_CH, w * s2);
-            }
-    }
-}
-
-__device__ __forceinline__ void roll_drain64(RollShared& sh, int wave, int slot, bool active, bool lower, bool upper, int pl_lower) {
-    float rx = 0.f, rz = 0.f, ry = 0.f, ob = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    float2 cs = make_float2(0.f, 0.f);
-    int lx = 0, lz = 0;
-    if (active) {
-        const uint32_t rec = sh.vq_rec[wave][slot];
-        rx = sh.vq_rx[wave][slot]; rz = sh.vq_rz[wave][slot];
-        const int e = rec & 63, rot = (rec >> 6) & 255;
-        lx = (int)((rec >> 14) & 63) - 1; lz = (int)((rec >> 20) & 63) - 1;
-        ry = sh.pq[wave][4][e]; ob = sh.pq[wave][5][e];
-        s0 = sh.pq[wave][6][e]; s1 = sh.pq[wave][7][e]; s2 = sh.pq[wave][8][e];
-        cs = sh.tab[rot];
-    }
-    const bool small = fabsf(ob) * fmaxf(1.f, fmaxf(fabsf(s0), fmaxf(fabsf(s1), fabsf(s2)))) < 16384.f;
-    if (__all(small)) {
-        if (active) roll_drain_vote<true>(sh, lower, upper, pl_lower, lx, lz, rx, rz, ry, ob, s0, s1, s2, cs);
-    } else {
-        if (active) roll_drain_vote<false>(sh, lower, upper, pl_lower, lx, lz, rx, rz, ry, ob, s0, s1, s2, cs);
-    }
-}
-
-__global__ __launch_bounds__(RTW * 64) void hv_fwd_roll(
-    int R, float res, F3 corner, I3 dims, const float2* __restrict__ tab, const int* __restrict__ ystart,
-    const float* __restrict__ rec, int64_t rec_stride, int tiles_x, int tiles_z, const int* __restrict__ range_start,
-    float* __restrict__ g_obj, float* __restrict__ g_rot, float* __restrict__ g_scale) {
-    __shared__ RollShared sh;
-    const int X = dims.x, Y = dims.y, Z = dims.z;
-    const int ntiles = tiles_x * tiles_z;
-    const int tile = blockIdx.x % ntiles, rg = blockIdx.x / ntiles;
-    const int p0 = range_start[rg], p1 = range_start[rg + 1];      // planes owned: [p0, p1)
-    if (p0 >= p1) return;
-    const int x0 = (tile / tiles_z) * RTX, z0 = (tile % tiles_z) * TZ;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 2 * R_ACC_PLANE; i += RTW * 64) (&sh.acc[0][0])[i] = 0ull;
-    for (int i = threadIdx.x; i < R; i += RTW * 64) sh.tab[i] = tab[i];
-    if (threadIdx.x == 0) sh.next_chunk = 0;
-    __syncthreads();
-
-    const float slack = 0.05f;
-    const float xlo = (float)(x0 - 1), xhi = (float)(x0 + RTX), zlo = (float)(z0 - 1), zhi = (float)(z0 + TZ);
-    const int nx = min(RTX, X - x0), nz = min(TZ, Z - z0);
-
-    for (int s = p0 - 1; s < p1; ++s) {
-        const bool lower = s >= p0, upper = s + 1 < p1;      // which of the bin's two planes this workgroup owns
-        if (s >= 0 && s <= Y - 2) {
-            const int beg = ystart[s], end = ystart[s + 1];
-            int vq_len = 0;   // wave-uniform
-            for (;;) {
-                int c = 0;
-                if (lane == 0) c = atomicAdd(&sh.next_chunk, 1);
-                c = __builtin_amdgcn_readfirstlane(c);
-                const int base = beg + c * 64;
-                if (base >= end) break;
-                const int idx = base + lane;
-                bool keep = false;
-                int a_start = 0, a_len = 0;
-                if (idx < end) {
-                    const float ux = rec[9 * rec_stride + idx], uz = rec[10 * rec_stride + idx], r = rec[11 * rec_stride + idx];
-                    // conservative ring-vs-rectangle test in grid units
-                    const float dxn = fmaxf(0.f, fmaxf(xlo - ux, ux - xhi));
-                    const float dzn = fmaxf(0.f, fmaxf(zlo - uz, uz - zhi));
-                    const float dxf = fmaxf(fabsf(ux - xlo), fabsf(ux - xhi));
-                    const float dzf = fmaxf(fabsf(uz - zlo), fabsf(uz - zhi));
-                    const float dmin = sqrtf(dxn * dxn + dzn * dzn), dmax = sqrtf(dxf * dxf + dzf * dzf);
-                    const float tol = slack + 1e-5f * (r + fabsf(ux) + fabsf(uz));
-                    keep = (r >= dmin - tol) && (r <= dmax + tol);
-                    if (keep) {
-                        a_len = R;
-                        if (dxn + dzn > 0.5f) {
-                            const float b0 = arc_atan2(0.5f * (zlo + zhi) - uz, 0.5f * (xlo + xhi) - ux);
-                            float lo = 0.f, hi = 0.f;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                float d = arc_atan2(((k & 2) ? zhi : zlo) - uz, ((k & 1) ? xhi : xlo) - ux) - b0;
-                                d -= 6.28318531f * rintf(d * 0.159154943f);
-                                lo = fminf(lo, d);
-                                hi = fmaxf(hi, d);
-                            }
-                            const float a0 = rec[12 * rec_stride + idx];
-                            const float inv_step = (float)R * 0.159154943f;          // 1 / rot_interval
-                            float first = (b0 + lo - a0) * inv_step - 2.f;           // 2 steps of slack per side
-                            const int len = (int)((hi - lo) * inv_step) + 6;
-                            first -= (float)R * floorf(first / (float)R);
-                            a_start = min(max((int)first, 0), R - 1);
-                            a_len = min(len, R);
-                        }
-                    }
-                }
-                const uint64_t m = __ballot(keep);
-                const int nq = __popcll(m);
-                if (nq == 0) continue;
-                int cum = keep ? a_len : 0;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int t = __shfl_up(cum, off);
-                    if (lane >= off) cum += t;
-                }
-                const int items = __shfl(cum, 63);
-                if (keep) {
-                    const int p = lanes_below(m);
-                    sh.pq[wave][0][p] = rec[0 * rec_stride + idx];
-                    sh.pq[wave][1][p] = rec[1 * rec_stride + idx];
-                    sh.pq[wave][2][p] = rec[2 * rec_stride + idx];
-                    sh.pq[wave][3][p] = rec[3 * rec_stride + idx];
-                    sh.pq[wave][4][p] = rec[4 * rec_stride + idx];
-                    sh.pq[wave][5][p] = rec[5 * rec_stride + idx];
-                    sh.pq[wave][6][p] = rec[6 * rec_stride + idx];
-                    sh.pq[wave][7][p] = rec[7 * rec_stride + idx];
-                    sh.pq[wave][8][p] = rec[8 * rec_stride + idx];
-                    sh.arc_start[wave][p] = a_start;
-                    sh.arc_cum[wave][p] = cum;
-                }
-                wave_sync_lds();
-                // lane l walks items [l*S, (l+1)*S) of the concatenated arcs (see hv_fwd_tiles)
-                const int S = (items + 63) >> 6;
-                int it0 = lane * S;
-                const int it1 = min(it0 + S, items);
-                int e = 0;
-                {
-                    int lo = 0, hi = nq - 1;                     // smallest e with cum[e] > it0
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (sh.arc_cum[wave][mid] > it0) hi = mid; else lo = mid + 1;
-                    }
-                    e = lo;
-                }
-                int e_end = it0 < items ? sh.arc_cum[wave][e] : 0;
-                int rot = 0;
-                float epx = 0.f, epz = 0.f, ecx = 0.f, ecz = 0.f;
-                if (it0 < items) {
-                    const int e_beg = e > 0 ? sh.arc_cum[wave][e - 1] : 0;
-                    rot = sh.arc_start[wave][e] + (it0 - e_beg);
-                    if (rot >= R) rot -= R;
-                    epx = sh.pq[wave][0][e]; epz = sh.pq[wave][1][e];
-                    ecx = sh.pq[wave][2][e]; ecz = sh.pq[wave][3][e];
-                }
-                for (int step = 0; step < S; ++step, ++it0) {
-                    bool isvote = false;
-                    uint32_t vrec = 0;
-                    float rx = 0, rz = 0;
-                    if (it0 < it1) {
-                        if (it0 == e_end) {                      // next arc
-                            ++e;
-                            e_end = sh.arc_cum[wave][e];
-                            rot = sh.arc_start[wave][e];
-                            epx = sh.pq[wave][0][e]; epz = sh.pq[wave][1][e];
-                            ecx = sh.pq[wave][2][e]; ecz = sh.pq[wave][3][e];
-                        }
-                        const float2 cs = sh.tab[rot];
-                        const float ox = (-cs.x) * ecx + cs.y * ecz;
-                        const float oz = (-cs.y) * ecx - cs.x * ecz;
-                        const float gx = grid_pos(epx, ox, corner.x, res);
-                        const float gz = grid_pos(epz, oz, corner.z, res);
-                        if (gx >= 0 && gz >= 0 && gx < (float)(X - 1) && gz < (float)(Z - 1)) {
-                            const int lx = (int)gx - x0, lz = (int)gz - z0;
-                            if (lx >= -1 && lx < RTX && lz >= -1 && lz < TZ) {
-                                isvote = true;
-                                rx = gx - floorf(gx);
-                                rz = gz - floorf(gz);
-                                vrec = (uint32_t)e | ((uint32_t)rot << 6) | ((uint32_t)(lx + 1) << 14) |
-                                       ((uint32_t)(lz + 1) << 20);
-                            }
-                        }
-                        if (++rot == R) rot = 0;
-                    }
-                    const uint64_t mv = __ballot(isvote);
-                    if (isvote) {
-                        const int p = vq_len + lanes_below(mv);
-                        sh.vq_rec[wave][p] = vrec;
-                        sh.vq_rx[wave][p] = rx;
-                        sh.vq_rz[wave][p] = rz;
-                    }
-                    vq_len += __popcll(mv);
-                    wave_sync_lds();
-                    if (vq_len >= 64) {
-                        vq_len -= 64;
-                        roll_drain64(sh, wave, vq_len + lane, true, lower, upper, s);
-                    }
-                }
-                // queued votes index this chunk's pq entries: flush before pq is overwritten
-                if (vq_len > 0) {
-                    roll_drain64(sh, wave, lane, lane < vq_len, lower, upper, s);
-                    vq_len = 0;
-                }
-                wave_sync_lds();
-            }
-        }
-        __syncthreads();
-        // plane s has every contribution (bins s - 1 and s): normalise (hv_cuda_kernel.cu:112-117), store, zero - one
-        // thread per cell, so nobody reads a word another thread zeroes
-        if (lower) for (int ci = threadIdx.x; ci < RCELLS; ci += RTW * 64) {
-            const int lx = ci / TZ, lz = ci % TZ;
-            unsigned long long* a = sh.acc[s & 1] + lx * ACC_PITCH + lz;
-            if (lx < nx && lz < nz) {
-                const int64_t cell = ((int64_t)(x0 + lx) * Y + s) * Z + z0 + lz;
-                const float w = (float)fx_value(a[0]);
-                const double d = (double)w + 1e-7;
-                g_obj[cell] = w;
-                const float r0 = (float)((double)(float)fx_value(a[R_ACC_CH]) / d);
-                const float r1 = (float)((double)(float)fx_value(a[2 * R_ACC_CH]) / d);
-                reinterpret_cast<float2*>(g_rot)[cell] = make_float2(r0, r1);
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    g_scale[cell * 3 + j] = (float)((double)(float)fx_value(a[(3 + j) * R_ACC_CH]) / d);
-            }
-#pragma unroll
-            for (int ch = 0; ch < 6; ++ch) a[ch * R_ACC_CH] = 0ull;
-        }
-        if (threadIdx.x == 0) sh.next_chunk = 0;
-        __syncthreads();
-    }
-}
-
+// (Round 3, measured and removed - git 5179aa0 holds the code: a ROLLING tile kernel, one workgroup per tile and RANGE of
+// planes with two planes in LDS, every vote expanded once and accumulated into both of its planes, plane s stored after
+// bin s.  Exact (all vote / decode / concurrency tests), half the cull and expansion work - and 0.56-0.85 ms against
+// 0.37-0.44 ms for hv_fwd_tiles in every tile width / waves / range-count configuration, fastest with the MOST ranges
+// (profiles/r3/vote_roll_sweep.txt): the op is bound by how many latency chains run side by side, not by the work in
+// them; a serial bin loop per workgroup takes parallelism away.)
+// ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
 // backward (hv_cuda_kernel.cu:168-261): one wave per point, lanes over rotations,
 // butterfly reduction (deterministic; no atomics, like the reference).
@@ -1633,7 +1340,7 @@ size_t cv_hv_forward_workspace_bytes(int64_t n, int num_rots, const int dims[3],
     const size_t ntiles = (size_t)((dims[0] + TX - 1) / TX) * (size_t)((dims[2] + TZ - 1) / TZ);
     const size_t max_chunks = Y + (size_t)((n + LIST_CHUNK_RECORDS - 1) / LIST_CHUNK_RECORDS);
     const size_t slots = std::max<size_t>((size_t)queue_max_slots(n, num_rots), (size_t)tiles_q_bound(n, (int)Y) * ntiles);
-    return 256 * 25 + sizeof(int) * ((size_t)n * (1 + REC_F) + Y * 8 + 16 + 4 * Y * ntiles + 64 + (ROLL_MAX_RANGES + 1) + max_chunks * (ntiles + 1) +
+    return 256 * 24 + sizeof(int) * ((size_t)n * (1 + REC_F) + Y * 8 + 16 + 4 * Y * ntiles + 64 + max_chunks * (ntiles + 1) +
                                      4 * (size_t)tiles_q_bound(n, (int)Y)) +
            sizeof(int4) * (size_t)queue_max_items(n, num_rots, (int64_t)Y, (int64_t)ntiles) +
            sizeof(int2) * (size_t)list_capacity(n, (int64_t)ntiles) + sizeof(float) * slots * 6 * TCELLS;
@@ -1701,16 +1408,7 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
     int* bin_of_chunk = cv.take<int>((size_t)max_chunks);
     int* chunk_off = cv.take<int>((size_t)max_chunks * ntiles);
     int2* entries = cv.take<int2>((size_t)list_cap);
-    int* range_start = cv.take<int>(ROLL_MAX_RANGES + 1);
     const int list_mode = queue ? 2 : 1;
-    // small grids: the rolling two-plane kernel (CV_HV_ROLL=0: the one-plane tile kernel; the profiling ablations stay on it)
-    static const bool roll_env = getenv("CV_HV_ROLL") && atoi(getenv("CV_HV_ROLL")) != 0;      // measured slower: off
-    static const int roll_target = getenv("CV_HV_ROLL_WGS") ? atoi(getenv("CV_HV_ROLL_WGS")) : ROLL_TARGET_WGS;
-    const int rtiles_x = (dims[0] + RTX - 1) / RTX;
-    const int rtiles = rtiles_x * tiles_z;
-    const bool roll = roll_env && !queue && !(algo >= 21 && algo <= 25) && Y >= 2;
-    const int n_ranges = roll ? (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ROLL_MAX_RANGES, Y),
-                                                                             (roll_target + rtiles - 1) / rtiles)) : 0;
     // (the streaming launch only needs ycount and the arrival counters zeroed)
     int* zero_from = queue ? list_ctl : ycount;
     CV_HIP_CHECK(hipMemsetAsync(zero_from, 0, (size_t)(reinterpret_cast<char*>(arrivals + (size_t)Y * ntiles) -
@@ -1718,8 +1416,7 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
     hv_prep_count<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, n, res, corner.y, Y, fy, ycount);
     CV_LAUNCH_CHECK();
-    hv_prep_scan<<<1, 1024, 0, st>>>(ycount, Y, ystart, cursor, part_start, q_info, (int)max_q, chunk_start, bin_of_chunk,
-                                     roll ? range_start : nullptr, n_ranges);
+    hv_prep_scan<<<1, 1024, 0, st>>>(ycount, Y, ystart, cursor, part_start, q_info, (int)max_q, chunk_start, bin_of_chunk);
     CV_LAUNCH_CHECK();
     hv_prep_scatter<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, d_obj, fy, n, Y, res, corner, cursor, rec, n);
@@ -1735,12 +1432,6 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
         hv_list_pass<true><<<(unsigned)max_chunks, 1024, 0, st>>>(ystart, chunk_start, bin_of_chunk, Y, rec, n, num_rots, tiles_x,
                                                               tiles_z, list_ctl, list_cnt, list_start, chunk_off, entries, tile_w, 1);
         CV_LAUNCH_CHECK();
-    }
-    if (roll) {
-        hv_fwd_roll<<<(unsigned)(n_ranges * rtiles), RTW * 64, 0, st>>>(num_rots, res, corner, d3, tab, ystart, rec, n, rtiles_x,
-                                                                       tiles_z, range_start, d_grid_obj, d_grid_rot, d_grid_scale);
-        CV_LAUNCH_CHECK();
-        return CV_OK;
     }
     const int64_t wgs = queue ? max_items : max_q * ntiles;
     CV_REQUIRE(wgs < (1ll << 31), CV_EINVAL, "grid too large");
