@@ -200,7 +200,7 @@ def test_config3_training_forward_and_loss_at_three_80k_scenes(cuda, built_lib):
     assert abs(float(loss.detach()) - float(lo)) < 1e-4 * max(1.0, abs(float(lo)))
 
 
-def test_config3_training_gradients_at_three_20k_scenes(cuda, built_lib):
+def _training_gradients_on_shared_relu_masks(cuda, n_points, seed0):
     """every parameter gradient of one train_joint.py step on 3 x 20k rows against autograd through the CPU oracle in
     DOUBLE precision: at 60k rows the finest two levels run the mask-sorted groups (>= 16384 rows), the weight-gradient
     kernels their chunked plans and the coarse levels their split-K sizing - the code paths of the 3 x 80k step, at a
@@ -214,7 +214,7 @@ def test_config3_training_gradients_at_three_20k_scenes(cuda, built_lib):
     both use one set of masks (profiles/r3/relu_flip_probe.txt).  A forced mask changes the forward only where
     |x| ~ 1e-6, so the loss still has to match."""
     from canonicalvoting_amd import train
-    coords, feats, (xyz, scale, cls) = _train_batch(cuda, 3, 20000, 60)
+    coords, feats, (xyz, scale, cls) = _train_batch(cuda, 3, n_points, seed0)
     torch.manual_seed(1)
     model = MinkUNet34C(3, 6 * 9 + 9 + 1).cuda().train()
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -252,6 +252,24 @@ def test_config3_training_gradients_at_three_20k_scenes(cuda, built_lib):
         g, go = p.grad.double().cpu().numpy(), sdo[name].grad.numpy()
         errs.append((float(np.abs(g - go).max() / max(1e-12, np.abs(go).max())), name))
     errs.sort(reverse=True)
-    print("largest parameter-gradient errors at 3 x 20k rows, same ReLU masks (max |d| / max |g|):",
+    print("largest parameter-gradient errors at 3 x %d rows, same ReLU masks (max |d| / max |g|):" % n_points,
           [(n, "%.2e" % e) for e, n in errs[:4]], "median %.2e" % errs[len(errs) // 2][0])
     assert errs[0][0] < 1e-4, errs[:6]
+
+
+def test_config3_training_gradients_at_three_20k_scenes(cuda, built_lib):
+    _training_gradients_on_shared_relu_masks(cuda, 20000, 60)
+
+
+def test_config3_training_gradients_at_three_80k_scenes(cuda, built_lib):
+    """the same at the size config/config.yaml:15 trains at: 240k rows, all 249 parameter gradients.
+    The fp64 autograd of the oracle keeps the [pairs, C] intermediates of every layer (~60 GB of host memory) and takes
+    five minutes on the GPU box's cores, so the test is opt-in (CV_TEST_3X80K=1); its output of this round is committed as
+    profiles/r3/train_gradients_3x80k.txt (worst parameter 6.5e-6, median 2.9e-6)."""
+    import os
+    if os.environ.get("CV_TEST_3X80K", "0") != "1":
+        pytest.skip("opt-in: CV_TEST_3X80K=1 (five minutes of CPU autograd in fp64, ~60 GB of host memory)")
+    mem = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES")
+    if mem < (128 << 30):
+        pytest.skip("the oracle's fp64 autograd at 3 x 80k rows needs ~60 GB of host memory")
+    _training_gradients_on_shared_relu_masks(cuda, 80000, 40)
