@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--min-warm-seconds", type=float, default=1.5,
                     help="the untimed warm-up lasts at least this long (sustained work before the clock starts); "
                          "--warmup is a minimum number of steps, not the whole warm-up")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=6,
                     help="scenes in flight per GPU: S host threads, each with its own HIP stream, take the steps "
                          "from one shared counter (scenes are independent; fills the launch tails and host syncs of one scene "
                          "with the kernels of another)")
@@ -615,7 +615,7 @@ def main():
     # HBM bytes of the vote kernel from the PMC counters are collected offline (rocprofv3 --pmc in its
     # own passes, profiles/r*/vote_hbm_traffic.json) for the default 80k workload; null otherwise
     traffic = None
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         tj = os.path.join(ROOT, "profiles", rnd, "vote_hbm_traffic.json")
         if os.path.exists(tj) and a.points == N_POINTS and not a.large and a.algo in (0, 2):
             traffic = json.load(open(tj))["hbm_bytes_per_launch"]

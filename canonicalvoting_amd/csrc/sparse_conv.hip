@@ -30,184 +30,11 @@
 #include <type_traits>
 #include <utility>
 
+#include "sparse_conv_common.h"
+
+using namespace cvsc;
+
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int KC = 32;            // K chunk (channels per staging step)
-constexpr int TM = 128;           // rows per workgroup
-constexpr int A_LD = TM + 2;      // A staged k-major: A_s[k][row]; +2 makes the 4-row-strided staging stores 2-way (free) instead of 4-way conflicted
-constexpr int THREADS = 256;
-
-struct ConvArgs {
-    const float* in; long long n_in; int in_ld; int cin;
-    const float* w; int K; int cout;
-    const int* nbr; long long n_out;
-    const float* scale; const float* shift;
-    const float* res; int res_ld;
-    int relu;
-    float* out; int out_ld;
-    int splits;            // >1: blockIdx.z handles a contiguous sub-range of the offsets and writes raw
-    float* partial;        //     partial sums to partial[split][n_out][cout] (finished by conv_finish)
-    const int* row_perm;   // optional processing order: tile row t works on output row row_perm[t]
-    int perm_per_split;    // 1: row_perm is [splits][n_out], one order per offset group (blockIdx.z)
-    int j_begin, j_end;    // kernel offsets handled by this launch
-    const float* acc_in;   // optional [n_out][acc_ld] added to the accumulator before the epilogue
-    int acc_ld;
-    const int* plan_ent;   // tile flavour: compacted (input row, tile row) lists per (tile, offset), see tile_plan
-    const int* plan_cnt;
-    const float4* wp;      // tile flavour: weights in MFMA operand order, see pack_weights
-    int wide;              // epilogue operands are 16-byte aligned with leading dimensions % 4 == 0: float4 row stores
-    const int* nbr_perm;   // mask-sorted groups: [splits][n_out][nbr_perm_w] kernel map rows in processing order
-    int nbr_perm_w;
-    int dbg;               // instrumented twin only (CV_CONV_DBG): 1 no MFMA, 2 no gathers, 4 no weight loads, 8 no epilogue
-    const unsigned short* wp6;   // weights split into bf16 pieces, see pack_weights_x6 (conv_rows_x6)
-    const float* in2;            // conv_rows_x6: second source on the output rows (out += in2 @ W2), or NULL
-    int in2_ld, cin2;
-    const unsigned short* wp6_2;
-    int pieces;                  // 3: wp6 holds bf16 triples (six piece products), 2: fp16 pairs (three piece products)
-    float acc_scale;             // fp16 pairs: the packed weights carry a power-of-two factor; accumulators *= acc_scale
-    int* range_flag;             // fp16 pairs: set to 1 when a staged input magnitude does not fit fp16
-    int in_hl, out_hl, res_hl;   // 1: the operand is in the hl format (fp16 pairs in place, see below) instead of fp32
-    int xcd_tiles;               // conv_rows_wp / conv_hl: XCD-aware tile numbering (xcd_tile)
-    int* tickets;                // conv_hl split-K: arrival counters per output tile (zero; the last arriver reduces, see there)
-};
-
-// ---- hl format: activations stored as the fp16 pairs the matrix cores multiply --------------------------------------
-// A row of C channels (C % 32 == 0) keeps its 4*C bytes: 32-channel chunk q occupies bytes [128 q, 128 q + 128) =
-// 32 fp16 high pieces h = RNE16(x), then the 32 low pieces l = RNE16(x - h) (split2h below).  A convolution that reads
-// the format loads its MFMA operand fragments straight from global memory (no split, no LDS staging of the gathered
-// rows: a lane's 16-byte pieces are contiguous), the producing epilogue splits every value ONCE instead of once per
-// gather (27 x for a 3x3x3 kernel).  Column windows that start at a multiple of 32 channels keep the plain pointer
-// arithmetic (32 channels = 32 floats = 128 bytes).  h + l reproduces x to 2^-24 relative (|x| < 65504).
-__device__ __forceinline__ void hl_split2(float x0, float x1, unsigned& h, unsigned& l);
-__device__ __forceinline__ float4 hl_load4(const float* row, int col) {          // col % 4 == 0
-    const unsigned char* p = reinterpret_cast<const unsigned char*>(row) + (col >> 5) * 128 + (col & 31) * 2;
-    const uint2 h = *reinterpret_cast<const uint2*>(p), l = *reinterpret_cast<const uint2*>(p + 64);
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const h2 h0 = __builtin_bit_cast(h2, h.x), h1 = __builtin_bit_cast(h2, h.y), l0 = __builtin_bit_cast(h2, l.x),
-             l1 = __builtin_bit_cast(h2, l.y);
-    return make_float4((float)h0[0] + (float)l0[0], (float)h0[1] + (float)l0[1], (float)h1[0] + (float)l1[0],
-                       (float)h1[1] + (float)l1[1]);
-}
-__device__ __forceinline__ void hl_store4(float* row, int col, float4 v) {
-    unsigned h0, l0, h1, l1;
-    hl_split2(v.x, v.y, h0, l0);
-    hl_split2(v.z, v.w, h1, l1);
-    unsigned char* p = reinterpret_cast<unsigned char*>(row) + (col >> 5) * 128 + (col & 31) * 2;
-    *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(p + 64) = make_uint2(l0, l1);
-}
-__device__ __forceinline__ bool hl_out_of_range(float4 v) {
-    return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) > 65000.f;
-}
-
-// Partial tiles (split-K / mask-group sums) are written once and read once by the finish launch: streamed past the
-// caches with the nontemporal policy (CV_NT_PARTIAL bit 0: the stores, bit 1: the finish launch's loads) so that they do
-// not push the activations and weight slabs, which ARE re-read, out of the 4 MB L2s.  Measured (profiles/r3/nt_partial_ab.txt):
-// net 2.42 -> 2.375 ms one scene in flight, 483 -> 495 scenes/s six in flight with both; the XCD-aware tile numbering on top of
-// either: 2.61-2.64 ms (still slower - the cost ordering of the tiles is worth more than the L2 hits).
-#ifndef CV_NT_PARTIAL
-#define CV_NT_PARTIAL 3
-#endif
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void partial_store4(float* p, float4 v) {
-    if (CV_NT_PARTIAL & 1) {
-        f32x4v t; t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
-        __builtin_nontemporal_store(t, reinterpret_cast<f32x4v*>(p));
-    } else {
-        *reinterpret_cast<float4*>(p) = v;
-    }
-}
-__device__ __forceinline__ float4 partial_load4(const float4* p) {
-    if (CV_NT_PARTIAL & 2) {
-        const f32x4v t = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));
-        return make_float4(t[0], t[1], t[2], t[3]);
-    }
-    return *p;
-}
-
-__device__ __forceinline__ void epilogue_store(const ConvArgs& a, const f32x16& acc, const int* rows,
-                                               int col, int lane) {
-    if (col >= a.cout) return;
-    if (a.splits > 1) {
-        float* p = a.partial + (long long)blockIdx.z * a.n_out * a.cout;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rows[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-            if (row >= 0) p[(long long)row * a.cout + col] = acc[r];
-        }
-        return;
-    }
-    const float sc = a.scale ? a.scale[col] : 1.f;
-    const float sh = a.shift ? a.shift[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = rows[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-        if (row < 0) continue;
-        float v = acc[r];
-        if (a.acc_in) v += a.acc_in[(long long)row * a.acc_ld + col];
-        v = v * sc + sh;
-        if (a.res) v += a.res[(long long)row * a.res_ld + col];
-        if (a.relu) v = fmaxf(v, 0.f);
-        a.out[(long long)row * a.out_ld + col] = v;
-    }
-}
-
-// the fused epilogue on four consecutive columns of one output row (16-byte aligned operands): partial-sum input, folded
-// BatchNorm affine / bias, residual (fp32 or hl), ReLU, store (fp32 or hl + range flag)
-__device__ __forceinline__ void epilogue_apply4(const ConvArgs& a, long long row, int col, float4 v) {
-    if (a.acc_in) {
-        const float4 p = *reinterpret_cast<const float4*>(a.acc_in + row * a.acc_ld + col);
-        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-    }
-    const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
-    const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-    if (a.res) {
-        const float4 p = a.res_hl ? hl_load4(a.res + row * a.res_ld, col)
-                                  : *reinterpret_cast<const float4*>(a.res + row * a.res_ld + col);
-        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-    }
-    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (a.out_hl) {
-        if (a.range_flag && hl_out_of_range(v)) *a.range_flag = 1;
-        hl_store4(a.out + row * a.out_ld, col, v);
-    } else {
-        *reinterpret_cast<float4*>(a.out + row * a.out_ld + col) = v;
-    }
-}
-
-// The same epilogue with 16-byte stores: the 32x32 accumulator tile goes through a wave-private LDS tile so that
-// 8 lanes write 128 contiguous bytes of one output row (4 dwordx4 stores per lane instead of 16 dword stores).
-// Measured with the instrumented twin (profiles/conv_phases.py): the dword epilogue was 63 % of the wave time
-// of the split ts16 convs and 20 % of the mask-sorted ts1 convs - it is store-ISSUE bound, not bandwidth bound.
-constexpr int EP_LD = 36;
-__device__ __forceinline__ void epilogue_store_wide(const ConvArgs& a, const f32x16& acc, const int* rows, int colbase,
-                                                    int lane, float (*T)[EP_LD]) {
-    const int h = lane >> 5, c = lane & 31;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) T[(r & 3) + 8 * (r >> 2) + 4 * h][c] = acc[r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int col = colbase + (lane & 7) * 4;
-    if (col < a.cout) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int rl = (lane >> 3) + 8 * it;
-            const int row = rows[rl];
-            if (row < 0) continue;
-            float4 v = *reinterpret_cast<const float4*>(&T[rl][(lane & 7) * 4]);
-            if (a.splits > 1) {
-                partial_store4(a.partial + ((long long)blockIdx.z * a.n_out + row) * a.cout + col, v);
-                continue;
-            }
-            epilogue_apply4(a, row, col, v);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();       // the tile is rewritten by the next column block
-}
 
 // VEC: Cin % 32 == 0 (float4 gathers inside one offset).  !VEC: flattened K = K*Cin (stem, Cin=3).
 template <int NB, bool VEC>
@@ -395,42 +222,6 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
 // and laid out per (offset, 32-channel chunk) once per weight tensor (cv_sp_pack_weights_x6_f32).
 // LDS operand tiles: [plane][row][32 k] bf16, 64-byte rows whose 16-byte chunks are XOR-swizzled with (row >> 2) & 3
 // so that the ds_read_b128 of the 16 lanes served together hit 16 different bank groups.
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {      // RNE, lo in bits 0-15
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-// two fp32 values -> their h / m / l bf16 pieces, packed (first value in the low half)
-__device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    h = cvt_pk_bf16(x0, x1);
-    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-    m = cvt_pk_bf16(r0, r1);
-    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-    l = cvt_pk_bf16(s0, s1);
-}
-
-// fp16 pairs: x = h + l with h = RNE16(x), l = RNE16(x - h): 11 + 11 significant bits and l's own sign, i.e. x to
-// 2^-24 relative as long as neither piece leaves the fp16 range (|x| < 65504; below 2^-14 the absolute error floor is
-// 2^-25).  Three piece products (hh, hl, lh; the dropped ll is <= 2^-24 of the product) instead of six.
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigned& l) {
-    const f16x2 hv = {(_Float16)x0, (_Float16)x1};                          // v_cvt_pk_f16_f32 (RNE)
-    h = __builtin_bit_cast(unsigned, hv);
-    // x - h with the fp16 half read in place: v_fma_mix_f32 (fma(h, -1, x) is the exactly rounded difference, the value
-    // v_sub_f32 gives) instead of v_cvt_f16_f32 + v_cvt_f32_f16 + v_sub_f32 on a second, scalar conversion of x:
-    // 4 -> 2 VALU instructions per value in the staging loop (64 -> 32 per unit and lane)
-    float r0, r1;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x0));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x1));
-    const f16x2 lv = {(_Float16)r0, (_Float16)r1};
-    l = __builtin_bit_cast(unsigned, lv);
-}
-
-__device__ __forceinline__ void hl_split2(float x0, float x1, unsigned& h, unsigned& l) { split2h(x0, x1, h, l); }
-
 // wp layout of the fp16 pairs (unsigned short): ((((j*nch + c)*2 + plane)*cout + col)*32 + k); values are
 // w * col_scale * mult (mult = 2^scale_log2 keeps the low pieces of small weights out of the fp16 subnormals)
 __global__ __launch_bounds__(256) void pack_weights_h2(const float* __restrict__ w, int K, int cin, int cout,
@@ -1066,7 +857,7 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 #endif
 constexpr int HL_MAX_UNITS = 512;      // live units of one workgroup: <= 10 offsets x Cin / 32 chunks + the second source's (host-checked)
 template <int NB, int NS, int NW>
-__global__ __attribute__((amdgpu_waves_per_eu((NW > 4 && NS == 2) ? 4 : 1, 8))) __launch_bounds__(NW * 64, (NW > 4 ? (NS == 2 ? 2 : 1) : NS == 2 ? (NB == 1 ? HL_OCC1 : NB == 2 ? HL_OCC2 : HL_OCC3) : 3)) void conv_hl(ConvArgs a) {
+__global__ __attribute__((amdgpu_waves_per_eu((NW > 4 && NS == 2) ? 4 : 1, 8))) __launch_bounds__(NW * 64, (NW > 4 ? (NS == 2 ? 2 : 1) : NS == 2 ? (NB == 1 ? HL_OCC1 : NB == 2 ? HL_OCC2 : NB == 3 ? HL_OCC3 : 2) : 3)) void conv_hl(ConvArgs a) {
     static_assert(NS == 3 || NS == 2, "three unit slots (or two: the loads of unit k + 2 follow the MFMAs of unit k)");
     constexpr int TMv = NW * 32, THv = NW * 64;
     constexpr int B_BYTES = 2 * NB * 32 * 64, EP_BYTES = NW * 32 * EP_LD * 4;
@@ -1371,201 +1162,6 @@ __global__ __attribute__((amdgpu_waves_per_eu((NW > 4 && NS == 2) ? 4 : 1, 8))) 
     }
 }
 
-// Instrumented twin of conv_rows (CV_CONV_PROF=1): shader-clock ticks per phase, summed over waves into prof[16].
-template <int NB, bool VEC>
-__global__ __launch_bounds__(THREADS) void conv_rows_prof(ConvArgs a, unsigned long long* prof) {
-    unsigned long long pacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long pt0 = __builtin_amdgcn_s_memtime();
-#define TICK(p) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pacc[p] += t_ - pt0; pt0 = t_; } while (0)
-    __shared__ float A_s[KC][A_LD];
-    __shared__ float B_s[KC][NB * 32];
-    __shared__ int nbr_s[TM];
-    __shared__ int rows_s[TM];
-    __shared__ __attribute__((aligned(16))) float ep_s[4][32][EP_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.y * (NB * 32);
-
-    if (tid < TM) {
-        // mask-sorted orders end with the rows that need the most offsets: start those tiles FIRST so the
-        // light tiles fill the tail of the launch (longest-processing-time-first)
-        const long long tile_id = a.row_perm ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
-        const long long t = tile_id * TM + tid;
-        const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)blockIdx.z * a.n_out : 0) : nullptr;
-        rows_s[tid] = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
-    }
-    __syncthreads();
-    TICK(0);
-
-    f32x16 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-
-    auto compute = [&]() {
-#pragma unroll
-        for (int kk = 0; kk < KC; kk += 2) {
-            const float av = A_s[kk + (lane >> 5)][wave * 32 + (lane & 31)];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const float bv = B_s[kk + (lane >> 5)][nb * 32 + (lane & 31)];
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
-            }
-        }
-    };
-
-    const int nj = a.j_end - a.j_begin;
-    if (VEC) {
-        // thread -> (row = tid/8 + 32*i, 4 channels at (tid%8)*4) : 8 lanes cover one 128 B row chunk
-        const int a_col = (tid & 7) * 4;
-        const int a_row = tid >> 3;                      // + 32*i, i = 0..3
-        constexpr int B_F4 = KC * NB * 32 / 4;           // float4s in the weight slab
-        constexpr int B_PER = (B_F4 + THREADS - 1) / THREADS;
-        // work units = (kernel offset, 32-channel chunk); a split owns a contiguous range of units,
-        // or a whole offset group when every group has its own row order
-        const int nch = a.cin / KC;
-        int u_lo, u_hi;
-        if (a.perm_per_split) {
-            u_lo = (int)((long long)nj * blockIdx.z / a.splits) * nch;
-            u_hi = (int)((long long)nj * (blockIdx.z + 1) / a.splits) * nch;
-        } else {
-            u_lo = (int)((long long)nj * nch * blockIdx.z / a.splits);
-            u_hi = (int)((long long)nj * nch * (blockIdx.z + 1) / a.splits);
-        }
-        const int j_first = a.j_begin + u_lo / nch, j_last = a.j_begin + (u_hi - 1) / nch;
-        for (int j = j_first; j <= j_last && u_hi > u_lo; ++j) {
-            const int kc_begin = (j == j_first ? u_lo % nch : 0) * KC;
-            const int kc_end = (j == j_last ? (u_hi - 1) % nch + 1 : nch) * KC;
-            int my = -1;
-            if (tid < TM) {
-                const int row = rows_s[tid];
-                if (row >= 0) {
-                    // mask-sorted orders visit the rows at random: the group's map rows were copied in processing
-                    // order next to the order itself, so this is a coalesced read (the row-indexed form costs a
-                    // 64-byte sector per 4-byte entry: 140 MB per ts1 conv, 35 % of its wave time)
-                    if (a.nbr_perm) {
-                        const long long tile_id = (long long)gridDim.x - 1 - blockIdx.x;
-                        my = a.nbr_perm[((long long)blockIdx.z * a.n_out + tile_id * TM + tid) * a.nbr_perm_w +
-                                        (j - (a.j_begin + (int)((long long)nj * blockIdx.z / a.splits)))];
-                    } else
-                        my = a.nbr ? a.nbr[(long long)row * a.K + j] : row;
-                }
-                nbr_s[tid] = my;
-            }
-            const int anyone = __syncthreads_or(my >= 0);
-            TICK(1);
-            if (!anyone) continue;    // nobody in the tile has this neighbour
-            // a wave whose 32 rows all miss this neighbour skips its MFMAs; it still takes part in
-            // the staging and the barriers.  Rows are processed in an order that groups equal
-            // neighbour masks (row_perm), which is what makes whole waves / tiles skippable.
-            const bool wave_live = __any(nbr_s[wave * 32 + (lane & 31)] >= 0);
-            float4 ra[4], rb[B_PER];
-            auto load = [&](int kc) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int src = nbr_s[a_row + 32 * i];
-                    ra[i] = (src >= 0 && !(a.dbg & 2)) ? *reinterpret_cast<const float4*>(a.in + (long long)src * a.in_ld + kc + a_col)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-#pragma unroll
-                for (int i = 0; i < B_PER; ++i) {
-                    const int f = tid + i * THREADS;
-                    if (f < B_F4) {
-                        const int kr = f / (NB * 8), c4 = (f % (NB * 8)) * 4;
-                        const int col = n0 + c4;
-                        const float* wp = a.w + ((long long)j * a.cin + kc + kr) * a.cout + col;
-                        if (a.dbg & 4) rb[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-                        else if (col + 3 < a.cout) rb[i] = *reinterpret_cast<const float4*>(wp);
-                        else {
-                            rb[i].x = col < a.cout ? wp[0] : 0.f;
-                            rb[i].y = col + 1 < a.cout ? wp[1] : 0.f;
-                            rb[i].z = col + 2 < a.cout ? wp[2] : 0.f;
-                            rb[i].w = 0.f;
-                        }
-                    }
-                }
-            };
-            auto stage = [&]() {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = a_row + 32 * i;
-                    A_s[a_col + 0][r] = ra[i].x; A_s[a_col + 1][r] = ra[i].y;
-                    A_s[a_col + 2][r] = ra[i].z; A_s[a_col + 3][r] = ra[i].w;
-                }
-#pragma unroll
-                for (int i = 0; i < B_PER; ++i) {
-                    const int f = tid + i * THREADS;
-                    if (f < B_F4) {
-                        const int kr = f / (NB * 8), c4 = (f % (NB * 8)) * 4;
-                        *reinterpret_cast<float4*>(&B_s[kr][c4]) = rb[i];
-                    }
-                }
-            };
-            load(kc_begin);
-            TICK(2);
-            for (int kc = kc_begin; kc < kc_end; kc += KC) {
-                __syncthreads();                 // previous chunk's MFMAs are done with the LDS tiles
-                TICK(3);
-                stage();
-                TICK(4);
-                __syncthreads();
-                TICK(5);
-                if (kc + KC < kc_end) load(kc + KC);  // in flight while the matrix cores run
-                TICK(6);
-                if (wave_live && !(a.dbg & 1)) compute();
-                TICK(7);
-            }
-            __syncthreads();
-            TICK(8);
-        }
-    } else {
-        const int k0 = a.j_begin * a.cin, ktot = a.j_end * a.cin;
-        const int nchunks = (ktot - k0 + KC - 1) / KC;
-        const int c_lo = (int)((long long)nchunks * blockIdx.z / a.splits);
-        const int c_hi = (int)((long long)nchunks * (blockIdx.z + 1) / a.splits);
-        for (int kc = k0 + c_lo * KC; kc < k0 + c_hi * KC; kc += KC) {
-            __syncthreads();
-            for (int e = tid; e < KC * TM; e += THREADS) {
-                const int kk = e / TM, r = e % TM;
-                const int kf = kc + kk;
-                float v = 0.f;
-                const int row = rows_s[r];
-                if (kf < ktot && row >= 0) {
-                    const int j = kf / a.cin, c = kf - j * a.cin;
-                    const int src = a.nbr ? a.nbr[(long long)row * a.K + j] : row;
-                    if (src >= 0) v = a.in[(long long)src * a.in_ld + c];
-                }
-                A_s[kk][r] = v;
-            }
-            for (int e = tid; e < KC * NB * 32; e += THREADS) {
-                const int kr = e / (NB * 32), c = e % (NB * 32);
-                const int kf = kc + kr, col = n0 + c;
-                B_s[kr][c] = (kf < ktot && col < a.cout) ? a.w[(long long)kf * a.cout + col] : 0.f;
-            }
-            __syncthreads();
-            compute();
-        }
-    }
-    if (a.dbg & 8) {
-        if (acc[0][0] == 123.456f) a.out[0] = 1.f;
-    } else if (a.wide) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            epilogue_store_wide(a, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep_s[wave]);
-    } else {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            epilogue_store(a, acc[nb], rows_s + wave * 32, n0 + nb * 32 + (lane & 31), lane);
-    }
-    TICK(9);
-    if (lane == 0 && prof) {
-        for (int p2 = 0; p2 < 10; ++p2) atomicAdd(&prof[p2], pacc[p2]);
-        atomicAdd(&prof[10], 1ull);
-    }
-#undef TICK
-}
-
-
 // ------------------------------------------------------------------ stem (tiny Cin, 32 outputs)
 // conv0p1s1 (utils/minkunet.py:53: 5x5x5, 3 or 6 -> 32 channels) is a kernel-map walk, not a GEMM: 13 % of its
 // 125 offsets exist per row and each pair is a CIN x 32 product.  One lane owns one output row and all 32
@@ -1777,396 +1373,6 @@ __global__ __launch_bounds__(256) void pack_weights_stem_h2(const float* __restr
         const long long base = ((((long long)(g * cin + ci) * 2) * 32 + col) * 2 + hf) * 8 + 2 * q;
         *reinterpret_cast<unsigned*>(wp + base) = h;
         *reinterpret_cast<unsigned*>(wp + base + 512) = l;
-    }
-}
-
-// ------------------------------------------------------------------ wave-independent flavour
-// For the big fine levels.  One wave owns 32 output rows (taken in mask-sorted order) and walks ONLY the
-// kernel offsets that at least one of its rows needs: no workgroup barriers, no LDS staging, no
-// waiting for neighbours' dead offsets.  MFMA operands come straight from L2 into registers:
-//   A: lane l holds row (l&31), channels 8q + 4(l>>5) + {0..3} as one float4 per 8-channel sub-step;
-//      sub-step (q, t) multiplies k = 8q + t (lanes 0-31) and k = 8q + 4 + t (lanes 32-63) - the
-//      k pairing inside a 32x32x2 MFMA is free as long as B uses the same rows;
-//   B: lane l loads NB consecutive floats of weight row k at columns NB*(l&31).. (one dwordxNB load),
-//      so MFMA block nb computes the output columns == nb (mod NB); the epilogue un-permutes.
-template <int NB>
-struct BVec;
-template <> struct BVec<1> { typedef float type; };
-template <> struct BVec<2> { typedef float2 type; };
-template <> struct BVec<3> { typedef float3 type; };
-template <> struct BVec<4> { typedef float4 type; };
-
-template <int NB>
-__device__ __forceinline__ float bcomp(const typename BVec<NB>::type& v, int i);
-template <> __device__ __forceinline__ float bcomp<1>(const float& v, int) { return v; }
-template <> __device__ __forceinline__ float bcomp<2>(const float2& v, int i) { return i ? v.y : v.x; }
-template <> __device__ __forceinline__ float bcomp<3>(const float3& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
-template <> __device__ __forceinline__ float bcomp<4>(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
-
-template <int NB>
-__global__ __launch_bounds__(THREADS) void conv_wave(ConvArgs a) {
-    typedef typename BVec<NB>::type bvec;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long blk = (long long)blockIdx.x * 4 + wave;            // 32-row block in processing order
-    if (blk * 32 >= a.n_out) return;
-    const int g = blockIdx.z;
-    const int n0 = blockIdx.y * (NB * 32);
-    const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)g * a.n_out : 0) : nullptr;
-    const long long t = blk * 32 + (lane & 31);
-    const int row = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
-    const int nj = a.j_end - a.j_begin;
-    const int j_lo = a.j_begin + (int)((long long)nj * g / a.splits);
-    const int j_hi = a.j_begin + (int)((long long)nj * (g + 1) / a.splits);
-    const int half = lane >> 5;
-    const int colb = n0 + NB * (lane & 31);                            // first of this lane's NB columns
-    const bool col_ok = colb + NB <= a.cout;
-
-    f32x16 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-
-    // software pipeline over the live (offset, chunk) steps: the loads of step s+1 are in flight while
-    // the 16*NB MFMAs of step s run (operands are double-buffered in registers)
-    struct Operands { float4 av[4]; bvec bv[4][4]; };
-    auto next_live = [&](int j, int& src) {          // first offset >= j that some row of the block needs
-        for (; j < j_hi; ++j) {
-            src = row >= 0 ? (a.nbr ? a.nbr[(long long)row * a.K + j] : row) : -1;
-            if (__any(src >= 0)) break;
-        }
-        return j;
-    };
-    auto load = [&](Operands& o, int j, int src, int kc) {
-        const float* arow = a.in + (long long)(src >= 0 ? src : 0) * a.in_ld + half * 4 + kc;
-        const float* wrow = a.w + ((long long)j * a.cin + half * 4 + kc) * a.cout + colb;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            o.av[q] = src >= 0 ? *reinterpret_cast<const float4*>(arow + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                if (col_ok) o.bv[q][tt] = *reinterpret_cast<const bvec*>(wrow + (long long)(8 * q + tt) * a.cout);
-                else {
-                    float tmp[4] = {0.f, 0.f, 0.f, 0.f};
-                    for (int i = 0; i < NB; ++i)
-                        if (colb + i < a.cout) tmp[i] = wrow[(long long)(8 * q + tt) * a.cout + i];
-                    o.bv[q][tt] = *reinterpret_cast<const bvec*>(tmp);
-                }
-            }
-    };
-    int src = -1;
-    int j = next_live(j_lo, src);
-    int kc = 0;
-    Operands cur, nxt;
-    if (j < j_hi) load(cur, j, src, 0);
-    while (j < j_hi) {
-        int j2 = j, src2 = src, kc2 = kc + KC;
-        if (kc2 >= a.cin) { kc2 = 0; j2 = next_live(j + 1, src2); }
-        if (j2 < j_hi) load(nxt, j2, src2, kc2);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float ak[4] = {cur.av[q].x, cur.av[q].y, cur.av[q].z, cur.av[q].w};
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[tt], bcomp<NB>(cur.bv[q][tt], nb), acc[nb], 0, 0, 0);
-        }
-        cur = nxt;
-        j = j2; src = src2; kc = kc2;
-    }
-    // epilogue: accumulator register r of lane l is output row (r&3) + 8(r>>2) + 4(l>>5) of the block,
-    // MFMA block nb / lane column (l&31) is output column colb + nb
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int orow = __shfl(row, rr);
-        if (orow < 0) continue;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const int col = colb + nb;
-            if (col >= a.cout) continue;
-            float v = acc[nb][r];
-            if (a.splits > 1) {
-                a.partial[((long long)g * a.n_out + orow) * a.cout + col] = v;
-            } else {
-                if (a.acc_in) v += a.acc_in[(long long)orow * a.acc_ld + col];
-                v = v * (a.scale ? a.scale[col] : 1.f) + (a.shift ? a.shift[col] : 0.f);
-                if (a.res) v += a.res[(long long)orow * a.res_ld + col];
-                if (a.relu) v = fmaxf(v, 0.f);
-                a.out[(long long)orow * a.out_ld + col] = v;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------ pair-compacted tile flavour
-// The matrix cores only ever see (input, output) pairs that exist.  A plan kernel (tile_plan, once per kernel
-// map, shared by every convolution on that map) cuts the output rows into tiles of TT = 128 consecutive rows
-// (Z-order: neighbours are nearby rows) and compacts, per tile and kernel offset, the rows that HAVE that
-// neighbour into a list of (input row, tile row) entries.  One workgroup of CS waves owns a tile x CS*32 output
-// channels whose fp32 accumulators live in LDS.  It walks the lists in steps of 32 entries (two 16-row MFMA
-// units; a step with <= 16 entries issues half the MFMAs): the 32 gathered input rows of a KW-channel chunk are
-// staged row-major in LDS with 16-byte stores (double buffered: the next step's gathers are in flight during
-// the MFMAs, entry lists are fetched two steps ahead), wave w multiplies them with columns [32w, 32w+32) of W_j
-// on v_mfma_f32_16x16x4_f32, the accumulator tiles being read from and written back to the LDS rows the entries
-// belong to - waves own disjoint column slices and the rows of one list are distinct, so no atomics are needed.
-// k order: MFMA k-slot q of step s multiplies channel q*KW/4 + s of the chunk, so a lane's A operands of four
-// consecutive steps are one ds_read_b128; the weights are pre-packed (pack_weights, once per weight tensor) in
-// exactly the per-lane order of the B operand: one fully coalesced dwordx4 load per four steps, kept in registers
-// while (offset, chunk) stays the same and prefetched one step before it changes.
-// MFMA work = pairs padded to 16 per (tile, offset): 79 % (ts1) - 90 % (coarse levels) useful, against 25 - 55 %
-// for output-stationary 32-row blocks.  The epilogue (BatchNorm affine, residual, ReLU) streams the finished
-// tile out as full coalesced rows.  Small coordinate sets split the offsets over blockIdx.z into partial tiles
-// reduced by conv_finish.
-constexpr int TT = 128;
-constexpr int T_MAXK = 27;
-constexpr int PAD_ENT = -128;          // list padding: negative (no gather) and (e & 255) == TT (scratch row)
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// one wave per tile: ent[(tile*K + j)*TT + p] = (input row << 8) | tile row of the p-th row of the tile that has
-// neighbour j, cnt[tile*32 + j] = number of such rows
-__global__ __launch_bounds__(256) void tile_plan(const int* __restrict__ nbr, long long n_out, int K,
-                                                 const int* __restrict__ row_perm, int* __restrict__ ent,
-                                                 int* __restrict__ cnt) {
-    const int lane = threadIdx.x & 63;
-    const long long tile = blockIdx.x * 4ll + (threadIdx.x >> 6);
-    if (tile * TT >= n_out) return;
-    const long long t0 = tile * TT + lane, t1 = t0 + 64;
-    const long long g0 = t0 < n_out ? (row_perm ? row_perm[t0] : t0) : -1;
-    const long long g1 = t1 < n_out ? (row_perm ? row_perm[t1] : t1) : -1;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (int j = 0; j < K; ++j) {
-        const int v0 = g0 >= 0 ? nbr[g0 * K + j] : -1, v1 = g1 >= 0 ? nbr[g1 * K + j] : -1;
-        const unsigned long long m0 = __ballot(v0 >= 0), m1 = __ballot(v1 >= 0);
-        const int n0v = __popcll(m0);
-        int* e = ent + (tile * K + j) * TT;
-        if (v0 >= 0) e[__popcll(m0 & below)] = (v0 << 8) | lane;
-        if (v1 >= 0) e[n0v + __popcll(m1 & below)] = (v1 << 8) | (lane + 64);
-        if (lane == 0) cnt[tile * 32 + j] = n0v + __popcll(m1);
-    }
-}
-
-// wp float4 index ((((j*NC + c)*NW + w)*NG + g)*2 + t)*64 + lane holds, for lane = 16*q + n,
-// W[j][c*KW + q*KW/4 + 4g + {0,1,2,3}][32w + 16t + n]      (NC = cin/KW, NW = cout/32, NG = KW/16)
-__global__ __launch_bounds__(256) void pack_weights(const float* __restrict__ w, int K, int cin, int cout, int KW,
-                                                    float4* __restrict__ wp) {
-    const long long total = (long long)K * cin * cout / 4;
-    const int NC = cin / KW, NW = cout / 32, NG = KW / 16;
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        long long r = i;
-        const int lane = (int)(r % 64); r /= 64;
-        const int t = (int)(r % 2); r /= 2;
-        const int g = (int)(r % NG); r /= NG;
-        const int ws = (int)(r % NW); r /= NW;
-        const int c = (int)(r % NC); r /= NC;
-        const int j = (int)r;
-        const int q = lane >> 4, n = lane & 15;
-        const float* p = w + ((long long)j * cin + c * KW + q * (KW / 4) + 4 * g) * cout + 32 * ws + 16 * t + n;
-        wp[i] = make_float4(p[0], p[cout], p[2 * (long long)cout], p[3 * (long long)cout]);
-    }
-}
-
-template <int CS, int KW>
-__global__ __launch_bounds__(64 * CS) void conv_tile(ConvArgs a) {
-    constexpr int NT = 64 * CS, CW = 32 * CS;
-    constexpr int ROW_F4 = KW / 4;                    // float4s per gathered row chunk
-    constexpr int A_F4 = 32 * ROW_F4;
-    constexpr int A_PER = (A_F4 + NT - 1) / NT;
-    constexpr int NG = KW / 16;                       // groups of four MFMA k-steps
-    constexpr int A_LD = KW + 4;                      // floats per staged row (16-byte aligned, odd multiple of 4 banks)
-    __shared__ float out_s[TT + 1][CW];               // row TT: scratch row of the list padding
-    __shared__ __attribute__((aligned(16))) float A_s[2][32][A_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kq = lane >> 4, l15 = lane & 15, l31 = lane & 31;
-    const int n0 = blockIdx.y * CW;
-    const int K = a.K;
-    const int nj = a.j_end - a.j_begin;
-    const int j_lo = a.j_begin + (int)((long long)nj * blockIdx.z / a.splits);
-    const int j_hi = a.j_begin + (int)((long long)nj * (blockIdx.z + 1) / a.splits);
-    const long long tile = blockIdx.x;
-    const int tile_rows = (int)min((long long)TT, a.n_out - tile * TT);
-    const int NC = a.cin / KW, NW = a.cout / 32;
-
-    // lane j holds the list length of offset j
-    int cntv = 0;
-    if (lane >= j_lo && lane < j_hi) cntv = a.plan_cnt ? a.plan_cnt[tile * 32 + lane] : tile_rows;
-    const unsigned long long live = __ballot(cntv > 0);
-    for (int e = tid; e < TT * CW / 4; e += NT) reinterpret_cast<float4*>(&out_s[0][0])[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    auto first_live = [&](int from) {        // first offset >= from with a non-empty list, 64 if none
-        const unsigned long long m = from < 64 ? (live >> from) << from : 0ull;
-        return m ? (int)__ffsll((long long)m) - 1 : 64;
-    };
-    struct Step { int j, c, b, cnt; };       // offset, K chunk, block of 32 list entries, list length
-    auto advance = [&](Step s) {             // b runs fastest so the weights stay in registers
-        ++s.b;
-        if (32 * s.b >= s.cnt) {
-            s.b = 0;
-            if (++s.c >= NC) {
-                s.c = 0;
-                s.j = first_live(s.j + 1);
-                s.cnt = s.j < 64 ? __builtin_amdgcn_readlane(cntv, s.j) : 0;
-            }
-        }
-        return s;
-    };
-    // entry of list slot 32*b + l31 (one per lane, lanes 32-63 mirror 0-31)
-    auto load_ent = [&](const Step& s) {
-        const int p = 32 * s.b + l31;
-        if (s.j >= 64 || p >= s.cnt) return PAD_ENT;
-        if (a.plan_ent) return a.plan_ent[(tile * K + s.j) * TT + p];
-        const long long g = tile * TT + p;                                   // K == 1 on the same coordinate set
-        return (int)(((a.row_perm ? a.row_perm[g] : (int)g) << 8) | p);
-    };
-    // gather mapping of this thread: float4 i covers list slot a_slot[i], channels 4*a_c4[i]..+3 of the chunk
-    int a_slot[A_PER], a_c4[A_PER];
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-        const int idx = tid + i * NT;
-        a_slot[i] = idx < A_F4 ? idx / ROW_F4 : -1;
-        a_c4[i] = idx - (idx / ROW_F4) * ROW_F4;
-    }
-    auto load_a = [&](int ent, int c, float4* ra) {
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            const int e = __shfl(ent, a_slot[i] & 31);
-            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_slot[i] >= 0 && e >= 0)
-                ra[i] = *reinterpret_cast<const float4*>(a.in + (long long)(e >> 8) * a.in_ld + c * KW + 4 * a_c4[i]);
-        }
-    };
-    auto store_a = [&](int buf, const float4* ra) {
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i)
-            if (a_slot[i] >= 0) *reinterpret_cast<float4*>(&A_s[buf][a_slot[i]][4 * a_c4[i]]) = ra[i];
-    };
-    const float4* wlane = a.wp + wave * (NG * 2 * 64) + lane;
-    auto load_b = [&](const Step& s, float4 (*bv)[2]) {
-        const float4* p = wlane + ((long long)(s.j * NC + s.c) * NW + blockIdx.y * CS) * (NG * 2 * 64);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) { bv[g][0] = p[(g * 2) * 64]; bv[g][1] = p[(g * 2 + 1) * 64]; }
-    };
-
-    Step s0, s1, s2;
-    s0.j = first_live(j_lo); s0.c = 0; s0.b = 0;
-    s0.cnt = s0.j < 64 ? __builtin_amdgcn_readlane(cntv, s0.j) : 0;
-    s1 = s0.j < 64 ? advance(s0) : s0;
-    s2 = s1.j < 64 ? advance(s1) : s1;
-    int e0 = load_ent(s0), e1 = load_ent(s1), e2 = load_ent(s2);
-    float4 bc[NG][2], bn[NG][2];
-    float4 ra[A_PER];
-    int cur = 0;
-    if (s0.j < 64) {
-        load_a(e0, s0.c, ra);
-        load_b(s0, bc);
-        store_a(0, ra);
-        if (s1.j < 64) load_a(e1, s1.c, ra);
-    }
-    __syncthreads();
-    const int col0 = wave * 32 + l15;
-    while (s0.j < 64) {
-        // entries of step u+3 and weights of step u+1 go out before the MFMAs of step u; gathers of u+1 are in ra
-        const Step s3 = s2.j < 64 ? advance(s2) : s2;
-        const int e3 = load_ent(s3);
-        const bool more = s1.j < 64;
-        const bool new_b = more && (s1.j != s0.j || s1.c != s0.c);
-        if (new_b) load_b(s1, bn);
-        const bool two = s0.cnt - 32 * s0.b > 16;
-        // accumulator tiles come from / go back to the LDS rows of the entries: D row 4*kq + i, col l15
-        int r0[4], r1[4];
-        f32x4 c00, c01, c10, c11;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            r0[i] = __shfl(e0, 4 * kq + i) & 255;
-            c00[i] = out_s[r0[i]][col0];
-            c01[i] = out_s[r0[i]][col0 + 16];
-        }
-        if (two) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                r1[i] = __shfl(e0, 16 + 4 * kq + i) & 255;
-                c10[i] = out_s[r1[i]][col0];
-                c11[i] = out_s[r1[i]][col0 + 16];
-            }
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const float4 a0 = *reinterpret_cast<const float4*>(&A_s[cur][l15][kq * (KW / 4) + 4 * g]);
-                const float4 a1 = *reinterpret_cast<const float4*>(&A_s[cur][16 + l15][kq * (KW / 4) + 4 * g]);
-                const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
-                const float b0v[4] = {bc[g][0].x, bc[g][0].y, bc[g][0].z, bc[g][0].w};
-                const float b1v[4] = {bc[g][1].x, bc[g][1].y, bc[g][1].z, bc[g][1].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[q], b0v[q], c00, 0, 0, 0);
-                    c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[q], b1v[q], c01, 0, 0, 0);
-                    c10 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[q], b0v[q], c10, 0, 0, 0);
-                    c11 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[q], b1v[q], c11, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { out_s[r1[i]][col0] = c10[i]; out_s[r1[i]][col0 + 16] = c11[i]; }
-        } else {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const float4 a0 = *reinterpret_cast<const float4*>(&A_s[cur][l15][kq * (KW / 4) + 4 * g]);
-                const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
-                const float b0v[4] = {bc[g][0].x, bc[g][0].y, bc[g][0].z, bc[g][0].w};
-                const float b1v[4] = {bc[g][1].x, bc[g][1].y, bc[g][1].z, bc[g][1].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    c00 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[q], b0v[q], c00, 0, 0, 0);
-                    c01 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[q], b1v[q], c01, 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { out_s[r0[i]][col0] = c00[i]; out_s[r0[i]][col0 + 16] = c01[i]; }
-        if (more) store_a(cur ^ 1, ra);
-        if (new_b) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) { bc[g][0] = bn[g][0]; bc[g][1] = bn[g][1]; }
-        }
-        if (s2.j < 64) load_a(e2, s2.c, ra);      // gathers of step u+2: in flight across the barrier and step u+1
-        __syncthreads();
-        cur ^= 1;
-        s0 = s1; s1 = s2; s2 = s3;
-        e0 = e1; e1 = e2; e2 = e3;
-    }
-
-    // epilogue: full rows, float4 per lane
-    constexpr int C4 = CS * 8;
-    for (int e = tid; e < TT * C4; e += NT) {
-        const int t = e / C4, q = e - t * C4;
-        if (t >= tile_rows) break;
-        const long long g = tile * TT + t;
-        const int row = a.row_perm ? a.row_perm[g] : (int)g;
-        const int col = n0 + 4 * q;
-        float4 v = *reinterpret_cast<const float4*>(&out_s[t][4 * q]);
-        if (a.splits > 1) {
-            *reinterpret_cast<float4*>(a.partial + ((long long)blockIdx.z * a.n_out + row) * a.cout + col) = v;
-            continue;
-        }
-        if (a.acc_in) {
-            const float4 p = *reinterpret_cast<const float4*>(a.acc_in + (long long)row * a.acc_ld + col);
-            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-        }
-        if (a.scale) {
-            const float4 s = *reinterpret_cast<const float4*>(a.scale + col);
-            v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
-        }
-        if (a.shift) {
-            const float4 s = *reinterpret_cast<const float4*>(a.shift + col);
-            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
-        }
-        if (a.res) {
-            const float4 p = *reinterpret_cast<const float4*>(a.res + (long long)row * a.res_ld + col);
-            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-        }
-        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<float4*>(a.out + (long long)row * a.out_ld + col) = v;
     }
 }
 
@@ -2522,6 +1728,8 @@ __global__ __launch_bounds__(256) void conv_finish_scalar(ConvArgs a) {
     }
 }
 
+}  // namespace
+namespace cvsc {
 int launch_finish(const ConvArgs& a, hipStream_t st) {
     const long long total = a.n_out * (long long)a.cout;
     if (a.wide && a.splits <= FINISH_SMALL_MAX)
@@ -2533,6 +1741,8 @@ int launch_finish(const ConvArgs& a, hipStream_t st) {
     CV_LAUNCH_CHECK();
     return CV_OK;
 }
+}  // namespace cvsc
+namespace {
 
 // sort key of a row = bit mask of its valid neighbours among offsets [j_begin, j_end)
 __global__ __launch_bounds__(256) void mask_keys(const int* __restrict__ nbr, long long n, int K, int j_begin,
@@ -3053,7 +2263,7 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
     if (a.in_hl) {
         CV_REQUIRE(per_wg * (a.cin / KC) + (a.in2 ? a.cin2 / KC : 0) <= HL_MAX_UNITS, CV_EINVAL,
                    "hl-format convolution: more than %d units per workgroup (Cin too wide)", HL_MAX_UNITS);
-        CV_REQUIRE(vec && a.wp6 && a.pieces == 2 && a.wide && per_wg <= WP_NPRE && NB <= 3, CV_EINVAL,
+        CV_REQUIRE(vec && a.wp6 && a.pieces == 2 && a.wide && per_wg <= WP_NPRE && NB <= 4, CV_EINVAL,
                    "hl-format input needs the fp16-pair weights, Cin %% 32 == 0, 16-byte aligned operands and at most %d "
                    "kernel offsets per workgroup", WP_NPRE);
         // (measured and dropped, profiles/r2/hl_burst.txt: a variant for workgroups of <= 8 units with every weight tile
@@ -3064,7 +2274,7 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         // default - measured slower, profiles/r2/hl_nw8.txt
         static const int nw8_mask = getenv("CV_HL_NW8") ? atoi(getenv("CV_HL_NW8")) : 0;        // bit NB - 1
         const bool nw8_on = (nw8_mask >> (NB - 1)) & 1;
-        if constexpr (NB <= 3) {
+        if constexpr (NB <= 4) {
             if (nw8_on && !ax.xcd_tiles && a.n_out >= 16384 && (a.splits == 1 || a.perm_per_split)) {
                 dim3 g8((unsigned)((a.n_out + 255) / 256), grid.y, grid.z);
                 conv_hl<NB, 2, 8><<<g8, 512, 0, st>>>(ax);
@@ -3108,36 +2318,9 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         if (a.splits > 1) return launch_finish(a, st);
         return CV_OK;
     }
-    if (vec && prof_on) {
-        static unsigned long long* d_prof = nullptr;
-        if (!d_prof) CV_HIP_CHECK(hipMalloc(&d_prof, 16 * sizeof(unsigned long long)));
-        CV_HIP_CHECK(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st));
-        static const bool quiet = getenv("CV_CONV_PROF")[0] == 'q';      // ablation timing: no counters, no print
-        conv_rows_prof<NB, true><<<grid, THREADS, 0, st>>>(a, quiet ? nullptr : d_prof);
-        if (quiet) {
-            CV_LAUNCH_CHECK();
-            return a.splits > 1 ? launch_finish(a, st) : CV_OK;
-        }
-        unsigned long long h[16];
-        CV_HIP_CHECK(hipMemcpyAsync(h, d_prof, sizeof h, hipMemcpyDeviceToHost, st));
-        CV_HIP_CHECK(hipStreamSynchronize(st));
-        static const char* names[10] = {"prologue", "nbr+or-barrier", "first-load-issue", "barrier-A", "stage(+vmcnt)",
-                                        "barrier-B", "load-issue", "compute", "end-barrier", "epilogue"};
-        fprintf(stderr, "conv_rows<%d> n_out %lld cin %d cout %d K %d splits %d: waves %llu, ticks/wave:", NB, a.n_out,
-                a.cin, a.cout, a.K, a.splits, h[10]);
-        for (int p2 = 0; p2 < 10; ++p2) fprintf(stderr, " %s %.0f", names[p2], (double)h[p2] / (double)std::max(1ull, h[10]));
-        fprintf(stderr, "\n");
-    } else if (vec) conv_rows<NB, true><<<grid, THREADS, 0, st>>>(a);
+    if (vec && prof_on) return launch_rows_prof(a, NB, st);          // instrumented twin: sparse_conv_alt.hip
+    if (vec) conv_rows<NB, true><<<grid, THREADS, 0, st>>>(a);
     else conv_rows<NB, false><<<grid, THREADS, 0, st>>>(a);
-    CV_LAUNCH_CHECK();
-    if (a.splits > 1) return launch_finish(a, st);
-    return CV_OK;
-}
-
-template <int NB>
-int launch_wave(const ConvArgs& a, hipStream_t st) {
-    dim3 grid((unsigned)((a.n_out + 127) / 128), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)), (unsigned)a.splits);
-    conv_wave<NB><<<grid, THREADS, 0, st>>>(a);
     CV_LAUNCH_CHECK();
     if (a.splits > 1) return launch_finish(a, st);
     return CV_OK;
@@ -3147,7 +2330,11 @@ int launch_wave(const ConvArgs& a, hipStream_t st) {
 // the tiny coarsest levels): measured 118 -> 97 us (2349 rows, 256 -> 256), 143 -> 117 us (9929 rows, 128 -> 128),
 // 40 -> 33 us (494 rows) against 128-column workgroups - more, lighter workgroups hide the gather latency better
 // than the saved operand re-reads are worth; 96 columns stay one workgroup (64 + 32 is uneven: 144 -> 180 us).
+}  // namespace
+namespace cvsc {
 int nb_full(int cout) { return cout <= 32 ? 1 : cout <= 64 ? 2 : cout <= 96 ? 3 : 4; }
+}  // namespace cvsc
+namespace {
 int nb_for(int cout, long long n_out) {
     static const int nb_max = getenv("CV_NB_MAX") ? atoi(getenv("CV_NB_MAX")) : 0;
     if (nb_max > 0) return std::min(nb_max, nb_full(cout));
@@ -3155,61 +2342,12 @@ int nb_for(int cout, long long n_out) {
     if (cout <= 64) return 2;
     if (cout <= 96) return 3;
     static const int nb_wide = getenv("CV_NB_WIDE") ? atoi(getenv("CV_NB_WIDE")) : 2;      // 128 / 256 columns: 64-column workgroups
+    // CV_NB_COARSE (round-3 experiment): column blocks per workgroup on the levels below CV_NB_COARSE_ROWS rows - their
+    // launches have two workgroups per CU at most, so wider workgroups cost no occupancy and halve the row gathers
+    static const int nb_coarse = getenv("CV_NB_COARSE") ? atoi(getenv("CV_NB_COARSE")) : 0;
+    static const long long coarse_rows = getenv("CV_NB_COARSE_ROWS") ? atoll(getenv("CV_NB_COARSE_ROWS")) : 16384;
+    if (nb_coarse > 0 && n_out < coarse_rows) return std::max(1, std::min(nb_coarse, 4));
     return n_out < 1024 ? 1 : std::max(1, std::min(nb_wide, 2));
-}
-
-// ---- tile flavour dispatch: CS = waves (32-column slices) per workgroup, KW = K chunk width
-int tile_cs(int cout) {
-    const int s = cout / 32;
-    return s % 2 == 0 ? 2 : s % 3 == 0 ? 3 : 1;
-}
-int tile_kw(int cin, int cout) {
-    if (cin % 32 || cout % 32) return 0;
-    const int cap = tile_cs(cout) == 3 ? 96 : 128;      // LDS: tile + double-buffered staging <= 80 KB (2 per CU)
-    for (int kw : {128, 96, 64, 32})
-        if (kw <= cap && cin % kw == 0) return kw;
-    return 0;
-}
-bool tile_ok(const ConvArgs& a, bool vec) {
-    return vec && a.K <= T_MAXK && tile_kw(a.cin, a.cout) > 0 && a.n_in < (1ll << 23) && a.out_ld % 4 == 0 && a.wp &&
-           (a.plan_ent || !a.nbr) && (!a.res || a.res_ld % 4 == 0) && (!a.acc_in || a.acc_ld % 4 == 0) &&
-           ((reinterpret_cast<uintptr_t>(a.out) | reinterpret_cast<uintptr_t>(a.res) |
-             reinterpret_cast<uintptr_t>(a.acc_in) | reinterpret_cast<uintptr_t>(a.scale) |
-             reinterpret_cast<uintptr_t>(a.shift) | reinterpret_cast<uintptr_t>(a.wp)) & 15) == 0;
-}
-// offsets are split over blockIdx.z only while the launch still fits the chip in one round (2 workgroups per CU)
-int tile_splits(long long n_out, int cout, int nj) {
-    const long long wgs = ((n_out + TT - 1) / TT) * (cout / (tile_cs(cout) * 32));
-    if (wgs >= 256) return 1;
-    long long s = std::min<long long>(512 / wgs, nj);
-    const long long by_traffic = (32ll << 20) / std::max<long long>(1, n_out * cout * 4);
-    s = std::min(s, std::max<long long>(by_traffic, 2));
-    return (int)std::max<long long>(s, 1);
-}
-
-template <int CS, int KW>
-int launch_tile_k(const ConvArgs& a, hipStream_t st) {
-    dim3 grid((unsigned)((a.n_out + TT - 1) / TT), (unsigned)(a.cout / (CS * 32)), (unsigned)a.splits);
-    conv_tile<CS, KW><<<grid, 64 * CS, 0, st>>>(a);
-    CV_LAUNCH_CHECK();
-    if (a.splits > 1) return launch_finish(a, st);
-    return CV_OK;
-}
-template <int CS>
-int launch_tile_cs(const ConvArgs& a, hipStream_t st) {
-    switch (tile_kw(a.cin, a.cout)) {
-        case 128: if (CS < 3) return launch_tile_k<CS < 3 ? CS : 1, 128>(a, st);
-        case 96: return launch_tile_k<CS, 96>(a, st);
-        case 64: return launch_tile_k<CS, 64>(a, st);
-        default: return launch_tile_k<CS, 32>(a, st);
-    }
-}
-int launch_tile(const ConvArgs& a, hipStream_t st) {
-    switch (tile_cs(a.cout)) {
-        case 3: return launch_tile_cs<3>(a, st);
-        case 2: return launch_tile_cs<2>(a, st);
-        default: return launch_tile_cs<1>(a, st);
-    }
 }
 
 // Enough workgroups to fill 256 CUs a few times with short dependent chains: split the (offset,
@@ -3415,12 +2553,7 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         }
         if (d->flavour == 3 && d->in_ld % 4 == 0 && d->cout % nb_full(d->cout) == 0 &&
             (reinterpret_cast<uintptr_t>(d->weight) & 15) == 0) {
-            switch (nb_full(d->cout)) {
-                case 1: return launch_wave<1>(a, st);
-                case 2: return launch_wave<2>(a, st);
-                case 3: return launch_wave<3>(a, st);
-                default: return launch_wave<4>(a, st);
-            }
+            return launch_wave_nb(a, nb_full(d->cout), st);
         }
     } else if (d->flavour == 4 && !tile_ok(a, vec)) {
         CV_REQUIRE(false, CV_EINVAL, "flavour 4 needs Cin %% 32 == 0, Cout %% 32 == 0, K <= 27, 16-byte aligned "
@@ -3490,46 +2623,6 @@ int cv_sp_mask_perms(const int32_t* d_nbr, long long n, int K, int groups, int32
     CV_LAUNCH_CHECK();
     mp_scatter<<<grid, MP_THREADS, 0, st>>>(d_nbr, n, K, groups, hist, d_perm,
                                             with_map ? d_perm + (long long)groups * n : nullptr, (K + groups - 1) / groups);
-    CV_LAUNCH_CHECK();
-    return CV_OK;
-}
-
-size_t cv_sp_tile_plan_ints(long long n_out, int K, size_t* cnt_offset) {
-    if (n_out <= 0 || K <= 0) return 0;
-    const size_t tiles = (size_t)((n_out + TT - 1) / TT);
-    const size_t ent = cv_align_up(tiles * (size_t)K * TT, 64);
-    if (cnt_offset) *cnt_offset = ent;
-    return ent + tiles * 32;
-}
-
-// Pair lists of the tile flavour for one kernel map (and one processing order): d_plan is
-// cv_sp_tile_plan_ints(n_out, K, &cnt_offset) int32 words; plan_ent = d_plan, plan_cnt = d_plan + cnt_offset.
-int cv_sp_tile_plan(const int32_t* d_nbr, long long n_out, int K, const int32_t* d_row_perm, int32_t* d_plan,
-                    void* stream) {
-    CV_REQUIRE(d_nbr && d_plan && n_out > 0 && K > 0 && K <= T_MAXK, CV_EINVAL, "bad tile plan arguments");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    size_t off = 0;
-    cv_sp_tile_plan_ints(n_out, K, &off);
-    const long long tiles = (n_out + TT - 1) / TT;
-    tile_plan<<<(unsigned)((tiles + 3) / 4), 256, 0, st>>>(d_nbr, n_out, K, d_row_perm, d_plan, d_plan + off);
-    CV_LAUNCH_CHECK();
-    return CV_OK;
-}
-
-// K chunk width the tile kernel uses for a Cin x Cout convolution (the packing of its weights depends on it);
-// 0 when the tile kernel does not take the shape.
-int cv_sp_tile_kw(int cin, int cout) { return tile_kw(cin, cout); }
-
-// d_wp[K*cin*cout] = d_w[K][cin][cout] re-ordered into the per-lane B operand order of the tile kernel.
-int cv_sp_pack_weights_f32(const float* d_w, int K, int cin, int cout, float* d_wp, void* stream) {
-    CV_REQUIRE(d_w && d_wp && K > 0, CV_EINVAL, "bad pack_weights arguments");
-    const int kw = tile_kw(cin, cout);
-    CV_REQUIRE(kw > 0, CV_EINVAL, "the tile kernel does not take Cin = %d, Cout = %d", cin, cout);
-    CV_REQUIRE((reinterpret_cast<uintptr_t>(d_wp) & 15) == 0, CV_EINVAL, "d_wp must be 16-byte aligned");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const long long total = (long long)K * cin * cout / 4;
-    pack_weights<<<(unsigned)std::min<long long>((total + 255) / 256, 4096), 256, 0, st>>>(
-        d_w, K, cin, cout, kw, reinterpret_cast<float4*>(d_wp));
     CV_LAUNCH_CHECK();
     return CV_OK;
 }
