@@ -186,3 +186,41 @@ def test_product_module_tree_has_the_reference_state_dict():
     _, names, _ = _net_golden()
     mine = [[k, list(v.shape)] for k, v in MinkUNet34C(3, 64).state_dict().items()]
     assert mine == names
+
+
+def test_relu_mask_hook_puts_two_precisions_on_one_activation_pattern():
+    """sparse_oracle.relu_masks / relu_trace (the hook the GPU gradient tests hand the HIP forward's masks through): the
+    fp64 run given the fp32 run's 55 ReLU masks reproduces the fp32 run's parameter gradients to fp32 rounding, and
+    consumes exactly one mask per ReLU of the forward."""
+    from canonicalvoting_amd import train
+    from canonicalvoting_amd.synth import make_scene
+    n = 1500
+    scenes = [make_scene(80 + b, n_points=n, res=0.06, room=(2.0, 1.0, 2.0), n_boxes=3, margin=0.6, box_scale=0.5) for b in range(2)]
+    coords = np.concatenate([np.concatenate([np.full((n, 1), b, np.int64), s.coords], 1) for b, s in enumerate(scenes)])
+    feats = np.concatenate([s.feats for s in scenes]).astype(np.float32) * 2 - 1
+    xyz, scale, cls = [np.concatenate([getattr(s, k) for s in scenes]) for k in ("xyz_labels", "scale_labels", "class_labels")]
+    sd = so.make_state_dict(3, 64, seed=3)
+    pn = [k for k, v in sd.items() if v.dtype.is_floating_point and k.split(".")[-1] in ("kernel", "weight", "bias")]
+
+    def run(dt):
+        s = {k: (v.clone().to(dt).requires_grad_(True) if k in pn else v.clone()) for k, v in sd.items()}
+        y = so.minkunet34c_forward(s, coords, feats.astype(np.float64 if dt == torch.float64 else np.float32), training=True, dtype=dt)
+        loss = train.joint_loss(y, torch.from_numpy(xyz).to(dt), torch.from_numpy(scale).to(dt), torch.from_numpy(cls))[0]
+        loss.backward()
+        return {k: s[k].grad.double() for k in pn}
+
+    so.relu_trace = []
+    try:
+        g32 = run(torch.float32)
+        masks = so.relu_trace
+    finally:
+        so.relu_trace = None
+    assert len(masks) == 55
+    so.relu_masks = iter(masks)
+    try:
+        g64 = run(torch.float64)
+        assert next(so.relu_masks, None) is None
+    finally:
+        so.relu_masks = None
+    worst = max(float((g32[k] - g64[k]).abs().max() / max(1e-12, float(g64[k].abs().max()))) for k in pn)
+    assert worst < 2e-5, worst
