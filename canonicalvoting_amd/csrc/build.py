@@ -16,8 +16,15 @@ OBJ_DIR = os.path.join(OUT_DIR, "obj")
 LIB = os.path.join(OUT_DIR, "libcvhip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
+# No packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) in any device code: on gfx950 a
+# `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (the form the SLP vectoriser emits for e.g. a 2-D rotation) returns wrong
+# results while another wave on the same CU issues the 16-bit matrix instructions v_mfma_f32_32x32x16_{f16,bf16} /
+# 16x16x32_f16 - found through the vote grids of scenes in flight (profiles/r3/vote_concurrency_findings.txt,
+# profiles/op_check_probe.py, profiles/microbench/lds_hammer.hip).  The feature switch is a device-target feature: the
+# host pass of hipcc warns that it does not know it (harmless, stderr is only shown on failure).
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
-          "-I" + HERE, "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+          "-I" + HERE, "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"] + NO_PACKED_FP32
 # strict fp32 (no FMA contraction) where results must match the oracle bit for bit
 STRICT = ["-ffp-contract=off"]
 SOURCES = {

@@ -194,19 +194,21 @@ __global__ __launch_bounds__(256) void hv_normalise(const float* __restrict__ g_
 // tiles algorithm
 // ---------------------------------------------------------------------------
 // Tile = HV_TX x 32 cells of one y plane, HV_TW waves per workgroup.
-// Round 3: 32 x 32 cells / 16 waves (133 KB of LDS, one workgroup per CU) is the default again.  The 16 x 32 / 8-wave
-// shape of rounds 1-2 (68 KB, two workgroups per CU, 4-5 % faster: profiles/r1/vote_tile_sweep.txt) gives WRONG cells -
-// a few dozen cells of one (plane, tile), weight moved between neighbouring cells - in about a third of the launches
-// that run while fp16 / bf16 matrix-core convolutions of OTHER streams are resident on the same CUs, i.e. in the
-// bench's scenes-in-flight mode (tests/test_concurrency_gpu.py, profiles/vote_race_probe3.py; evidence and the list of
-// causes excluded - stale LDS, scratch, f64 conversions, record order, LDS ordering inside a wave - in
-// profiles/r3/vote_concurrency_findings.txt and DESIGN.md 4.1).  Workgroups of 1024 threads leave no room for a
-// convolution wave on their CU and are exact under the same load (0 of 4800 scenes differ).
+// 16 x 32 cells / 8 waves (68 KB of LDS, two workgroups per CU): the fastest shape one scene in flight (0.36 ms) and with
+// scenes in flight (profiles/r3/vote_tile_sweep.txt).  Round 3 found it giving WRONG cells - a few dozen cells of one
+// (plane, tile), weight moved between neighbouring cells - in about a third of the launches that ran while fp16 / bf16
+// matrix-core convolutions of OTHER streams were resident on the same CU (tests/test_concurrency_gpu.py).  The cause is
+// not in this kernel: on gfx950 a `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` - what the SLP vectoriser makes of the
+// 2-D rotation of the offset below - returns wrong results while another wave of the CU issues
+// v_mfma_f32_32x32x16_{f16,bf16} / 16x16x32_f16 (never next to the fp32 or the 32x32x8 f16 MFMA; pinned with synthetic
+// co-resident loads and an instruction-class checker: profiles/vote_hammer_probe.py, op_check_probe.py,
+// microbench/lds_hammer.hip, r3/vote_concurrency_findings.txt).  The whole library is built without packed fp32
+// instructions now (csrc/build.py); with that every tile shape is exact under the same load (0 of 400 / 0 of 4800).
 #ifndef HV_TX
-#define HV_TX 32
+#define HV_TX 16
 #endif
 #ifndef HV_TW
-#define HV_TW 16
+#define HV_TW 8
 #endif
 #ifndef HV_PART_RECORDS
 #define HV_PART_RECORDS 4096
@@ -711,6 +713,9 @@ struct TileShared {
     float vq_rz[TW][VQ];
     float2 tab[MAX_R_TILES];
     int next_chunk[2];         // dynamic hand-out of 64-record chunks of the two y-bins to the waves
+#ifdef HV_LDS_PAD
+    char lds_pad[HV_LDS_PAD];  // experiment: LDS the workgroup does not use, to control what else fits on its CU
+#endif
 };
 
 template <bool SMALL>
@@ -1254,9 +1259,12 @@ int64_t tiles_q_bound(int64_t n, int Y) { return (int64_t)Y + (2 * n + PART_RECO
 // the launch shape: work lists + work queue where a plane has many tiles (measured, bench vote stage: 300k-point scene,
 // 200 tiles: 2.01 -> 1.32 ms; 80k scene, 66 tiles: 0.37 -> 0.40 ms - the weight pass and the queue build cost more than
 // the tile kernel gains there), the streaming launch below that.  CV_HV_LISTS=1 / 2 forces one of them.
+#ifndef HV_QUEUE_MIN_TILES
+#define HV_QUEUE_MIN_TILES 128      // 16-wide tiles: an 80k-point grid has 66 (streaming launch), a 300k-point grid 190 (work lists)
+#endif
 bool use_queue(int64_t ntiles) {
     static const int lists_env = getenv("CV_HV_LISTS") ? atoi(getenv("CV_HV_LISTS")) : -1;
-    return lists_env >= 1 ? lists_env == 2 : ntiles >= 64;
+    return lists_env >= 1 ? lists_env == 2 : ntiles >= HV_QUEUE_MIN_TILES;
 }
 // work queue: partial-tile slots for the (plane, tile) pairs with more than one part (sum of arc lengths <= about
 // 2 * n * num_rots counting both planes of a vote and the slack steps; twice that again as room) and items = one per
