@@ -20,8 +20,5 @@ python bench.py --points 8000 --steps 240 --cpu-scenes 0 --train-steps 0 2>/dev/
 bash profiles/trace_one.sh r3final --train-steps 0 > /dev/null 2>&1
 bash profiles/vote_pmc_sq.sh r3final > /dev/null 2>&1
 bash profiles/vote_pmc.sh > $O/vote_pmc.log 2>&1; cp gpurun_out/vote_pmc/* $O/ 2>/dev/null
-bash profiles/net_traffic_pmc.sh > $O/net_traffic_pmc.txt 2>&1
 MICRO_HL=1 bash profiles/conv_pmc.sh > $O/conv_pmc_hl.txt 2>&1
-for t in 512 768 1024; do echo "CV_SPLIT_TARGET=$t: $(CV_SPLIT_TARGET=$t python bench.py --steps 240 --cpu-scenes 0 --train-steps 0 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1), d['stage_ms_isolated']['net'])")" >> $O/sweep_split_target.txt; done
-for s in 3 4 6 8; do echo "streams=$s: $(python bench.py --steps 240 --cpu-scenes 0 --train-steps 0 --streams $s 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1))")" >> $O/sweep_streams.txt; done
 ls -la $O
