@@ -855,6 +855,9 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 #ifndef HL_COAL
 #define HL_COAL 0
 #endif
+#ifndef HL_SETPRIO
+#define HL_SETPRIO 0      // experiment: s_setprio 1 around a unit's MFMA cluster
+#endif
 constexpr int HL_MAX_UNITS = 512;      // live units of one workgroup: <= 10 offsets x Cin / 32 chunks + the second source's (host-checked)
 template <int NB, int NS, int NW>
 __global__ __attribute__((amdgpu_waves_per_eu((NW > 4 && NS == 2) ? 4 : 1, 8))) __launch_bounds__(NW * 64, (NW > 4 ? (NS == 2 ? 2 : 1) : NS == 2 ? (NB == 1 ? HL_OCC1 : NB == 2 ? HL_OCC2 : NB == 3 ? HL_OCC3 : 2) : 3)) void conv_hl(ConvArgs a) {
@@ -1045,6 +1048,7 @@ __global__ __attribute__((amdgpu_waves_per_eu((NW > 4 && NS == 2) ? 4 : 1, 8))) 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        if (HL_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int piece = ((2 * ks + half) ^ bswz) << 4;
@@ -1059,6 +1063,7 @@ __global__ __attribute__((amdgpu_waves_per_eu((NW > 4 && NS == 2) ? 4 : 1, 8))) 
                 if constexpr (NB >= HL_CB_MIN_NB && NS == 2) asm volatile("" ::: "memory");   // keep the next fragments' reads behind these MFMAs (registers)
             }
         }
+        if (HL_SETPRIO) __builtin_amdgcn_s_setprio(0);
     };
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
