@@ -859,14 +859,22 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_in
 #define HL_SETPRIO 0      // experiment: s_setprio 1 around a unit's MFMA cluster
 #endif
 constexpr int HL_MAX_UNITS = 512;      // live units of one workgroup: <= 10 offsets x Cin / 32 chunks + the second source's (host-checked)
+// workgroups per CU the register allocation aims at (the second __launch_bounds__ argument; the waves-per-SIMD attribute
+// restates it, because an explicit amdgpu_waves_per_eu replaces the bound __launch_bounds__ implies - a (1, 8) range
+// silently cost the 96-column kernel a workgroup per CU for most of round 3)
+constexpr int hl_blocks(int NB, int NS, int NW) {
+    return NW > 4 ? (NS == 2 ? 2 : 1) : NS == 1 ? (NB == 1 ? 7 : 5) : NS == 2 ? (NB == 1 ? HL_OCC1 : NB == 2 ? HL_OCC2 : NB == 3 ? HL_OCC3 : 2) : 3;
+}
 template <int NB, int NS, int NW>
-__global__ __attribute__((amdgpu_waves_per_eu((NW > 4 && NS == 2) ? 4 : 1, 8))) __launch_bounds__(NW * 64, (NW > 4 ? (NS == 2 ? 2 : 1) : NS == 2 ? (NB == 1 ? HL_OCC1 : NB == 2 ? HL_OCC2 : NB == 3 ? HL_OCC3 : 2) : 3)) void conv_hl(ConvArgs a) {
-    static_assert(NS == 3 || NS == 2, "three unit slots (or two: the loads of unit k + 2 follow the MFMAs of unit k)");
+__global__ __attribute__((amdgpu_waves_per_eu(hl_blocks(NB, NS, NW) * NW / 4 > 8 ? 8 : hl_blocks(NB, NS, NW) * NW / 4, 8)))
+__launch_bounds__(NW * 64, hl_blocks(NB, NS, NW)) void conv_hl(ConvArgs a) {
+    static_assert(NS == 3 || NS == 2 || NS == 1, "three unit slots, two (the loads of unit k + 2 follow the MFMAs of unit k) or one (no prefetch: more workgroups per CU)");
     constexpr int TMv = NW * 32, THv = NW * 64;
     constexpr int B_BYTES = 2 * NB * 32 * 64, EP_BYTES = NW * 32 * EP_LD * 4;
     constexpr bool COAL = (HL_COAL >> (NB - 1)) & 1;
     constexpr int A_STAGE = COAL ? NW * 4096 : 0;                           // per wave: [32 rows][8 pieces x 16 B], swizzled
-    constexpr int SM_BYTES = NS * B_BYTES + A_STAGE > EP_BYTES ? NS * B_BYTES + A_STAGE : EP_BYTES;
+    constexpr int NT = NS == 1 ? 2 : NS;                                    // weight tiles in LDS (one register slot still alternates two)
+    constexpr int SM_BYTES = NT * B_BYTES + A_STAGE > EP_BYTES ? NT * B_BYTES + A_STAGE : EP_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char sm[SM_BYTES];     // NS x weight tile [plane][col][64 B], the A tiles; then the epilogue tile
     __shared__ int rows_s[TMv];
     __shared__ int nbr_all[WP_NPRE + 1][TMv];
@@ -1019,23 +1027,23 @@ __global__ __attribute__((amdgpu_waves_per_eu((NW > 4 && NS == 2) ? 4 : 1, 8))) 
             rb[sl][i] = (b_src[i] >= 0 && !(CV_HL_ABL & 4)) ? *reinterpret_cast<const uint4*>(slab + b_src[i])
                                                             : make_uint4(0u, 0u, 0u, 0u);
     };
-    auto stage_b = [&](auto S) {
+    auto stage_b = [&](auto S, int toff) {            // toff: byte offset of the LDS weight tile (slot * B_BYTES; NS == 1: (k & 1) * B_BYTES)
         constexpr int sl = decltype(S)::value;
 #pragma unroll
         for (int i = 0; i < B_PER; ++i)
-            if (b_dst[i] >= 0 && !(CV_HL_ABL & 4)) *reinterpret_cast<uint4*>(sm + sl * B_BYTES + b_dst[i]) = rb[sl][i];
+            if (b_dst[i] >= 0 && !(CV_HL_ABL & 4)) *reinterpret_cast<uint4*>(sm + toff + b_dst[i]) = rb[sl][i];
     };
     const int b_rd = l31 * 64;
     const int bswz = (l31 >> 2) & 3;
-    auto compute = [&](auto S) {
+    auto compute = [&](auto S, int toff) {
         constexpr int sl = decltype(S)::value;
-        const unsigned char* Bb = sm + sl * B_BYTES + b_rd;
+        const unsigned char* Bb = sm + toff + b_rd;
         uint4 (&fa)[4] = ra[sl];
         if constexpr (COAL) {
             // [32 rows][128 B] image of the wave's gathered chunk -> lane = row, pieces half, 2 + half, 4 + half, 6 + half,
             // back into the slot's own registers.  The tile is the wave's own: program order + the in-order LDS pipe are
             // the only synchronisation needed.
-            unsigned char* st = sm + NS * B_BYTES + wave * 4096;
+            unsigned char* st = sm + NT * B_BYTES + wave * 4096;
 #pragma unroll
             for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(st + q * 1024 + lane * 16) = ra[sl][q];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1068,18 +1076,30 @@ __global__ __attribute__((amdgpu_waves_per_eu((NW > 4 && NS == 2) ? 4 : 1, 8))) 
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
     typedef std::integral_constant<int, 2> S2;
+    if constexpr (NS == 1) {
+        // one register slot, two LDS tiles: nothing of unit k + 1 is requested before unit k has multiplied - the latency of a
+        // unit's loads is covered by the OTHER workgroups of the CU (fewer registers: one more of them fits)
+#pragma unroll 1
+        for (int k = 0; k < n_units; ++k) {
+            const int toff = (k & 1) * B_BYTES;
+            load(S0{}, k);
+            stage_b(S0{}, toff);
+            __syncthreads();         // tile k visible; everyone is past the MFMAs of unit k - 2, whose tile unit k + ... reuses next
+            if (live[0] && (!(CV_HL_ABL & 2) || a.acc_scale == 12345.f)) compute(S0{}, toff);
+        }
+    } else {
     if (n_units > 0) load(S0{}, 0);
     if (n_units > 1) load(S1{}, 1);
-    if (n_units > 0) stage_b(S0{});
+    if (n_units > 0) stage_b(S0{}, 0);
     // step: unit k in slot s.  barrier: tile k visible, tile k - 1 consumed by everyone (its slot takes the loads of unit
     // k + 2); the tile of unit k + 1 goes to LDS; MFMAs of unit k
     if constexpr (NS == 3) {
         auto step = [&](auto S, auto SN, auto SP, int k) {
             constexpr int sl = decltype(S)::value;
             __syncthreads();
-            if (k + 1 < n_units) stage_b(SN);
+            if (k + 1 < n_units) stage_b(SN, decltype(SN)::value * B_BYTES);
             if (k + 2 < n_units) load(SP, k + 2);
-            if (live[sl] && (!(CV_HL_ABL & 2) || a.acc_scale == 12345.f)) compute(S);
+            if (live[sl] && (!(CV_HL_ABL & 2) || a.acc_scale == 12345.f)) compute(S, sl * B_BYTES);
         };
 #pragma unroll 1
         for (int k = 0; k < n_units; k += 3) {
@@ -1095,8 +1115,8 @@ __global__ __attribute__((amdgpu_waves_per_eu((NW > 4 && NS == 2) ? 4 : 1, 8))) 
         auto step = [&](auto S, auto SN, int k) {
             constexpr int sl = decltype(S)::value;
             __syncthreads();
-            if (k + 1 < n_units) stage_b(SN);
-            if (live[sl] && (!(CV_HL_ABL & 2) || a.acc_scale == 12345.f)) compute(S);
+            if (k + 1 < n_units) stage_b(SN, decltype(SN)::value * B_BYTES);
+            if (live[sl] && (!(CV_HL_ABL & 2) || a.acc_scale == 12345.f)) compute(S, sl * B_BYTES);
             if (k + 2 < n_units) load(S, k + 2);
         };
 #pragma unroll 1
@@ -1105,6 +1125,7 @@ __global__ __attribute__((amdgpu_waves_per_eu((NW > 4 && NS == 2) ? 4 : 1, 8))) 
             if (k + 1 >= n_units) break;
             step(S1{}, S0{}, k + 1);
         }
+    }
     }
     __syncthreads();                                 // weight tiles are dead: the epilogue tile reuses their LDS
     {
@@ -2296,7 +2317,10 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
                 static const bool fuse_on = !(getenv("CV_HL_FUSE_FINISH") && atoi(getenv("CV_HL_FUSE_FINISH")) == 0);
                 if (!(fuse_on && ax.splits > 1 && !ax.perm_per_split && !ax.xcd_tiles &&
                       (long long)gridx.x * gridx.y <= CV_SPLIT_TICKETS)) ax.tickets = nullptr;
-                if ((ns2 >> (NB - 1)) & 1) conv_hl<NB, 2, 4><<<gridx, THREADS, 0, st>>>(ax);
+                // CV_HL_NS1 (round-3 experiment): bit nb-1 = ONE slot for NB = nb
+                static const int ns1 = getenv("CV_HL_NS1") ? atoi(getenv("CV_HL_NS1")) : 0;
+                if ((ns1 >> (NB - 1)) & 1) conv_hl<NB, 1, 4><<<gridx, THREADS, 0, st>>>(ax);
+                else if ((ns2 >> (NB - 1)) & 1) conv_hl<NB, 2, 4><<<gridx, THREADS, 0, st>>>(ax);
                 else conv_hl<NB, 3, 4><<<gridx, THREADS, 0, st>>>(ax);
                 CV_LAUNCH_CHECK();
                 if (a.splits > 1 && !ax.tickets) return launch_finish(a, st);
