@@ -269,89 +269,62 @@ __global__ __launch_bounds__(PREP_THREADS) void hv_prep_count(
 constexpr int PART_RECORDS = HV_PART_RECORDS;
 constexpr int MAX_PARTS = HV_MAX_PARTS;
 
-__global__ __launch_bounds__(1024) void hv_prep_scan(const int* __restrict__ ycount, int Y,
-                                                     int* __restrict__ ystart,
-                                                     int* __restrict__ cursor,
-                                                     int* __restrict__ part_start, int4* __restrict__ q_info, int max_q,
-                                                     int* __restrict__ chunk_start, int* __restrict__ bin_of_chunk) {
-    __shared__ int s[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < Y; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < Y ? ycount[i] : 0;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
+// (round 3: the three scans used to be Hillis-Steele passes over 1024 LDS slots with two workgroup barriers per step -
+// sixty barriers for Y = 88 bins, 7.5 us; they are independent, so three waves run one wave-level scan each: 64 bins per step)
+template <class V, class E>
+__device__ __forceinline__ int wave_excl_scan(int Y, V value, E emit) {
+    const int lane = threadIdx.x & 63;
+    int carry = 0;
+    for (int base = 0; base < Y; base += 64) {
+        const int i = base + lane;
+        const int v = i < Y ? value(i) : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
         }
-        const int incl = s[threadIdx.x] + carry;
-        if (i < Y) { ystart[i] = incl - v; cursor[i] = incl - v; }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = incl;
-        __syncthreads();
+        if (i < Y) emit(i, carry + incl - v, v);
+        carry += __shfl(incl, 63);
     }
-    if (threadIdx.x == 0) { ystart[Y] = carry; carry = 0; }
-    __syncthreads();
-    // streaming path (small grids): part_start[y] = exclusive scan of the number of workgroups per tile of plane y, by
-    // the records of its two bins; q_info[(plane, part) slot] = (plane, part, parts of the plane, first slot of the plane),
-    // nparts = -1 on the unused slots behind the last one: ONE 16-byte load in front of a tile workgroup's work (round 1: a
-    // binary search over part_start, seven dependent loads; round 2: three dependent loads part_start[Y] ->
-    // plane_of_q[q] -> part_start[y], part_start[y + 1])
-    for (int base = 0; base < Y; base += 1024) {
-        const int i = base + threadIdx.x;
-        int v = 0;
-        if (i < Y) {
-            const int n2 = (i >= 1 ? ycount[i - 1] : 0) + (i <= Y - 2 ? ycount[i] : 0);
-            v = min(max((n2 + PART_RECORDS - 1) / PART_RECORDS, 1), MAX_PARTS);
-        }
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        const int incl = s[threadIdx.x] + carry;
-        if (i < Y) {
-            part_start[i] = incl - v;
-            for (int p2 = 0; p2 < v; ++p2) q_info[incl - v + p2] = make_int4(i, p2, v, incl - v);
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = incl;
-        __syncthreads();
+    return carry;
+}
+__global__ __launch_bounds__(256) void hv_prep_scan(const int* __restrict__ ycount, int Y,
+                                                    int* __restrict__ ystart,
+                                                    int* __restrict__ cursor,
+                                                    int* __restrict__ part_start, int4* __restrict__ q_info, int max_q,
+                                                    int* __restrict__ chunk_start, int* __restrict__ bin_of_chunk) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {
+        const int total = wave_excl_scan(Y, [&](int i) { return ycount[i]; },
+                                         [&](int i, int excl, int) { ystart[i] = excl; cursor[i] = excl; });
+        if (lane == 0) ystart[Y] = total;
+    } else if (wave == 1) {
+        // streaming path (small grids): part_start[y] = exclusive scan of the number of workgroups per tile of plane y, by
+        // the records of its two bins; q_info[(plane, part) slot] = (plane, part, parts of the plane, first slot of the plane),
+        // nparts = -1 on the unused slots behind the last one: ONE 16-byte load in front of a tile workgroup's work (round 1: a
+        // binary search over part_start, seven dependent loads; round 2: three dependent loads part_start[Y] ->
+        // plane_of_q[q] -> part_start[y], part_start[y + 1])
+        const int total = wave_excl_scan(Y,
+            [&](int i) {
+                const int n2 = (i >= 1 ? ycount[i - 1] : 0) + (i <= Y - 2 ? ycount[i] : 0);
+                return min(max((n2 + PART_RECORDS - 1) / PART_RECORDS, 1), MAX_PARTS);
+            },
+            [&](int i, int excl, int v) {
+                part_start[i] = excl;
+                for (int p2 = 0; p2 < v; ++p2) q_info[excl + p2] = make_int4(i, p2, v, excl);
+            });
+        for (int q = total + lane; q < max_q; q += 64) q_info[q] = make_int4(0, 0, -1, 0);
+        if (lane == 0) part_start[Y] = total;
+    } else if (wave == 2) {
+        // chunks of up to LIST_CHUNK_RECORDS records of one bin (the work-list passes run one workgroup per chunk)
+        const int total = wave_excl_scan(Y, [&](int i) { return (ycount[i] + LIST_CHUNK_RECORDS - 1) / LIST_CHUNK_RECORDS; },
+                                         [&](int i, int excl, int v) {
+                                             chunk_start[i] = excl;
+                                             for (int p2 = 0; p2 < v; ++p2) bin_of_chunk[excl + p2] = i;
+                                         });
+        if (lane == 0) chunk_start[Y] = total;
     }
-    for (int q = carry + (int)threadIdx.x; q < max_q; q += 1024) q_info[q] = make_int4(0, 0, -1, 0);
-    __syncthreads();
-    if (threadIdx.x == 0) { part_start[Y] = carry; carry = 0; }
-    __syncthreads();
-    // chunks of up to LIST_CHUNK_RECORDS records of one bin (the work-list passes run one workgroup per chunk)
-    for (int base = 0; base < Y; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < Y ? (ycount[i] + LIST_CHUNK_RECORDS - 1) / LIST_CHUNK_RECORDS : 0;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        const int incl = s[threadIdx.x] + carry;
-        if (i < Y) {
-            chunk_start[i] = incl - v;
-            for (int p2 = 0; p2 < v; ++p2) bin_of_chunk[incl - v + p2] = i;
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) chunk_start[Y] = carry;
 }
 
 // Scatters every point with an in-bounds y into its y-bin and writes a compact SoA record
@@ -1424,7 +1397,7 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
     hv_prep_count<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, n, res, corner.y, Y, fy, ycount);
     CV_LAUNCH_CHECK();
-    hv_prep_scan<<<1, 1024, 0, st>>>(ycount, Y, ystart, cursor, part_start, q_info, (int)max_q, chunk_start, bin_of_chunk);
+    hv_prep_scan<<<1, 256, 0, st>>>(ycount, Y, ystart, cursor, part_start, q_info, (int)max_q, chunk_start, bin_of_chunk);
     CV_LAUNCH_CHECK();
     hv_prep_scatter<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, d_obj, fy, n, Y, res, corner, cursor, rec, n);
