@@ -21,7 +21,7 @@ def _launch(nproc, gpus, extra=()):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
            "--gpus", str(gpus), "--steps", "5", "--warmup", "1", "--rendezvous-only", *extra]
-    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
 
 
 def test_two_rank_launch_rendezvous_and_single_json_line():
@@ -45,11 +45,11 @@ def test_single_process_default_is_one_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rendezvous-only"], cwd=ROOT, env=env,
-                       capture_output=True, text=True, timeout=300)
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rendezvous-only", "--gpus", "2"], cwd=ROOT,
-                       env=env, capture_output=True, text=True, timeout=300)
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode != 0
 
 
