@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--min-warm-seconds", type=float, default=1.5,
                     help="the untimed warm-up lasts at least this long (sustained work before the clock starts); "
                          "--warmup is a minimum number of steps, not the whole warm-up")
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=6,
                     help="scenes in flight per GPU: S host threads, each with its own HIP stream, take the steps "
                          "from one shared counter (scenes are independent; fills the launch tails and host syncs of one scene "
                          "with the kernels of another)")
