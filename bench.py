@@ -71,11 +71,15 @@ def parse():
     ap.add_argument("--min-warm-seconds", type=float, default=1.5,
                     help="the untimed warm-up lasts at least this long (sustained work before the clock starts); "
                          "--warmup is a minimum number of steps, not the whole warm-up")
-    ap.add_argument("--streams", type=int, default=6,
+    ap.add_argument("--streams", type=int, default=8,
                     help="scenes in flight per GPU: S host threads, each with its own HIP stream, take the steps "
                          "from one shared counter (scenes are independent; fills the launch tails and host syncs of one scene "
                          "with the kernels of another)")
     ap.add_argument("--switch-interval", type=float, default=0.0005, help="sys.setswitchinterval for the scene threads")
+    ap.add_argument("--stagger-us", type=float, default=400.0,
+                    help="scene thread i takes its first timed step i x this many microseconds after the clock started: scenes that "
+                         "start together stay in the same stage (all in the convolutions, then all in the vote) and share the chip "
+                         "worse than scenes a fraction of a scene apart")
     ap.add_argument("--mode", default="eval", choices=["eval", "train", "separate"],
                     help="eval (default, the BASELINE metric): eval_joint.py path.  train: train_joint.py step "
                          "(fwd + bwd + Adam, fp32) on --train-batch scenes per GPU-step, DDP gradient all-reduce over "
@@ -548,6 +552,8 @@ def main():
                     j += 1
                 streams[i].synchronize()
                 gate.wait()
+                if a.stagger_us > 0 and i > 0:
+                    time.sleep(i * a.stagger_us * 1e-6)
                 while True:
                     with ticket_lock:
                         k = next(ticket)
