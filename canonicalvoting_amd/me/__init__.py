@@ -754,6 +754,22 @@ def col_sum(x):
     return out
 
 
+# training: weight gradient of a layer on a side stream next to its input gradient (CV_BACKWARD_OVERLAP=0: one stream)
+BACKWARD_OVERLAP = os.environ.get("CV_BACKWARD_OVERLAP", "1") != "0"
+_wgrad_streams = {}
+_wgrad_lock = threading.Lock()
+
+
+def _wgrad_stream(dev):
+    """the side stream of (device, current stream) for _ConvFn.backward"""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    with _wgrad_lock:
+        s = _wgrad_streams.get(key)
+        if s is None:
+            s = _wgrad_streams[key] = torch.cuda.Stream(device=dev)
+    return s
+
+
 class _ConvFn(torch.autograd.Function):
     """Sparse convolution with HIP forward, input-gradient (the same kernel on the transposed map with
     transposed weights) and weight-gradient kernels."""
@@ -774,11 +790,25 @@ class _ConvFn(torch.autograd.Function):
         grad = grad.contiguous()
         k3 = kernel if kernel.dim() == 3 else kernel[None]
         d_feats = d_kernel = d_bias = None
+        # The two gradients of a layer read the same dy and write different tensors: the weight gradient goes to a
+        # side stream next to the input gradient (each alone leaves most SIMDs with one or two waves and a tail of
+        # long tasks).  The layer's own stream waits for the side stream before backward returns, so everything that
+        # consumes d_kernel, frees feats / dy or reuses their memory is ordered behind both; results are the same
+        # kernels' results, bit for bit.
+        side = _wgrad_stream(grad.device) if (BACKWARD_OVERLAP and ctx.needs_input_grad[0] and
+                                              ctx.needs_input_grad[1]) else None
+        if side is not None:
+            cur = torch.cuda.current_stream(grad.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                d_kernel = conv_wgrad(feats, grad, nbr, k3.shape[0]).reshape(kernel.shape)
         if ctx.needs_input_grad[0]:
             w_t = k3.detach().permute(0, 2, 1).contiguous()
             nbr_t = transposed_map(nbr, feats.shape[0]) if nbr is not None else None
             d_feats = conv_forward(grad, w_t, nbr_t, feats.shape[0], cache_weights=False)
-        if ctx.needs_input_grad[1]:
+        if side is not None:
+            cur.wait_stream(side)
+        elif ctx.needs_input_grad[1]:
             d_kernel = conv_wgrad(feats, grad, nbr, k3.shape[0]).reshape(kernel.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             d_bias = col_sum(grad).reshape(1, -1)
