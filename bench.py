@@ -367,6 +367,7 @@ def main_train(a):
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss, _ = train.train_step(net, opt, coords, feats, xyz, scale, cls)
+    t_enq = time.perf_counter() - t0             # the host side of the steps (launches queued, nothing waited for)
     cvd.barrier(dev)
     dt = cvd.reduce_scalar(time.perf_counter() - t0, "max", dev)
     if rank == 0:
@@ -375,6 +376,7 @@ def main_train(a):
             "value": a.steps * B * world / dt, "unit": "scenes/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "host_enqueue_ms_per_step": t_enq / a.steps * 1e3, "backward_overlap": ME.BACKWARD_OVERLAP,
             "config": {"workload": "train_joint.py step on %d x %d-point synthetic scenes per GPU-step, MinkUNet34C(3, 64) "
                                    "%s, Adam lr 1e-3" % (B, n, "bf16 conv products, fp32 accumulation / storage / "
                                                          "BatchNorm / optimizer" if a.dtype == "bf16" else "fp32"),

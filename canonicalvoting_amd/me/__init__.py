@@ -754,10 +754,15 @@ def col_sum(x):
     return out
 
 
-# training: weight gradient of a layer on a side stream next to its input gradient (CV_BACKWARD_OVERLAP=0: one stream)
-BACKWARD_OVERLAP = os.environ.get("CV_BACKWARD_OVERLAP", "1") != "0"
+# training: weight gradient of a layer on a side stream next to its input gradient.
+#   CV_BACKWARD_OVERLAP=0: one stream; 1: the layer's stream waits for the side stream before backward() returns;
+#   2 (default): that wait moves to the end of the backward pass (the side stream works through the weight gradients
+#   while the layer's stream goes on with the BatchNorm backward and the next input gradient) whenever nothing can
+#   touch the gradient earlier - see _ConvFn.backward.
+BACKWARD_OVERLAP = int(os.environ.get("CV_BACKWARD_OVERLAP", "2"))
 _wgrad_streams = {}
 _wgrad_lock = threading.Lock()
+_wgrad_pending = threading.local()
 
 
 def _wgrad_stream(dev):
@@ -768,6 +773,39 @@ def _wgrad_stream(dev):
         if s is None:
             s = _wgrad_streams[key] = torch.cuda.Stream(device=dev)
     return s
+
+
+def _join_at_end_of_backward(cur, side):
+    """queue ONE callback per backward pass and (stream, side stream) pair: the stream waits for the side stream when
+    the autograd engine has run the last node (before it hands the gradients to the caller's stream)"""
+    pend = getattr(_wgrad_pending, "pairs", None)
+    if pend is None:
+        pend = _wgrad_pending.pairs = {}
+    key = (cur.cuda_stream, side.cuda_stream)
+    if key in pend:
+        return
+    pend[key] = (cur, side)
+
+    def join():
+        pend.pop(key, None)
+        cur.wait_stream(side)
+        torch.cuda.current_stream(cur.device).wait_stream(side)
+
+    torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
+def _gradient_untouched_until_end(kernel):
+    """True when nothing reads or writes the weight gradient between _ConvFn.backward and the end of the backward pass:
+    no gradient to accumulate into (AccumulateGrad then keeps the tensor itself, no kernel), no hooks on the parameter,
+    no process group with more than one rank (DDP's reducer copies gradients into its buckets as they arrive), no
+    anomaly / graph-building mode.  Code that hooks the gradient accumulators by other means sets
+    CV_BACKWARD_OVERLAP=1."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return False          # (reducer hooks sit on the gradient accumulators, invisible from here)
+    return (kernel.is_leaf and kernel.grad is None and not kernel._backward_hooks
+            and not getattr(kernel, "_post_accumulate_grad_hooks", None)
+            and not torch.is_grad_enabled() and not torch.is_anomaly_enabled())
 
 
 class _ConvFn(torch.autograd.Function):
@@ -792,22 +830,34 @@ class _ConvFn(torch.autograd.Function):
         d_feats = d_kernel = d_bias = None
         # The two gradients of a layer read the same dy and write different tensors: the weight gradient goes to a
         # side stream next to the input gradient (each alone leaves most SIMDs with one or two waves and a tail of
-        # long tasks).  The layer's own stream waits for the side stream before backward returns, so everything that
-        # consumes d_kernel, frees feats / dy or reuses their memory is ordered behind both; results are the same
-        # kernels' results, bit for bit.
+        # long tasks).  Either the layer's own stream waits for the side stream before backward returns (everything
+        # that consumes d_kernel, frees x / dy or reuses their memory is then ordered behind both), or - when nothing
+        # can touch the gradient before the end of the pass - that wait is queued for the end of the backward pass and
+        # x / dy are marked as in use by the side stream.  The same kernels on the same inputs: results bit for bit.
         side = _wgrad_stream(grad.device) if (BACKWARD_OVERLAP and ctx.needs_input_grad[0] and
                                               ctx.needs_input_grad[1]) else None
+        late = False
         if side is not None:
             cur = torch.cuda.current_stream(grad.device)
+            late = BACKWARD_OVERLAP >= 2 and _gradient_untouched_until_end(kernel)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 d_kernel = conv_wgrad(feats, grad, nbr, k3.shape[0]).reshape(kernel.shape)
+            if late:
+                # the side stream still reads x and dy after this node has released them: their blocks go back to the
+                # allocator only when the side stream has passed this point
+                feats.record_stream(side)
+                grad.record_stream(side)
+                if nbr is not None:
+                    nbr.record_stream(side)
+                _join_at_end_of_backward(cur, side)
         if ctx.needs_input_grad[0]:
             w_t = k3.detach().permute(0, 2, 1).contiguous()
             nbr_t = transposed_map(nbr, feats.shape[0]) if nbr is not None else None
             d_feats = conv_forward(grad, w_t, nbr_t, feats.shape[0], cache_weights=False)
         if side is not None:
-            cur.wait_stream(side)
+            if not late:
+                cur.wait_stream(side)
         elif ctx.needs_input_grad[1]:
             d_kernel = conv_wgrad(feats, grad, nbr, k3.shape[0]).reshape(kernel.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:

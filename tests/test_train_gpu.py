@@ -97,8 +97,10 @@ def test_minkunet_training_step_gradients_match_oracle(cuda, built_lib):
 
 def test_backward_overlap_changes_no_gradient_bit(cuda, built_lib, monkeypatch):
     """_ConvFn.backward runs a layer's weight gradient on a side stream next to its input gradient
-    (ME.BACKWARD_OVERLAP).  Same kernels, same inputs: every parameter gradient of a training step (three scenes in a
-    batch, three steps so that freed blocks are reused across the two streams) equals the one-stream run bit for bit."""
+    (ME.BACKWARD_OVERLAP: 1 joins the streams per layer, 2 at the end of the backward pass).  Same kernels, same
+    inputs: every parameter gradient of a training step (three scenes in a batch, three steps so that freed blocks are
+    reused across the two streams) equals the one-stream run bit for bit; a gradient accumulated over two passes
+    (which mode 2 must not defer) does too."""
     coords, feats = scene_coords(17, 2500, batch=3)
     n = len(coords)
     sd = so.make_state_dict(3, 64, seed=9)
@@ -106,13 +108,14 @@ def test_backward_overlap_changes_no_gradient_bit(cuda, built_lib, monkeypatch):
     tgt = torch.from_numpy(rng.normal(0, 1, (n, 54)).astype(np.float32)).to(cuda)
     labels = torch.from_numpy(rng.integers(0, 10, n)).to(cuda)
     grads = {}
-    for overlap in (False, True):
+    for overlap in (0, 1, 2):
         monkeypatch.setattr(ME, "BACKWARD_OVERLAP", overlap)
         model = MinkUNet34C(3, 64)
         model.load_state_dict(sd)
         model = model.cuda().train()
-        for _ in range(3):
-            model.zero_grad(set_to_none=True)
+        for it in range(4):
+            if it != 3:                        # the last pass accumulates into the third one's gradients
+                model.zero_grad(set_to_none=True)
             x = ME.SparseTensor(torch.from_numpy(feats), torch.from_numpy(coords).int(), device="cuda")
             out = model(x).F
             loss = ((out[:, :54] - tgt) ** 2).mean() + torch.nn.functional.cross_entropy(out[:, 54:], labels)
@@ -120,14 +123,15 @@ def test_backward_overlap_changes_no_gradient_bit(cuda, built_lib, monkeypatch):
         torch.cuda.synchronize()
         grads[overlap] = {k: p.grad.clone() for k, p in model.named_parameters()}
     assert len(ME._wgrad_streams) >= 1
-    for k, g in grads[False].items():
-        assert torch.isfinite(g).all(), k
-        if k == "final.bias":
-            # the bias gradient's column sums meet through fp32 atomics (col_sum): the last bit depends on the order
-            # in which workgroups arrive, on one stream as well (profiles/r3/backward_overlap_ab.txt, control run)
-            assert torch.allclose(g, grads[True][k], rtol=1e-5, atol=0)
-            continue
-        assert torch.equal(g, grads[True][k]), k
+    for mode in (1, 2):
+        for k, g in grads[0].items():
+            assert torch.isfinite(g).all(), k
+            if k == "final.bias":
+                # the bias gradient's column sums meet through fp32 atomics (col_sum): the last bit depends on the
+                # order in which workgroups arrive, on one stream as well (profiles/r3/backward_overlap_ab.txt)
+                assert torch.allclose(g, grads[mode][k], rtol=1e-5, atol=0)
+                continue
+            assert torch.equal(g, grads[mode][k]), (mode, k)
 
 
 def test_train_step_reduces_loss_and_matches_reference_loss(cuda, built_lib):
