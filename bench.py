@@ -76,6 +76,11 @@ def parse():
                          "from one shared counter (scenes are independent; fills the launch tails and host syncs of one scene "
                          "with the kernels of another)")
     ap.add_argument("--switch-interval", type=float, default=0.0005, help="sys.setswitchinterval for the scene threads")
+    ap.add_argument("--split-target", type=int, default=-1,
+                    help="cv_sp_set_split_target for the timed region: workgroups a split convolution launch aims at. "
+                         "-1 (default): 256 from four scenes in flight (the other scenes fill the chip, the partial "
+                         "tiles only cost traffic), else the library's 512; the one-scene-in-flight side pass always "
+                         "runs on the library default")
     ap.add_argument("--stagger-us", type=float, default=400.0,
                     help="scene thread i takes its first timed step i x this many microseconds after the clock started: scenes that "
                          "start together stay in the same stage (all in the convolutions, then all in the vote) and share the chip "
@@ -515,6 +520,8 @@ def main():
                     s.v_in = hv_cuda.count_votes(s.points, xyz, scale, RES, NUM_ROTS, s.corner, s.dims)
                     s.vote_bytes = 40 * a.points + 192 * s.v_in + 68 * s.cells
     S = scene_threads(a.streams)
+    split_target = a.split_target if a.split_target >= 0 else (256 if S >= 4 else 0)
+    ME.set_split_target(split_target)
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
     hvs = [hv] + [HoughVoting(RES, NUM_ROTS) for _ in range(S - 1)]
     hv_cuda.reserve_pinned(4 * S + 8)
@@ -608,6 +615,7 @@ def main():
         # This pass runs on the main thread's stream, which has its own allocator pool and scratch: two passes over the
         # resident scenes first, then the MEDIAN over the measured steps (one cold step used to double the mean)
         iso_steps = max(min(a.steps, 48), 24)
+        ME.set_split_target(0)                    # one scene in flight: the library's default launch sizing
         for k in range(2 * len(scenes)):
             run_step(model, hv, scenes[k % len(scenes)], teacher=teacher)
         ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(iso_steps)]
@@ -655,7 +663,8 @@ def main():
                                   if teacher else "network output (random init: no cell reaches thresh_high)",
                    "points": a.points, "num_rots": NUM_ROTS, "res": RES, "grid": s0.dims,
                    "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}.get(a.algo, "ablation-%d" % a.algo),
-                   "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": S},
+                   "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": S,
+                   "conv_split_target": split_target or 512},
         "roofline": {"bound": "hbm", "kernel": "vote op (all launches of cv_hv_forward_f32)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

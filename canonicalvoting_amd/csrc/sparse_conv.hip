@@ -27,6 +27,7 @@
 // 90 %, and dead waves / tiles skip their MFMAs / staging.
 #include "cv_common.h"
 
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -2379,6 +2380,17 @@ int nb_for(int cout, long long n_out) {
     return n_out < 1024 ? 1 : std::max(1, std::min(nb_wide, 2));
 }
 
+// workgroups a split launch aims at: CV_SPLIT_TARGET or 512 until cv_sp_set_split_target changes it
+std::atomic<long long> g_split_target{-1};
+long long split_target() {
+    long long v = g_split_target.load(std::memory_order_relaxed);
+    if (v <= 0) {
+        v = getenv("CV_SPLIT_TARGET") ? std::max(1ll, atoll(getenv("CV_SPLIT_TARGET"))) : 512;
+        g_split_target.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 // Enough workgroups to fill 256 CUs a few times with short dependent chains: split the (offset,
 // chunk) units over blockIdx.z; the partial tiles cost 8 bytes of traffic per output element per split.
 int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
@@ -2389,7 +2401,9 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
     // workgroups a split launch aims at.  512 since round 2: 384 / 512 / 768 / 1024 = 513 / 508 / 496 / 491 scenes/s six in
     // flight, net 2.58 / 2.51 / 2.47 / 2.47 ms one in flight - the partial tiles of the coarse levels are 0.8 GB of the
     // 1.7 GB a forward writes, and with several scenes in flight the other scenes fill the chip, not the splits
-    static const long long target = getenv("CV_SPLIT_TARGET") ? atoll(getenv("CV_SPLIT_TARGET")) : 512;
+    // (cv_sp_set_split_target: with EIGHT scenes in flight 256 gives 562-566 scenes/s against 550 for 512 and 549-555
+    // for 128, profiles/r3/split_target_8streams.txt - the host picks the value by how many scenes it keeps in flight)
+    const long long target = split_target();
     long long s = (target + tiles - 1) / tiles;
     // (measured without gain: sizing by the chip's resident workgroup slots, floor(256 x waves-per-SIMD / tiles), so that
     // no second round of workgroups starts: 257 vs 265 scenes/s one scene in flight, 401-409 vs 410-412 with six)
@@ -2402,6 +2416,12 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
 }
 
 }  // namespace
+
+int cv_sp_set_split_target(int workgroups) {
+    const int before = (int)split_target();
+    g_split_target.store(workgroups > 0 ? workgroups : -1, std::memory_order_relaxed);
+    return before;
+}
 
 int cv_sp_mask_perms_batch(const CvPermJob* jobs, int n_jobs, void* d_ws, size_t ws_bytes, void* stream, bool pre_zeroed) {
     CV_REQUIRE(jobs && d_ws && n_jobs > 0 && n_jobs <= CV_MAX_PERM_JOBS, CV_EINVAL, "bad mask perm batch");

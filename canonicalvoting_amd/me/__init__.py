@@ -491,6 +491,12 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
     return out
 
 
+def set_split_target(workgroups):
+    """cv_sp_set_split_target: workgroups a split convolution launch aims at (0: the library default, 512 - best for one
+    scene in flight; 256 pays from about four scenes in flight).  Returns the previous value."""
+    return int(_lib.lib().cv_sp_set_split_target(int(workgroups)))
+
+
 def to_hl(x):
     """fp32 rows [n, C] (C % 32 == 0) -> the hl format (same shape and dtype, the bytes hold the fp16 pairs)"""
     y = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)

@@ -274,6 +274,14 @@ int cv_sp_pack_weights_f32(const float* d_w, int K, int cin, int cout, float* d_
 
 size_t cv_sp_conv_workspace_bytes(long long n_out, int cout, int K);
 int cv_sp_conv_f32(const cv_conv_desc* desc, void* stream);
+/* Launch sizing of the convolutions whose output tiles alone do not fill the chip (the coarse levels): the number of
+ * workgroups a launch is split up to (over the kernel offsets; partial tiles, then a finish pass).  Default 512
+ * (or CV_SPLIT_TARGET) - best for ONE scene in flight; a host that keeps several scenes in flight on separate streams
+ * lets the other scenes fill the chip and sets a smaller value (bench.py: 256 from four scenes in flight).  Results
+ * change in the summation order only (fp32 rounding).  workgroups <= 0 restores the default.  Returns the previous
+ * value.  Process-wide; set it before launching, not concurrently with cv_sp_conv_f32 / cv_sp_net_forward callers that
+ * need one fixed value.  (No reference counterpart: MinkowskiEngine's launch sizes are internal.) */
+int cv_sp_set_split_target(int workgroups);
 
 /* Every kernel map and processing order the fused MinkUNet forward needs, built by ONE call per scene into one
  * int32 arena (offsets in int32 words; -1 = absent):

@@ -437,6 +437,29 @@ def test_minkunet34c_fused_and_modular_match_oracle(cuda, built_lib, n, small):
     np.testing.assert_allclose(prob.cpu().numpy(), rp.numpy(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("target", [64, 256, 2048])
+def test_split_target_changes_launch_sizes_not_results(cuda, built_lib, target):
+    """cv_sp_set_split_target (the launch sizing a host picks by its scenes in flight): the network output stays within
+    the 1e-4 bar of the oracle for small / bench / large targets, the setter returns the previous value and 0 restores
+    the default."""
+    coords, feats = scene_coords(5, 8000, small=False)
+    sd = so.make_state_dict(3, 64, seed=1)
+    model = MinkUNet34C(3, 64)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    ref = so.minkunet34c_forward(sd, coords, feats).numpy()
+    default = ME.set_split_target(target)
+    try:
+        assert ME.set_split_target(target) == target
+        x = ME.SparseTensor(torch.from_numpy(feats), torch.from_numpy(coords).int(), device="cuda")
+        with torch.no_grad():
+            out = model(x).F.cpu().numpy()
+    finally:
+        ME.set_split_target(0)
+    assert ME.set_split_target(0) == default
+    assert np.abs(out - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
 def test_minkunet_batch_of_scenes_and_row_order(cuda, built_lib):
     coords, feats = scene_coords(7, 1200, batch=3)
     sd = so.make_state_dict(3, 8, seed=2)                       # separate-model head (8 channels)
