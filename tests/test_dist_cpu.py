@@ -153,3 +153,39 @@ def test_convert_sync_batchnorm_keeps_the_state_dict():
     assert list(m.state_dict()) == keys
     bns = [x for x in m.modules() if isinstance(x, ME.MinkowskiBatchNorm)]
     assert len(bns) == 62 and all(type(x) is ME.MinkowskiSyncBatchNorm for x in bns)
+
+
+def _late_join_worker(rank, world_size, port, q):
+    import torch.distributed as dist
+    from canonicalvoting_amd import me as ME
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world_size)
+    w = torch.nn.Parameter(torch.zeros(3, 4))
+    with torch.no_grad():
+        q.put((rank, ME._gradient_untouched_until_end(w)))
+    dist.destroy_process_group()
+
+
+def test_late_wgrad_join_only_when_nothing_can_touch_the_gradient():
+    """me._ConvFn.backward may leave a layer's weight gradient running on its side stream until the end of the backward
+    pass (CV_BACKWARD_OVERLAP=2) only if nothing reads or writes that gradient earlier: not with a gradient to
+    accumulate into, a tensor hook, graph-building mode, a non-leaf weight - and never with more than one rank (DDP's
+    reducer copies gradients into its buckets as they arrive)."""
+    from canonicalvoting_amd import me as ME
+    w = torch.nn.Parameter(torch.zeros(3, 4))
+    derived = w * 1.0
+    with torch.no_grad():                                   # the engine runs backward nodes with grad mode off
+        assert ME._gradient_untouched_until_end(w)
+        w.grad = torch.zeros_like(w)
+        assert not ME._gradient_untouched_until_end(w)      # accumulation launches an add on the layer's stream
+        w.grad = None
+        h = w.register_hook(lambda g: g)
+        assert not ME._gradient_untouched_until_end(w)
+        h.remove()
+        assert ME._gradient_untouched_until_end(w)
+        assert not ME._gradient_untouched_until_end(derived)            # not a leaf: its gradient flows on
+    assert not ME._gradient_untouched_until_end(w)          # create_graph / double backward
+    port = _free_port()
+    q = mp.get_context("spawn").SimpleQueue()
+    mp.spawn(_late_join_worker, args=(2, port, q), nprocs=2, join=True)
+    got = dict(q.get() for _ in range(2))
+    assert got == {0: False, 1: False}
