@@ -119,9 +119,12 @@ def conv_transpose_k2s2(x, kernel, nbr_down):
 # x * mask_k instead of max(x, 0): a second evaluation (another precision, the HIP path) can be given the FIRST one's
 # activation pattern, so that gradients are compared on the same piecewise-linear branch - pre-activations within
 # rounding of zero otherwise pick different branches and change a gradient element by its whole value
-# (tests/test_production_size_gpu.py).  relu_trace, when a list, receives every ReLU's mask (x > 0).
+# (tests/test_production_size_gpu.py).  relu_trace, when a list, receives every ReLU's mask (x > 0); relu_peaks, when a
+# list, the largest value every ReLU lets through (the inputs of the next convolution: tests/test_train_gpu.py checks
+# them against the fp16 range on trained weights).
 relu_masks = None
 relu_trace = None
+relu_peaks = None
 
 
 def _relu(x):
@@ -132,6 +135,8 @@ def _relu(x):
         y = torch.relu(x)
     if relu_trace is not None:
         relu_trace.append((y.detach() > 0))
+    if relu_peaks is not None:
+        relu_peaks.append(float(y.detach().abs().max()) if y.numel() else 0.0)
     return y
 
 

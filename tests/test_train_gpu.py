@@ -316,3 +316,50 @@ def test_training_then_eval_uses_current_weights(cuda, built_lib):
         y2_mod = model.modular_forward(ME.SparseTensor(feats, coords, device=cuda)).F
     assert float((y2 - y_prog).abs().max()) > 1e-6                      # the weights did move
     assert float((y2 - y2_mod).abs().max()) < 1e-4 * max(1.0, float(y2_mod.abs().max()))
+
+
+def test_briefly_trained_network_stays_on_fp16_pairs_and_within_the_bar(cuda, built_lib):
+    """VERDICT r2 "what's weak" 3: the fp16-pair eval path had only seen randomly initialised weights.  There is no
+    checkpoint offline, so the network is TRAINED here - 150 `train_joint.py` steps (Adam 1e-3, three synthetic scenes per
+    step, fresh scenes every 10 steps) - until weights, BatchNorm gains and running statistics are those of a network that
+    has learnt something (loss down by more than half).  Then, on a scene it has not seen: the eval forward stays on the
+    fp16 pairs (no range fallback), the largest activation between the convolutions is far inside the fp16 range, and the
+    output is within the 1e-4 bar of the CPU oracle run on the trained state dict."""
+    from canonicalvoting_amd import train
+    from canonicalvoting_amd.synth import make_scene
+    kw = dict(n_points=4000, res=0.05, room=(2.4, 1.4, 2.4), n_boxes=4, margin=0.6, box_scale=0.5)
+
+    def batch(seed0):
+        scenes = [make_scene(seed0 + b, **kw) for b in range(3)]
+        coords = torch.cat([torch.cat([torch.full((len(s.coords), 1), b, dtype=torch.int32), torch.from_numpy(s.coords)], 1)
+                            for b, s in enumerate(scenes)]).to(cuda)
+        t = lambda name: torch.cat([torch.from_numpy(getattr(s, name)) for s in scenes]).to(cuda)
+        return coords, t("feats") * 2 - 1, t("xyz_labels"), t("scale_labels"), t("class_labels")
+
+    torch.manual_seed(0)
+    model = MinkUNet34C(3, 64).cuda().train()
+    opt = train.make_optimizer(model, lr=1e-3)
+    hist = []
+    for step in range(150):
+        if step % 10 == 0:
+            data = batch(1000 + step)
+        hist.append(float(train.train_step(model, opt, *data)[0]))
+    assert np.isfinite(hist).all() and np.mean(hist[-10:]) < 0.5 * np.mean(hist[:3]), (hist[:3], hist[-10:])
+    model.eval()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    sc = make_scene(77, **dict(kw, n_points=12000))
+    coords = np.concatenate([np.zeros((len(sc.coords), 1), np.int64), sc.coords], 1)
+    feats = (sc.feats * 2 - 1).astype(np.float32)
+    x = ME.SparseTensor(torch.from_numpy(feats), torch.from_numpy(coords).int(), device="cuda")
+    with torch.no_grad():
+        out = model(x).F.cpu().numpy()
+    assert getattr(model, "range_fallbacks", 0) == 0
+    so.relu_peaks = peaks = []
+    try:
+        ref = so.minkunet34c_forward(sd, coords, feats).numpy()
+    finally:
+        so.relu_peaks = None
+    assert len(peaks) >= 50 and max(peaks) < 65504.0 / 16, max(peaks)     # fp16 range with a factor of 16 to spare
+    print("trained-network activations: largest conv input %.3g over %d ReLUs; loss %.3f -> %.3f; max |out - oracle| %.2e"
+          % (max(peaks), len(peaks), np.mean(hist[:3]), np.mean(hist[-10:]), np.abs(out - ref).max()))
+    assert np.abs(out - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
