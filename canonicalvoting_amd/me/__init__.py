@@ -787,7 +787,8 @@ def _join_at_end_of_backward(cur, side):
     pend = getattr(_wgrad_pending, "pairs", None)
     if pend is None:
         pend = _wgrad_pending.pairs = {}
-    key = (cur.cuda_stream, side.cuda_stream)
+    # (the pass is part of the key: two backward passes interleaved on one engine thread each get their own join)
+    key = (torch._C._current_graph_task_id(), cur.cuda_stream, side.cuda_stream)
     if key in pend:
         return
     pend[key] = (cur, side)
