@@ -137,6 +137,8 @@ SIGNATURES = {
                                                ctypes.c_int, ctypes.c_longlong, vp, vp, ctypes.c_size_t, ctypes.c_int,
                                                vp]),
     "cv_sp_col_sum_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "cv_sp_col_sum_workspace_bytes": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int]),
+    "cv_sp_col_sum_det_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t, vp]),
     "cv_sp_bn_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "cv_sp_bn_stats_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_float,
                                           ctypes.c_float, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]),

@@ -1627,6 +1627,40 @@ __global__ __launch_bounds__(256) void col_sum(const float* __restrict__ x, long
     }
 }
 
+// the same sums without atomics: every (32 columns, row chunk) block writes its partial sums to ws[chunk][c], a second
+// launch adds the chunks of a column in chunk order - the result does not depend on the order in which workgroups run
+__global__ __launch_bounds__(256) void col_sum_partial(const float* __restrict__ x, long long n, int c, int ld,
+                                                       float* __restrict__ ws) {
+    __shared__ float s[8][32];
+    const int col = blockIdx.x * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
+    const long long r_lo = n * blockIdx.y / gridDim.y, r_hi = n * (blockIdx.y + 1) / gridDim.y;
+    float acc = 0.f;
+    if (col < c)
+        for (long long r = r_lo + ry; r < r_hi; r += 8) acc += x[r * ld + col];
+    s[ry][threadIdx.x & 31] = acc;
+    __syncthreads();
+    if (ry == 0 && col < c) {
+        float t = 0.f;
+        for (int k = 0; k < 8; ++k) t += s[k][threadIdx.x & 31];
+        ws[(long long)blockIdx.y * c + col] = t;
+    }
+}
+__global__ __launch_bounds__(256) void col_sum_chunks(const float* __restrict__ ws, int chunks, int c,
+                                                      float* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= c) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four load chains, combined in a fixed order
+    int k = 0;
+    for (; k + 3 < chunks; k += 4) {
+        s0 += ws[(long long)k * c + col];
+        s1 += ws[(long long)(k + 1) * c + col];
+        s2 += ws[(long long)(k + 2) * c + col];
+        s3 += ws[(long long)(k + 3) * c + col];
+    }
+    for (; k < chunks; ++k) s0 += ws[(long long)k * c + col];
+    out[col] = (s0 + s1) + (s2 + s3);
+}
+
 // sums the per-split partial tiles and applies the epilogue (scale/shift/residual/relu).
 // One thread per 4 consecutive columns (float4 loads, cout % 4 == 0) and per quarter of the splits;
 // the four quarter-sums meet through LDS, so small outputs with many splits still have enough loads
@@ -2863,6 +2897,27 @@ int cv_sp_col_sum_f32(const float* d_x, long long n, int c, int ld, float* d_out
     CV_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(float) * c, st));
     dim3 grid((unsigned)((c + 31) / 32), (unsigned)std::min<long long>(256, (n + 1023) / 1024));
     col_sum<<<grid, 256, 0, st>>>(d_x, n, c, ld, d_out);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+static unsigned col_sum_chunks_for(long long n) { return (unsigned)std::min<long long>(256, (n + 1023) / 1024); }
+
+size_t cv_sp_col_sum_workspace_bytes(long long n, int c) {
+    if (n <= 0 || c <= 0) return 0;
+    return sizeof(float) * (size_t)col_sum_chunks_for(n) * (size_t)c;
+}
+
+int cv_sp_col_sum_det_f32(const float* d_x, long long n, int c, int ld, float* d_out, void* d_ws, size_t ws_bytes,
+                          void* stream) {
+    CV_REQUIRE(d_x && d_out && d_ws && n > 0 && c > 0 && ld >= c, CV_EINVAL, "bad col_sum arguments");
+    CV_REQUIRE(ws_bytes >= cv_sp_col_sum_workspace_bytes(n, c), CV_ENOMEM, "workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const unsigned chunks = col_sum_chunks_for(n);
+    float* ws = static_cast<float*>(d_ws);
+    col_sum_partial<<<dim3((unsigned)((c + 31) / 32), chunks), 256, 0, st>>>(d_x, n, c, ld, ws);
+    CV_LAUNCH_CHECK();
+    col_sum_chunks<<<(unsigned)((c + 255) / 256), 256, 0, st>>>(ws, (int)chunks, c, d_out);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

@@ -752,11 +752,13 @@ def conv_wgrad(x_feats, grad_out, nbr, K):
 
 
 def col_sum(x):
+    """column sums (bias gradient) in a fixed summation order: cv_sp_col_sum_det_f32"""
     L = _lib.lib()
     out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
+    ws = _lib.scratch(x.device, "col_sum", int(L.cv_sp_col_sum_workspace_bytes(x.shape[0], x.shape[1])))
     with torch.cuda.device(x.device):
-        _lib.check(L.cv_sp_col_sum_f32(_ptr(x), x.shape[0], x.shape[1], x.stride(0), _ptr(out), _stream(x.device)),
-                   "cv_sp_col_sum_f32")
+        _lib.check(L.cv_sp_col_sum_det_f32(_ptr(x), x.shape[0], x.shape[1], x.stride(0), _ptr(out), _ptr(ws), ws.numel(),
+                                           _stream(x.device)), "cv_sp_col_sum_det_f32")
     return out
 
 

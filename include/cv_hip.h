@@ -382,8 +382,14 @@ int cv_sp_conv_wgrad_f32(const float* d_x, int x_ld, int cin, const float* d_dy,
 int cv_sp_conv_wgrad_px_f32(const float* d_x, int x_ld, int cin, const float* d_dy, int dy_ld, int cout,
                             const int32_t* d_nbr, int K, long long n_out, float* d_dw, void* d_ws, size_t ws_bytes,
                             int pieces, void* stream);
-/* out[c] = sum over rows of x[:, c] (bias gradient). */
+/* out[c] = sum over rows of x[:, c] (bias gradient).  cv_sp_col_sum_f32 joins the row chunks through fp32 atomics: the
+ * last bit depends on the order in which workgroups arrive.  cv_sp_col_sum_det_f32 writes the chunk sums to a workspace
+ * (cv_sp_col_sum_workspace_bytes) and adds them in chunk order: the same bits on every run (what the training path uses,
+ * so that a train_joint.py step is reproducible bit for bit). */
 int cv_sp_col_sum_f32(const float* d_x, long long n, int c, int ld, float* d_out, void* stream);
+size_t cv_sp_col_sum_workspace_bytes(long long n, int c);
+int cv_sp_col_sum_det_f32(const float* d_x, long long n, int c, int ld, float* d_out, void* d_ws, size_t ws_bytes,
+                          void* stream);
 
 /* Training-mode MinkowskiBatchNorm (= nn.BatchNorm1d over the feature rows, utils/minkunet.py:56):
  * batch mean / biased variance per channel, running statistics updated in place (NULL to skip), folded

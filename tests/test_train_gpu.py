@@ -126,12 +126,31 @@ def test_backward_overlap_changes_no_gradient_bit(cuda, built_lib, monkeypatch):
     for mode in (1, 2):
         for k, g in grads[0].items():
             assert torch.isfinite(g).all(), k
-            if k == "final.bias":
-                # the bias gradient's column sums meet through fp32 atomics (col_sum): the last bit depends on the
-                # order in which workgroups arrive, on one stream as well (profiles/r3/backward_overlap_ab.txt)
-                assert torch.allclose(g, grads[mode][k], rtol=1e-5, atol=0)
-                continue
+            # (final.bias included: its column sums are added in a fixed order since cv_sp_col_sum_det_f32)
             assert torch.equal(g, grads[mode][k]), (mode, k)
+
+
+def test_column_sums_are_the_same_bits_on_every_run(cuda, built_lib):
+    """ME.col_sum (bias gradient, cv_sp_col_sum_det_f32): chunk sums added in chunk order - equal bits over repeated
+    runs and on another stream with other kernels in flight, and the fp64 column sums to fp32 accuracy; strided rows and
+    a column count that is not a multiple of 32 included."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for n, c, ld in ((240000, 64, 64), (70001, 37, 48), (5, 3, 3)):
+        x = (torch.randn((n, ld), generator=g) * torch.logspace(-3, 3, ld)).to(cuda)[:, :c]
+        want = x.double().sum(0)
+        first = ME.col_sum(x)
+        err = ((first.double() - want).abs() / x.double().abs().sum(0).clamp_min(1e-30)).max()
+        assert float(err) < 2e-6, (n, c, float(err))
+        side = torch.cuda.Stream()
+        noise = torch.randn((4096, 4096), device=cuda)
+        for _ in range(5):
+            assert torch.equal(ME.col_sum(x), first)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                (noise @ noise).sum()
+                again = ME.col_sum(x)
+            torch.cuda.current_stream().wait_stream(side)
+            assert torch.equal(again, first)
 
 
 def test_train_step_reduces_loss_and_matches_reference_loss(cuda, built_lib):
