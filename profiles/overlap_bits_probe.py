@@ -1,5 +1,7 @@
 """Which parameter gradients differ between two training runs: one stream twice (control) and one stream vs the
 side-stream weight gradient (ME.BACKWARD_OVERLAP)."""
+import sys
+
 import numpy as np
 import torch
 from oracle import sparse_oracle as so
@@ -7,7 +9,8 @@ from canonicalvoting_amd import me as ME
 from canonicalvoting_amd.minkunet import MinkUNet34C
 from tests.test_sparse_gpu import scene_coords
 
-coords, feats = scene_coords(17, 2500, batch=3)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2500          # points per scene (80000: the production size)
+coords, feats = scene_coords(17, N, batch=3, small=N <= 5000)
 n = len(coords)
 sd = so.make_state_dict(3, 64, seed=9)
 rng = np.random.default_rng(1)
@@ -33,4 +36,4 @@ def run(overlap, steps=3):
 a, b, c, d = run(False), run(False), run(True), run(True)
 for name, (p, q) in {"one stream vs one stream": (a, b), "one stream vs overlap": (a, c), "overlap vs overlap": (c, d)}.items():
     bad = [(k, float((p[k] - q[k]).abs().max() / p[k].abs().max().clamp_min(1e-30))) for k in p if not torch.equal(p[k], q[k])]
-    print(name, ":", len(bad), "of", len(p), "differ", bad[:8])
+    print("3 x %d points," % N, name, ":", len(bad), "of", len(p), "differ", bad[:8])
