@@ -76,6 +76,12 @@ def parse():
                          "from one shared counter (scenes are independent; fills the launch tails and host syncs of one scene "
                          "with the kernels of another)")
     ap.add_argument("--switch-interval", type=float, default=0.0005, help="sys.setswitchinterval for the scene threads")
+    ap.add_argument("--event-every", type=int, default=1,
+                    help="steps of the timed region that carry HIP events (stage boundaries + the vote kernel): every K-th "
+                         "(1: all).  An event is a marker packet in the stream's hardware queue; the stage times and the "
+                         "`roofline` of the line come from the steps that have them")
+    ap.add_argument("--kernel-events", type=int, default=1,
+                    help="0: no cv_hv_set_kernel_events pair around the vote kernel (`roofline` then prices the whole op)")
     ap.add_argument("--split-target", type=int, default=-1,
                     help="cv_sp_set_split_target for the timed region: workgroups a split convolution launch aims at. "
                          "-1 (default): 256 from four scenes in flight (the other scenes fill the chip, the partial "
@@ -160,6 +166,19 @@ class ResidentScene:
         self.vote_bytes_floor = 40 * n_points + 24 * G                   # compulsory traffic
 
 
+KERNEL_EVENTS = True
+
+
+def step_events():
+    """the events of one step: [0..4] stage boundaries (recorded by run_step on the scene's stream), [5], [6] around the
+    vote accumulation kernel itself (recorded by the library: cv_hv_set_kernel_events).  torch creates the hipEvent_t
+    at the first record, and the library needs the handles: every event is recorded once here."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(7 if KERNEL_EVENTS else 5)]
+    for e in evs[5:]:
+        e.record()
+    return evs
+
+
 def run_step(model, hv, s, ev=None, teacher=False, keep=None):
     """One scene through eval_joint.py:163-280: network -> head -> vote -> decode -> per-class NMS.
     keep: optional dict that receives the device tensors of the step (the parity check reads them)."""
@@ -179,7 +198,13 @@ def run_step(model, hv, s, ev=None, teacher=False, keep=None):
         if model is None or teacher:
             xyz, scale, prob, cls = s.xyz, s.scale, s.prob, s.cls
         rec(2)
-        grid_obj, grid_rot, grid_scale = hv(s.points, xyz, scale, prob)
+        if ev is not None and len(ev) > 6:
+            _lib.lib().cv_hv_set_kernel_events(ev[5].cuda_event, ev[6].cuda_event)
+        try:
+            grid_obj, grid_rot, grid_scale = hv(s.points, xyz, scale, prob)
+        finally:
+            if ev is not None and len(ev) > 6:
+                _lib.lib().cv_hv_set_kernel_events(None, None)
         rec(3)
     raw = decode.decode_boxes(grid_obj, grid_rot, grid_scale, s.points, xyz, prob, cls, RES)
     rec(4)
@@ -529,8 +554,12 @@ def main():
     import itertools
     import threading
     sys.setswitchinterval(a.switch_interval)      # GIL hand-off between the scene threads
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(a.steps)]
+    global KERNEL_EVENTS
+    KERNEL_EVENTS = bool(a.kernel_events)
+    every = max(1, a.event_every)
+    events = [step_events() if k % every == 0 else None for k in range(a.steps)]
     counts = [0] * S
+    step_log = [None] * a.steps         # (thread, host time at start, at end) of every timed step
     warm_steps = [0] * S
     errors = []
     # the K steps are handed out from one counter: a thread whose scene was cheap takes the next step at once
@@ -568,7 +597,9 @@ def main():
                         k = next(ticket)
                     if k >= a.steps:
                         break
+                    ts = time.perf_counter()
                     dets, _ = run_step(model, hvs[i], scenes[k % len(scenes)], events[k], teacher)
+                    step_log[k] = (i, ts, time.perf_counter())
                     counts[i] += len(dets)
                 streams[i].synchronize()
         except BaseException as e:      # a dead worker must not leave the others parked on a barrier
@@ -585,6 +616,14 @@ def main():
     if errors:
         raise errors[0]
     torch.cuda.synchronize()
+    # no cyclic garbage collection inside the timed region: a full collection walks every object of the process with
+    # the GIL held - all scene threads stand still for its milliseconds, which a 40 ms region (the driver's 20 steps)
+    # shows as a 10-20 % outlier.  What the warm-up left is collected now and what survives is moved out of the
+    # collector's sight (a serving process does the same after start-up).
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     cvd.barrier(dev)
     t0 = time.perf_counter()
     gate.wait()
@@ -592,9 +631,15 @@ def main():
         t.join()
     cvd.barrier(dev)
     dt = time.perf_counter() - t0
+    gc.enable()
+    gc.unfreeze()
     if errors:
         raise errors[0]
     n_det = sum(counts)
+    if os.environ.get("CV_BENCH_TRACE"):
+        for k, (i, b, e) in enumerate(step_log):
+            print("step %3d thread %d start %8.3f ms end %8.3f ms (%.3f)" % (k, i, (b - t0) * 1e3, (e - t0) * 1e3, (e - b) * 1e3),
+                  file=sys.stderr)
     dt = cvd.reduce_scalar(dt, "max", dev)
     torch.cuda.synchronize()
 
@@ -604,11 +649,26 @@ def main():
                 "vote": float(stat([e[2].elapsed_time(e[3]) for e in evs])),
                 "decode": float(stat([e[3].elapsed_time(e[4]) for e in evs]))}
 
-    vb = np.array([scenes[k % len(scenes)].vote_bytes for k in range(a.steps)], dtype=np.float64)
+    timed_steps = [k for k in range(a.steps) if events[k] is not None]
+    events = [events[k] for k in timed_steps]
+    vb = np.array([scenes[k % len(scenes)].vote_bytes for k in timed_steps], dtype=np.float64)
     stage_ms = stage_times(events)
-    vote_ms = np.array([e[2].elapsed_time(e[3]) for e in events])
+    # the op (prep launches + accumulation kernel, event to event on the scene's stream) and the accumulation kernel alone
+    # (events recorded by the library around hv_fwd_tiles): `roofline` prices the kernel, the op is a side field
+    op_ms = np.array([e[2].elapsed_time(e[3]) for e in events])
+
+    def kernel_times(evs, op):
+        if len(evs[0]) < 7:
+            return op
+        k = np.array([e[5].elapsed_time(e[6]) for e in evs])
+        # (the direct-atomics algorithm has no tile kernel: its events only hold the record of step_events, microseconds apart)
+        return k if (k > 0.02).all() else op
+
+    vote_ms = kernel_times(events, op_ms)
+    kernel_timed = vote_ms is not op_ms
     achieved = float((vb / (vote_ms * 1e-3)).mean() / 1e9)
-    iso_stage = iso_achieved = iso_vote = None
+    op_achieved = float((vb / (op_ms * 1e-3)).mean() / 1e9)
+    iso_stage = iso_achieved = iso_vote = iso_op = None
     if S > 1:
         # kernels of concurrent scenes stretch each other's event-to-event times: the same steps once more with ONE
         # scene in flight, after the timed region, give the op on its own (side fields; `frac` is the timed region's).
@@ -618,13 +678,15 @@ def main():
         ME.set_split_target(0)                    # one scene in flight: the library's default launch sizing
         for k in range(2 * len(scenes)):
             run_step(model, hv, scenes[k % len(scenes)], teacher=teacher)
-        ev2 = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(iso_steps)]
+        ev2 = [step_events() for _ in range(iso_steps)]
         for k in range(iso_steps):
             run_step(model, hv, scenes[k % len(scenes)], ev2[k], teacher)
         torch.cuda.synchronize()
         iso_stage = stage_times(ev2, np.median)
-        v2 = np.array([e[2].elapsed_time(e[3]) for e in ev2])
+        op2 = np.array([e[2].elapsed_time(e[3]) for e in ev2])
+        v2 = kernel_times(ev2, op2)
         iso_vote = float(np.median(v2))
+        iso_op = float(np.median(op2))
         vb2 = np.array([scenes[k % len(scenes)].vote_bytes for k in range(iso_steps)], dtype=np.float64)
         iso_achieved = float(np.median(vb2 / (v2 * 1e-3)) / 1e9)
     s0 = scenes[0]
@@ -665,15 +727,20 @@ def main():
                    "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}.get(a.algo, "ablation-%d" % a.algo),
                    "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": S,
                    "conv_split_target": split_target or 512},
-        "roofline": {"bound": "hbm", "kernel": "vote op (all launches of cv_hv_forward_f32)",
+        "roofline": {"bound": "hbm",
+                     "kernel": "hv_fwd_tiles (the accumulation kernel of cv_hv_forward_f32)" if kernel_timed
+                               else "vote op (all launches of cv_hv_forward_f32)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_ms": float(vote_ms.mean()), "bytes_per_launch": float(vb.mean()),
                      "compulsory_bytes": float(s0.vote_bytes_floor), "v_in": s0.v_in,
-                     "measured_in": "the timed region (HIP events on the scene's stream, %d scene%s in flight)"
-                                    % (S, "s" if S > 1 else ""),
+                     "measured_in": "the timed region (HIP events %s, on the scene's stream, %d scene%s in flight)"
+                                    % ("recorded by the library directly around the kernel" if kernel_timed
+                                       else "around the op", S, "s" if S > 1 else ""),
+                     "op_avg_ms": float(op_ms.mean()), "op_frac": op_achieved / HBM_PEAK_GBS,
                      "isolated_avg_ms": iso_vote, "isolated_achieved": iso_achieved,
                      "isolated_frac": iso_achieved / HBM_PEAK_GBS if iso_achieved else None,
+                     "isolated_op_avg_ms": iso_op,
                      "note": "algorithmic-byte model of the reference's scatter (48 fp32 atomics per vote); the tile "
                              "kernel accumulates in LDS, its real HBM traffic is `traffic`"},
         "roofline_conv": None if not full else {
@@ -704,6 +771,9 @@ def main():
         "stage_ms_median": stage_times(events, np.median),
         "stage_ms_isolated": iso_stage,
         "warmup_steps_run": int(sum(warm_steps)),
+        # host-side latency of the timed steps (launches + the waits of one scene): a stall shows as a max far above the median
+        "step_host_ms": {"median": float(np.median([(e - b) * 1e3 for _, b, e in step_log])),
+                         "max": float(max((e - b) * 1e3 for _, b, e in step_log))},
     }
     out["cpu_baseline"] = out["parity"] = out["train_step_ms"] = None
     if rank == 0 and full and a.train_steps > 0 and not a.large:

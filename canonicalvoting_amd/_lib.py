@@ -78,6 +78,7 @@ SIGNATURES = {
     "cv_hv_forward_f32": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_int,
                                          c_float_p, c_int_p, vp, vp, vp, vp, ctypes.c_size_t,
                                          ctypes.c_int, vp]),
+    "cv_hv_set_kernel_events": (ctypes.c_int, [vp, vp]),
     "cv_hv_backward_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float,
                                           ctypes.c_int, c_float_p, c_int_p, vp, vp, vp, vp]),
     "cv_hv_count_votes_f32": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_int,

@@ -1327,6 +1327,16 @@ size_t cv_hv_forward_workspace_bytes(int64_t n, int num_rots, const int dims[3],
            sizeof(int2) * (size_t)list_capacity(n, (int64_t)ntiles) + sizeof(float) * slots * 6 * TCELLS;
 }
 
+// cv_hv_set_kernel_events: the calling thread's next cv_hv_forward_f32 calls record these events directly before and
+// after the accumulation kernel (hv_fwd_tiles), on the stream of the call
+static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
+
+int cv_hv_set_kernel_events(void* ev_start, void* ev_stop) {
+    t_ev_start = static_cast<hipEvent_t>(ev_start);
+    t_ev_stop = static_cast<hipEvent_t>(ev_stop);
+    return CV_OK;
+}
+
 int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_scale,
                       const float* d_obj, int64_t n, float res, int num_rots,
                       const float h_corner3[3], const int dims[3], float* d_grid_obj,
@@ -1420,8 +1430,10 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
                       d_grid_rot, d_grid_scale, prof, list_ctl, list_start, list_cnt, entries, list_mode, q_info
 #define CV_TILES_LAUNCH(V)                                                                                   \
     do {                                                                                                     \
+        if (t_ev_start) CV_HIP_CHECK(hipEventRecord(t_ev_start, st));                                         \
         if (queue) hv_fwd_tiles<V, true><<<(unsigned)wgs, TW * 64, 0, st>>>(CV_TILES_ARGS);                   \
         else hv_fwd_tiles<V, false><<<(unsigned)wgs, TW * 64, 0, st>>>(CV_TILES_ARGS);                        \
+        if (t_ev_stop) CV_HIP_CHECK(hipEventRecord(t_ev_stop, st));                                           \
     } while (0)
     unsigned long long* prof = nullptr;
     if (algo == 24) {

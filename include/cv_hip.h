@@ -71,6 +71,12 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
                       float* d_grid_rot, float* d_grid_scale, void* d_ws, size_t ws_bytes,
                       int algo, void* stream);
 
+/* Measurement hook (no reference counterpart): the CALLING THREAD's following cv_hv_forward_f32 calls record the two
+ * hipEvent_t handles directly before and after the accumulation kernel of the tile algorithm (hv_fwd_tiles), on the
+ * stream of the call - bench.py times exactly the kernel its `roofline` prices, with other scenes in flight, instead
+ * of the whole op.  NULL, NULL switches it off.  The events stay the caller's. */
+int cv_hv_set_kernel_events(void* ev_start, void* ev_stop);
+
 /* Gradient of sum(grad_obj * grid_obj) wrt xyz/scale/obj (hv_cuda_kernel.cu:168-261),
  * including the reference's missing 1/res factor.  Outputs are overwritten.
  * Asynchronous on `stream`. */

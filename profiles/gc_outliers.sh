@@ -1,0 +1,3 @@
+# the driver's command twelve times in a row (fresh process each): spread of the 20-step value with garbage collection off inside the timed region
+cd $GRAFT_REPO_ROOT
+for i in 1 2 3 4 5 6 7 8 9 10 11 12; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-scenes 0 --train-steps 0 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value'],1))"; done | tr '\n' ' '; echo

@@ -213,3 +213,44 @@ def test_huge_scale_contributions_take_the_exact_slow_path(cuda, built_lib):
     live = ref[0] > 1e-3 * max(1.0, float(np.abs(ref[0]).max()))
     np.testing.assert_allclose(hip[2][live], ref[2][live], rtol=1e-4, atol=1e-4)
     assert float(np.abs(ref[2]).max()) > 2e4                    # the slow path was exercised
+
+
+def test_kernel_events_bracket_the_accumulation_kernel(cuda, built_lib):
+    """cv_hv_set_kernel_events (bench.py's `roofline` timing): the two events are recorded around hv_fwd_tiles on the
+    stream of the call - a positive time below the whole op's, the grids unchanged, nothing recorded once switched off
+    or on another thread."""
+    import threading
+    from canonicalvoting_amd import _lib
+    L = _lib.lib()
+    sc = make_scene(3, n_points=20000)
+    xyz, scale, prob, _ = synth_predictions(sc)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    args = (t(sc.points), t(xyz), t(scale), t(prob))
+    hv = HoughVoting(sc.res, 120)
+    plain = [g.clone() for g in hv(*args)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for e in ev:
+        e.record()                                       # creates the hipEvent_t handles
+    assert all(e.cuda_event for e in ev)
+    torch.cuda.synchronize()
+    assert L.cv_hv_set_kernel_events(ev[1].cuda_event, ev[2].cuda_event) == 0
+    try:
+        ev[0].record()
+        timed = hv(*args)
+        ev[3].record()
+        torch.cuda.synchronize()
+        k_ms, op_ms = ev[1].elapsed_time(ev[2]), ev[0].elapsed_time(ev[3])
+        assert 0.02 < k_ms < op_ms, (k_ms, op_ms)
+        assert ev[0].elapsed_time(ev[1]) >= 0 and ev[2].elapsed_time(ev[3]) >= 0
+        for a, b in zip(plain, timed):
+            assert torch.equal(a, b)
+        # thread-local: another thread's call leaves the events alone
+        before = ev[1].elapsed_time(ev[2])
+        th = threading.Thread(target=lambda: (hv(*args), torch.cuda.synchronize()))
+        th.start(); th.join()
+        assert ev[1].elapsed_time(ev[2]) == before
+    finally:
+        L.cv_hv_set_kernel_events(None, None)
+    hv(*args)
+    torch.cuda.synchronize()
+    assert ev[1].elapsed_time(ev[2]) == before
