@@ -624,6 +624,7 @@ def main():
     gc.collect()
     gc.freeze()
     gc.disable()
+    mem0 = torch.cuda.memory_stats(dev)
     cvd.barrier(dev)
     t0 = time.perf_counter()
     gate.wait()
@@ -633,6 +634,10 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
     gc.unfreeze()
+    mem1 = torch.cuda.memory_stats(dev)
+    # hipMalloc / hipFree calls of the caching allocator inside the timed region (0 when the warm-up did its job)
+    device_allocs = {k: int(mem1.get(k, 0)) - int(mem0.get(k, 0)) for k in ("num_device_alloc", "num_device_free",
+                                                                            "num_alloc_retries", "num_sync_all_streams")}
     if errors:
         raise errors[0]
     n_det = sum(counts)
@@ -772,6 +777,7 @@ def main():
         "stage_ms_isolated": iso_stage,
         "warmup_steps_run": int(sum(warm_steps)),
         # host-side latency of the timed steps (launches + the waits of one scene): a stall shows as a max far above the median
+        "device_allocs_in_timed_region": device_allocs,
         "step_host_ms": {"median": float(np.median([(e - b) * 1e3 for _, b, e in step_log])),
                          "max": float(max((e - b) * 1e3 for _, b, e in step_log))},
     }
