@@ -493,7 +493,7 @@ __global__ __launch_bounds__(1024) void hv_list_pass(const int* __restrict__ yst
 __global__ __launch_bounds__(1024) void hv_list_scan(const int* __restrict__ list_cnt, int Y, int ntiles, long long list_cap,
                                                      int* __restrict__ list_ctl, int* __restrict__ list_start) {
     __shared__ int s[1024];
-    __shared__ int carry_s;
+    __shared__ long long carry_s;      // 64 bits: a total past 2^31 must raise the overflow flag, not wrap
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     const int total_lists = Y * ntiles;
@@ -508,13 +508,13 @@ __global__ __launch_bounds__(1024) void hv_list_scan(const int* __restrict__ lis
             s[threadIdx.x] += t;
             __syncthreads();
         }
-        const int incl = s[threadIdx.x] + carry_s;
-        if (i < total_lists) list_start[i] = incl - v;
+        const long long incl = (long long)s[threadIdx.x] + carry_s;
+        if (i < total_lists) list_start[i] = incl - v < 0x7fffffffll ? (int)(incl - v) : 0x7fffffff;
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { list_ctl[0] = carry_s; list_ctl[1] = (long long)carry_s > list_cap ? 1 : 0; }
+    if (threadIdx.x == 0) { list_ctl[0] = carry_s < 0x7fffffffll ? (int)carry_s : 0x7fffffff; list_ctl[1] = carry_s > list_cap ? 1 : 0; }
 }
 
 // ---- work queue of the tile kernel (round 3) -----------------------------------------------------------------------
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(1024) void hv_build_queue(const int* __restrict__ t
             }
             const unsigned long long excl = s[threadIdx.x] + carry_s - v;
             const int item0 = (int)(excl >> 32), slot0 = (int)(excl & 0xffffffffull);
-            if (i < total && item0 + max(parts, 1) <= max_items && slot0 + parts <= max_slots) {
+            if (i < total && item0 + max(parts, 1) <= max_items && slot0 + (parts > 1 ? parts : 0) <= max_slots) {
                 if (parts == 0) items[item0] = make_int4(y, t, 0, 0);
                 for (int p2 = 0; p2 < parts; ++p2) items[item0 + p2] = make_int4(y, t, p2 | (parts << 8), slot0);
             }
@@ -763,7 +763,7 @@ template <int VARIANT, bool QUEUE>
 __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     int R, float res, F3 corner, I3 dims, const float2* __restrict__ tab,
     const int* __restrict__ ystart, const int4* __restrict__ items, const float* __restrict__ rec,
-    int64_t rec_stride, int tiles_x, int tiles_z, float* __restrict__ partials,
+    int64_t rec_stride, int tiles_x, int tiles_z, unsigned long long* __restrict__ partials,
     int* __restrict__ arrivals, float* __restrict__ g_obj, float* __restrict__ g_rot,
     float* __restrict__ g_scale, unsigned long long* __restrict__ prof,
     const int* __restrict__ list_ctl, const int* __restrict__ list_start, const int* __restrict__ list_cnt,
@@ -1036,11 +1036,12 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
     HV_TICK(3);
 
     if (nparts > 1) {
-        // publish this part's tile, the last arriver sums the parts in part order (deterministic):
+        // publish this part's tile as the raw 2^-36 fixed-point words, the last arriver adds the parts as integers: the
+        // merged sums are the same bits whichever records landed in whichever part (until round 4 the parts went through
+        // fp32, so the last bit of a hot cell depended on the atomic order of the scatter that fills the parts)
         // plain stores -> per-wave vmcnt(0) -> barrier -> one-lane agent release -> ticket.
-        float* mine = partials + ((int64_t)slot0 + (int64_t)part * slot_stride) * (6 * TCELLS);
-        for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64)
-            mine[i] = (float)acc_value(sh.acc[acc_idx(i / TCELLS, i % TCELLS)], i);
+        unsigned long long* mine = partials + ((int64_t)slot0 + (int64_t)part * slot_stride) * (6 * TCELLS);
+        for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) mine[i] = sh.acc[acc_idx(i / TCELLS, i % TCELLS)];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1053,11 +1054,11 @@ __global__ __launch_bounds__(TW * 64) void hv_fwd_tiles(
         }
         __syncthreads();
         if (!last_flag) return;
-        const float* base = partials + (int64_t)slot0 * (6 * TCELLS);
+        const unsigned long long* base = partials + (int64_t)slot0 * (6 * TCELLS);
         for (int i = threadIdx.x; i < 6 * TCELLS; i += TW * 64) {
-            double sum = 0.0;
-            for (int p2 = 0; p2 < nparts; ++p2) sum += (double)base[(int64_t)p2 * slot_stride * (6 * TCELLS) + i];
-            sh.acc[acc_idx(i / TCELLS, i % TCELLS)] = (unsigned long long)__double2ll_rn(sum * FX_SCALE);
+            unsigned long long sum = 0ull;
+            for (int p2 = 0; p2 < nparts; ++p2) sum += base[(int64_t)p2 * slot_stride * (6 * TCELLS) + i];
+            sh.acc[acc_idx(i / TCELLS, i % TCELLS)] = sum;
         }
         __syncthreads();
     }
@@ -1314,17 +1315,30 @@ int cv_hv_grid_dims_f32(const float h_min3[3], const float h_max3[3], float res,
     return CV_OK;
 }
 
+// work queue + work lists (large grids) or the streaming launch: one decision for the workspace size and the launch
+static bool tiles_queue_mode(int64_t n, int num_rots, int64_t Y, int64_t ntiles, int algo) {
+    return use_queue(ntiles) && ntiles <= LIST_MAX_TILES && list_capacity(n, ntiles) < (1ll << 31) &&
+           queue_max_items(n, num_rots, Y, ntiles) < (1ll << 31) && algo != 23;
+}
+
+// The workspace follows the launch shape actually chosen: the streaming launch (80k-point scenes) carries neither the
+// work lists nor the queue items (they were > 60 MB of every stream's 100 MB vote scratch until round 4).
 size_t cv_hv_forward_workspace_bytes(int64_t n, int num_rots, const int dims[3], int algo) {
     if (!dims || n <= 0) return 0;
     if (pick_algo(algo, n, num_rots, dims) == 1) return 256;
     const size_t Y = (size_t)dims[1];
     const size_t ntiles = (size_t)((dims[0] + TX - 1) / TX) * (size_t)((dims[2] + TZ - 1) / TZ);
+    const bool queue = tiles_queue_mode(n, num_rots, (int64_t)Y, (int64_t)ntiles, algo);
     const size_t max_chunks = Y + (size_t)((n + LIST_CHUNK_RECORDS - 1) / LIST_CHUNK_RECORDS);
-    const size_t slots = std::max<size_t>((size_t)queue_max_slots(n, num_rots), (size_t)tiles_q_bound(n, (int)Y) * ntiles);
-    return 256 * 24 + sizeof(int) * ((size_t)n * (1 + REC_F) + Y * 8 + 16 + 4 * Y * ntiles + 64 + max_chunks * (ntiles + 1) +
-                                     4 * (size_t)tiles_q_bound(n, (int)Y)) +
-           sizeof(int4) * (size_t)queue_max_items(n, num_rots, (int64_t)Y, (int64_t)ntiles) +
-           sizeof(int2) * (size_t)list_capacity(n, (int64_t)ntiles) + sizeof(float) * slots * 6 * TCELLS;
+    const size_t slots = queue ? (size_t)queue_max_slots(n, num_rots) : (size_t)tiles_q_bound(n, (int)Y) * ntiles;
+    size_t b = 256 * 24 + sizeof(int) * ((size_t)n * (1 + REC_F) + Y * 8 + 16 + 64 + Y * ntiles + max_chunks +
+                                         4 * (size_t)tiles_q_bound(n, (int)Y)) +
+               sizeof(unsigned long long) * slots * 6 * TCELLS;
+    if (queue)
+        b += sizeof(int) * (3 * Y * ntiles + max_chunks * ntiles) +
+             sizeof(int4) * (size_t)queue_max_items(n, num_rots, (int64_t)Y, (int64_t)ntiles) +
+             sizeof(int2) * (size_t)list_capacity(n, (int64_t)ntiles);
+    return b;
 }
 
 // cv_hv_set_kernel_events: the calling thread's next cv_hv_forward_f32 calls record these events directly before and
@@ -1379,26 +1393,26 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
     const int64_t max_items = queue_max_items(n, num_rots, Y, ntiles), max_slots = queue_max_slots(n, num_rots);
     const int64_t max_q = tiles_q_bound(n, Y);
     const int64_t list_cap = list_capacity(n, ntiles);
-    const bool queue = use_queue(ntiles) && ntiles <= LIST_MAX_TILES && list_cap < (1ll << 31) && max_items < (1ll << 31) &&
-                       algo != 23;
-    // the zero-initialised arrays sit next to each other: one fill launch
+    const bool queue = tiles_queue_mode(n, num_rots, Y, ntiles, algo);
+    // the zero-initialised arrays sit next to each other: one fill launch.  The streaming launch takes none of the list /
+    // queue arrays (zero-length carves: nothing of it reads them)
     int* list_ctl = cv.take<int>(64);
-    int* list_cnt = cv.take<int>((size_t)Y * ntiles);      // (zeroed with the rest: the count pass adds to them)
-    int* tile_w = cv.take<int>((size_t)Y * ntiles);
+    int* list_cnt = cv.take<int>(queue ? (size_t)Y * ntiles : 0);      // (zeroed with the rest: the count pass adds to them)
+    int* tile_w = cv.take<int>(queue ? (size_t)Y * ntiles : 0);
     int* ycount = cv.take<int>(Y);
     int* arrivals = cv.take<int>((size_t)Y * ntiles);
     int* ystart = cv.take<int>(Y + 1);
     int* cursor = cv.take<int>(Y);
     int* part_start = cv.take<int>(Y + 1);
     int4* q_info = cv.take<int4>((size_t)max_q);
-    float* partials = cv.take<float>((size_t)std::max<int64_t>(max_slots, max_q * ntiles) * 6 * TCELLS);
-    int4* items = cv.take<int4>((size_t)max_items);
-    int* list_start = cv.take<int>((size_t)Y * ntiles);
+    unsigned long long* partials = cv.take<unsigned long long>((size_t)(queue ? max_slots : max_q * ntiles) * 6 * TCELLS);
+    int4* items = cv.take<int4>(queue ? (size_t)max_items : 0);
+    int* list_start = cv.take<int>(queue ? (size_t)Y * ntiles : 0);
     const int64_t max_chunks = (int64_t)Y + (n + LIST_CHUNK_RECORDS - 1) / LIST_CHUNK_RECORDS;
     int* chunk_start = cv.take<int>((size_t)Y + 1);
     int* bin_of_chunk = cv.take<int>((size_t)max_chunks);
-    int* chunk_off = cv.take<int>((size_t)max_chunks * ntiles);
-    int2* entries = cv.take<int2>((size_t)list_cap);
+    int* chunk_off = cv.take<int>(queue ? (size_t)max_chunks * ntiles : 0);
+    int2* entries = cv.take<int2>(queue ? (size_t)list_cap : 0);
     const int list_mode = queue ? 2 : 1;
     // (the streaming launch only needs ycount and the arrival counters zeroed)
     int* zero_from = queue ? list_ctl : ycount;

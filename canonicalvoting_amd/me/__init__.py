@@ -812,7 +812,9 @@ def _gradient_untouched_until_end(kernel):
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         return False          # (reducer hooks sit on the gradient accumulators, invisible from here)
-    return (kernel.is_leaf and kernel.grad is None and not kernel._backward_hooks
+    # (AccumulateGrad keeps a gradient tensor as it is - no kernel on the layer's stream - only when its layout is the
+    # parameter's: a non-contiguous kernel parameter would make it clone d_kernel on the main stream, racing the side stream)
+    return (kernel.is_leaf and kernel.grad is None and kernel.is_contiguous() and not kernel._backward_hooks
             and not getattr(kernel, "_post_accumulate_grad_hooks", None)
             and not torch.is_grad_enabled() and not torch.is_anomaly_enabled())
 

@@ -32,7 +32,7 @@ def test_eight_threads_two_hundred_scenes_each(cuda):
         f = (torch.from_numpy(sc.feats) * 2 - 1).to(dev)
         scenes.append((c4, f))
 
-    from canonicalvoting_amd import decode, hv_cuda
+    from canonicalvoting_amd import _lib, decode, hv_cuda
     from canonicalvoting_amd import me as ME
 
     def run(hv, k):
@@ -59,12 +59,15 @@ def test_eight_threads_two_hundred_scenes_each(cuda):
         try:
             torch.cuda.set_device(dev)
             hv = HoughVoting(0.06, 120)
-            with torch.cuda.stream(torch.cuda.Stream(dev)):
+            stream = torch.cuda.Stream(dev)
+            with torch.cuda.stream(stream):
                 for k in range(N):
                     got = run(hv, k + i)
                     want = ref[(k + i) % len(scenes)]
                     if got != want:
                         bad.append((i, k, got, want))
+            stream.synchronize()
+            _lib.release_scratch(dev, stream)      # a retired stream gives its scratch back
         except BaseException as e:           # noqa: BLE001 - reported below
             errors.append(repr(e))
 
@@ -74,6 +77,9 @@ def test_eight_threads_two_hundred_scenes_each(cuda):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+    held = _lib.scratch_bytes()
+    _lib.release_scratch(dev, torch.cuda.current_stream(dev))
+    assert _lib.scratch_bytes() < held or held == 0      # only the main stream's buffers were left, and they go too
     names = ["n_cand", "dets", "y_abs_sum", "grid_shape", "grid_obj_sum", "cells_ge_5", "grid_scale_abs_sum", "cand_idx",
              "xyz_sum", "scale_sum", "prob_sum", "corner", "touched_cells"]
     diff = {}
