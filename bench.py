@@ -389,7 +389,8 @@ def main_train(a):
     model = MinkUNet34C(3, 6 * 9 + 9 + 1).cuda().train()
     if a.sync_bn and world > 1:
         ME.convert_sync_batchnorm(model)
-    net = train.make_ddp(model, dev) if world > 1 else model
+    import torch.distributed as tdist
+    net = train.make_ddp(model, dev) if (world > 1 or tdist.is_initialized()) else model      # (CV_DIST_FORCE=1: one-rank RCCL group)
     opt = train.make_optimizer(model)
     for _ in range(max(a.warmup, 1)):
         train.train_step(net, opt, coords, feats, xyz, scale, cls)

@@ -78,5 +78,41 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def ext_path():
+    import sysconfig
+    return os.path.join(OUT_DIR, "hv_cuda" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_ext(force=False, verbose=False):
+    """canonicalvoting_amd/_C/hv_cuda.<abi>.so: the compiled pybind / torch extension module `hv_cuda`
+    (csrc/hv_cuda_ext.cpp = houghvoting/src/hv_cuda.cpp over the C ABI).  Host-only C++ (it calls libcvhip.so), so g++
+    compiles it against torch's headers; rpath $ORIGIN finds libcvhip.so next to it."""
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension as ce
+    lib = build(force=force, verbose=verbose)
+    src = os.path.join(HERE, "hv_cuda_ext.cpp")
+    out = ext_path()
+    if not (force or _stale(out, [src, lib, os.path.join(ROOT, "include", "cv_hip.h"), os.path.abspath(__file__)])):
+        return out
+    inc = ce.include_paths() + ["/opt/rocm/include", sysconfig.get_paths()["include"], os.path.join(ROOT, "include")]
+    torch_lib = ce.library_paths()[0]
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=hv_cuda", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-Wno-deprecated-declarations"]
+    cmd += ["-I" + i for i in inc]
+    cmd += [src, "-o", out, "-L" + torch_lib, "-L" + OUT_DIR, "-L/opt/rocm/lib", "-ltorch", "-ltorch_cpu", "-ltorch_hip",
+            "-lc10", "-lc10_hip", "-ltorch_python", "-lamdhip64", "-lcvhip", "-Wl,-rpath,$ORIGIN",
+            "-Wl,-rpath," + torch_lib, "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building the hv_cuda extension failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build_ext(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

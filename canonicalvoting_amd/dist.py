@@ -18,7 +18,10 @@ def init(backend=None, device=None):
     # CV_DIST_BACKEND=gloo: the launch path (env rendezvous, barriers, max / sum reductions) on a box whose ranks
     # share one GPU, where RCCL refuses to start (profiles/two_ranks_one_gpu.sh); never set in production
     backend = os.environ.get("CV_DIST_BACKEND", backend)
-    if ws > 1 and not dist.is_initialized():
+    # CV_DIST_FORCE=1: create the group for a single rank too (RCCL with one rank: `bench.py --mode train` under
+    # `torch.distributed.run --nproc-per-node 1` then runs the DDP path a multi-GPU node runs)
+    force = os.environ.get("CV_DIST_FORCE", "0") == "1" and "MASTER_ADDR" in os.environ
+    if (ws > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}

@@ -810,8 +810,9 @@ def _gradient_untouched_until_end(kernel):
     anomaly / graph-building mode.  Code that hooks the gradient accumulators by other means sets
     CV_BACKWARD_OVERLAP=1."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return False          # (reducer hooks sit on the gradient accumulators, invisible from here)
+    if dist.is_available() and dist.is_initialized():
+        return False          # (DDP's reducer hooks sit on the gradient accumulators, invisible from here - also with ONE rank,
+                              #  where the bucket copy still runs on the layer's stream as the gradient arrives)
     # (AccumulateGrad keeps a gradient tensor as it is - no kernel on the layer's stream - only when its layout is the
     # parameter's: a non-contiguous kernel parameter would make it clone d_kernel on the main stream, racing the side stream)
     return (kernel.is_leaf and kernel.grad is None and kernel.is_contiguous() and not kernel._backward_hooks

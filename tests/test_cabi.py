@@ -161,3 +161,30 @@ def test_no_packed_fp32_instructions_in_device_code(built_lib, tmp_path):
             assert not packed, "%s: %d packed fp32 instructions" % (name, len(packed))
             seen += 1
     assert seen >= 4          # hv_vote, hv_decode, sparse_coords, sparse_conv, sparse_conv_alt
+
+
+def test_compiled_hv_cuda_extension_loads_and_checks_its_inputs(built_lib):
+    """the compiled pybind / torch extension `hv_cuda` (csrc/hv_cuda_ext.cpp = houghvoting/src/hv_cuda.cpp:30-77 over the
+    C ABI): builds without a GPU, is a module named hv_cuda with forward / backward, and refuses CPU / non-contiguous
+    tensors with the reference's messages (hv_cuda.cpp:26-28) - no compute call without a GPU"""
+    import torch
+    from canonicalvoting_amd import hv_cuda_ext
+    from canonicalvoting_amd.csrc import build
+    assert os.path.exists(build.build_ext())
+    m = hv_cuda_ext.load()
+    assert m.__name__ == "hv_cuda" and m.abi_version() == _lib.lib().cv_abi_version()
+    assert m.__file__.endswith(".so") and os.path.dirname(m.__file__) == os.path.dirname(built_lib)      # in-tree, next to libcvhip.so
+    p, s = torch.rand(10, 3), torch.rand(10)
+    res, rots = torch.tensor(0.03), torch.tensor(120, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="points must be a CUDA tensor"):
+        m.forward(p, p, p, s, res, rots)
+    with pytest.raises(RuntimeError, match="grad_grid must be a CUDA tensor"):
+        m.backward(torch.zeros(2, 2, 2), p, p, p, s, res, rots)
+    import inspect
+    doc = m.forward.__doc__
+    for name in ("points", "xyz_labels", "scale_labels", "obj_labels", "res", "num_rots"):      # hv_cuda.cpp:30-36 order
+        assert name in doc
+    assert doc.index("points") < doc.index("xyz_labels") < doc.index("scale_labels") < doc.index("obj_labels") < doc.index("num_rots")
+    assert inspect.ismodule(hv_cuda_ext.install()) and __import__("hv_cuda") is m
+    import sys
+    del sys.modules["hv_cuda"]

@@ -382,3 +382,67 @@ def test_briefly_trained_network_stays_on_fp16_pairs_and_within_the_bar(cuda, bu
     print("trained-network activations: largest conv input %.3g over %d ReLUs; loss %.3f -> %.3f; max |out - oracle| %.2e"
           % (max(peaks), len(peaks), np.mean(hist[:3]), np.mean(hist[-10:]), np.abs(out - ref).max()))
     assert np.abs(out - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def _rccl_one_rank_worker(port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from canonicalvoting_amd import train
+    from canonicalvoting_amd.minkunet import MinkUNet34C
+    from canonicalvoting_amd.synth import make_scene
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    sc = make_scene(41, n_points=1500, res=0.06, room=(1.5, 0.9, 1.5), n_boxes=2, margin=0.5, box_scale=0.4)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    c = torch.cat([torch.zeros((1500, 1), dtype=torch.int32), torch.from_numpy(sc.coords).int()], 1).to(dev)
+    data = (c, t(sc.feats) * 2 - 1, t(sc.xyz_labels), t(sc.scale_labels), t(sc.class_labels))
+
+    def two_steps(wrap):
+        torch.manual_seed(0)
+        model = MinkUNet34C(3, 64).cuda().train()
+        net = wrap(model)
+        opt = train.make_optimizer(model)
+        losses = [float(train.train_step(net, opt, *data)[0]) for _ in range(2)]
+        torch.cuda.synchronize()
+        # gradients of the second step + the weights after it
+        return losses, {n: p.grad.detach().clone() for n, p in model.named_parameters()}, \
+            {n: p.detach().clone() for n, p in model.named_parameters()}
+
+    plain = two_steps(lambda m: m)                       # before any process group exists: the non-DDP step
+    dist.init_process_group("nccl", world_size=1, rank=0, device_id=dev)       # RCCL (backend "nccl" on ROCm)
+    probe = torch.ones(4, device=dev)
+    dist.all_reduce(probe)                               # librccl loaded, a communicator created, a collective run
+    torch.cuda.synchronize()
+    ddp = two_steps(lambda m: train.make_ddp(m, dev))
+    backend = dist.get_backend()
+    dist.barrier()
+    dist.destroy_process_group()
+    bad = [n for n in plain[1] if not torch.equal(plain[1][n], ddp[1][n])]
+    badw = [n for n in plain[2] if not torch.equal(plain[2][n], ddp[2][n])]
+    loaded = [ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln]
+    q.put({"backend": backend, "losses": (plain[0], ddp[0]), "grad_diff": bad[:5], "n_grad_diff": len(bad),
+           "n_weight_diff": len(badw), "rccl": sorted(set(loaded))[:2], "probe": float(probe.sum())})
+
+
+def test_rccl_one_rank_ddp_equals_the_plain_step_bit_for_bit(cuda, built_lib):
+    """RCCL at least once, on the one GPU there is.  A single-rank `nccl` (= RCCL) process group,
+    train.make_ddp, two HIP training steps: librccl is mapped, DDP's bucket views and the reducer's hooks work with the
+    custom autograd Functions (and with the side-stream weight gradients: a process group switches the late join off),
+    and every gradient and every updated weight equals the non-DDP run bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(port, q))
+    p.start()
+    got = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert got["backend"] == "nccl" and got["rccl"], got
+    assert got["probe"] == 4.0
+    assert got["losses"][0] == got["losses"][1], got
+    assert got["n_grad_diff"] == 0 and got["n_weight_diff"] == 0, got

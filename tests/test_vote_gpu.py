@@ -280,3 +280,59 @@ def test_production_size_grids_are_the_same_bits_on_every_run(cuda, built_lib, p
                 assert torch.equal(x, y), "grid_%s differs on repetition %d (%d cells)" % (name, rep, int((x != y).sum()))
     torch.cuda.synchronize()
     assert float(first[0].max()) > 60.0                # peaked maps: the hot planes that get split exist
+
+
+def test_compiled_extension_equals_the_ctypes_module_and_the_goldens(cuda, built_lib):
+    """the compiled `hv_cuda` (csrc/hv_cuda_ext.cpp) and the ctypes `hv_cuda` call the same C ABI: forward and backward
+    bit-identical on a seeded scene, incl. the 7-argument corners variant, on a non-default stream; the reference's error
+    strings; and eval_joint.py's HVFunction / HoughVoting (lines 24-57) run unchanged over it."""
+    from canonicalvoting_amd import hv_cuda_ext
+    ext = hv_cuda_ext.load()
+    sc = make_scene(5, n_points=6000)
+    xyz, scale, prob, _ = synth_predictions(sc)
+    args = dev_inputs(cuda, sc.points, xyz, scale, prob)
+    hv = HoughVoting(sc.res, 120)
+    with torch.no_grad():
+        want = hv_cuda.forward(*args, hv.res, hv.num_rots)
+        got = ext.forward(*args, hv.res, hv.num_rots)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            got_side = ext.forward(*args, hv.res, hv.num_rots)
+        side.synchronize()
+    for a, b, c in zip(want, got, got_side):
+        assert a.shape == b.shape and torch.equal(a, b) and torch.equal(a, c)
+    assert got[0].data_ptr() != want[0].data_ptr() and got[0].is_contiguous()
+    ref = oracle.hv_forward(sc.points, xyz, scale, prob, sc.res, 120)
+    assert_grids_close([g.cpu().numpy() for g in got], ref, "compiled ext", inputs=(sc.points, xyz, scale, sc.res, 120))
+    gg = torch.rand_like(want[0])
+    for a, b in zip(hv_cuda.backward(gg, *args, hv.res, hv.num_rots), ext.backward(gg, *args, hv.res, hv.num_rots)):
+        assert torch.equal(a, b)
+    corners = torch.from_numpy(np.stack([sc.points.min(0) - 0.2, sc.points.max(0) + 0.3]).astype(np.float32)).to(cuda)
+    for a, b in zip(hv_cuda.forward(*args, hv.res, hv.num_rots, corners), ext.forward(*args, hv.res, hv.num_rots, corners)):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="xyz_labels must be contiguous"):
+        ext.forward(args[0], torch.rand(3, len(sc.points), device=cuda).t(), args[2], args[3], hv.res, hv.num_rots)
+    with pytest.raises(RuntimeError, match="res must be a CUDA tensor"):
+        ext.forward(*args, hv.res.cpu(), hv.num_rots)
+    with pytest.raises(RuntimeError):
+        ext.forward(args[0][:0], args[1][:0], args[2][:0], args[3][:0], hv.res, hv.num_rots)
+
+    # the reference's autograd wrapper, as written at eval_joint.py:24-38, over the compiled module
+    class HVFunction(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, points, xyz_labels, scale_labels, obj_labels, res, num_rots):
+            outputs = ext.forward(points, xyz_labels, scale_labels, obj_labels, res, num_rots)
+            ctx.save_for_backward(points, xyz_labels, scale_labels, obj_labels, res, num_rots)
+            return tuple(outputs)
+
+        @staticmethod
+        def backward(ctx, grad_obj, grad_rot, grad_scale):
+            d = ext.backward(grad_obj.contiguous(), *ctx.saved_tensors)
+            return None, d[0], d[1], d[2], None, None
+
+    x = args[1].clone().requires_grad_(True)
+    HVFunction.apply(args[0], x, args[2], args[3], hv.res, hv.num_rots)[0].sum().backward()
+    x2 = args[1].clone().requires_grad_(True)
+    hv(args[0], x2, args[2], args[3])[0].sum().backward()
+    assert torch.equal(x.grad, x2.grad)
