@@ -113,6 +113,9 @@ def parse():
                     help="what vote + decode are fed with (see the module docstring); the network forward and the head "
                          "kernel run and are timed either way")
     ap.add_argument("--teacher-forced", action="store_true", help="same as --predictions teacher (kept for old scripts)")
+    ap.add_argument("--ablate", default="", help="timing ablations, WRONG results, never for a reported number: comma list of "
+                                                  "`finish` (cv_sp_set_ablation bit 0, switched on after the warm-up), `novote`, "
+                                                  "`nodecode` (the stage is skipped in every step)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launch-path check without a GPU: parse, rendezvous (CV_DIST_BACKEND=gloo on CPU), barrier, "
                          "max-reduce, print the JSON skeleton")
@@ -179,6 +182,9 @@ def step_events():
     return evs
 
 
+ABLATE = ()
+
+
 def run_step(model, hv, s, ev=None, teacher=False, keep=None):
     """One scene through eval_joint.py:163-280: network -> head -> vote -> decode -> per-class NMS.
     keep: optional dict that receives the device tensors of the step (the parity check reads them)."""
@@ -198,6 +204,10 @@ def run_step(model, hv, s, ev=None, teacher=False, keep=None):
         if model is None or teacher:
             xyz, scale, prob, cls = s.xyz, s.scale, s.prob, s.cls
         rec(2)
+        if "novote" in ABLATE:
+            for i in (3, 4):
+                rec(i)
+            return [], {}
         if ev is not None and len(ev) > 6:
             _lib.lib().cv_hv_set_kernel_events(ev[5].cuda_event, ev[6].cuda_event)
         try:
@@ -206,6 +216,9 @@ def run_step(model, hv, s, ev=None, teacher=False, keep=None):
             if ev is not None and len(ev) > 6:
                 _lib.lib().cv_hv_set_kernel_events(None, None)
         rec(3)
+    if "nodecode" in ABLATE:
+        rec(4)
+        return [], {}
     raw = decode.decode_boxes(grid_obj, grid_rot, grid_scale, s.points, xyz, prob, cls, RES)
     rec(4)
     if model is not None and model.check_range(x, y) is not y:
@@ -555,8 +568,9 @@ def main():
     import itertools
     import threading
     sys.setswitchinterval(a.switch_interval)      # GIL hand-off between the scene threads
-    global KERNEL_EVENTS
+    global KERNEL_EVENTS, ABLATE
     KERNEL_EVENTS = bool(a.kernel_events)
+    ABLATE = tuple(x for x in a.ablate.split(",") if x)
     every = max(1, a.event_every)
     events = [step_events() if k % every == 0 else None for k in range(a.steps)]
     counts = [0] * S
@@ -590,6 +604,8 @@ def main():
                     warm_steps[i] += 1
                     j += 1
                 streams[i].synchronize()
+                if i == 0 and "finish" in ABLATE:
+                    _lib.lib().cv_sp_set_ablation(1)
                 gate.wait()
                 if a.stagger_us > 0 and i > 0:
                     time.sleep(i * a.stagger_us * 1e-6)
@@ -732,7 +748,8 @@ def main():
                    "points": a.points, "num_rots": NUM_ROTS, "res": RES, "grid": s0.dims,
                    "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}.get(a.algo, "ablation-%d" % a.algo),
                    "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": S,
-                   "conv_split_target": split_target or 512},
+                   "conv_split_target": split_target or 512,
+                   **({"ablate": a.ablate, "INVALID": "timing ablation: results are wrong, not a reportable number"} if a.ablate else {})},
         "roofline": {"bound": "hbm",
                      "kernel": "hv_fwd_tiles (the accumulation kernel of cv_hv_forward_f32)" if kernel_timed
                                else "vote op (all launches of cv_hv_forward_f32)",

@@ -265,9 +265,9 @@ int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int 
     int32_t* tickets = nullptr;
     size_t conv_ws_bytes = ws_bytes;
     const size_t ticket_bytes = sizeof(int32_t) * CV_SPLIT_TICKETS;
-    // OFF unless CV_HL_FUSE_FINISH=1: measured 2.50 -> 3.79 ms per forward (the per-workgroup agent-scope release writes
-    // the whole L2 of the XCD back), profiles/r2/fused_finish.txt
-    static const bool fuse_on = getenv("CV_HL_FUSE_FINISH") && atoi(getenv("CV_HL_FUSE_FINISH")) != 0;
+    // ON since round 4 (CV_HL_FUSE_FINISH=0 restores the finish launches): the partial tiles are published with write-through
+    // stores (round 2's release-fence version cost 2.50 -> 3.79 ms per forward, profiles/r2/fused_finish.txt)
+    static const bool fuse_on = !(getenv("CV_HL_FUSE_FINISH") && atoi(getenv("CV_HL_FUSE_FINISH")) == 0);
     if (fuse_on && d_ws && ws_bytes > ((size_t)1 << 20) + ticket_bytes) {
         conv_ws_bytes = (ws_bytes - ticket_bytes) & ~(size_t)255;
         tickets = reinterpret_cast<int32_t*>(static_cast<char*>(d_ws) + conv_ws_bytes);

@@ -1142,17 +1142,17 @@ __launch_bounds__(NW * 64, hl_blocks(NB, NS, NW)) void conv_hl(ConvArgs a) {
     for (int nb = 0; nb < NB; ++nb) epilogue_store_wide(a, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep);
     if (a.splits > 1 && a.tickets) {
         // split-K without a second launch: every workgroup of an output tile publishes its partial tile, the LAST one to
-        // arrive sums the partial tiles in split order and runs the epilogue (plain stores -> per-wave vmcnt(0) -> barrier
-        // -> one-lane agent release -> ticket; the last arriver's agent acquire -> plain loads: the hot-plane merge of
-        // hv_vote.hip).  Summation order = conv_finish's (four running sums over the splits k % 4, then ((s0 + s1) + s2)
-        // + s3): bit-identical to the two-launch path.  The last arriver leaves the counter at zero for the next launch.
+        // arrive sums the partial tiles in split order and runs the epilogue.  Publish = write-through (sc1) stores in the
+        // epilogue above -> per-wave vmcnt(0) -> barrier -> one relaxed agent-scope ticket; the last arriver's agent acquire
+        // (an L1 invalidate) -> plain loads.  No release fence: the stores are already past the L2 (round 2 published with
+        // plain stores + an agent release per workgroup and ran 50 % slower, profiles/r2/fused_finish.txt).
+        // Summation order = conv_finish's (four running sums over the splits k % 4, then ((s0 + s1) + s2) + s3):
+        // bit-identical to the two-launch path.  The last arriver leaves the counter at zero for the next launch.
         __shared__ int last_flag;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int* ticket = a.tickets + tile_id * gridDim.y + blockIdx.y;
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int old = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last_flag = old == a.splits - 1;
             if (last_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1791,7 +1791,9 @@ __global__ __launch_bounds__(256) void conv_finish_scalar(ConvArgs a) {
 
 }  // namespace
 namespace cvsc {
+std::atomic<int> g_ablation{0};
 int launch_finish(const ConvArgs& a, hipStream_t st) {
+    if (g_ablation.load(std::memory_order_relaxed) & 1) return CV_OK;      // cv_sp_set_ablation: timing only
     const long long total = a.n_out * (long long)a.cout;
     if (a.wide && a.splits <= FINISH_SMALL_MAX)
         conv_finish_small<<<(unsigned)std::min<long long>((total / 4 + 255) / 256, 16384), 256, 0, st>>>(a);
@@ -2451,6 +2453,8 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
 
 }  // namespace
 
+int cv_sp_set_ablation(int bits) { return cvsc::g_ablation.exchange(bits, std::memory_order_relaxed); }
+
 int cv_sp_set_split_target(int workgroups) {
     const int before = (int)split_target();
     g_split_target.store(workgroups > 0 ? workgroups : -1, std::memory_order_relaxed);
@@ -2544,6 +2548,7 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         static const int dbg = getenv("CV_CONV_DBG") ? atoi(getenv("CV_CONV_DBG")) : 0;
         a.dbg = dbg;
     }
+    if (!d->in_hl) a.tickets = nullptr;       // the in-launch split-K reduction exists in conv_hl only
     CV_REQUIRE(!d->plan_ent == !d->plan_cnt, CV_EINVAL, "plan_ent and plan_cnt go together");
     a.wide = d->cout % 4 == 0 && d->out_ld % 4 == 0 && (!d->residual || d->res_ld % 4 == 0) &&
              (!d->acc_in || d->acc_ld % 4 == 0) &&

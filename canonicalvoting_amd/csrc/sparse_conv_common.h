@@ -96,6 +96,14 @@ __device__ __forceinline__ void partial_store4(float* p, float4 v) {
         *reinterpret_cast<float4*>(p) = v;
     }
 }
+// split-K partial tiles that the LAST-ARRIVING workgroup of the output tile reduces inside the same launch
+// (ConvArgs.tickets): written through to memory with sc1 stores - visible to every XCD once the wave's vmcnt has drained,
+// no agent-scope release (whose buffer_wbl2 writes the whole XCD's dirty L2 back: round 2's version of this path ran the
+// forward 50 % slower for it).  The statement ends with s_nop 1: hipcc does not know the store still reads its registers.
+__device__ __forceinline__ void partial_store4_wt(float* p, float4 v) {
+    f32x4v t; t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(t) : "memory");
+}
 __device__ __forceinline__ float4 partial_load4(const float4* p) {
     if (CV_NT_PARTIAL & 2) {
         const f32x4v t = __builtin_nontemporal_load(reinterpret_cast<const f32x4v*>(p));
@@ -177,7 +185,9 @@ __device__ __forceinline__ void epilogue_store_wide(const ConvArgs& a, const f32
             if (row < 0) continue;
             float4 v = *reinterpret_cast<const float4*>(&T[rl][(lane & 7) * 4]);
             if (a.splits > 1) {
-                partial_store4(a.partial + ((long long)blockIdx.z * a.n_out + row) * a.cout + col, v);
+                float* pp = a.partial + ((long long)blockIdx.z * a.n_out + row) * a.cout + col;
+                if (a.tickets) partial_store4_wt(pp, v);
+                else partial_store4(pp, v);
                 continue;
             }
             epilogue_apply4(a, row, col, v);

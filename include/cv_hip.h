@@ -288,6 +288,10 @@ int cv_sp_conv_f32(const cv_conv_desc* desc, void* stream);
  * value.  Process-wide; set it before launching, not concurrently with cv_sp_conv_f32 / cv_sp_net_forward callers that
  * need one fixed value.  (No reference counterpart: MinkowskiEngine's launch sizes are internal.) */
 int cv_sp_set_split_target(int workgroups);
+/* Measurement hook (no reference counterpart; results are WRONG while a bit is set): timing ablations that can be switched
+ * at run time, after a warm-up has filled every buffer with valid values.  bit 0: the finish launches of the split / mask-group
+ * convolutions are skipped (what the partial-tile reductions cost with scenes in flight).  Returns the previous bits. */
+int cv_sp_set_ablation(int bits);
 
 /* Every kernel map and processing order the fused MinkUNet forward needs, built by ONE call per scene into one
  * int32 arena (offsets in int32 words; -1 = absent):
