@@ -16,8 +16,8 @@
 #include <torch/extension.h>
 
 #include <ATen/hip/HIPContext.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <hip/hip_runtime.h>
 
 #include <mutex>
@@ -137,8 +137,10 @@ std::vector<torch::Tensor> hv_forward(torch::Tensor points, torch::Tensor xyz_la
                                       torch::Tensor obj_labels, torch::Tensor res, torch::Tensor num_rots,
                                       c10::optional<torch::Tensor> corners) {
     CHECK_CUDA(points);
-    const c10::hip::HIPGuard guard(points.device());
-    hipStream_t st = c10::hip::getCurrentHIPStream(points.device().index()).stream();
+    // (PyTorch-ROCm presents HIP devices under the "cuda" device type: the guard and stream accessors that accept it are
+    // the ...MasqueradingAsCUDA ones; this is what at::cuda::CUDAGuard / getCurrentCUDAStream hipify to)
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(points.device());
+    hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(points.device().index()).stream();
     Checked c = checked_inputs(points, xyz_labels, scale_labels, obj_labels, res, num_rots, !corners.has_value(), st);
     if (corners.has_value()) box_from_corners(*corners, c.mn, c.mx);
     int dims[3];
@@ -164,8 +166,8 @@ std::vector<torch::Tensor> hv_backward(torch::Tensor grad_grid, torch::Tensor po
     CHECK_INPUT(grad_grid);
     CHECK_CUDA(points);
     TORCH_CHECK(grad_grid.scalar_type() == torch::kFloat32 && grad_grid.dim() == 3, "grad_grid must be a float32 [X,Y,Z] tensor");
-    const c10::hip::HIPGuard guard(points.device());
-    hipStream_t st = c10::hip::getCurrentHIPStream(points.device().index()).stream();
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(points.device());
+    hipStream_t st = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(points.device().index()).stream();
     // the grid origin is recomputed from the points (hv_cuda_kernel.cu:274-276), the sizes come from grad_grid (:200)
     Checked c = checked_inputs(points, xyz_labels, scale_labels, obj_labels, res, num_rots, !corners.has_value(), st);
     if (corners.has_value()) box_from_corners(*corners, c.mn, c.mx);
