@@ -714,11 +714,13 @@ def main():
     s0 = scenes[0]
     # HBM bytes of the vote kernel from the PMC counters are collected offline (rocprofv3 --pmc in its
     # own passes, profiles/r*/vote_hbm_traffic.json) for the default 80k workload; null otherwise
-    traffic = None
-    for rnd in ("r3", "r2", "r1"):
+    traffic = traffic_source = None
+    for rnd in ("r4", "r3", "r2", "r1"):
         tj = os.path.join(ROOT, "profiles", rnd, "vote_hbm_traffic.json")
         if os.path.exists(tj) and a.points == N_POINTS and not a.large and a.algo in (0, 2):
             traffic = json.load(open(tj))["hbm_bytes_per_launch"]
+            traffic_source = "file: profiles/%s/vote_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, " \
+                             "profiles/vote_pmc.sh; not measured by this run)" % rnd
             break
     conv_peak = 2500.0 if a.dtype == "bf16" else 157.3       # dense bf16 / fp32 matrix peak, TFLOP/s
     pieces_n = 1 if a.dtype == "bf16" else 3 if (full and model.USE_PROGRAM and model.PIECES == 2) else 6
@@ -754,7 +756,10 @@ def main():
                      "kernel": "hv_fwd_tiles (the accumulation kernel of cv_hv_forward_f32)" if kernel_timed
                                else "vote op (all launches of cv_hv_forward_f32)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     # what the kernel really moves through HBM per second, against the peak (the scatter itself stays in LDS)
+                     "real_hbm_frac": (traffic / (float(vote_ms.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "isolated_real_hbm_frac": (traffic / (iso_vote * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and iso_vote) else None,
                      "avg_ms": float(vote_ms.mean()), "bytes_per_launch": float(vb.mean()),
                      "compulsory_bytes": float(s0.vote_bytes_floor), "v_in": s0.v_in,
                      "measured_in": "the timed region (HIP events %s, on the scene's stream, %d scene%s in flight)"

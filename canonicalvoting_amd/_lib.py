@@ -106,6 +106,7 @@ SIGNATURES = {
     "cv_sp_conv_f32": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp]),
     "cv_sp_set_split_target": (ctypes.c_int, [ctypes.c_int]),
     "cv_sp_set_ablation": (ctypes.c_int, [ctypes.c_int]),
+    "cv_sp_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
     "cv_sp_tile_plan_ints": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
     "cv_sp_tile_plan": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, vp, vp, vp]),
     "cv_sp_pack_weights_x6_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),

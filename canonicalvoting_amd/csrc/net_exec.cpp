@@ -265,9 +265,12 @@ int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int 
     int32_t* tickets = nullptr;
     size_t conv_ws_bytes = ws_bytes;
     const size_t ticket_bytes = sizeof(int32_t) * CV_SPLIT_TICKETS;
-    // ON since round 4 (CV_HL_FUSE_FINISH=0 restores the finish launches): the partial tiles are published with write-through
-    // stores (round 2's release-fence version cost 2.50 -> 3.79 ms per forward, profiles/r2/fused_finish.txt)
-    static const bool fuse_on = !(getenv("CV_HL_FUSE_FINISH") && atoi(getenv("CV_HL_FUSE_FINISH")) == 0);
+    // OFF unless CV_HL_FUSE_FINISH=1.  Round 2 published with plain stores + an agent-scope release per workgroup: 2.50 -> 3.79 ms
+    // per forward.  Round 4 publishes write-through (sc1 stores, no release fence): the publish is cheap now, but the LAST
+    // ARRIVER reads splits x 32 KB alone (~65 GB/s per workgroup): one scene in flight 2.43 -> 3.21 ms per forward (16-32
+    // splits), eight in flight 555 -> 545 scenes/s (2-8 splits) - profiles/r4/throughput_ablations.txt.  A finish launch
+    // spreads the same reads over the chip.
+    static const bool fuse_on = getenv("CV_HL_FUSE_FINISH") && atoi(getenv("CV_HL_FUSE_FINISH")) != 0;
     if (fuse_on && d_ws && ws_bytes > ((size_t)1 << 20) + ticket_bytes) {
         conv_ws_bytes = (ws_bytes - ticket_bytes) & ~(size_t)255;
         tickets = reinterpret_cast<int32_t*>(static_cast<char*>(d_ws) + conv_ws_bytes);

@@ -28,6 +28,7 @@
 #include "cv_common.h"
 
 #include <atomic>
+#include <cstring>
 #include <type_traits>
 #include <utility>
 
@@ -1189,6 +1190,309 @@ __launch_bounds__(NW * 64, hl_blocks(NB, NS, NW)) void conv_hl(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ hl convolution fed by LDS-DMA rings (round 4)
+// What the timing ablations of round 4 say binds the throughput with eight scenes in flight (profiles/r4/
+// throughput_ablations.txt): conv_hl's row gathers (21 % of the scene rate: the vector cache's address pipe takes one
+// lane per clock when every lane of a load sits on its own 128-byte line - 187 M lane-loads per scene = 0.30 ms of every
+// CU), its weight tiles (0.21 ms) and the partial-tile machinery - not the matrix pipe (7 %).  conv_hd keeps conv_hl's
+// units, MFMA sequence and epilogue (bit-identical accumulators) and changes how the operands travel:
+//  * 8 waves x 32 rows = 256 rows per workgroup: a unit's weight tile is fetched once per 256 rows instead of per 128;
+//  * both operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, asynchronous): the gathered rows
+//    line-coalesced - 8 lanes fetch the 8 x 16-byte pieces of one row's 128-byte chunk, 8 rows per instruction - into a
+//    wave-private [32 rows][128 B] image whose pieces are XOR-swizzled on the SOURCE side (the DMA writes lane-linear) so
+//    that the b128 fragment reads are conflict-free; the weight tile in the layout conv_hl stages by hand;
+//  * a ring of three stages (3 x 44 KB at 96 columns): the operands of units k + 1 and k + 2 are in flight while unit k
+//    multiplies; one workgroup barrier per unit (weight tile visible + the stage of unit k - 1 free), waits by counted
+//    vmcnt (the LDS-DMA instructions a wave issued for the units behind the one it needs stay in flight);
+//  * the accumulators are the only long-lived registers: one workgroup of 8 waves per CU (LDS-bound), two waves per SIMD.
+// Dead rows of a live wave fetch a row of zeros (one line, all lanes); dead waves issue nothing for the unit.
+__device__ __attribute__((aligned(128))) unsigned char g_zero_chunk[128];
+#ifndef CV_HD_ABL
+#define CV_HD_ABL 0
+#endif
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {      // n is wave-uniform, 0 ... 6
+    switch (n) {
+        case 0: wait_vmcnt_le<0>(); break;
+        case 1: wait_vmcnt_le<1>(); break;
+        case 2: wait_vmcnt_le<2>(); break;
+        case 3: wait_vmcnt_le<3>(); break;
+        case 4: wait_vmcnt_le<4>(); break;
+        case 5: wait_vmcnt_le<5>(); break;
+        default: wait_vmcnt_le<6>(); break;
+    }
+}
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// one LDS-DMA request: every lane's 16 bytes at g land at l + 16 * lane (l wave-uniform).  A plain device function: inside a
+// generic lambda the builtin keeps hipcc's host pass from emitting the kernel's launch stub.
+__device__ __forceinline__ void lds_dma16(const void* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)l, 16, 0, 0);
+}
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+// MFMA fragments of one k-step out of a ring stage: A high / low piece of the lane's row, NB x (high, low) weight pieces.
+// Inline asm (and a plain device function, not a lambda: the host pass must not meet the register constraints): hipcc
+// orders every LDS read that may alias an LDS-DMA destination behind vmcnt(0) - it would drain the requests of units k + 1
+// and k + 2 in front of unit k's MFMAs.  The waits that matter are conv_hd's counted vmcnt and its workgroup barrier.
+template <int NB>
+__device__ __forceinline__ void hd_read_frags(unsigned aa0, unsigned aa1, unsigned ab, u32x4v& A0, u32x4v& A1,
+                                              u32x4v (&B0)[NB], u32x4v (&B1)[NB]) {
+    constexpr int P1 = NB * 32 * 64;                            // low-piece plane of the weight tile
+    if constexpr (NB == 1) {
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %6 offset:%7\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(A0), "=&v"(A1), "=&v"(B0[0]), "=&v"(B1[0])
+                     : "v"(aa0), "v"(aa1), "v"(ab), "i"(P1) : "memory");
+    } else if constexpr (NB == 2) {
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %8 offset:%9\n\t"
+                     "ds_read_b128 %4, %8 offset:%10\n\tds_read_b128 %5, %8 offset:%11\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(A0), "=&v"(A1), "=&v"(B0[0]), "=&v"(B1[0]), "=&v"(B0[1]), "=&v"(B1[1])
+                     : "v"(aa0), "v"(aa1), "v"(ab), "i"(P1), "i"(2048), "i"(P1 + 2048) : "memory");
+    } else {
+        static_assert(NB == 3, "conv_hd: 32, 64 or 96 columns per workgroup");
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %10 offset:%11\n\t"
+                     "ds_read_b128 %4, %10 offset:%12\n\tds_read_b128 %5, %10 offset:%13\n\t"
+                     "ds_read_b128 %6, %10 offset:%14\n\tds_read_b128 %7, %10 offset:%15\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(A0), "=&v"(A1), "=&v"(B0[0]), "=&v"(B1[0]), "=&v"(B0[1]), "=&v"(B1[1]), "=&v"(B0[2]), "=&v"(B1[2])
+                     : "v"(aa0), "v"(aa1), "v"(ab), "i"(P1), "i"(2048), "i"(P1 + 2048), "i"(4096), "i"(P1 + 4096) : "memory");
+    }
+}
+template <int NB>
+__global__ __launch_bounds__(512, 2) void conv_hd(ConvArgs a) {
+    constexpr int NW = 8, TMv = NW * 32, THv = NW * 64, NSTG = 3;
+    constexpr int A_BYTES = NW * 4096, B_BYTES = 2 * NB * 32 * 64, STAGE = A_BYTES + B_BYTES;
+    constexpr int B_INSTR = B_BYTES / 1024;                         // 1 KB (64 lanes x 16 B) per LDS-DMA instruction
+    constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
+    constexpr int EP_BYTES = NW * 32 * EP_LD * 4;
+    static_assert(EP_BYTES <= NSTG * STAGE, "the epilogue tile aliases the ring");
+    constexpr int OFF_ROWS = NSTG * STAGE, OFF_NBR = OFF_ROWS + TMv * 4, OFF_MASK = OFF_NBR + (WP_NPRE + 1) * TMv * 4,
+                  OFF_UNITS = OFF_MASK + NW * 4, LDS_TOTAL = OFF_UNITS + (HL_MAX_UNITS + 4) * 2;
+    static_assert(LDS_TOTAL <= 160 * 1024, "one workgroup per CU");
+    // ONE __shared__ object (a second one makes hipcc drain vmcnt in front of the LDS reads of an LDS-DMA pipeline)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_TOTAL];
+    unsigned char* const sm = lds;
+    int* const rows_s = reinterpret_cast<int*>(lds + OFF_ROWS);
+    int (*const nbr_all)[TMv] = reinterpret_cast<int (*)[TMv]>(lds + OFF_NBR);
+    unsigned* const wave_mask = reinterpret_cast<unsigned*>(lds + OFF_MASK);
+    unsigned short* const units_s = reinterpret_cast<unsigned short*>(lds + OFF_UNITS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.y * (NB * 32);
+    const long long tile_id = xcd_tile(a);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nj = a.j_end - a.j_begin;
+    const int nch = a.cin / KC;
+    int u_lo, u_hi;
+    if (a.perm_per_split) {
+        u_lo = (int)((long long)nj * blockIdx.z / a.splits) * nch;
+        u_hi = (int)((long long)nj * (blockIdx.z + 1) / a.splits) * nch;
+    } else {
+        u_lo = (int)((long long)nj * nch * blockIdx.z / a.splits);
+        u_hi = (int)((long long)nj * nch * (blockIdx.z + 1) / a.splits);
+    }
+    const int j_first = a.j_begin + u_lo / nch, j_last = a.j_begin + (u_hi - 1) / nch;
+    const int njl = u_hi > u_lo ? j_last - j_first + 1 : 0;       // <= WP_NPRE (host)
+    const int nch2 = a.in2 ? a.cin2 / KC : 0;
+
+    // ---- tile set-up as conv_hl: processing order, map entries of the workgroup's offsets, live-unit list
+    const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)blockIdx.z * a.n_out : 0) : nullptr;
+    if (tid < TMv) {
+        const long long t = tile_id * TMv + tid;
+        const int row = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
+        rows_s[tid] = row;
+        if (a.in2) nbr_all[njl][tid] = row;
+    }
+    {
+        unsigned m = 0u;
+        const int jg0 = a.j_begin + (int)((long long)nj * blockIdx.z / a.splits);      // first offset of this mask group
+        for (int e = tid; e < njl * TMv; e += THv) {
+            const int jj = e / TMv, t = e - jj * TMv;
+            const long long pos = tile_id * TMv + t;
+            int v = -1;
+            if (pos < a.n_out) {
+                if (a.nbr_perm) {
+                    v = a.nbr_perm[((long long)blockIdx.z * a.n_out + pos) * a.nbr_perm_w + (j_first + jj - jg0)];
+                } else {
+                    const int row = perm ? perm[pos] : (int)pos;
+                    v = a.nbr ? a.nbr[(long long)row * a.K + j_first + jj] : row;
+                }
+            }
+            nbr_all[jj][t] = v;
+            if (v >= 0) m |= 1u << jj;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m |= __shfl_xor(m, off);
+        if (lane == 0) wave_mask[wave] = m;
+    }
+    __syncthreads();
+    unsigned lm = 0u;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) lm |= wave_mask[w];
+    if (wave == 0) {
+        const int n_first = u_hi - u_lo, n_second = nch2 > (int)blockIdx.z ? (nch2 - (int)blockIdx.z + a.splits - 1) / a.splits : 0;
+        int cnt = 0;
+        for (int base = 0; base < n_first + n_second; base += 64) {
+            const int e = base + lane;
+            int code = -1;
+            if (e < n_first) {
+                const int u = u_lo + e, q = u / nch;
+                const int jj = a.j_begin + q - j_first;
+                if ((lm >> jj) & 1u) code = (jj << 8) | (u - q * nch);
+            } else if (e < n_first + n_second) {
+                code = (njl << 8) | ((int)blockIdx.z + (e - n_first) * a.splits);
+            }
+            const unsigned long long bal = __ballot(code >= 0);
+            if (code >= 0) units_s[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)code;
+            cnt += __popcll(bal);
+        }
+        if (lane == 0) units_s[HL_MAX_UNITS] = (unsigned short)cnt;
+    }
+    __syncthreads();
+    const int n_units = __builtin_amdgcn_readfirstlane((int)units_s[HL_MAX_UNITS]);
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    // ---- per-thread invariants of the LDS-DMA requests
+    // weight tile: instruction t (1 KB) covers pieces f = t * 64 + lane of the [plane][col][4 slots] image; slot s of column
+    // col holds the slab's 16-byte piece s ^ ((col >> 2) & 3) (the swizzle conv_hl applies when it stages by hand)
+    int b_src[B_PER_WAVE];                                          // offset inside a unit's slab in 16-bit words
+#pragma unroll
+    for (int i = 0; i < B_PER_WAVE; ++i) {
+        const int t = wave + i * NW;
+        const int f = t * 64 + lane;
+        const int pl = f / (NB * 32 * 4), rem = f - pl * (NB * 32 * 4);
+        const int col = rem >> 2, slot = rem & 3;
+        const int gc = min(n0 + col, a.cout - 1);                   // columns beyond Cout are never stored
+        b_src[i] = (pl * a.cout + gc) * 32 + ((slot ^ ((col >> 2) & 3)) << 3);
+    }
+    const unsigned slab_words = 2u * (unsigned)a.cout * 32u;
+    const unsigned in_row_bytes = (unsigned)a.in_ld * 4u, in2_row_bytes = (unsigned)a.in2_ld * 4u;
+    const unsigned char* const in_b = reinterpret_cast<const unsigned char*>(a.in);
+    const unsigned char* const in2_b = reinterpret_cast<const unsigned char*>(a.in2);
+    // gathered rows: instruction q covers rows 8 q + (lane >> 3) of the wave, LDS slot lane & 7 of the row receives its
+    // piece (lane & 7) ^ ((row >> 1) & 7)
+    const int a_row = lane >> 3;
+    unsigned a_piece[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a_piece[q] = (unsigned)(((lane & 7) ^ (((8 * q + a_row) >> 1) & 7)) << 4);
+
+    bool live[NSTG];
+#pragma unroll
+    for (int q = 0; q < NSTG; ++q) live[q] = false;
+
+    // requests of unit k into ring stage S; returns the number of LDS-DMA instructions this wave issued
+    auto issue = [&](auto S, int k) -> int {
+        constexpr int st = decltype(S)::value;
+        const int code = __builtin_amdgcn_readfirstlane((int)units_s[k]);
+        const int jj = code >> 8, c = code & 255;
+        const bool second = jj == njl;
+        int n_issued = 0;
+        int src[4];
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            src[q] = nbr_all[jj][wave * 32 + 8 * q + a_row];
+            any |= src[q] >= 0;
+        }
+        const bool lv = __any(any);
+        live[st] = lv;
+        if (lv && !(CV_HD_ABL & 1)) {
+            const unsigned rb_ = second ? in2_row_bytes : in_row_bytes;
+            const unsigned char* const base = (second ? in2_b : in_b) + (unsigned)(c * 128);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned char* g = src[q] >= 0 ? base + ((unsigned)src[q] * rb_ + a_piece[q]) : g_zero_chunk + a_piece[q];
+                lds_dma16(g, sm + st * STAGE + wave * 4096 + q * 1024);
+            }
+            n_issued += 4;
+        }
+        const unsigned short* slab = second ? a.wp6_2 + (size_t)c * slab_words
+                                            : a.wp6 + (size_t)((j_first + jj) * nch + c) * slab_words;
+#pragma unroll
+        for (int i = 0; i < B_PER_WAVE; ++i) {
+            const int t = wave + i * NW;                            // wave-uniform
+            if (t < B_INSTR && !(CV_HD_ABL & 4)) {
+                lds_dma16(slab + b_src[i], sm + st * STAGE + A_BYTES + t * 1024);
+                ++n_issued;
+            }
+        }
+        return n_issued;
+    };
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)lds;
+    const int bswz = (l31 >> 2) & 3, a_g = (l31 >> 1) & 7;
+    unsigned a_off[4], b_off[2];                                    // byte addresses inside stage 0
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) a_off[kk] = lds0 + (unsigned)(wave * 4096 + l31 * 128 + (((2 * kk + half) ^ a_g) << 4));
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b_off[ks] = lds0 + (unsigned)(A_BYTES + l31 * 64 + (((2 * ks + half) ^ bswz) << 4));
+    auto compute = [&](auto S) {
+        constexpr int st = decltype(S)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // pieces of the 128-byte chunk: 0-3 = high halves of channels 0-31, 4-7 = low halves; k-step ks takes
+            // channels 16 ks ... 16 ks + 15: high piece 2 ks + half, low piece 4 + 2 ks + half
+            const unsigned aa0 = a_off[ks] + st * STAGE, aa1 = a_off[2 + ks] + st * STAGE, ab = b_off[ks] + st * STAGE;
+            u32x4v A0, A1, B0[NB], B1[NB];
+            hd_read_frags<NB>(aa0, aa1, ab, A0, A1, B0, B1);
+            const f16x8 a0 = __builtin_bit_cast(f16x8, A0), a1 = __builtin_bit_cast(f16x8, A1);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const f16x8 b0 = __builtin_bit_cast(f16x8, B0[nb]), b1 = __builtin_bit_cast(f16x8, B1[nb]);
+                if (!(CV_HD_ABL & 2)) {
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[nb], 0, 0, 0);
+                }
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, 2> S2;
+    // step k (stage S = k % 3): this wave's requests of unit k have landed (those of unit k + 1 may stay in flight);
+    // barrier = every wave's share of weight tile k is visible AND everyone is past the MFMAs of unit k - 1, whose stage
+    // takes the requests of unit k + 2; then the MFMAs of unit k
+    int pend1 = 0;                                     // LDS-DMA instructions this wave has in flight for the NEXT unit
+    if (n_units > 0) issue(S0{}, 0);
+    if (n_units > 1) pend1 = issue(S1{}, 1);
+    auto step = [&](auto S, auto SP, int k) {
+        constexpr int st = decltype(S)::value;
+        wait_vmcnt_dyn(__builtin_amdgcn_readfirstlane(k + 1 < n_units ? pend1 : 0));
+        __builtin_amdgcn_s_barrier();
+        if (k + 2 < n_units) pend1 = issue(SP, k + 2);
+        else pend1 = 0;
+        if (live[st]) compute(S);
+    };
+    // (pend1 at the wait of step k must count the requests of unit k + 1: it was set by the issue of step k - 1)
+#pragma unroll 1
+    for (int k = 0; k < n_units; k += 3) {
+        step(S0{}, S2{}, k);
+        if (k + 1 >= n_units) break;
+        step(S1{}, S0{}, k + 1);
+        if (k + 2 >= n_units) break;
+        step(S2{}, S1{}, k + 2);
+    }
+    wait_vmcnt_le<0>();
+    __syncthreads();                                 // the ring is dead: the epilogue tile reuses its LDS
+    {
+        const float sc = a.acc_scale;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] *= sc;
+    }
+    float (*ep)[EP_LD] = reinterpret_cast<float (*)[EP_LD]>(sm + wave * 32 * EP_LD * 4);
+    ConvArgs ae = a;
+    ae.tickets = nullptr;                            // (the in-launch split-K reduction is conv_hl's)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) epilogue_store_wide(ae, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep);
+}
+
 // ------------------------------------------------------------------ stem (tiny Cin, 32 outputs)
 // conv0p1s1 (utils/minkunet.py:53: 5x5x5, 3 or 6 -> 32 channels) is a kernel-map walk, not a GEMM: 13 % of its
 // 125 offsets exist per row and each pair is a CIN x 32 product.  One lane owns one output row and all 32
@@ -2293,6 +2597,10 @@ __global__ __launch_bounds__(256) void head_separate(const float* __restrict__ f
     prob[i] = e1 / (e0 + e1);
 }
 
+// run-time options (cv_sp_set_option): conv_hd switch (bit NB - 1) and its row threshold; defaults from the environment
+std::atomic<long long> g_opt_hd_mask{getenv("CV_HD") ? atoll(getenv("CV_HD")) : 0};
+std::atomic<long long> g_opt_hd_min_rows{getenv("CV_HD_MIN_ROWS") ? atoll(getenv("CV_HD_MIN_ROWS")) : 16384};
+
 template <int NB>
 int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
     dim3 grid((unsigned)((a.n_out + TM - 1) / TM), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)),
@@ -2335,6 +2643,21 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         // instead of three or four cost more than the deeper prefetch gains, profiles/r2/hl_slots.txt)
         // 256-row workgroups where the launch has plenty of tiles and no split-K: an experiment (CV_HL_NW8=1), off by
         // default - measured slower, profiles/r2/hl_nw8.txt
+        // conv_hd (round 4): LDS-DMA operand rings, 256-row workgroups; CV_HD bit NB - 1 switches the NB x 32-column kernel on
+        // for launches of at least CV_HD_MIN_ROWS output rows
+        const int hd_mask = (int)g_opt_hd_mask.load(std::memory_order_relaxed);
+        const long long hd_min_rows = g_opt_hd_min_rows.load(std::memory_order_relaxed);
+        if constexpr (NB <= 3) {
+            if (((hd_mask >> (NB - 1)) & 1) && a.n_out >= hd_min_rows && !ax.xcd_tiles) {
+                dim3 g((unsigned)((a.n_out + 255) / 256), grid.y, grid.z);
+                ConvArgs ah = a;
+                ah.tickets = nullptr;
+                conv_hd<NB><<<g, 512, 0, st>>>(ah);
+                CV_LAUNCH_CHECK();
+                if (a.splits > 1) return launch_finish(a, st);
+                return CV_OK;
+            }
+        }
         static const int nw8_mask = getenv("CV_HL_NW8") ? atoi(getenv("CV_HL_NW8")) : 0;        // bit NB - 1
         const bool nw8_on = (nw8_mask >> (NB - 1)) & 1;
         if constexpr (NB <= 4) {
@@ -2452,6 +2775,15 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
 }
 
 }  // namespace
+
+int cv_sp_set_option(const char* name, long long value, long long* previous) {
+    CV_REQUIRE(name, CV_EINVAL, "null option name");
+    std::atomic<long long>* o = !strcmp(name, "hd_mask") ? &g_opt_hd_mask : !strcmp(name, "hd_min_rows") ? &g_opt_hd_min_rows : nullptr;
+    CV_REQUIRE(o, CV_EINVAL, "unknown option '%s' (hd_mask, hd_min_rows)", name);
+    const long long before = o->exchange(value, std::memory_order_relaxed);
+    if (previous) *previous = before;
+    return CV_OK;
+}
 
 int cv_sp_set_ablation(int bits) { return cvsc::g_ablation.exchange(bits, std::memory_order_relaxed); }
 

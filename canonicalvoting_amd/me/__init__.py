@@ -497,6 +497,14 @@ def set_split_target(workgroups):
     return int(_lib.lib().cv_sp_set_split_target(int(workgroups)))
 
 
+def set_option(name, value):
+    """cv_sp_set_option: kernel selection knobs of the convolutions ("hd_mask", "hd_min_rows"); returns the previous value"""
+    import ctypes
+    prev = ctypes.c_longlong(0)
+    _lib.check(_lib.lib().cv_sp_set_option(name.encode(), int(value), ctypes.byref(prev)), "cv_sp_set_option")
+    return int(prev.value)
+
+
 def to_hl(x):
     """fp32 rows [n, C] (C % 32 == 0) -> the hl format (same shape and dtype, the bytes hold the fp16 pairs)"""
     y = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)

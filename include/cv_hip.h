@@ -292,6 +292,12 @@ int cv_sp_set_split_target(int workgroups);
  * at run time, after a warm-up has filled every buffer with valid values.  bit 0: the finish launches of the split / mask-group
  * convolutions are skipped (what the partial-tile reductions cost with scenes in flight).  Returns the previous bits. */
 int cv_sp_set_ablation(int bits);
+/* Kernel selection knobs of cv_sp_conv_f32 / cv_net_run_f32 (process-wide, like cv_sp_set_split_target; results are
+ * bit-identical under every setting).  "hd_mask": bit NB - 1 sends the hl-format convolutions whose workgroups are
+ * NB x 32 columns wide to conv_hd (LDS-DMA operand rings, 256-row workgroups) instead of conv_hl when the launch has at
+ * least "hd_min_rows" output rows.  *previous (may be NULL) receives the old value.  Environment defaults: CV_HD,
+ * CV_HD_MIN_ROWS. */
+int cv_sp_set_option(const char* name, long long value, long long* previous);
 
 /* Every kernel map and processing order the fused MinkUNet forward needs, built by ONE call per scene into one
  * int32 arena (offsets in int32 words; -1 = absent):

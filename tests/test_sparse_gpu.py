@@ -786,3 +786,50 @@ def test_reference_checkpoint_in_z_fastest_offset_order_loads_and_matches_oracle
     wrong = load_reference_checkpoint(MinkUNet34C(3, 64), path, offset_order="x_fastest", key=wrapper).cuda().eval()
     with torch.no_grad():
         assert np.abs(wrong(x).F.cpu().numpy() - ref).max() > 1e-2 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("cin,cout,n,masked", [(96, 96, 40000, True), (128, 96, 40000, True), (32, 32, 20000, True),
+                                                (64, 64, 20000, False), (96, 96, 300, False), (32, 64, 17000, True)])
+def test_conv_hd_is_bit_identical_to_conv_hl(cuda, built_lib, cin, cout, n, masked):
+    """conv_hd (LDS-DMA operand rings, 256-row workgroups, cv_sp_set_option "hd_mask") keeps conv_hl's units and MFMA
+    sequence per accumulator: the same bits for mask-grouped and split launches, with a residual / ReLU / hl epilogue and a
+    ragged last tile (n is no multiple of 256); the second source rides through the network-level comparison."""
+    coords, _ = scene_coords(3, n, small=n < 10000)
+    N = len(coords)
+    rng = np.random.default_rng(cin + 3 * cout)
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    x = t(rng.normal(0, 1, (N, cin)).astype(np.float32))
+    w = t((rng.normal(0, 1, (27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32))
+    scale = t(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = t(rng.normal(0, 0.2, cout).astype(np.float32))
+    res = t(rng.normal(0, 1, (N, cout)).astype(np.float32))
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(cuda, torch.int32))
+    nbr = cm.kernel_map(3, 1)
+    xh, rh = ME.to_hl(x), ME.to_hl(res)
+    if masked:
+        perms = cm.mask_perms(3, 1, 3)
+        conv = lambda **e: ME.conv_forward_masked(xh, w, nbr, perms, N, pieces=2, in_hl=True, **e)
+    else:
+        conv = lambda **e: ME.conv_forward(xh, w, nbr, N, pieces=2, in_hl=True, **e)
+
+    def run():
+        plain = conv()
+        out = torch.empty((N, cout), device=cuda)
+        conv(scale=scale, shift=shift, residual=rh, relu=True, out=out, out_hl=True, res_hl=True)
+        return plain, out
+
+    prev = ME.set_option("hd_mask", 0)
+    prev_rows = ME.set_option("hd_min_rows", 1)
+    try:
+        want = run()
+        ME.set_option("hd_mask", 7)
+        got = run()
+        got2 = run()
+    finally:
+        ME.set_option("hd_mask", prev)
+        ME.set_option("hd_min_rows", prev_rows)
+    for a, b, c in zip(want, got, got2):
+        assert torch.equal(a, b), "conv_hd differs from conv_hl: %d of %d elements, max %g" % (
+            int((a != b).sum()), a.numel(), float((a - b).abs().max()))
+        assert torch.equal(b, c)
+    assert float(want[0].abs().max()) > 0.1
