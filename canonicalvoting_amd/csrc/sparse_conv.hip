@@ -1212,7 +1212,7 @@ __device__ __attribute__((aligned(128))) unsigned char g_zero_chunk[128];
 #endif
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {      // n is wave-uniform, 0 ... 6
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {      // n is wave-uniform, 0 ... 8
     switch (n) {
         case 0: wait_vmcnt_le<0>(); break;
         case 1: wait_vmcnt_le<1>(); break;
@@ -1220,7 +1220,9 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {      // n is wave-unifor
         case 3: wait_vmcnt_le<3>(); break;
         case 4: wait_vmcnt_le<4>(); break;
         case 5: wait_vmcnt_le<5>(); break;
-        default: wait_vmcnt_le<6>(); break;
+        case 6: wait_vmcnt_le<6>(); break;
+        case 7: wait_vmcnt_le<7>(); break;
+        default: wait_vmcnt_le<8>(); break;
     }
 }
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -1259,9 +1261,50 @@ __device__ __forceinline__ void hd_read_frags(unsigned aa0, unsigned aa1, unsign
                      : "v"(aa0), "v"(aa1), "v"(ab), "i"(P1), "i"(2048), "i"(P1 + 2048), "i"(4096), "i"(P1 + 4096) : "memory");
     }
 }
-template <int NB>
-__global__ __launch_bounds__(512, 2) void conv_hd(ConvArgs a) {
-    constexpr int NW = 8, TMv = NW * 32, THv = NW * 64, NSTG = 3;
+// LDS of one workgroup: NSTG ring stages (gathered rows of NW waves + the weight tile), the tile's row / map tables, unit list
+constexpr int hd_lds_bytes(int NB, int NW, int NSTG) {
+    return NSTG * (NW * 4096 + 2 * NB * 32 * 64) + NW * 32 * 4 + (WP_NPRE + 1) * NW * 32 * 4 + NW * 4 + (HL_MAX_UNITS + 4) * 2;
+}
+constexpr int hd_blocks(int NB, int NW, int NSTG) {          // workgroups per CU (LDS-bound), at most 8 waves per SIMD
+    const int b = (160 * 1024) / hd_lds_bytes(NB, NW, NSTG);
+    return b * NW > 32 ? 32 / NW : (b < 1 ? 1 : b);
+}
+// NW waves x 32 rows per workgroup, NSTG ring stages: <8, 3> one workgroup per CU with the requests of two units in flight
+// behind the one that multiplies; <4, 2> two workgroups per CU, one unit of prefetch each
+// All sixteen fragment reads of a 96-column unit in one go (no wait inside), then two waits that name the registers they
+// release: the second k-step's fragments travel while the first one multiplies, and the requests of the next unit are
+// issued while the first ones travel (conv_hd, HD_EARLY).
+#ifndef HD_EARLY
+#define HD_EARLY 1
+#endif
+__device__ __forceinline__ void hd_reads3_issue(const unsigned (&aa)[4], const unsigned (&ab)[2], u32x4v (&A)[4],
+                                                u32x4v (&B0)[2][3], u32x4v (&B1)[2][3]) {
+    constexpr int P1 = 3 * 32 * 64;
+    asm volatile("ds_read_b128 %0, %16\n\tds_read_b128 %1, %17\n\t"
+                 "ds_read_b128 %2, %20\n\tds_read_b128 %3, %20 offset:%22\n\t"
+                 "ds_read_b128 %4, %20 offset:%23\n\tds_read_b128 %5, %20 offset:%24\n\t"
+                 "ds_read_b128 %6, %20 offset:%25\n\tds_read_b128 %7, %20 offset:%26\n\t"
+                 "ds_read_b128 %8, %18\n\tds_read_b128 %9, %19\n\t"
+                 "ds_read_b128 %10, %21\n\tds_read_b128 %11, %21 offset:%22\n\t"
+                 "ds_read_b128 %12, %21 offset:%23\n\tds_read_b128 %13, %21 offset:%24\n\t"
+                 "ds_read_b128 %14, %21 offset:%25\n\tds_read_b128 %15, %21 offset:%26"
+                 : "=&v"(A[0]), "=&v"(A[2]), "=&v"(B0[0][0]), "=&v"(B1[0][0]), "=&v"(B0[0][1]), "=&v"(B1[0][1]), "=&v"(B0[0][2]),
+                   "=&v"(B1[0][2]), "=&v"(A[1]), "=&v"(A[3]), "=&v"(B0[1][0]), "=&v"(B1[1][0]), "=&v"(B0[1][1]), "=&v"(B1[1][1]),
+                   "=&v"(B0[1][2]), "=&v"(B1[1][2])
+                 : "v"(aa[0]), "v"(aa[2]), "v"(aa[1]), "v"(aa[3]), "v"(ab[0]), "v"(ab[1]), "i"(P1), "i"(2048), "i"(P1 + 2048),
+                   "i"(4096), "i"(P1 + 4096)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void hd_reads3_wait(u32x4v& a0, u32x4v& a1, u32x4v (&b0)[3], u32x4v (&b1)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(a0), "+v"(a1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2])
+                 : "n"(N) : "memory");
+}
+template <int NB, int NW, int NSTG>
+__global__ __launch_bounds__(NW * 64, (hd_blocks(NB, NW, NSTG) * NW + 3) / 4) void conv_hd(ConvArgs a) {
+    static_assert(NSTG == 2 || NSTG == 3, "two or three ring stages");
+    constexpr int TMv = NW * 32, THv = NW * 64;
     constexpr int A_BYTES = NW * 4096, B_BYTES = 2 * NB * 32 * 64, STAGE = A_BYTES + B_BYTES;
     constexpr int B_INSTR = B_BYTES / 1024;                         // 1 KB (64 lanes x 16 B) per LDS-DMA instruction
     constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
@@ -1269,7 +1312,7 @@ __global__ __launch_bounds__(512, 2) void conv_hd(ConvArgs a) {
     static_assert(EP_BYTES <= NSTG * STAGE, "the epilogue tile aliases the ring");
     constexpr int OFF_ROWS = NSTG * STAGE, OFF_NBR = OFF_ROWS + TMv * 4, OFF_MASK = OFF_NBR + (WP_NPRE + 1) * TMv * 4,
                   OFF_UNITS = OFF_MASK + NW * 4, LDS_TOTAL = OFF_UNITS + (HL_MAX_UNITS + 4) * 2;
-    static_assert(LDS_TOTAL <= 160 * 1024, "one workgroup per CU");
+    static_assert(LDS_TOTAL == hd_lds_bytes(NB, NW, NSTG) && LDS_TOTAL <= 160 * 1024, "LDS budget");
     // ONE __shared__ object (a second one makes hipcc drain vmcnt in front of the LDS reads of an LDS-DMA pipeline)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_TOTAL];
     unsigned char* const sm = lds;
@@ -1451,31 +1494,89 @@ __global__ __launch_bounds__(512, 2) void conv_hd(ConvArgs a) {
             }
         }
     };
+    auto reads_early = [&](auto S, u32x4v (&A)[4], u32x4v (&B0)[2][3], u32x4v (&B1)[2][3]) {
+        constexpr int st = decltype(S)::value;
+        const unsigned aa[4] = {a_off[0] + st * STAGE, a_off[1] + st * STAGE, a_off[2] + st * STAGE, a_off[3] + st * STAGE};
+        const unsigned ab[2] = {b_off[0] + st * STAGE, b_off[1] + st * STAGE};
+        if constexpr (NB == 3) hd_reads3_issue(aa, ab, A, B0, B1);
+    };
+    auto mfma_early = [&](u32x4v (&A)[4], u32x4v (&B0)[2][3], u32x4v (&B1)[2][3]) {
+        if constexpr (NB == 3) {
+            hd_reads3_wait<8>(A[0], A[2], B0[0], B1[0]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 1) hd_reads3_wait<0>(A[1], A[3], B0[1], B1[1]);
+                const f16x8 a0 = __builtin_bit_cast(f16x8, A[ks]), a1 = __builtin_bit_cast(f16x8, A[2 + ks]);
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) {
+                    const f16x8 b0 = __builtin_bit_cast(f16x8, B0[ks][nb]), b1 = __builtin_bit_cast(f16x8, B1[ks][nb]);
+                    if (!(CV_HD_ABL & 2)) {
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
     typedef std::integral_constant<int, 2> S2;
     // step k (stage S = k % 3): this wave's requests of unit k have landed (those of unit k + 1 may stay in flight);
     // barrier = every wave's share of weight tile k is visible AND everyone is past the MFMAs of unit k - 1, whose stage
     // takes the requests of unit k + 2; then the MFMAs of unit k
-    int pend1 = 0;                                     // LDS-DMA instructions this wave has in flight for the NEXT unit
-    if (n_units > 0) issue(S0{}, 0);
-    if (n_units > 1) pend1 = issue(S1{}, 1);
-    auto step = [&](auto S, auto SP, int k) {
-        constexpr int st = decltype(S)::value;
-        wait_vmcnt_dyn(__builtin_amdgcn_readfirstlane(k + 1 < n_units ? pend1 : 0));
-        __builtin_amdgcn_s_barrier();
-        if (k + 2 < n_units) pend1 = issue(SP, k + 2);
-        else pend1 = 0;
-        if (live[st]) compute(S);
-    };
-    // (pend1 at the wait of step k must count the requests of unit k + 1: it was set by the issue of step k - 1)
+    if constexpr (NSTG == 3) {
+        int pend1 = 0;                                     // LDS-DMA instructions this wave has in flight for the NEXT unit
+        if (n_units > 0) issue(S0{}, 0);
+        if (n_units > 1) pend1 = issue(S1{}, 1);
+        // (pend1 at the wait of step k counts the requests of unit k + 1: it was set by the issue of step k - 1)
+        auto step = [&](auto S, auto SP, int k) {
+            constexpr int st = decltype(S)::value;
+            wait_vmcnt_dyn(__builtin_amdgcn_readfirstlane(k + 1 < n_units ? pend1 : 0));
+            __builtin_amdgcn_s_barrier();
+            if constexpr (NB == 3 && HD_EARLY) {
+                u32x4v A[4], B0[2][3], B1[2][3];
+                if (live[st]) reads_early(S, A, B0, B1);
+                if (k + 2 < n_units) pend1 = issue(SP, k + 2);
+                else pend1 = 0;
+                if (live[st]) mfma_early(A, B0, B1);
+            } else {
+                if (k + 2 < n_units) pend1 = issue(SP, k + 2);
+                else pend1 = 0;
+                if (live[st]) compute(S);
+            }
+        };
 #pragma unroll 1
-    for (int k = 0; k < n_units; k += 3) {
-        step(S0{}, S2{}, k);
-        if (k + 1 >= n_units) break;
-        step(S1{}, S0{}, k + 1);
-        if (k + 2 >= n_units) break;
-        step(S2{}, S1{}, k + 2);
+        for (int k = 0; k < n_units; k += 3) {
+            step(S0{}, S2{}, k);
+            if (k + 1 >= n_units) break;
+            step(S1{}, S0{}, k + 1);
+            if (k + 2 >= n_units) break;
+            step(S2{}, S1{}, k + 2);
+        }
+    } else {
+        // two stages: only unit k is in flight at its wait; the requests of unit k + 1 go out behind the barrier
+        if (n_units > 0) issue(S0{}, 0);
+        auto step = [&](auto S, auto SN, int k) {
+            constexpr int st = decltype(S)::value;
+            wait_vmcnt_le<0>();
+            __builtin_amdgcn_s_barrier();
+            if constexpr (NB == 3 && HD_EARLY) {
+                u32x4v A[4], B0[2][3], B1[2][3];
+                if (live[st]) reads_early(S, A, B0, B1);
+                if (k + 1 < n_units) issue(SN, k + 1);
+                if (live[st]) mfma_early(A, B0, B1);
+            } else {
+                if (k + 1 < n_units) issue(SN, k + 1);
+                if (live[st]) compute(S);
+            }
+        };
+#pragma unroll 1
+        for (int k = 0; k < n_units; k += 2) {
+            step(S0{}, S1{}, k);
+            if (k + 1 >= n_units) break;
+            step(S1{}, S0{}, k + 1);
+        }
     }
     wait_vmcnt_le<0>();
     __syncthreads();                                 // the ring is dead: the epilogue tile reuses its LDS
@@ -2600,6 +2701,7 @@ __global__ __launch_bounds__(256) void head_separate(const float* __restrict__ f
 // run-time options (cv_sp_set_option): conv_hd switch (bit NB - 1) and its row threshold; defaults from the environment
 std::atomic<long long> g_opt_hd_mask{getenv("CV_HD") ? atoll(getenv("CV_HD")) : 0};
 std::atomic<long long> g_opt_hd_min_rows{getenv("CV_HD_MIN_ROWS") ? atoll(getenv("CV_HD_MIN_ROWS")) : 16384};
+std::atomic<long long> g_opt_hd_shape{getenv("CV_HD_SHAPE") ? atoll(getenv("CV_HD_SHAPE")) : 0};      // 0: 8 waves x 3 stages, 1: 4 x 2, 2: 8 x 2
 
 template <int NB>
 int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
@@ -2647,12 +2749,16 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         // for launches of at least CV_HD_MIN_ROWS output rows
         const int hd_mask = (int)g_opt_hd_mask.load(std::memory_order_relaxed);
         const long long hd_min_rows = g_opt_hd_min_rows.load(std::memory_order_relaxed);
+        const int hd_shape = (int)g_opt_hd_shape.load(std::memory_order_relaxed);
         if constexpr (NB <= 3) {
             if (((hd_mask >> (NB - 1)) & 1) && a.n_out >= hd_min_rows && !ax.xcd_tiles) {
-                dim3 g((unsigned)((a.n_out + 255) / 256), grid.y, grid.z);
                 ConvArgs ah = a;
                 ah.tickets = nullptr;
-                conv_hd<NB><<<g, 512, 0, st>>>(ah);
+                const int nw = hd_shape == 1 ? 4 : 8;
+                dim3 g((unsigned)((a.n_out + nw * 32 - 1) / (nw * 32)), grid.y, grid.z);
+                if (hd_shape == 1) conv_hd<NB, 4, 2><<<g, 256, 0, st>>>(ah);
+                else if (hd_shape == 2) conv_hd<NB, 8, 2><<<g, 512, 0, st>>>(ah);
+                else conv_hd<NB, 8, 3><<<g, 512, 0, st>>>(ah);
                 CV_LAUNCH_CHECK();
                 if (a.splits > 1) return launch_finish(a, st);
                 return CV_OK;
@@ -2778,8 +2884,9 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
 
 int cv_sp_set_option(const char* name, long long value, long long* previous) {
     CV_REQUIRE(name, CV_EINVAL, "null option name");
-    std::atomic<long long>* o = !strcmp(name, "hd_mask") ? &g_opt_hd_mask : !strcmp(name, "hd_min_rows") ? &g_opt_hd_min_rows : nullptr;
-    CV_REQUIRE(o, CV_EINVAL, "unknown option '%s' (hd_mask, hd_min_rows)", name);
+    std::atomic<long long>* o = !strcmp(name, "hd_mask") ? &g_opt_hd_mask : !strcmp(name, "hd_min_rows") ? &g_opt_hd_min_rows :
+                                !strcmp(name, "hd_shape") ? &g_opt_hd_shape : nullptr;
+    CV_REQUIRE(o, CV_EINVAL, "unknown option '%s' (hd_mask, hd_min_rows, hd_shape)", name);
     const long long before = o->exchange(value, std::memory_order_relaxed);
     if (previous) *previous = before;
     return CV_OK;

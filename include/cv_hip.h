@@ -295,8 +295,9 @@ int cv_sp_set_ablation(int bits);
 /* Kernel selection knobs of cv_sp_conv_f32 / cv_net_run_f32 (process-wide, like cv_sp_set_split_target; results are
  * bit-identical under every setting).  "hd_mask": bit NB - 1 sends the hl-format convolutions whose workgroups are
  * NB x 32 columns wide to conv_hd (LDS-DMA operand rings, 256-row workgroups) instead of conv_hl when the launch has at
- * least "hd_min_rows" output rows.  *previous (may be NULL) receives the old value.  Environment defaults: CV_HD,
- * CV_HD_MIN_ROWS. */
+ * least "hd_min_rows" output rows; "hd_shape": 0 = 8 waves x 3 ring stages (one workgroup per CU), 1 = 4 waves x 2 stages
+ * (two per CU), 2 = 8 waves x 2 stages.  *previous (may be NULL) receives the old value.  Environment defaults: CV_HD,
+ * CV_HD_MIN_ROWS, CV_HD_SHAPE. */
 int cv_sp_set_option(const char* name, long long value, long long* previous);
 
 /* Every kernel map and processing order the fused MinkUNet forward needs, built by ONE call per scene into one
