@@ -113,6 +113,10 @@ def parse():
                     help="what vote + decode are fed with (see the module docstring); the network forward and the head "
                          "kernel run and are timed either way")
     ap.add_argument("--teacher-forced", action="store_true", help="same as --predictions teacher (kept for old scripts)")
+    ap.add_argument("--scene-call", default="c", choices=["c", "py"],
+                    help="c (default): one cv_detect_scene_f32 call per scene (plan -> network -> head -> vote -> decode -> NMS "
+                         "inside the library, the GIL released for the whole scene); py: the same entry points issued one "
+                         "by one from Python (the path of rounds 1-3; bit-identical results)")
     ap.add_argument("--ablate", default="", help="timing ablations, WRONG results, never for a reported number: comma list of "
                                                   "`finish` (cv_sp_set_ablation bit 0, switched on after the warm-up), `novote`, "
                                                   "`nodecode` (the stage is skipped in every step)")
@@ -177,18 +181,32 @@ def step_events():
     vote accumulation kernel itself (recorded by the library: cv_hv_set_kernel_events).  torch creates the hipEvent_t
     at the first record, and the library needs the handles: every event is recorded once here."""
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(7 if KERNEL_EVENTS else 5)]
-    for e in evs[5:]:
+    for e in evs:           # (all of them: cv_detect_scene_f32 records the stage boundaries too)
         e.record()
     return evs
 
 
 ABLATE = ()
+SCENE_CALL = "c"
 
 
 def run_step(model, hv, s, ev=None, teacher=False, keep=None):
     """One scene through eval_joint.py:163-280: network -> head -> vote -> decode -> per-class NMS.
     keep: optional dict that receives the device tensors of the step (the parity check reads them)."""
     rec = (lambda i: ev[i].record()) if ev is not None else (lambda i: None)
+    if SCENE_CALL == "c" and model is not None and not ABLATE and model.USE_PROGRAM:
+        # the whole scene behind ONE C call (cv_detect_scene_f32): same kernels, same order, bit-identical results; the
+        # scene thread holds the GIL for one foreign call instead of ~40
+        if ev is not None and len(ev) > 6:
+            _lib.lib().cv_hv_set_kernel_events(ev[5].cuda_event, ev[6].cuda_event)
+        try:
+            dets, raw, y = pipeline.detect_scene_c(model, hv, s.coords4, s.feats_in, RES, scan_points=s.points,
+                                                   predictions=(s.xyz, s.scale, s.prob, s.cls) if teacher else None,
+                                                   events=ev[:5] if ev is not None else None, keep=keep)
+        finally:
+            if ev is not None and len(ev) > 6:
+                _lib.lib().cv_hv_set_kernel_events(None, None)
+        return dets, raw
     with torch.no_grad():
         rec(0)
         hv_cuda.prefetch_geometry(s.points)       # bounds reduction of the vote grid starts before the network
@@ -568,7 +586,8 @@ def main():
     import itertools
     import threading
     sys.setswitchinterval(a.switch_interval)      # GIL hand-off between the scene threads
-    global KERNEL_EVENTS, ABLATE
+    global KERNEL_EVENTS, ABLATE, SCENE_CALL
+    SCENE_CALL = a.scene_call
     KERNEL_EVENTS = bool(a.kernel_events)
     ABLATE = tuple(x for x in a.ablate.split(",") if x)
     every = max(1, a.event_every)

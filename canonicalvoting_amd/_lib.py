@@ -66,6 +66,31 @@ class NetOp(ctypes.Structure):
                 ("in2_col", ctypes.c_int), ("cin2", ctypes.c_int), ("weight2_x6", vp), ("weight_pieces", ctypes.c_int), ("acc_scale", ctypes.c_float)]
 
 
+class SceneDesc(ctypes.Structure):
+    """struct cv_scene_desc (include/cv_hip.h)"""
+    _fields_ = [("d_coords4", vp), ("n", ctypes.c_longlong), ("d_feats", vp), ("feats_ld", ctypes.c_int), ("d_points", vp),
+                ("res", ctypes.c_float), ("num_rots", ctypes.c_int), ("ops", vp), ("n_ops", ctypes.c_int), ("bufs", vp),
+                ("n_bufs", ctypes.c_int), ("stem_k", ctypes.c_int), ("mask_groups", ctypes.c_int),
+                ("masked_min_rows", ctypes.c_longlong), ("max_channels", ctypes.c_int), ("use_range_flag", ctypes.c_int),
+                ("d_out_feats", vp), ("out_ld", ctypes.c_int), ("out_channels", ctypes.c_int), ("nclasses", ctypes.c_int),
+                ("log_scale", ctypes.c_int), ("d_xyz_in", vp), ("d_scale_in", vp), ("d_prob_in", vp), ("d_class_in", vp),
+                ("vote_algo", ctypes.c_int), ("decode", DecodeParams), ("max_candidates", ctypes.c_int),
+                ("nms_threshold", ctypes.c_double), ("d_ws", vp), ("ws_bytes", ctypes.c_size_t), ("d_grids", vp),
+                ("grid_capacity_floats", ctypes.c_size_t), ("h_pinned", vp), ("pinned_bytes", ctypes.c_size_t),
+                ("h_cand_idx", vp), ("h_verdict", vp), ("h_boxes", vp), ("h_scores", vp), ("h_classes", vp), ("h_pick", vp),
+                ("events", vp * 5)]
+
+
+class SceneResult(ctypes.Structure):
+    """struct cv_scene_result (include/cv_hip.h)"""
+    _fields_ = [("n_cand", ctypes.c_int), ("n_boxes", ctypes.c_int), ("n_det", ctypes.c_int), ("truncated", ctypes.c_int),
+                ("range_flag", ctypes.c_int), ("duplicates", ctypes.c_int), ("out_of_window", ctypes.c_int),
+                ("dims", ctypes.c_int * 3), ("corner", ctypes.c_float * 3), ("level_rows", ctypes.c_longlong * 5),
+                ("needed_ws_bytes", ctypes.c_size_t), ("needed_grid_floats", ctypes.c_size_t),
+                ("d_grid_obj", vp), ("d_grid_rot", vp), ("d_grid_scale", vp), ("d_xyz", vp), ("d_scale", vp),
+                ("d_prob", vp), ("d_class", vp)]
+
+
 # symbol -> (restype, argtypes); tests check every symbol of include/cv_hip.h is here and exported
 SIGNATURES = {
     "cv_abi_version": (ctypes.c_int, []),
@@ -153,6 +178,7 @@ SIGNATURES = {
     "cv_head_joint_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          vp, vp, vp, vp, vp]),
     "cv_head_separate_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
+    "cv_detect_scene_f32": (ctypes.c_int, [ctypes.POINTER(SceneDesc), ctypes.POINTER(SceneResult), vp]),
     "cv_iou_obb": (ctypes.c_double, [c_float_p, c_float_p]),
     "cv_nms_obb": (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_double, c_i32_p]),
 }

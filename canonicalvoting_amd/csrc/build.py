@@ -35,6 +35,7 @@ SOURCES = {
     "sparse_conv.hip": os.environ.get("CV_SC_DEFS", "").split(),          # kernel experiments (-DCV_WP_CLAMPED_GATHER=1)
     "sparse_conv_alt.hip": os.environ.get("CV_SC_DEFS", "").split(),      # flavours 3 / 4 and the instrumented twin (not on the default path)
     "net_exec.cpp": [],
+    "scene_exec.cpp": [],
 }
 
 

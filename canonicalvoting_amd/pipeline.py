@@ -86,3 +86,131 @@ def detect_scene_separate(models, hv, coords4, feats, res, log_scale=True, overl
             for i in decode.nms(raw["boxes"], raw["scores"], overlap_threshold):
                 out.append((category, raw["boxes"][i], float(raw["scores"][i])))
     return out
+
+
+class _SceneHost:
+    """per-(device, stream) host-side scratch of detect_scene_c: pinned landing words and the result arrays"""
+
+    def __init__(self, max_candidates):
+        import numpy as np
+        self.M = max_candidates
+        self.pinned = torch.empty(256, dtype=torch.uint8).pin_memory()
+        self.cand = np.zeros(max_candidates, np.int64)
+        self.verdict = np.zeros(max_candidates, np.int32)
+        self.boxes = np.zeros((max_candidates, 8, 3), np.float32)
+        self.scores = np.zeros(max_candidates, np.float32)
+        self.classes = np.zeros(max_candidates, np.int32)
+        self.pick = np.zeros(max_candidates, np.int32)
+        self.ws_hint = 0
+
+
+_scene_hosts = {}
+_scene_lock = __import__("threading").Lock()
+
+
+def detect_scene_c(model, hv, coords4, feats, res, nclasses=9, log_scale=True, scan_points=None, predictions=None,
+                   max_candidates=512, keep=None, events=None, **decode_kw):
+    """detect_scene through ONE C call (cv_detect_scene_f32: coordinate plan -> network program -> head -> vote -> decode
+    -> per-class NMS; two host waits inside it, the GIL released for its whole duration).  Same kernels in the same order
+    as detect_scene: bit-identical results (tests/test_scene_call_gpu.py).  ``predictions`` = (xyz, scale, prob, class)
+    fed to vote + decode instead of the network's (bench.py --predictions teacher).  A scene that needs what the call
+    does not do - a range fallback onto the bf16 triples, a decode walk beyond ``max_candidates`` - is redone by the
+    call-by-call path.  ``events``: five recorded torch.cuda.Event that the call re-records at the stage boundaries.
+    Returns (detections, raw decode dict, network output [N, C])."""
+    import numpy as np
+    L = _lib.lib()
+    dev = feats.device
+    n = coords4.shape[0]
+    if scan_points is None:
+        scan_points = (coords4[:, 1:].to(dev) * res).float().contiguous()
+    pieces = 1 if ME.COMPUTE_DTYPE == "bf16" else model.PIECES
+    c_ops, c_bufs, _ = model._program(dev, pieces)
+    cm_cls = ME.CoordinateManager
+    G = cm_cls.MASK_GROUPS if (27 + cm_cls.MASK_GROUPS - 1) // cm_cls.MASK_GROUPS <= 10 else 0
+    coords4 = coords4.to(device=dev, dtype=torch.int32).contiguous()
+    feats = feats.contiguous()
+    y = torch.empty((n, model.final.out_channels), dtype=torch.float32, device=dev)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    with _scene_lock:
+        host = _scene_hosts.get(key)
+        if host is None or host.M < max_candidates:
+            host = _scene_hosts[key] = _SceneHost(max_candidates)
+    d = _lib.SceneDesc()
+    vp = ctypes.c_void_p
+    d.d_coords4, d.n, d.d_feats, d.feats_ld = vp(coords4.data_ptr()), n, vp(feats.data_ptr()), feats.stride(0)
+    d.d_points, d.res, d.num_rots = vp(scan_points.data_ptr()), float(res), hv_cuda._scalar(hv.num_rots, "i")
+    d.ops, d.n_ops, d.bufs, d.n_bufs = ctypes.cast(c_ops, vp), len(c_ops), ctypes.cast(c_bufs, vp), len(c_bufs)
+    d.stem_k, d.mask_groups, d.masked_min_rows = model.conv0p1s1.kernel_size, G, cm_cls.MASKED_MIN_ROWS
+    d.max_channels, d.use_range_flag = max(model.PLANES), 1 if pieces == 2 else 0
+    d.d_out_feats, d.out_ld, d.out_channels = vp(y.data_ptr()), y.stride(0), y.shape[1]
+    d.nclasses, d.log_scale = nclasses, 1 if log_scale else 0
+    if predictions is not None:
+        px, ps, pp, pc = predictions
+        pc = pc.to(torch.int32).contiguous()
+        d.d_xyz_in, d.d_scale_in, d.d_prob_in, d.d_class_in = (vp(px.data_ptr()), vp(ps.data_ptr()), vp(pp.data_ptr()),
+                                                                 vp(pc.data_ptr()))
+    d.vote_algo = hv_cuda._algo
+    p = d.decode
+    p.thresh_high = float(decode_kw.get("thresh_high", decode.thresh_high))
+    p.thresh_low = float(decode_kw.get("thresh_low", decode.thresh_low))
+    p.valid_ratio = float(decode_kw.get("valid_ratio", decode.valid_ratio))
+    p.elimination = int(decode_kw.get("elimination", decode.elimination))
+    p.prob_thresh = float(decode_kw.get("prob_thresh", 0.3))
+    p.elim_hi_plus1 = 0 if decode_kw.get("separate_variant", False) else 1
+    p.err_thresh = float(decode_kw.get("err_thresh", 0.3))
+    d.max_candidates, d.nms_threshold = host.M, 0.3
+    if events is not None:          # five torch.cuda.Event (recorded once, so that their handles exist): scene start, after
+        for i in range(5):          # the network, after the head split, after the vote, after the decode
+            d.events[i] = events[i].cuda_event
+    d.h_pinned, d.pinned_bytes = vp(host.pinned.data_ptr()), host.pinned.numel()
+    d.h_cand_idx, d.h_verdict = vp(host.cand.ctypes.data), vp(host.verdict.ctypes.data)
+    d.h_boxes, d.h_scores, d.h_classes, d.h_pick = (vp(host.boxes.ctypes.data), vp(host.scores.ctypes.data),
+                                                    vp(host.classes.ctypes.data), vp(host.pick.ctypes.data))
+    r = _lib.SceneResult()
+    need = max(host.ws_hint, 64 << 20)
+    for attempt in range(4):
+        ws = _lib.scratch(dev, "scene_call", need)
+        d.d_ws, d.ws_bytes = vp(ws.data_ptr()), ws.numel()
+        with torch.cuda.device(dev):
+            rc = L.cv_detect_scene_f32(ctypes.byref(d), ctypes.byref(r), vp(torch.cuda.current_stream(dev).cuda_stream))
+        if rc == -12 and r.needed_ws_bytes > ws.numel():            # CV_ENOMEM: grow the scratch and run the scene again
+            torch.cuda.current_stream(dev).synchronize()
+            need = int(r.needed_ws_bytes)
+            continue
+        _lib.check(rc, "cv_detect_scene_f32")
+        break
+    host.ws_hint = max(host.ws_hint, int(r.needed_ws_bytes))
+    if r.range_flag or r.truncated:
+        # rare: a convolution input beyond the fp16 range, or more candidate cells than the result arrays hold
+        if r.range_flag:
+            model.range_fallbacks = getattr(model, "range_fallbacks", 0) + 1
+        with torch.no_grad():
+            x = ME.SparseTensor(feats, coords4, device=dev)
+            yy = model.program_forward(x, pieces=3) if r.range_flag else x._like(y, 1)
+            pred = head_joint(yy.F, nclasses, log_scale) if predictions is None else predictions
+            dets, raw = decode.detect(hv, coords4[:, 1:], pred[0], pred[1], pred[2], pred[3], res, nclasses,
+                                      scan_points=scan_points, **decode_kw)
+        return dets, raw, yy.F
+    k, m = r.n_boxes, r.n_cand
+    raw = dict(boxes=host.boxes[:k].copy(), scores=host.scores[:k].copy(), classes=host.classes[:k].copy(),
+               cand_idx=host.cand[:m].copy(), verdict=host.verdict[:m].copy(), truncated=False)
+    dets = [(int(raw["classes"][i]), raw["boxes"][i], float(raw["scores"][i])) for i in host.pick[:r.n_det]]
+    if keep is not None:
+        cells = r.dims[0] * r.dims[1] * r.dims[2]
+        view = lambda ptr, shape, dt=torch.float32: _device_view(ptr, shape, dt, dev, ws)
+        X, Y, Z = r.dims
+        keep.update(y=y, dims=(X, Y, Z), corner=tuple(r.corner), level_rows=list(r.level_rows),
+                    grids=(view(r.d_grid_obj, (X, Y, Z)), view(r.d_grid_rot, (X, Y, Z, 2)), view(r.d_grid_scale, (X, Y, Z, 3))),
+                    net_pred=(view(r.d_xyz, (n, 3)), view(r.d_scale, (n, 3)), view(r.d_prob, (n,)),
+                              view(r.d_class, (n,), torch.int32)), raw=raw)
+    return dets, raw, y
+
+
+def _device_view(ptr, shape, dtype, dev, owner):
+    """tensor view of a region of the scene scratch (valid until the next scene call on the same stream)"""
+    import numpy as np
+    count = int(np.prod(shape))
+    off = int(ptr) - owner.data_ptr()
+    nbytes = count * torch.empty((), dtype=dtype).element_size()
+    assert 0 <= off and off + nbytes <= owner.numel()
+    return owner[off:off + nbytes].view(dtype).view(*shape).clone()

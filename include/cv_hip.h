@@ -438,6 +438,62 @@ int cv_head_joint_f32(const float* d_feats, long long n, int ld, int nclasses, i
 int cv_head_separate_f32(const float* d_feats, long long n, int ld, int log_scale, float* d_xyz, float* d_scale,
                          float* d_prob, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * One call per scene: eval_joint.py:163-280 (network -> head split -> vote -> decode -> per-class NMS) behind ONE
+ * entry point.  Same kernels in the same order as the call-by-call path (cv_sp_scene_plan, cv_net_run_f32,
+ * cv_head_joint_f32, cv_hv_forward_f32, cv_decode_f32, cv_nms_obb): bit-identical results.  The host waits twice (level
+ * counts of the coordinate plan - the bounds of the points arrive with them - and the decode results); a binding that
+ * releases its interpreter lock around foreign calls (ctypes does) keeps it released for the whole scene.
+ * ------------------------------------------------------------------------ */
+typedef struct cv_scene_desc {
+    /* the scene */
+    const int32_t* d_coords4;     /* [n][4] (batch, x, y, z), unique rows (eval_joint.py:169) */
+    long long n;
+    const float* d_feats;         /* [n][feats_ld] network input features (eval_joint.py:167-168) */
+    int feats_ld;
+    const float* d_points;        /* [n][3] world points = coords * res (eval_joint.py:193) */
+    float res;
+    int num_rots;
+    /* the network: program of MinkUNet34C.forward (cv_net_run_f32) and the sizes its coordinate plan is built with */
+    const cv_net_op* ops; int n_ops;
+    const cv_net_buf* bufs; int n_bufs;
+    int stem_k, mask_groups;
+    long long masked_min_rows;
+    int max_channels;             /* widest convolution output (workspace sizing) */
+    int use_range_flag;           /* 1: the program runs on fp16 pairs; result.range_flag reports an input beyond the fp16 range */
+    float* d_out_feats;           /* [n][out_ld] network output, caller's buffer, caller's row order */
+    int out_ld, out_channels;
+    int nclasses, log_scale;      /* head split (eval_joint.py:173-190) */
+    /* optional: predictions fed to vote + decode instead of the network's (NULL = the network's) */
+    const float* d_xyz_in; const float* d_scale_in; const float* d_prob_in; const int32_t* d_class_in;
+    int vote_algo;                /* cv_hv_forward_f32 algo (0 auto) */
+    cv_decode_params decode;      /* max_iters is taken from max_candidates */
+    int max_candidates;           /* capacity of h_cand_idx / h_verdict / h_boxes / h_scores / h_classes / h_pick */
+    double nms_threshold;         /* eval_joint.py:273 (0.3) */
+    /* scratch: grown by the caller to result.needed_* after a CV_ENOMEM return */
+    void* d_ws; size_t ws_bytes;
+    float* d_grids; size_t grid_capacity_floats;   /* optional caller buffer for the three grids (6 floats per cell); NULL: in d_ws */
+    void* h_pinned; size_t pinned_bytes;           /* >= 256 bytes of page-locked host memory */
+    /* host results */
+    int64_t* h_cand_idx; int32_t* h_verdict;
+    float* h_boxes; float* h_scores; int32_t* h_classes;      /* accepted boxes in acceptance order: [k][8][3], [k], [k] */
+    int32_t* h_pick;                                          /* detections after per-class NMS: indices into the box list, class by class */
+    /* optional measurement hook: hipEvent_t handles recorded on `stream` at the scene's start, behind the network, the head
+     * split, the vote and the decode (NULL entries are skipped) */
+    void* events[5];
+} cv_scene_desc;
+typedef struct cv_scene_result {
+    int n_cand, n_boxes, n_det, truncated, range_flag, duplicates, out_of_window;
+    int dims[3];
+    float corner[3];
+    long long level_rows[5];
+    size_t needed_ws_bytes, needed_grid_floats;
+    /* device views into d_ws / d_grids, valid until the next call that uses the same scratch */
+    float* d_grid_obj; float* d_grid_rot; float* d_grid_scale;
+    float* d_xyz; float* d_scale; float* d_prob; int32_t* d_class;      /* the network's own head outputs */
+} cv_scene_result;
+int cv_detect_scene_f32(const cv_scene_desc* desc, cv_scene_result* result, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
