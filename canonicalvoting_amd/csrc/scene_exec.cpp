@@ -11,7 +11,9 @@
 // grid's shape) and for the decode results.  Same kernels, same launch order, same arguments: results are bit-identical
 // to the call-by-call path (tests/test_scene_call_gpu.py).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "cv_common.h"
@@ -31,6 +33,14 @@ struct Carver {
         return r;
     }
 };
+
+// CV_SCENE_SERIALIZE=1 (experiment): the pure-enqueue part of a scene (network program, head, vote: ~110 launches) is issued
+// under one process-wide lock, as the interpreter lock did for the call-by-call path
+std::mutex g_enqueue_mu;
+bool serialize_enqueue() {
+    static const bool on = getenv("CV_SCENE_SERIALIZE") && atoi(getenv("CV_SCENE_SERIALIZE")) != 0;
+    return on;
+}
 
 }  // namespace
 
@@ -149,6 +159,8 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
     const int32_t* perms[9];
     for (int i = 0; i < 5; ++i) perms[i] = (off.mask_perm[i] >= 0 && rows[i] >= d->masked_min_rows) ? ap + off.mask_perm[i] : nullptr;
     for (int i = 0; i < 4; ++i) perms[5 + i] = ap + off.up_perm[i];
+    std::unique_lock<std::mutex> enq(g_enqueue_mu, std::defer_lock);
+    if (serialize_enqueue()) enq.lock();
     const void* ext_ptr[2] = {d->d_feats, d->d_out_feats};
     const int ext_ld[2] = {d->feats_ld, d->out_ld};
     rc = cv_net_run_f32(d->ops, d->n_ops, d->bufs, d->n_bufs, rows, NL, arena, arena_b, ext_ptr, ext_ld, maps, 15, perms, 9, conv_ws,
@@ -170,6 +182,7 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
                            std::max<size_t>(vote_ws_b, 256), d->vote_algo, stream);
     if (rc != CV_OK) return rc;
     CV_HIP_CHECK(mark(3));
+    if (enq.owns_lock()) enq.unlock();
     cv_decode_params prm = d->decode;
     prm.max_iters = d->max_candidates;
     int n_cand = 0, n_boxes = 0, truncated = 0;

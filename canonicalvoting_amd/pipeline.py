@@ -2,6 +2,7 @@
 (eval_joint.py:163-280), everything on the device, three host syncs per scene (coordinate-set
 sizes, vote-grid shape, decode results)."""
 import ctypes
+import os
 
 import torch
 
@@ -102,6 +103,7 @@ class _SceneHost:
         self.classes = np.zeros(max_candidates, np.int32)
         self.pick = np.zeros(max_candidates, np.int32)
         self.ws_hint = 0
+        self.grid_hint = 0
 
 
 _scene_hosts = {}
@@ -167,6 +169,10 @@ def detect_scene_c(model, hv, coords4, feats, res, nclasses=9, log_scale=True, s
     d.h_boxes, d.h_scores, d.h_classes, d.h_pick = (vp(host.boxes.ctypes.data), vp(host.scores.ctypes.data),
                                                     vp(host.classes.ctypes.data), vp(host.pick.ctypes.data))
     r = _lib.SceneResult()
+    grids_t = None
+    if os.environ.get("CV_SCENE_GRIDS", "ws") == "torch" and host.grid_hint:
+        grids_t = torch.empty(host.grid_hint, dtype=torch.float32, device=dev)      # experiment: the grids as a fresh allocation
+        d.d_grids, d.grid_capacity_floats = vp(grids_t.data_ptr()), grids_t.numel()
     need = max(host.ws_hint, 64 << 20)
     for attempt in range(4):
         ws = _lib.scratch(dev, "scene_call", need)
@@ -180,6 +186,7 @@ def detect_scene_c(model, hv, coords4, feats, res, nclasses=9, log_scale=True, s
         _lib.check(rc, "cv_detect_scene_f32")
         break
     host.ws_hint = max(host.ws_hint, int(r.needed_ws_bytes))
+    host.grid_hint = max(host.grid_hint, int(r.needed_grid_floats) * 9 // 8)
     if r.range_flag or r.truncated:
         # rare: a convolution input beyond the fp16 range, or more candidate cells than the result arrays hold
         if r.range_flag:
