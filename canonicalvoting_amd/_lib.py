@@ -130,6 +130,7 @@ SIGNATURES = {
     "cv_sp_conv_workspace_bytes": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int]),
     "cv_sp_conv_f32": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp]),
     "cv_sp_set_split_target": (ctypes.c_int, [ctypes.c_int]),
+    "cv_sp_pack_weights_t_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_set_ablation": (ctypes.c_int, [ctypes.c_int]),
     "cv_sp_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
     "cv_sp_tile_plan_ints": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),

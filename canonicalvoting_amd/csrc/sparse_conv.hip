@@ -228,7 +228,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
 // w * col_scale * mult (mult = 2^scale_log2 keeps the low pieces of small weights out of the fp16 subnormals)
 __global__ __launch_bounds__(256) void pack_weights_h2(const float* __restrict__ w, int K, int cin, int cout,
                                                        const float* __restrict__ col_scale, float mult,
-                                                       unsigned short* __restrict__ wp) {
+                                                       unsigned short* __restrict__ wp, int trans = 0) {
     const long long total = (long long)K * cin * cout / 2;
     const int nch = cin / 32;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -237,10 +237,12 @@ __global__ __launch_bounds__(256) void pack_weights_h2(const float* __restrict__
         const int col = (int)(r % cout); r /= cout;
         const int c = (int)(r % nch); r /= nch;
         const int j = (int)r;
-        const float* p = w + ((long long)j * cin + c * 32 + 2 * k2) * cout + col;
+        // trans: w is [K][cout][cin] - the weights of the convolution whose transpose (input gradient) is being packed
+        const float* p = trans ? w + ((long long)j * cout + col) * cin + c * 32 + 2 * k2
+                               : w + ((long long)j * cin + c * 32 + 2 * k2) * cout + col;
         const float sc = (col_scale ? col_scale[col] : 1.f) * mult;
         unsigned h, l;
-        split2h(p[0] * sc, p[cout] * sc, h, l);
+        split2h(p[0] * sc, p[trans ? 1 : cout] * sc, h, l);
         const long long base = ((long long)(j * nch + c) * 2 * cout + col) * 32 + 2 * k2;
         *reinterpret_cast<unsigned*>(wp + base) = h;
         *reinterpret_cast<unsigned*>(wp + base + (long long)cout * 32) = l;
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void pack_weights_h2(const float* __restrict__
 // wp6 layout (unsigned short): ((((j*nch + c)*3 + plane)*cout + col)*32 + k) for channel c*32 + k of offset j
 __global__ __launch_bounds__(256) void pack_weights_x6(const float* __restrict__ w, int K, int cin, int cout,
                                                        const float* __restrict__ col_scale,
-                                                       unsigned short* __restrict__ wp) {
+                                                       unsigned short* __restrict__ wp, int trans = 0) {
     const long long total = (long long)K * cin * cout / 2;                   // pairs of consecutive k
     const int nch = cin / 32;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -259,10 +261,11 @@ __global__ __launch_bounds__(256) void pack_weights_x6(const float* __restrict__
         const int col = (int)(r % cout); r /= cout;
         const int c = (int)(r % nch); r /= nch;
         const int j = (int)r;
-        const float* p = w + ((long long)j * cin + c * 32 + 2 * k2) * cout + col;
+        const float* p = trans ? w + ((long long)j * cout + col) * cin + c * 32 + 2 * k2
+                               : w + ((long long)j * cin + c * 32 + 2 * k2) * cout + col;
         unsigned h, m, l;
         const float sc = col_scale ? col_scale[col] : 1.f;
-        split3(p[0] * sc, p[cout] * sc, h, m, l);
+        split3(p[0] * sc, p[trans ? 1 : cout] * sc, h, m, l);
         const long long base = ((long long)(j * nch + c) * 3 * cout + col) * 32 + 2 * k2;
         *reinterpret_cast<unsigned*>(wp + base) = h;
         *reinterpret_cast<unsigned*>(wp + base + (long long)cout * 32) = m;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256) void pack_weights_x6(const float* __restrict__
 // one bf16 plane (RNE): ((j*nch + c)*cout + col)*32 + k
 __global__ __launch_bounds__(256) void pack_weights_b1(const float* __restrict__ w, int K, int cin, int cout,
                                                        const float* __restrict__ col_scale,
-                                                       unsigned short* __restrict__ wp) {
+                                                       unsigned short* __restrict__ wp, int trans = 0) {
     const long long total = (long long)K * cin * cout / 2;
     const int nch = cin / 32;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -282,10 +285,11 @@ __global__ __launch_bounds__(256) void pack_weights_b1(const float* __restrict__
         const int col = (int)(r % cout); r /= cout;
         const int c = (int)(r % nch); r /= nch;
         const int j = (int)r;
-        const float* p = w + ((long long)j * cin + c * 32 + 2 * k2) * cout + col;
+        const float* p = trans ? w + ((long long)j * cout + col) * cin + c * 32 + 2 * k2
+                               : w + ((long long)j * cin + c * 32 + 2 * k2) * cout + col;
         const float sc = col_scale ? col_scale[col] : 1.f;
         *reinterpret_cast<unsigned*>(wp + ((long long)(j * nch + c) * cout + col) * 32 + 2 * k2) =
-            cvt_pk_bf16(p[0] * sc, p[cout] * sc);
+            cvt_pk_bf16(p[0] * sc, p[trans ? 1 : cout] * sc);
     }
 }
 
@@ -1275,7 +1279,7 @@ constexpr int hd_blocks(int NB, int NW, int NSTG) {          // workgroups per C
 // release: the second k-step's fragments travel while the first one multiplies, and the requests of the next unit are
 // issued while the first ones travel (conv_hd, HD_EARLY).
 #ifndef HD_EARLY
-#define HD_EARLY 1
+#define HD_EARLY 0      // measured (profiles/r4/hd2_grid.txt): 562-565 scenes/s with it against 573-575 without
 #endif
 __device__ __forceinline__ void hd_reads3_issue(const unsigned (&aa)[4], const unsigned (&ab)[2], u32x4v (&A)[4],
                                                 u32x4v (&B0)[2][3], u32x4v (&B1)[2][3]) {
@@ -2699,9 +2703,12 @@ __global__ __launch_bounds__(256) void head_separate(const float* __restrict__ f
 }
 
 // run-time options (cv_sp_set_option): conv_hd switch (bit NB - 1) and its row threshold; defaults from the environment
-std::atomic<long long> g_opt_hd_mask{getenv("CV_HD") ? atoll(getenv("CV_HD")) : 0};
+// defaults (profiles/r4/hd2_grid.txt, hd_shapes.txt): the 96-column fine-level launches (>= 16384 rows) on conv_hd, 8 waves x 2 ring
+// stages: 558 -> 573 scenes/s with eight scenes in flight (528 -> 575 under the one-call scene path); 32- and 64-column
+// launches and the coarse levels stay on conv_hl (conv_hd measured slower there)
+std::atomic<long long> g_opt_hd_mask{getenv("CV_HD") ? atoll(getenv("CV_HD")) : 4};
 std::atomic<long long> g_opt_hd_min_rows{getenv("CV_HD_MIN_ROWS") ? atoll(getenv("CV_HD_MIN_ROWS")) : 16384};
-std::atomic<long long> g_opt_hd_shape{getenv("CV_HD_SHAPE") ? atoll(getenv("CV_HD_SHAPE")) : 0};      // 0: 8 waves x 3 stages, 1: 4 x 2, 2: 8 x 2
+std::atomic<long long> g_opt_hd_shape{getenv("CV_HD_SHAPE") ? atoll(getenv("CV_HD_SHAPE")) : 2};      // 0: 8 waves x 3 stages, 1: 4 x 2, 2: 8 x 2
 
 template <int NB>
 int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
@@ -3198,6 +3205,27 @@ int cv_sp_pack_weights_h2_f32(const float* d_w, int K, int cin, int cout, const 
     const long long total = (long long)K * cin * cout / 2;
     pack_weights_h2<<<(unsigned)std::min<long long>((total + 255) / 256, 8192), 256, 0, st>>>(
         d_w, K, cin, cout, d_col_scale, ldexpf(1.f, scale_log2), static_cast<unsigned short*>(d_wp));
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+// Packed weights of the TRANSPOSED convolution (the input gradient: dX = conv over the transposed map with W_j^T) straight
+// from the forward weights d_w[K][rows][cols]: the packed tensor is that of W'[K][cin = cols][cout = rows] with
+// W'[j][a][b] = d_w[j][b][a] - no transposed copy of the weights per layer and step.  pieces 3: bf16 triples, 2: fp16 pairs
+// (times 2^scale_log2), 1: one bf16 plane.
+int cv_sp_pack_weights_t_f32(const float* d_w, int K, int rows, int cols, int pieces, int scale_log2, void* d_wp, void* stream) {
+    CV_REQUIRE(d_w && d_wp && K > 0 && rows > 0 && cols > 0, CV_EINVAL, "bad pack_weights_t arguments");
+    const int cin = cols, cout = rows;
+    CV_REQUIRE(cin % 32 == 0, CV_EINVAL, "pack_weights_t needs %d (the input channels of the transposed convolution) %% 32 == 0", cin);
+    CV_REQUIRE(pieces >= 1 && pieces <= 3 && scale_log2 >= -60 && scale_log2 <= 60, CV_EINVAL, "pieces is 1, 2 or 3");
+    CV_REQUIRE((reinterpret_cast<uintptr_t>(d_wp) & 15) == 0, CV_EINVAL, "d_wp must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long total = (long long)K * cin * cout / 2;
+    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 8192);
+    unsigned short* wp = static_cast<unsigned short*>(d_wp);
+    if (pieces == 3) pack_weights_x6<<<grid, 256, 0, st>>>(d_w, K, cin, cout, nullptr, wp, 1);
+    else if (pieces == 2) pack_weights_h2<<<grid, 256, 0, st>>>(d_w, K, cin, cout, nullptr, ldexpf(1.f, scale_log2), wp, 1);
+    else pack_weights_b1<<<grid, 256, 0, st>>>(d_w, K, cin, cout, nullptr, wp, 1);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

@@ -421,7 +421,7 @@ def range_flag(dev):
 def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=None, relu=False,
                  out=None, flavour=0, row_perm=None, j_begin=0, j_end=0, acc_in=None, perm_groups=0,
                  cache_weights=True, pieces=None, in_hl=False, out_hl=False, res_hl=False, stem_mfma=False,
-                 split_tickets=None):
+                 split_tickets=None, weight_t=False):
     """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout].
     in_hl / out_hl / res_hl: the operand is in the hl format (to_hl / from_hl; cv_conv_desc.in_hl), pieces=2 only.
     pieces=2: fp16-pair products (weights packed per call; the caller reads range_flag(dev) after synchronising);
@@ -431,7 +431,17 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
     L = _lib.lib()
     dev = x_feats.device
     w = weight if weight.dim() == 3 else weight[None]
-    K, cin, cout = w.shape
+    if weight_t:
+        # the TRANSPOSED convolution of `weight` ([K, Cout', Cin'] = a layer's forward kernel; the input gradient):
+        # packed straight from the forward layout where the 16-bit piece path runs, transposed by a copy otherwise
+        K, cout, cin = w.shape
+        x6_ok = (CONV_X6 and flavour in (0, 1) and cin % 32 == 0 and cout % 4 == 0 and pieces in (1, 3)
+                 and not (flavour == 4 or (TILE_KERNEL and flavour == 0)))
+        if not x6_ok:
+            w = w.permute(0, 2, 1)
+            weight_t = False
+    else:
+        K, cin, cout = w.shape
     assert x_feats.shape[1] == cin and x_feats.stride(1) == 1
     w = w.contiguous()
     if out is None:
@@ -455,13 +465,21 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
             ver = (weight.data_ptr(), weight._version, tuple(weight.shape))
             hit = _packed_h2.get(key) if cache_weights else None
             if hit is None or hit[0] != ver:
-                k = h2_scale_log2((w, None))
+                hints = getattr(_train_state, "pair_scales", None)
+                k = hints.get(weight.data_ptr()) if hints is not None else None
+                if k is None:
+                    k = h2_scale_log2((w, None))          # (one host wait: the training step hands the scales over instead)
                 hit = (ver, packed_weights_h2(w, None, k), k)
                 if cache_weights:
                     if len(_packed_h2) > 512:
                         _packed_h2.clear()
                     _packed_h2[key] = hit
             wp6, acc_scale, flag = hit[1], 2.0 ** -hit[2], range_flag(dev)
+        elif weight_t:
+            wp6 = torch.empty((3 if pieces == 3 else 1) * w.numel(), dtype=torch.int16, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.cv_sp_pack_weights_t_f32(_ptr(w), K, cout, cin, pieces, 0, _ptr(wp6), _stream(dev)),
+                           "cv_sp_pack_weights_t_f32")
         elif pieces == 1:
             wp6 = packed_weights_bf16(w)
         else:
@@ -828,6 +846,51 @@ def _gradient_untouched_until_end(kernel):
             and not torch.is_grad_enabled() and not torch.is_anomaly_enabled())
 
 
+TRAIN_FWD_PIECES = int(os.environ.get("CV_TRAIN_FWD_PIECES", "2"))      # 2: fp16 pairs in the training forward, 3: bf16 triples
+_train_state = threading.local()
+
+
+class pair_scale_hints:
+    """power-of-two weight scales of the fp16-pair products for every convolution of `module`, from ONE multi-tensor
+    max-norm and ONE host read, valid inside the `with` block (a training step: the weights do not move between its forward
+    and its optimizer step).  Without it every fp16-pair convolution whose packed weights are not cached reads its own
+    maximum back (63 host waits per MinkUNet34C forward)."""
+
+    def __init__(self, module):
+        self.module = module
+
+    def __enter__(self):
+        self.outer = getattr(_train_state, "pair_scales", None)
+        ks = [m.kernel for m in self.module.modules() if isinstance(m, MinkowskiConvolutionBase) and m.kernel.is_cuda]
+        scales = {}
+        if ks and TRAIN_FWD_PIECES == 2 and COMPUTE_DTYPE != "bf16":
+            with torch.no_grad():
+                amax = torch.stack(torch._foreach_norm([k.detach() for k in ks], float("inf"))).tolist()
+            for k, a in zip(ks, amax):
+                scales[k.data_ptr()] = (max(-60, min(60, 13 - math.ceil(math.log2(a)))) if (math.isfinite(a) and a > 0) else 0)
+        _train_state.pair_scales = scales
+        return self
+
+    def __exit__(self, *exc):
+        _train_state.pair_scales = self.outer
+        return False
+
+
+def training_forward_left_fp16_range(dev):
+    """True when a convolution of this thread's training forwards since the last call staged an input beyond the fp16
+    range on the current stream (synchronises the stream; the flag is reset).  False without a wait when no forward used
+    the fp16 pairs."""
+    if not getattr(_train_state, "used_pairs", False):
+        return False
+    _train_state.used_pairs = False
+    torch.cuda.current_stream(dev).synchronize()
+    flag = range_flag(dev)
+    if int(flag[0]) == 0:
+        return False
+    flag.zero_()
+    return True
+
+
 class _ConvFn(torch.autograd.Function):
     """Sparse convolution with HIP forward, input-gradient (the same kernel on the transposed map with
     transposed weights) and weight-gradient kernels."""
@@ -839,7 +902,14 @@ class _ConvFn(torch.autograd.Function):
         ctx.has_nbr = nbr is not None
         ctx.has_bias = bias is not None
         shift = bias.reshape(-1).contiguous() if bias is not None else None
-        return conv_forward(feats, kernel, nbr, n_out, shift=shift, cache_weights=False)
+        # fp32-level products of the training FORWARD: fp16 pairs (three piece products) while the activations are inside
+        # the fp16 range - they sit behind BatchNorm - with the range flag as the guard (train.train_step reads it once per
+        # step and redoes the step on the bf16 triples); the input gradient keeps the triples (gradients have no bound)
+        pieces = None
+        if TRAIN_FWD_PIECES == 2 and COMPUTE_DTYPE != "bf16" and feats.shape[1] % 32 == 0:
+            pieces = 2
+            _train_state.used_pairs = True
+        return conv_forward(feats, kernel, nbr, n_out, shift=shift, cache_weights=False, pieces=pieces)
 
     @staticmethod
     def backward(ctx, grad):
@@ -872,9 +942,8 @@ class _ConvFn(torch.autograd.Function):
                     nbr.record_stream(side)
                 _join_at_end_of_backward(cur, side)
         if ctx.needs_input_grad[0]:
-            w_t = k3.detach().permute(0, 2, 1).contiguous()
             nbr_t = transposed_map(nbr, feats.shape[0]) if nbr is not None else None
-            d_feats = conv_forward(grad, w_t, nbr_t, feats.shape[0], cache_weights=False)
+            d_feats = conv_forward(grad, k3.detach(), nbr_t, feats.shape[0], cache_weights=False, weight_t=True)
         if side is not None:
             if not late:
                 cur.wait_stream(side)
@@ -1016,6 +1085,27 @@ class _BNTrainFn(torch.autograd.Function):
         return dx, dg[0], dg[1], None, None, None, None, dres, None
 
 
+# `num_batches_tracked += 1` of every BatchNorm of a training forward (62 one-element launches per MinkUNet34C step) as ONE
+# multi-tensor add: a network forward opens the batch (batched_counter_updates), the modules append their counters
+_nbt_pending = threading.local()
+
+
+class batched_counter_updates:
+    def __enter__(self):
+        self.outer = getattr(_nbt_pending, "tensors", None)
+        if self.outer is None:
+            _nbt_pending.tensors = []
+        return self
+
+    def __exit__(self, *exc):
+        if self.outer is None:
+            pend, _nbt_pending.tensors = _nbt_pending.tensors, None
+            if pend:
+                with torch.no_grad():
+                    torch._foreach_add_(pend, 1)
+        return False
+
+
 class MinkowskiBatchNorm(nn.Module):
     """``nn.BatchNorm1d`` over the feature rows; sub-module name ``bn`` (utils/resnet.py:115-116)."""
 
@@ -1031,8 +1121,12 @@ class MinkowskiBatchNorm(nn.Module):
         """relu?(bn(x) + residual) in one pass (BasicBlock's tail, resnet_block.py forward)."""
         bn = self.bn
         if self.training and bn.affine and bn.track_running_stats and bn.momentum is not None and x.F.shape[0] > 1:
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
+            pend = getattr(_nbt_pending, "tensors", None)
+            if pend is not None:
+                pend.append(bn.num_batches_tracked)         # one multi-tensor add at the end of the network forward
+            else:
+                with torch.no_grad():
+                    bn.num_batches_tracked += 1
             return x._like(_BNTrainFn.apply(x.F, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                             bn.momentum, bn.eps, residual, bool(relu)))
         if self.training or torch.is_grad_enabled() and (x.F.requires_grad or residual is not None and

@@ -106,7 +106,8 @@ class MinkUNetBase(ResNetBase):
     def forward(self, x, defer_check=None):
         if (not self.training) and (not torch.is_grad_enabled()) and self.BLOCK is BasicBlock:
             return self.program_forward(x, defer_check=defer_check) if self.USE_PROGRAM else self.fused_forward(x)
-        return self.modular_forward(x)
+        with ME.batched_counter_updates():
+            return self.modular_forward(x)
 
     def modular_forward(self, x):
         out_p1 = self.bn0.forward_fused(self.conv0p1s1(x), relu=True)

@@ -79,11 +79,25 @@ def separate_loss(out_feats, xyz_labels, scale_labels, obj_labels, coords4=None,
 
 def train_step(model, optimizer, coords4, feats, xyz_labels, scale_labels, class_labels, **loss_kw):
     """one iteration of train_joint.py:246-288; feats already recentred (:248-249)."""
-    optimizer.zero_grad(set_to_none=True)
-    x = ME.SparseTensor(feats, coords4, device=feats.device)
-    out = model(x)
-    loss, parts = joint_loss(out.F, xyz_labels, scale_labels, class_labels, **loss_kw)
-    loss.backward()
+    def fwd_bwd():
+        optimizer.zero_grad(set_to_none=True)
+        x = ME.SparseTensor(feats, coords4, device=feats.device)
+        out = model(x)
+        loss, parts = joint_loss(out.F, xyz_labels, scale_labels, class_labels, **loss_kw)
+        loss.backward()
+        return loss, parts
+
+    with ME.pair_scale_hints(model):
+        loss, parts = fwd_bwd()
+    if ME.training_forward_left_fp16_range(feats.device):
+        # the forward's fp16-pair products met an activation beyond 65000 (never behind a healthy BatchNorm): the step is
+        # redone on the bf16 triples before the optimizer sees a gradient
+        prev, ME.TRAIN_FWD_PIECES = ME.TRAIN_FWD_PIECES, 3
+        try:
+            loss, parts = fwd_bwd()
+        finally:
+            ME.TRAIN_FWD_PIECES = prev
+        model.train_range_fallbacks = getattr(model, "train_range_fallbacks", 0) + 1
     optimizer.step()
     return loss.detach(), {k: v.detach() for k, v in parts.items()}
 

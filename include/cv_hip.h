@@ -270,6 +270,11 @@ int cv_sp_pack_weights_h2_f32(const float* d_w, int K, int cin, int cout, const 
  * bits); the reference trains and evaluates in fp32 (train_joint.py:218), BASELINE config 3 asks for bf16. */
 int cv_sp_pack_weights_bf16_f32(const float* d_w, int K, int cin, int cout, const float* d_col_scale, void* d_wp,
                                 void* stream);
+/* Packed weights of the TRANSPOSED convolution (the input gradient of a layer: the same kernel on the transposed map with
+ * W_j^T) straight from the layer's forward weights d_w[K][rows][cols]: what cv_sp_pack_weights_{x6,h2,bf16}_f32 would make
+ * of W'[K][cols][rows], W'[j][a][b] = d_w[j][b][a], without materialising W'.  cols % 32 == 0.  pieces: 3 bf16 triples,
+ * 2 fp16 pairs (times 2^scale_log2), 1 one bf16 plane. */
+int cv_sp_pack_weights_t_f32(const float* d_w, int K, int rows, int cols, int pieces, int scale_log2, void* d_wp, void* stream);
 /* Weights of the matrix-core stem (Cin 3 or 6 -> 32 channels, K <= 128 offsets; cv_conv_desc with weight_pieces = 2 and
  * this buffer in weight_x6): (w * d_col_scale * 2^scale_log2) as fp16 pairs in MFMA B-operand order, 8 * cin * 2048 bytes;
  * pass acc_scale = 2^-scale_log2 and no `scale` in the descriptor. */
