@@ -133,13 +133,9 @@ SIGNATURES = {
     "cv_sp_pack_weights_t_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_set_ablation": (ctypes.c_int, [ctypes.c_int]),
     "cv_sp_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
-    "cv_sp_tile_plan_ints": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
-    "cv_sp_tile_plan": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, vp, vp, vp]),
     "cv_sp_pack_weights_x6_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     "cv_sp_pack_weights_h2_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
     "cv_sp_pack_weights_bf16_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
-    "cv_sp_tile_kw": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
-    "cv_sp_pack_weights_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_scene_maps_words": (ctypes.c_size_t, [c_i64_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_longlong, ctypes.POINTER(SceneMaps)]),
     "cv_sp_scene_maps": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_longlong,

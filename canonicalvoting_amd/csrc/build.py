@@ -33,7 +33,6 @@ SOURCES = {
     "hv_decode.hip": STRICT + os.environ.get("CV_DEC_DEFS", "").split(),  # greedy-walk experiments (-DDEC_BLOCKED=0)
     "sparse_coords.hip": [],
     "sparse_conv.hip": os.environ.get("CV_SC_DEFS", "").split(),          # kernel experiments (-DCV_WP_CLAMPED_GATHER=1)
-    "sparse_conv_alt.hip": os.environ.get("CV_SC_DEFS", "").split(),      # flavours 3 / 4 and the instrumented twin (not on the default path)
     "net_exec.cpp": [],
     "scene_exec.cpp": [],
 }

@@ -2714,7 +2714,6 @@ template <int NB>
 int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
     dim3 grid((unsigned)((a.n_out + TM - 1) / TM), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)),
               (unsigned)a.splits);
-    static const bool prof_on = getenv("CV_CONV_PROF") != nullptr;
     // one-barrier-per-unit kernel (CV_CONV_WP=0: conv_rows_x6 everywhere): no ablation switches, and every workgroup's
     // offsets fit the map prefetch
     static const bool wp_on = !(getenv("CV_CONV_WP") && atoi(getenv("CV_CONV_WP")) == 0);
@@ -2804,7 +2803,7 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         if (a.splits > 1) return launch_finish(a, st);
         return CV_OK;
     }
-    if (vec && a.wp6 && !prof_on && wp_on && !a.dbg && per_wg <= WP_NPRE) {
+    if (vec && a.wp6 && wp_on && !a.dbg && per_wg <= WP_NPRE) {
         if (a.pieces == 2) conv_rows_wp<NB, 2><<<gridx, THREADS, 0, st>>>(ax);
         else if (a.pieces == 1) conv_rows_wp<NB, 1><<<gridx, THREADS, 0, st>>>(ax);
         else conv_rows_wp<NB, 3><<<gridx, THREADS, 0, st>>>(ax);
@@ -2812,7 +2811,7 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         if (a.splits > 1) return launch_finish(a, st);
         return CV_OK;
     }
-    if (vec && a.wp6 && (!prof_on || a.in2)) {
+    if (vec && a.wp6) {
         if (a.pieces == 2) conv_rows_x6<NB, 2><<<grid, THREADS, 0, st>>>(a);
         else if (a.pieces == 1) conv_rows_x6<NB, 1><<<grid, THREADS, 0, st>>>(a);
         else conv_rows_x6<NB, 3><<<grid, THREADS, 0, st>>>(a);
@@ -2820,7 +2819,6 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         if (a.splits > 1) return launch_finish(a, st);
         return CV_OK;
     }
-    if (vec && prof_on) return launch_rows_prof(a, NB, st);          // instrumented twin: sparse_conv_alt.hip
     if (vec) conv_rows<NB, true><<<grid, THREADS, 0, st>>>(a);
     else conv_rows<NB, false><<<grid, THREADS, 0, st>>>(a);
     CV_LAUNCH_CHECK();
@@ -2975,7 +2973,7 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
                    CV_EINVAL, "hl-format output: Cout and leading dimension %% 32 == 0, 128-byte aligned rows");
         CV_REQUIRE(!d->res_hl || !d->residual || (d->res_ld % 32 == 0 && (reinterpret_cast<uintptr_t>(d->residual) & 127) == 0),
                    CV_EINVAL, "hl-format residual: leading dimension %% 32 == 0, 128-byte aligned rows");
-        CV_REQUIRE(d->flavour == 0 && !d->plan_ent, CV_EINVAL, "the hl format runs on the rows flavour only");
+        CV_REQUIRE(d->flavour == 0, CV_EINVAL, "the hl format runs with flavour 0 only");
         // conv_hl forms its gather addresses in 32 bits (row * row bytes + chunk offset)
         CV_REQUIRE(!d->in_hl || ((unsigned long long)d->n_in * (unsigned long long)d->in_ld * 4ull + (unsigned long long)d->cin * 4ull < (1ull << 32) &&
                                  (!d->in2 || (unsigned long long)d->n_out * (unsigned long long)d->in2_ld * 4ull + (unsigned long long)d->cin2 * 4ull < (1ull << 32))),
@@ -2995,7 +2993,9 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         a.dbg = dbg;
     }
     if (!d->in_hl) a.tickets = nullptr;       // the in-launch split-K reduction exists in conv_hl only
-    CV_REQUIRE(!d->plan_ent == !d->plan_cnt, CV_EINVAL, "plan_ent and plan_cnt go together");
+    CV_REQUIRE(!d->plan_ent && !d->plan_cnt && !d->weight_packed && (d->flavour == 0 || d->flavour == 1), CV_EINVAL,
+               "flavours 3 / 4 (the experimental wave / tile kernels of rounds 1-3) are gone: flavour is 0 or 1, plan_ent / plan_cnt / "
+               "weight_packed must be NULL");
     a.wide = d->cout % 4 == 0 && d->out_ld % 4 == 0 && (!d->residual || d->res_ld % 4 == 0) &&
              (!d->acc_in || d->acc_ld % 4 == 0) &&
              ((reinterpret_cast<uintptr_t>(d->out) | reinterpret_cast<uintptr_t>(d->residual) |
@@ -3006,7 +3006,7 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
                      ((reinterpret_cast<uintptr_t>(d->weight) & 15) == 0);
     if (d->in2) {
         CV_REQUIRE(vec && d->weight_x6 && d->weight2_x6 && d->cin2 > 0 && d->cin2 % KC == 0 && d->in2_ld >= d->cin2 &&
-                       d->in2_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->in2) & 15) == 0 && d->flavour != 4,
+                       d->in2_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->in2) & 15) == 0,
                    CV_EINVAL, "a second source needs the bf16x6 vector path (weight_x6, weight2_x6, Cin2 %% 32 == 0, "
                               "16-byte aligned rows)");
     }
@@ -3085,22 +3085,6 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
             }
             return CV_OK;
         }
-        if (d->flavour == 3 && d->in_ld % 4 == 0 && d->cout % nb_full(d->cout) == 0 &&
-            (reinterpret_cast<uintptr_t>(d->weight) & 15) == 0) {
-            return launch_wave_nb(a, nb_full(d->cout), st);
-        }
-    } else if (d->flavour == 4 && !tile_ok(a, vec)) {
-        CV_REQUIRE(false, CV_EINVAL, "flavour 4 needs Cin %% 32 == 0, Cout %% 32 == 0, K <= 27, 16-byte aligned "
-                                     "operands, packed weights (cv_sp_pack_weights_f32) and a tile plan "
-                                     "(cv_sp_tile_plan) for the kernel map");
-    } else if ((d->flavour == 0 || d->flavour == 4) && !d->in2 && !d->in_hl && !d->out_hl && !d->res_hl && tile_ok(a, vec)) {
-        const int sp = tile_splits(d->n_out, d->cout, je - jb);
-        const size_t need = sizeof(float) * (size_t)sp * (size_t)d->n_out * (size_t)d->cout;
-        if (sp > 1 && d->ws && d->ws_bytes >= need) {
-            a.splits = sp;
-            a.partial = static_cast<float*>(d->ws);
-        }
-        return launch_tile(a, st);
     } else if (d->flavour == 0) {
         int sp = pick_splits(d->n_out, d->cout, je - jb, d->cin, vec);
         if (d->in_hl) {

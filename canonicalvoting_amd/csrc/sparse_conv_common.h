@@ -1,6 +1,6 @@
-// Shared by sparse_conv.hip (the kernels the product runs) and sparse_conv_alt.hip (parity-tested experiments: the
-// wave-independent flavour, the pair-compacted tile flavour, the instrumented twin of conv_rows): launch arguments, the
-// hl format, the fused epilogue, and the few host functions the two translation units call across.
+// Launch arguments, the hl format and the fused epilogue of the convolution kernels in sparse_conv.hip.  (Rounds 1-3 kept
+// parity-tested experiments - a wave-independent flavour, a pair-compacted tile flavour, an instrumented twin - in a
+// second translation unit over this header; they were removed in round 4, git history and LABNOTES.md hold them.)
 #pragma once
 #include "cv_common.h"
 
@@ -236,11 +236,4 @@ __device__ __forceinline__ void hl_split2(float x0, float x1, unsigned& h, unsig
 // ---- across the two translation units
 int launch_finish(const ConvArgs& a, hipStream_t st);                  // sparse_conv.hip: reduce the partial tiles + epilogue
 int nb_full(int cout);                                                 // sparse_conv.hip
-int launch_wave_nb(const ConvArgs& a, int nb, hipStream_t st);         // sparse_conv_alt.hip (flavour 3)
-bool tile_ok(const ConvArgs& a, bool vec);                             // sparse_conv_alt.hip (flavour 4)
-int tile_kw(int cin, int cout);
-int tile_splits(long long n_out, int cout, int nj);
-int launch_tile(const ConvArgs& a, hipStream_t st);
-int launch_rows_prof(const ConvArgs& a, int nb, hipStream_t st);       // sparse_conv_alt.hip (CV_CONV_PROF)
-
 }  // namespace cvsc

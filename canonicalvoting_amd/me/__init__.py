@@ -435,8 +435,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
         # the TRANSPOSED convolution of `weight` ([K, Cout', Cin'] = a layer's forward kernel; the input gradient):
         # packed straight from the forward layout where the 16-bit piece path runs, transposed by a copy otherwise
         K, cout, cin = w.shape
-        x6_ok = (CONV_X6 and flavour in (0, 1) and cin % 32 == 0 and cout % 4 == 0 and pieces in (1, 3)
-                 and not (flavour == 4 or (TILE_KERNEL and flavour == 0)))
+        x6_ok = CONV_X6 and flavour in (0, 1) and cin % 32 == 0 and cout % 4 == 0 and pieces in (1, 3)
         if not x6_ok:
             w = w.permute(0, 2, 1)
             weight_t = False
@@ -452,14 +451,9 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
         # generic (module-by-module / training) path: mask-sorted offset groups, orders cached on the map
         row_perm = map_mask_perms(nbr, AUTO_MASK_GROUPS)
         perm_groups = AUTO_MASK_GROUPS
-    plan = wp = None
-    if ((flavour == 4 or (TILE_KERNEL and flavour == 0)) and perm_groups == 0 and K <= 27 and cin % 32 == 0
-            and cout % 32 == 0 and L.cv_sp_tile_kw(cin, cout) > 0):
-        plan = tile_plan(nbr, row_perm) if nbr is not None else None
-        wp = packed_weights(weight, w, cache_weights)
     wp6 = None
     acc_scale, flag = 0.0, None
-    if CONV_X6 and flavour in (0, 1) and cin % 32 == 0 and cout % 4 == 0 and plan is None:
+    if CONV_X6 and flavour in (0, 1) and cin % 32 == 0 and cout % 4 == 0:
         if pieces == 2:
             key = id(weight)
             ver = (weight.data_ptr(), weight._version, tuple(weight.shape))
@@ -491,7 +485,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
     ws = None
     if perm_groups > 1:
         ws = _workspace(dev, 4 * perm_groups * n_out * cout + 256)
-    elif flavour in (0, 4) and n_out < 128 * 384:
+    elif flavour == 0 and n_out < 128 * 384:
         ws = _workspace(dev, int(L.cv_sp_conv_workspace_bytes(n_out, cout, K)))
     p = lambda t: t.data_ptr() if t is not None else None
     d = _lib.ConvDesc(p(x_feats), x_feats.shape[0], x_feats.stride(0), cin, p(w), K, cout, p(nbr), n_out,
@@ -499,8 +493,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
                       1 if relu else 0, p(out), out.stride(0), flavour, p(ws),
                       ws.numel() if ws is not None else 0, p(row_perm), j_begin, j_end, p(acc_in),
                       acc_in.stride(0) if acc_in is not None else 0, perm_groups,
-                      plan[0].data_ptr() if plan is not None else None,
-                      plan[0].data_ptr() + 4 * plan[1] if plan is not None else None, p(wp), p(wp6), None, 0, 0, None,
+                      None, None, None, p(wp6), None, 0, 0, None,
                       1 if (perm_groups > 1 and getattr(row_perm, "_cv_has_map", False)) else 0,
                       2 if flag is not None else (1 if (pieces == 1 and wp6 is not None) else 0), acc_scale, p(flag),
                       1 if in_hl else 0, 1 if out_hl else 0, 1 if res_hl else 0, p(split_tickets))
@@ -568,11 +561,6 @@ def _perms_with_map(nbr, groups):
     m._cv_has_map = True
     m._cv_flat = flat
     return m
-
-
-# 1: flavour 0 (auto) runs the pair-compacted tile kernel wherever it applies.  Off by default: measured on MI355X
-# (profiles/tile_ablate.py) it ties the output-stationary kernel on the coarse levels and loses on the fine ones.
-TILE_KERNEL = os.environ.get("CV_TILE_KERNEL", "0") != "0"
 
 
 _packed = {}
@@ -691,58 +679,12 @@ def packed_weights_x6(weight, w3, cache=True):
 
 
 
-def packed_weights(weight, w3, cache=True):
-    """weights in the tile kernel's MFMA operand order (cv_sp_pack_weights_f32), cached per parameter tensor and
-    re-packed when it is modified in place (optimizer step, load_state_dict) or re-allocated."""
-    key = id(weight)
-    ver = (weight.data_ptr(), weight._version, tuple(weight.shape))
-    hit = _packed.get(key) if cache else None
-    if hit is None or hit[0] != ver or hit[2]() is not weight:
-        import weakref
-        L = _lib.lib()
-        K, cin, cout = w3.shape
-        wp = torch.empty(w3.numel(), dtype=torch.float32, device=w3.device)
-        with torch.cuda.device(w3.device):
-            _lib.check(L.cv_sp_pack_weights_f32(_ptr(w3), K, cin, cout, _ptr(wp), _stream(w3.device)),
-                       "cv_sp_pack_weights_f32")
-        try:
-            ref = weakref.ref(weight, lambda _r, k=key: _packed.pop(k, None))
-        except TypeError:
-            ref = lambda: weight
-        hit = _packed[key] = (ver, wp, ref)
-    return hit[1]
-
-
-def tile_plan(nbr, row_perm=None):
-    """(int32 plan words, offset of the counts) of the pair-compacted tile kernel for a kernel map and a
-    processing order (cv_sp_tile_plan); cached on the map tensor, shared by every conv that uses the map."""
-    cache = getattr(nbr, "_cv_tile_plans", None)
-    if cache is None:
-        cache = nbr._cv_tile_plans = {}
-    key = row_perm.data_ptr() if row_perm is not None else 0
-    hit = cache.get(key)
-    if hit is None:
-        L = _lib.lib()
-        n, K = nbr.shape
-        off = ctypes.c_size_t(0)
-        words = int(L.cv_sp_tile_plan_ints(n, K, ctypes.byref(off)))
-        buf = torch.empty(words, dtype=torch.int32, device=nbr.device)
-        with torch.cuda.device(nbr.device):
-            _lib.check(L.cv_sp_tile_plan(_ptr(nbr), n, K, _ptr(row_perm), _ptr(buf), _stream(nbr.device)),
-                       "cv_sp_tile_plan")
-        hit = cache[key] = (buf, int(off.value), row_perm)     # keeps the order tensor alive with the plan
-    return hit
-
-
-MASKED_FLAVOUR = 0      # 0: workgroup-tiled kernel (default, slightly faster here), 3: wave-independent kernel
-
-
 def conv_forward_masked(x_feats, weight, nbr, perms, n_out, **epilogue):
     """k^3 conv with the kernel offsets split into G groups, each group processed with the rows in the
     order sorted by that group's neighbour mask (see sparse_conv.hip); one launch + one reduce.
     perms: int32 [G, n_out] from CoordinateManager.mask_perms."""
     return conv_forward(x_feats, weight, nbr, n_out, row_perm=perms, perm_groups=perms.shape[0],
-                        flavour=epilogue.pop("flavour", MASKED_FLAVOUR), **epilogue)
+                        flavour=epilogue.pop("flavour", 0), **epilogue)
 
 
 def transposed_map(nbr, n_in):

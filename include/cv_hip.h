@@ -195,9 +195,7 @@ typedef struct cv_conv_desc {
     int relu;
     float* out;             /* [n_out][out_ld] */
     int out_ld;
-    int flavour;            /* 0 auto (may split offsets over workgroups through ws), 1 never split,
-                               3 wave-independent kernel (with perm_groups; big fine levels),
-                               4 pair-compacted tile kernel or fail (0 picks it when plan_ent is given) */
+    int flavour;            /* 0 auto (may split offsets over workgroups through ws), 1 never split */
     void* ws;               /* optional workspace, cv_sp_conv_workspace_bytes */
     size_t ws_bytes;
     const int32_t* row_perm;/* optional [n_out] processing order (rows with equal neighbour masks adjacent) */
@@ -206,9 +204,9 @@ typedef struct cv_conv_desc {
     int acc_ld;
     int perm_groups;        /* >1: row_perm is [perm_groups][n_out]; the offsets are split into that many
                                contiguous groups, each run in its own order in ONE launch (needs ws) */
-    const int32_t* plan_ent;/* optional pair lists of the kernel map (cv_sp_tile_plan, built with the same row_perm): */
-    const int32_t* plan_cnt;/* lets flavour 0 / 4 run the pair-compacted tile kernel (K <= 27, Cin, Cout % 32 == 0) */
-    const float* weight_packed; /* the same weights from cv_sp_pack_weights_f32; required by the tile kernel */
+    const int32_t* plan_ent;/* reserved, must be NULL (round 1-3: the pair lists of an experimental tile kernel, removed) */
+    const int32_t* plan_cnt;/* reserved, must be NULL */
+    const float* weight_packed; /* reserved, must be NULL */
     const void* weight_x6;  /* optional: the same weights from cv_sp_pack_weights_x6_f32.  When given (and Cin % 32 == 0)
                                the products run on the bf16 matrix cores as six bf16 x bf16 piece products per fp32
                                product (fp32-level accuracy, 0.375x the matrix time of v_mfma_f32_32x32x2_f32) */
@@ -245,15 +243,6 @@ typedef struct cv_conv_desc {
 int cv_sp_to_hl_f32(const float* d_x, long long n, int c, int x_ld, float* d_y, int y_ld, int32_t* range_flag, void* stream);
 int cv_sp_from_hl_f32(const float* d_x, long long n, int c, int x_ld, float* d_y, int y_ld, void* stream);
 
-/* Pair lists for the tile kernel, built once per kernel map and processing order and shared by every convolution
- * on that map: d_plan holds cv_sp_tile_plan_ints(n_out, K, &cnt_offset) int32 words; pass plan_ent = d_plan and
- * plan_cnt = d_plan + cnt_offset in cv_conv_desc.  Asynchronous. */
-size_t cv_sp_tile_plan_ints(long long n_out, int K, size_t* cnt_offset);
-int cv_sp_tile_plan(const int32_t* d_nbr, long long n_out, int K, const int32_t* d_row_perm, int32_t* d_plan,
-                    void* stream);
-/* Weights of the tile kernel: cv_sp_tile_kw = K chunk width it uses for Cin x Cout (0: shape not taken);
- * cv_sp_pack_weights_f32 re-orders [K][cin][cout] into the per-lane MFMA B-operand order for that width
- * (K*cin*cout floats, 16-byte aligned; redo whenever the weights change).  Asynchronous. */
 /* Weights of the bf16x6 path: [K][cin][cout] fp32 split into three bf16 pieces per value (h + m + l == value to half
  * an fp32 ulp), laid out per (offset, 32-channel chunk) as [piece][cout][32]: 3*K*cin*cout 16-bit words, 16-byte aligned;
  * cin % 32 == 0; redo whenever the weights change.  Asynchronous. */
@@ -280,8 +269,6 @@ int cv_sp_pack_weights_t_f32(const float* d_w, int K, int rows, int cols, int pi
  * pass acc_scale = 2^-scale_log2 and no `scale` in the descriptor. */
 int cv_sp_pack_weights_stem_h2_f32(const float* d_w, int K, int cin, const float* d_col_scale, int scale_log2, void* d_wp,
                                    void* stream);
-int cv_sp_tile_kw(int cin, int cout);
-int cv_sp_pack_weights_f32(const float* d_w, int K, int cin, int cout, float* d_wp, void* stream);
 
 size_t cv_sp_conv_workspace_bytes(long long n_out, int cout, int K);
 int cv_sp_conv_f32(const cv_conv_desc* desc, void* stream);

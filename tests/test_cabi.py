@@ -129,12 +129,6 @@ def test_host_side_layout_functions(built_lib):
     # arena of a two-buffer program: one external, one level-1 buffer of 96 channels
     bufs = (_lib.NetBuf * 2)(_lib.NetBuf(-1, 3, 0), _lib.NetBuf(1, 96, 1))
     assert L.cv_net_arena_bytes(bufs, 2, rows, 5) >= 36822 * 96 * 4
-    # tile plan and K-chunk helpers
-    coff = ctypes.c_size_t(0)
-    n_words = L.cv_sp_tile_plan_ints(1000, 27, ctypes.byref(coff))
-    assert coff.value >= 8 * 27 * 128 and n_words == coff.value + 8 * 32
-    assert [L.cv_sp_tile_kw(c, o) for c, o in ((96, 96), (128, 96), (128, 128), (256, 256), (160, 64), (3, 32))] == \
-        [96, 64, 128, 128, 32, 0]
 
 
 def test_no_packed_fp32_instructions_in_device_code(built_lib, tmp_path):
@@ -160,7 +154,7 @@ def test_no_packed_fp32_instructions_in_device_code(built_lib, tmp_path):
             packed = re.findall(r"\bv_pk_(?:add|mul|fma)_f32\b", asm)
             assert not packed, "%s: %d packed fp32 instructions" % (name, len(packed))
             seen += 1
-    assert seen >= 4          # hv_vote, hv_decode, sparse_coords, sparse_conv, sparse_conv_alt
+    assert seen >= 4          # hv_vote, hv_decode, sparse_coords, sparse_conv
 
 
 def test_compiled_hv_cuda_extension_loads_and_checks_its_inputs(built_lib):

@@ -158,13 +158,7 @@ def rel_err(a, b):
                                                (64, 64, 3, 0), (32, 32, 3, 0), (3, 32, 5, 1), (6, 32, 5, 1),
                                                (3, 32, 5, 0), (6, 32, 5, 0), (3, 32, 3, 0),   # flavour 0: stem kernel
 
-                                               (128, 96, 1, 1), (96, 64, 1, 1), (384, 256, 1, 0),
-                                               # flavour 4 = pair-compacted tile kernel (every CS / KW instance)
-                                               (32, 32, 3, 4), (64, 32, 3, 4), (96, 32, 3, 4), (32, 64, 3, 4),
-                                               (64, 64, 3, 4), (96, 96, 3, 4), (128, 96, 3, 4), (32, 96, 3, 4),
-                                               (64, 128, 3, 4), (128, 256, 3, 4), (256, 256, 3, 4),
-                                               (192, 128, 3, 4), (384, 256, 3, 4), (160, 64, 3, 4),
-                                               (128, 96, 1, 4), (96, 64, 1, 4)])
+                                               (128, 96, 1, 1), (96, 64, 1, 1), (384, 256, 1, 0)])
 def test_conv_matches_oracle(cuda, built_lib, cin, cout, k, flavour):
     coords, _ = scene_coords(2, 1500)
     rng = np.random.default_rng(cin * 1000 + cout)
@@ -298,33 +292,6 @@ def test_matrix_core_stem_matches_oracle(cuda, built_lib, cin, n, hl):
     ME.range_flag(cuda).zero_()
 
 
-def test_tile_conv_single_launch_and_row_perm(cuda, built_lib):
-    """pair-compacted tile kernel on a coordinate set large enough to run without offset splits, in natural and
-    permuted processing order, with the fused epilogue"""
-    coords, _ = scene_coords(11, 40000, small=False)
-    rng = np.random.default_rng(5)
-    n = len(coords)
-    x = rng.normal(0, 1, (n, 32)).astype(np.float32)
-    w = (rng.normal(0, 1, (27, 32, 96)) / 30).astype(np.float32)
-    scale = rng.uniform(0.5, 1.5, 96).astype(np.float32)
-    shift = rng.normal(0, 0.2, 96).astype(np.float32)
-    res = rng.normal(0, 1, (n, 96)).astype(np.float32)
-    cm = ME.CoordinateManager(torch.from_numpy(coords).to(cuda, torch.int32))
-    t = lambda a: torch.from_numpy(a).to(cuda)
-    ref = so.conv(torch.from_numpy(x), torch.from_numpy(w), so.kernel_map(coords, coords, 3, 1, 1)).numpy()
-    ref = np.maximum(ref * scale + shift + res, 0)
-    perm = torch.from_numpy(rng.permutation(n).astype(np.int32)).to(cuda)
-    for rp in (None, perm):
-        got = ME.conv_forward(t(x), t(w), cm.kernel_map(3, 1), n, scale=t(scale), shift=t(shift), residual=t(res),
-                              relu=True, flavour=4, row_perm=rp).cpu().numpy()
-        assert rel_err(got, ref) < 1e-5
-    # offset sub-range chained through acc_in
-    part = ME.conv_forward(t(x), t(w), cm.kernel_map(3, 1), n, flavour=4, j_begin=0, j_end=10)
-    got = ME.conv_forward(t(x), t(w), cm.kernel_map(3, 1), n, flavour=4, j_begin=10, j_end=27, acc_in=part,
-                          scale=t(scale), shift=t(shift), residual=t(res), relu=True).cpu().numpy()
-    assert rel_err(got, ref) < 1e-5
-
-
 def test_masked_two_pass_conv_matches_oracle(cuda, built_lib):
     """mask-sorted processing order + offset halves + acc_in give the same conv"""
     coords, _ = scene_coords(6, 5000, small=False)
@@ -342,15 +309,13 @@ def test_masked_two_pass_conv_matches_oracle(cuda, built_lib):
         perms = cm.mask_perms(3, 1, groups)
         for p in perms:
             assert sorted(p.cpu().tolist()) == list(range(len(coords)))
-        for flavour in (0, 3):
-            got = ME.conv_forward_masked(t(x), t(w), cm.kernel_map(3, 1), perms, len(coords), scale=t(scale),
-                                         shift=t(shift), residual=t(res), relu=True, flavour=flavour).cpu().numpy()
-            assert rel_err(got, ref) < 1e-5, (groups, flavour)
-    for cout in (32, 64, 128, 256):            # every B-vector width of the wave kernel
+        got = ME.conv_forward_masked(t(x), t(w), cm.kernel_map(3, 1), perms, len(coords), scale=t(scale),
+                                     shift=t(shift), residual=t(res), relu=True).cpu().numpy()
+        assert rel_err(got, ref) < 1e-5, groups
+    for cout in (32, 64, 128, 256):            # every column-block width
         w2 = (rng.normal(0, 1, (27, 64, cout)) / 40).astype(np.float32)
         ref2 = so.conv(torch.from_numpy(x), torch.from_numpy(w2), so.kernel_map(coords, coords, 3, 1, 1)).numpy()
-        got2 = ME.conv_forward_masked(t(x), t(w2), cm.kernel_map(3, 1), cm.mask_perms(3, 1, 3), len(coords),
-                                      flavour=3).cpu().numpy()
+        got2 = ME.conv_forward_masked(t(x), t(w2), cm.kernel_map(3, 1), cm.mask_perms(3, 1, 3), len(coords)).cpu().numpy()
         assert rel_err(got2, ref2) < 1e-5, cout
     # explicit two-launch form: offset halves chained through acc_in
     perms = cm.mask_perms(3, 1, 2)
