@@ -788,7 +788,7 @@ def _gradient_untouched_until_end(kernel):
             and not torch.is_grad_enabled() and not torch.is_anomaly_enabled())
 
 
-TRAIN_FWD_PIECES = int(os.environ.get("CV_TRAIN_FWD_PIECES", "2"))      # 2: fp16 pairs in the training forward, 3: bf16 triples
+TRAIN_FWD_PIECES = int(os.environ.get("CV_TRAIN_FWD_PIECES", "3"))      # 3 (default): bf16 triples; 2: fp16 pairs in the training forward (measured: no gain, profiles/r4/train_ab.txt)
 _train_state = threading.local()
 
 
