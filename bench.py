@@ -119,7 +119,8 @@ def parse():
                          "by one from Python (the path of rounds 1-3; bit-identical results)")
     ap.add_argument("--ablate", default="", help="timing ablations, WRONG results, never for a reported number: comma list of "
                                                   "`finish` (cv_sp_set_ablation bit 0, switched on after the warm-up), `novote`, "
-                                                  "`nodecode` (the stage is skipped in every step)")
+                                                  "`nodecode` (the stage is skipped in every step), `noplan` (the coordinate plan of a resident "
+                                                  "scene is built once and reused)")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="launch-path check without a GPU: parse, rendezvous (CV_DIST_BACKEND=gloo on CPU), barrier, "
                          "max-reduce, print the JSON skeleton")
@@ -211,7 +212,12 @@ def run_step(model, hv, s, ev=None, teacher=False, keep=None):
         rec(0)
         hv_cuda.prefetch_geometry(s.points)       # bounds reduction of the vote grid starts before the network
         if model is not None:
-            x = ME.SparseTensor(s.feats_in, s.coords4, device=s.feats_in.device)   # coordinate hash + levels
+            if "noplan" in ABLATE:          # timing ablation: the coordinate plan of a resident scene is built once
+                x = getattr(s, "_x_cached", None)
+                if x is None:
+                    x = s._x_cached = ME.SparseTensor(s.feats_in, s.coords4, device=s.feats_in.device)
+            else:
+                x = ME.SparseTensor(s.feats_in, s.coords4, device=s.feats_in.device)   # coordinate hash + levels
             # the fp16-range flag of the network's convolutions is read after decode's wait (no extra wait per scene)
             y = model(x, defer_check=True)
             rec(1)
