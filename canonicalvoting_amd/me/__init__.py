@@ -281,7 +281,9 @@ class CoordinateManager:
                 if off.mask_perm[i] >= 0:
                     mp = view(off.mask_perm[i], G, c[i])
                     mp._cv_has_map = True              # the map rows in processing order follow in the arena
+                    mp._cv_from_plan = True
                     cm_s._maps[("mp", 3, 1 << i, G)] = mp
+                    cm_s._maps[("k", 3, 1 << i, 1)]._cv_mask_perms = mp      # the generic conv path finds the orders on the map
             plan.views = (cm_s, stem_map, out_map)
         return plan.views
 
@@ -450,7 +452,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
             and acc_in is None):
         # generic (module-by-module / training) path: mask-sorted offset groups, orders cached on the map
         row_perm = map_mask_perms(nbr, AUTO_MASK_GROUPS)
-        perm_groups = AUTO_MASK_GROUPS
+        perm_groups = row_perm.shape[0]
     wp6 = None
     acc_scale, flag = 0.0, None
     if CONV_X6 and flavour in (0, 1) and cin % 32 == 0 and cout % 4 == 0:
@@ -541,6 +543,8 @@ AUTO_MASK_MIN_ROWS = 16384
 def map_mask_perms(nbr, groups):
     """[groups, n] processing orders of a kernel map (see CoordinateManager.mask_perms), cached on the map."""
     hit = getattr(nbr, "_cv_mask_perms", None)
+    if hit is not None and getattr(hit, "_cv_from_plan", False):
+        return hit          # built with the scene's coordinate plan (its own group count): no second sort of the same map
     if hit is None or hit.shape[0] != groups:
         hit = nbr._cv_mask_perms = _perms_with_map(nbr, groups)
     return hit

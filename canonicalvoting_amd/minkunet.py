@@ -109,8 +109,27 @@ class MinkUNetBase(ResNetBase):
         with ME.batched_counter_updates():
             return self.modular_forward(x)
 
+    # Training / autograd forward on the SPATIALLY SORTED twin of the coordinate set (round 4): the caller's rows arrive in
+    # arbitrary order (sparse_quantize keeps the point cloud's; synthetic scenes are random), so every gather of the 63
+    # forward, 63 input-gradient and 63 weight-gradient launches of a step was a random one.  As the eval paths do, the stem
+    # reads the caller's rows through its map and writes Z-order rows, `final` writes back through the inverse order (the
+    # row-order invariant of train_joint.py:256-272 holds), and every level, kernel map and mask order comes from ONE
+    # cv_sp_scene_plan call instead of ~25 lazy ones.  CV_TRAIN_SORTED=0 restores the caller-order forward.
+    SORTED_TRAINING = os.environ.get("CV_TRAIN_SORTED", "1") != "0"
+
     def modular_forward(self, x):
-        out_p1 = self.bn0.forward_fused(self.conv0p1s1(x), relu=True)
+        if self.SORTED_TRAINING and x.tensor_stride == 1 and type(self.conv0p1s1) is ME.MinkowskiConvolution:
+            cm_s, stem_map, out_map = x.coordinate_manager.fused_plan(self.conv0p1s1.kernel_size)
+            n = x.F.shape[0]
+            f0 = ME._ConvFn.apply(x.F, self.conv0p1s1.kernel, self.conv0p1s1.bias, stem_map, n)
+            out = self._modular_body(ME.SparseTensor(f0, coordinate_manager=cm_s, tensor_stride=1))
+            k = self.final.kernel
+            y = ME._ConvFn.apply(out.F, k, self.final.bias, out_map, n)
+            return x._like(y, 1)
+        return self.final(self._modular_body(self.conv0p1s1(x)))
+
+    def _modular_body(self, stem_out):
+        out_p1 = self.bn0.forward_fused(stem_out, relu=True)
         skips = [out_p1]
         out = out_p1
         for i, (cname, bname) in enumerate(_DOWN):
@@ -122,7 +141,7 @@ class MinkUNetBase(ResNetBase):
             out = getattr(self, bname).forward_fused(getattr(self, cname)(out), relu=True)
             out = ME.cat(out, skips.pop())
             out = getattr(self, "block%d" % (5 + i))(out)
-        return self.final(out)
+        return out
 
     # ------------------------------------------------------------------ fused eval forward
     def _fold(self, bn_module):
