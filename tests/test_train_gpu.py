@@ -446,3 +446,35 @@ def test_rccl_one_rank_ddp_equals_the_plain_step_bit_for_bit(cuda, built_lib):
     assert got["probe"] == 4.0
     assert got["losses"][0] == got["losses"][1], got
     assert got["n_grad_diff"] == 0 and got["n_weight_diff"] == 0, got
+
+
+def test_sorted_training_forward_equals_the_caller_order_forward(cuda, built_lib, monkeypatch):
+    """MinkUNetBase.SORTED_TRAINING (CV_TRAIN_SORTED=1): the training forward on the spatially sorted twin of the coordinate
+    set (stem through its map, `final` back through the inverse order, every map and mask order from one scene plan) is
+    the same function: output rows in the caller's order, loss and every parameter gradient equal to the caller-order
+    forward up to summation order."""
+    from canonicalvoting_amd import train
+    coords, feats = scene_coords(21, 9000, batch=2, small=False)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(len(coords))                       # the caller's rows in random order
+    coords, feats = coords[perm], feats[perm]
+    n = len(coords)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    xyz, scale = rng.normal(0, 0.5, (n, 3)).astype(np.float32), rng.uniform(0.2, 0.9, (n, 3)).astype(np.float32)
+    cls = rng.integers(-1, 10, n).astype(np.int64)
+    res = {}
+    for mode in (False, True):
+        monkeypatch.setattr(MinkUNet34C, "SORTED_TRAINING", mode)
+        torch.manual_seed(4)
+        model = MinkUNet34C(3, 64).cuda().train()
+        out = model(ME.SparseTensor(t(feats), t(coords).int(), device=cuda)).F
+        loss = train.joint_loss(out, t(xyz), t(scale), t(cls))[0]
+        loss.backward()
+        res[mode] = (out.detach(), float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()},
+                     {k: v.detach().clone() for k, v in model.state_dict().items() if "running" in k})
+    a, b = res[False], res[True]
+    assert float((a[0] - b[0]).abs().max()) < 1e-4 * max(1.0, float(a[0].abs().max()))
+    assert abs(a[1] - b[1]) < 1e-5 * max(1.0, abs(a[1]))
+    worst = max(float((a[2][k] - b[2][k]).abs().max() / (a[2][k].abs().max() + 1e-12)) for k in a[2])
+    assert worst < 2e-3, worst                                # (ReLU flips on rounding-level differences, see LABNOTES)
+    assert all(float((a[3][k] - b[3][k]).abs().max()) < 1e-5 for k in a[3])
