@@ -117,6 +117,9 @@ def parse():
                     help="c (default): one cv_detect_scene_f32 call per scene (plan -> network -> head -> vote -> decode -> NMS "
                          "inside the library, the GIL released for the whole scene); py: the same entry points issued one "
                          "by one from Python (the path of rounds 1-3; bit-identical results)")
+    ap.add_argument("--adaptive-split", type=int, default=0,
+                    help="--scene-call c without an explicit --split-target: every scene picks its split target by the scenes "
+                         "inside cv_detect_scene_f32 when it starts (cv_scene_desc.adaptive_split); 0: the fixed setting")
     ap.add_argument("--ablate", default="", help="timing ablations, WRONG results, never for a reported number: comma list of "
                                                   "`finish` (cv_sp_set_ablation bit 0, switched on after the warm-up), `novote`, "
                                                   "`nodecode` (the stage is skipped in every step), `noplan` (the coordinate plan of a resident "
@@ -188,6 +191,7 @@ def step_events():
 
 
 ABLATE = ()
+ADAPTIVE_SPLIT = False
 SCENE_CALL = "c"
 
 
@@ -203,7 +207,8 @@ def run_step(model, hv, s, ev=None, teacher=False, keep=None):
         try:
             dets, raw, y = pipeline.detect_scene_c(model, hv, s.coords4, s.feats_in, RES, scan_points=s.points,
                                                    predictions=(s.xyz, s.scale, s.prob, s.cls) if teacher else None,
-                                                   events=ev[:5] if ev is not None else None, keep=keep)
+                                                   events=ev[:5] if ev is not None else None, keep=keep,
+                                                   adaptive_split=ADAPTIVE_SPLIT)
         finally:
             if ev is not None and len(ev) > 6:
                 _lib.lib().cv_hv_set_kernel_events(None, None)
@@ -585,6 +590,10 @@ def main():
     S = scene_threads(a.streams)
     split_target = a.split_target if a.split_target >= 0 else (256 if S >= 4 else 0)
     ME.set_split_target(split_target)
+    # one-call scenes size their coarse-level launches by the scenes in flight when they start (512 workgroups below four, 256
+    # from four on): the tail of a short run, where the scene threads run dry one by one, gets the one-scene sizing
+    global ADAPTIVE_SPLIT
+    ADAPTIVE_SPLIT = bool(a.adaptive_split) and a.split_target < 0 and a.scene_call == "c"
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
     hvs = [hv] + [HoughVoting(RES, NUM_ROTS) for _ in range(S - 1)]
     hv_cuda.reserve_pinned(4 * S + 8)
@@ -775,7 +784,7 @@ def main():
                    "points": a.points, "num_rots": NUM_ROTS, "res": RES, "grid": s0.dims,
                    "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}.get(a.algo, "ablation-%d" % a.algo),
                    "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": S,
-                   "conv_split_target": split_target or 512,
+                   "conv_split_target": "adaptive: 512 below four scenes in flight, 256 from four on" if ADAPTIVE_SPLIT else (split_target or 512),
                    **({"ablate": a.ablate, "INVALID": "timing ablation: results are wrong, not a reportable number"} if a.ablate else {})},
         "roofline": {"bound": "hbm",
                      "kernel": "hv_fwd_tiles (the accumulation kernel of cv_hv_forward_f32)" if kernel_timed

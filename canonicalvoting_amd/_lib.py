@@ -78,14 +78,14 @@ class SceneDesc(ctypes.Structure):
                 ("nms_threshold", ctypes.c_double), ("d_ws", vp), ("ws_bytes", ctypes.c_size_t), ("d_grids", vp),
                 ("grid_capacity_floats", ctypes.c_size_t), ("h_pinned", vp), ("pinned_bytes", ctypes.c_size_t),
                 ("h_cand_idx", vp), ("h_verdict", vp), ("h_boxes", vp), ("h_scores", vp), ("h_classes", vp), ("h_pick", vp),
-                ("events", vp * 5)]
+                ("adaptive_split", ctypes.c_int), ("events", vp * 5)]
 
 
 class SceneResult(ctypes.Structure):
     """struct cv_scene_result (include/cv_hip.h)"""
     _fields_ = [("n_cand", ctypes.c_int), ("n_boxes", ctypes.c_int), ("n_det", ctypes.c_int), ("truncated", ctypes.c_int),
                 ("range_flag", ctypes.c_int), ("duplicates", ctypes.c_int), ("out_of_window", ctypes.c_int),
-                ("dims", ctypes.c_int * 3), ("corner", ctypes.c_float * 3), ("level_rows", ctypes.c_longlong * 5),
+                ("scenes_in_flight", ctypes.c_int), ("dims", ctypes.c_int * 3), ("corner", ctypes.c_float * 3), ("level_rows", ctypes.c_longlong * 5),
                 ("needed_ws_bytes", ctypes.c_size_t), ("needed_grid_floats", ctypes.c_size_t),
                 ("d_grid_obj", vp), ("d_grid_rot", vp), ("d_grid_scale", vp), ("d_xyz", vp), ("d_scale", vp),
                 ("d_prob", vp), ("d_class", vp)]
@@ -131,6 +131,7 @@ SIGNATURES = {
     "cv_sp_conv_f32": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp]),
     "cv_sp_set_split_target": (ctypes.c_int, [ctypes.c_int]),
     "cv_sp_pack_weights_t_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "cv_sp_set_split_target_thread": (ctypes.c_int, [ctypes.c_int]),
     "cv_sp_set_ablation": (ctypes.c_int, [ctypes.c_int]),
     "cv_sp_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
     "cv_sp_pack_weights_x6_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),

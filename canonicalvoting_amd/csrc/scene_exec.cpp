@@ -11,6 +11,7 @@
 // grid's shape) and for the decode results.  Same kernels, same launch order, same arguments: results are bit-identical
 // to the call-by-call path (tests/test_scene_call_gpu.py).
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -36,6 +37,21 @@ struct Carver {
 
 // CV_SCENE_SERIALIZE=1 (experiment): the pure-enqueue part of a scene (network program, head, vote: ~110 launches) is issued
 // under one process-wide lock, as the interpreter lock did for the call-by-call path
+std::atomic<int> g_scenes_inside{0};
+struct SceneCount {
+    int before;
+    bool adaptive;
+    int prev_target = 0;
+    explicit SceneCount(bool adaptive_) : before(g_scenes_inside.fetch_add(1, std::memory_order_relaxed)), adaptive(adaptive_) {
+        // scenes in flight (this one included) when the scene starts: the other scenes fill the chip from about four on, below
+        // that the deeper splits of the one-scene optimum pay (profiles/r3/split_target_8streams.txt)
+        if (adaptive) prev_target = cv_sp_set_split_target_thread(before + 1 >= 4 ? 256 : 512);
+    }
+    ~SceneCount() {
+        if (adaptive) cv_sp_set_split_target_thread(prev_target);
+        g_scenes_inside.fetch_sub(1, std::memory_order_relaxed);
+    }
+};
 std::mutex g_enqueue_mu;
 bool serialize_enqueue() {
     static const bool on = getenv("CV_SCENE_SERIALIZE") && atoi(getenv("CV_SCENE_SERIALIZE")) != 0;
@@ -58,6 +74,8 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
     const long long n = d->n;
     const int NL = 5;
     std::memset(r, 0, sizeof(*r));
+    SceneCount in_flight(d->adaptive_split != 0);
+    r->scenes_in_flight = in_flight.before + 1;
     Carver cv(d->d_ws, d->ws_bytes);
     auto mark = [&](int i) { return d->events[i] ? hipEventRecord(static_cast<hipEvent_t>(d->events[i]), st) : hipSuccess; };
     CV_HIP_CHECK(mark(0));

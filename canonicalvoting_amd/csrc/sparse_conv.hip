@@ -2852,7 +2852,9 @@ int nb_for(int cout, long long n_out) {
 
 // workgroups a split launch aims at: CV_SPLIT_TARGET or 512 until cv_sp_set_split_target changes it
 std::atomic<long long> g_split_target{-1};
+thread_local long long t_split_target = 0;       // cv_sp_set_split_target_thread: this thread's launches (0 = the process-wide value)
 long long split_target() {
+    if (t_split_target > 0) return t_split_target;
     long long v = g_split_target.load(std::memory_order_relaxed);
     if (v <= 0) {
         v = getenv("CV_SPLIT_TARGET") ? std::max(1ll, atoll(getenv("CV_SPLIT_TARGET"))) : 512;
@@ -2898,6 +2900,12 @@ int cv_sp_set_option(const char* name, long long value, long long* previous) {
 }
 
 int cv_sp_set_ablation(int bits) { return cvsc::g_ablation.exchange(bits, std::memory_order_relaxed); }
+
+int cv_sp_set_split_target_thread(int workgroups) {
+    const int before = (int)t_split_target;
+    t_split_target = workgroups > 0 ? workgroups : 0;
+    return before;
+}
 
 int cv_sp_set_split_target(int workgroups) {
     const int before = (int)split_target();

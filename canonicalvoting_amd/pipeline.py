@@ -111,7 +111,7 @@ _scene_lock = __import__("threading").Lock()
 
 
 def detect_scene_c(model, hv, coords4, feats, res, nclasses=9, log_scale=True, scan_points=None, predictions=None,
-                   max_candidates=512, keep=None, events=None, **decode_kw):
+                   max_candidates=512, keep=None, events=None, adaptive_split=False, **decode_kw):
     """detect_scene through ONE C call (cv_detect_scene_f32: coordinate plan -> network program -> head -> vote -> decode
     -> per-class NMS; two host waits inside it, the GIL released for its whole duration).  Same kernels in the same order
     as detect_scene: bit-identical results (tests/test_scene_call_gpu.py).  ``predictions`` = (xyz, scale, prob, class)
@@ -161,6 +161,7 @@ def detect_scene_c(model, hv, coords4, feats, res, nclasses=9, log_scale=True, s
     p.elim_hi_plus1 = 0 if decode_kw.get("separate_variant", False) else 1
     p.err_thresh = float(decode_kw.get("err_thresh", 0.3))
     d.max_candidates, d.nms_threshold = host.M, 0.3
+    d.adaptive_split = 1 if adaptive_split else 0
     if events is not None:          # five torch.cuda.Event (recorded once, so that their handles exist): scene start, after
         for i in range(5):          # the network, after the head split, after the vote, after the decode
             d.events[i] = events[i].cuda_event

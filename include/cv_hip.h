@@ -280,6 +280,9 @@ int cv_sp_conv_f32(const cv_conv_desc* desc, void* stream);
  * value.  Process-wide; set it before launching, not concurrently with cv_sp_conv_f32 / cv_sp_net_forward callers that
  * need one fixed value.  (No reference counterpart: MinkowskiEngine's launch sizes are internal.) */
 int cv_sp_set_split_target(int workgroups);
+/* The same for the CALLING THREAD's launches only (0 = follow the process-wide value); returns the previous thread value.
+ * cv_detect_scene_f32 uses it to size a scene's launches by how many scenes are in flight when it starts. */
+int cv_sp_set_split_target_thread(int workgroups);
 /* Measurement hook (no reference counterpart; results are WRONG while a bit is set): timing ablations that can be switched
  * at run time, after a warm-up has filled every buffer with valid values.  bit 0: the finish launches of the split / mask-group
  * convolutions are skipped (what the partial-tile reductions cost with scenes in flight).  Returns the previous bits. */
@@ -470,12 +473,16 @@ typedef struct cv_scene_desc {
     int64_t* h_cand_idx; int32_t* h_verdict;
     float* h_boxes; float* h_scores; int32_t* h_classes;      /* accepted boxes in acceptance order: [k][8][3], [k], [k] */
     int32_t* h_pick;                                          /* detections after per-class NMS: indices into the box list, class by class */
+    int adaptive_split;           /* 1: launch sizing of the coarse-level convolutions by the scenes inside cv_detect_scene_f32 when this
+                                     one starts - the one-scene optimum (512 workgroups) below four, 256 from four on (what
+                                     bench.py sets by hand for the call-by-call path); 0: the process-wide cv_sp_set_split_target */
     /* optional measurement hook: hipEvent_t handles recorded on `stream` at the scene's start, behind the network, the head
      * split, the vote and the decode (NULL entries are skipped) */
     void* events[5];
 } cv_scene_desc;
 typedef struct cv_scene_result {
     int n_cand, n_boxes, n_det, truncated, range_flag, duplicates, out_of_window;
+    int scenes_in_flight;          /* scenes inside cv_detect_scene_f32 when this one started (itself included) */
     int dims[3];
     float corner[3];
     long long level_rows[5];
