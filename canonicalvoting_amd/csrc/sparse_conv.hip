@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(NW * 64, (hd_blocks(NB, NW, NSTG) * NW + 3) / 4) vo
         if (lane == 0) units_s[HL_MAX_UNITS] = (unsigned short)cnt;
     }
     __syncthreads();
-    const int n_units = __builtin_amdgcn_readfirstlane((int)units_s[HL_MAX_UNITS]);
+    const int n_units = (CV_HD_ABL & 8) ? 0 : __builtin_amdgcn_readfirstlane((int)units_s[HL_MAX_UNITS]);      // (8: no unit loop)
 
     f32x16 acc[NB];
 #pragma unroll
@@ -1594,6 +1594,7 @@ __global__ __launch_bounds__(NW * 64, (hd_blocks(NB, NW, NSTG) * NW + 3) / 4) vo
     float (*ep)[EP_LD] = reinterpret_cast<float (*)[EP_LD]>(sm + wave * 32 * EP_LD * 4);
     ConvArgs ae = a;
     ae.tickets = nullptr;                            // (the in-launch split-K reduction is conv_hl's)
+    if ((CV_HD_ABL & 16) && a.acc_scale != 12345.f) return;      // (16: no epilogue)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) epilogue_store_wide(ae, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep);
 }
