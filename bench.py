@@ -15,7 +15,7 @@ therefore runs the network and the head kernel of every step as eval_joint.py do
 with predictions synthesised from the scene's labels (SURVEY 8d recipe: the peaked vote maps a trained network
 produces, ~12 boxes per scene).  "network" feeds the network's own output (detections_per_scene 0).
 
-Scenes in flight: --streams S (default 4) host threads, each with its own HIP stream, take the K steps from one
+Scenes in flight: --streams S (default 7) host threads, each with its own HIP stream, take the K steps from one
 shared counter.  The threads are created, bound to their streams and parked on a barrier BEFORE the timed region
 starts.  Per-scene work and results are unchanged (tests assert bit-identity with the one-at-a-time path).
 
@@ -71,10 +71,12 @@ def parse():
     ap.add_argument("--min-warm-seconds", type=float, default=1.5,
                     help="the untimed warm-up lasts at least this long (sustained work before the clock starts); "
                          "--warmup is a minimum number of steps, not the whole warm-up")
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=7,
                     help="scenes in flight per GPU: S host threads, each with its own HIP stream, take the steps "
                          "from one shared counter (scenes are independent; fills the launch tails and host syncs of one scene "
-                         "with the kernels of another)")
+                         "with the kernels of another).  7 and 8 give the same rate over 240 steps (575-577 scenes/s); a "
+                         "20-step region ends with fewer idle threads at 7 (rounds of 7 + 7 + 6 against 8 + 8 + 4: 528-532 "
+                         "against 503-516 scenes/s, profiles/r4/streams_20steps.txt, hwq_20steps.txt)")
     ap.add_argument("--switch-interval", type=float, default=0.0005, help="sys.setswitchinterval for the scene threads")
     ap.add_argument("--event-every", type=int, default=1,
                     help="steps of the timed region that carry HIP events (stage boundaries + the vote kernel): every K-th "
