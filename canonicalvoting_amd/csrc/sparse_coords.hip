@@ -480,83 +480,108 @@ __global__ __launch_bounds__(SORT_T) void sort_hist(const int* __restrict__ coor
 // stable scatter of one digit.  vals_in == nullptr: the value of row i is i (first pass).
 // Last pass (coords != nullptr): instead of keys_out / vals_out it writes perm[pos] = original row,
 // inv[original row] = pos and sorted[pos] = coords[original row].
+// A wave owns SORT_ROWS / 4 consecutive rows of the block (8 rounds of 64): it ranks them against its OWN running
+// counters in LDS (leader lane per digit value, no workgroup barrier between the rounds), the four waves' counters are
+// then chained per bin.  Three workgroup barriers after the clear (the first version took 48: a turn per wave and round, and a
+// 256-wide scan with two barriers per step).
 __global__ __launch_bounds__(SORT_T) void sort_scatter(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in,
                                                        long long n, int pass, const int* __restrict__ hist, int nblk,
                                                        unsigned* __restrict__ keys_out, int* __restrict__ vals_out,
                                                        const int* __restrict__ coords_in, int* __restrict__ perm,
                                                        int* __restrict__ inv, int* __restrict__ sorted,
                                                        const int* __restrict__ mm) {
-    __shared__ int start[SORT_BINS];
+    constexpr int NWAVE = SORT_T / 64, ROUNDS = SORT_ROWS / SORT_T, PER_T = SORT_BINS / SORT_T;
+    __shared__ int wcnt[NWAVE][SORT_BINS];          // rows of (wave, bin); then the first output slot of (wave, bin)
+    __shared__ int wave_tot[NWAVE];
     // a single scene (largest batch index 0) is sorted after two digits: pass 1 then writes the final outputs and
     // pass 2 has nothing to do (two launches that exit at once instead of 30 us of histogram + scatter)
     const bool single = mm[6] == 0;
     if (pass == 2 && single) return;
-    const int* coords = (pass == 2 || (pass == 1 && single)) ? coords_in : nullptr;      // first output slot of (this block, bin); then the running slot
-    __shared__ int scan[SORT_T];
-    // totals and this block's prefix per bin (two bins per thread, coalesced over the block-major histogram)
-    int tot[SORT_BINS / SORT_T], pre[SORT_BINS / SORT_T];
+    const int* coords = (pass == 2 || (pass == 1 && single)) ? coords_in : nullptr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < NWAVE * SORT_BINS; i += SORT_T) (&wcnt[0][0])[i] = 0;
+    // totals and this block's prefix per bin (PER_T bins per thread, coalesced over the block-major histogram): requested
+    // now, consumed after the ranking
+    int tot[PER_T], pre[PER_T];
 #pragma unroll
-    for (int q = 0; q < SORT_BINS / SORT_T; ++q) { tot[q] = 0; pre[q] = 0; }
+    for (int q = 0; q < PER_T; ++q) { tot[q] = 0; pre[q] = 0; }
     for (int b = 0; b < nblk; ++b) {
 #pragma unroll
-        for (int q = 0; q < SORT_BINS / SORT_T; ++q) {
-            const int h = hist[(long long)b * SORT_BINS + threadIdx.x * (SORT_BINS / SORT_T) + q];
+        for (int q = 0; q < PER_T; ++q) {
+            const int h = hist[(long long)b * SORT_BINS + threadIdx.x * PER_T + q];
             tot[q] += h;
             if (b < (int)blockIdx.x) pre[q] += h;
         }
     }
-    // exclusive scan of the bin totals (bins threadIdx.x * 2 + q, in bin order)
-    int mine = 0;
+    __syncthreads();                                 // counters cleared
+    // ---- ranking: rows base + wave * 512 + r * 64 + lane
+    const long long base = blockIdx.x * (long long)SORT_ROWS + wave * (SORT_ROWS / NWAVE);
+    unsigned k[ROUNDS];
+    int d[ROUNDS], local[ROUNDS];
 #pragma unroll
-    for (int q = 0; q < SORT_BINS / SORT_T; ++q) mine += tot[q];
-    scan[threadIdx.x] = mine;
-    __syncthreads();
-    for (int off = 1; off < SORT_T; off <<= 1) {
-        const int t = (int)threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
-        __syncthreads();
-        scan[threadIdx.x] += t;
-        __syncthreads();
+    for (int r = 0; r < ROUNDS; ++r) {
+        const long long i = base + r * 64 + lane;
+        k[r] = i < n ? keys_in[i] : 0u;
     }
-    int run = scan[threadIdx.x] - mine;
 #pragma unroll
-    for (int q = 0; q < SORT_BINS / SORT_T; ++q) {
-        start[threadIdx.x * (SORT_BINS / SORT_T) + q] = run + pre[q];
-        run += tot[q];
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long base = blockIdx.x * (long long)SORT_ROWS;
-    for (int r = 0; r < SORT_ROWS / SORT_T; ++r) {
-        const long long i = base + r * SORT_T + threadIdx.x;
+    for (int r = 0; r < ROUNDS; ++r) {
+        const long long i = base + r * 64 + lane;
         const bool have = i < n;
-        unsigned k = 0;
-        int d = 0;
-        if (have) { k = keys_in[i]; d = (int)((k >> (SORT_BITS * pass)) & (SORT_BINS - 1)); }
-        // lanes of this wave with the same digit
-        uint64_t peers = __ballot(have);
+        d[r] = (int)((k[r] >> (SORT_BITS * pass)) & (SORT_BINS - 1));
+        uint64_t peers = __ballot(have);             // lanes of this wave with the same digit
 #pragma unroll
         for (int bit = 0; bit < SORT_BITS; ++bit) {
-            const uint64_t bm = __ballot(have && ((d >> bit) & 1));
-            peers &= ((d >> bit) & 1) ? bm : ~bm;
+            const uint64_t bm = __ballot(have && ((d[r] >> bit) & 1));
+            peers &= ((d[r] >> bit) & 1) ? bm : ~bm;
         }
         const int rank_w = __popcll(peers & ((1ull << lane) - 1ull)), cnt_w = __popcll(peers);
         const int leader = have ? (int)__ffsll((unsigned long long)peers) - 1 : lane;
-        int slot = 0;
-        // waves take their turn on the running slots (rows of wave w precede those of wave w + 1)
-        for (int w = 0; w < SORT_T / 64; ++w) {
-            if (wave == w && have && lane == leader) { slot = start[d]; start[d] = slot + cnt_w; }
-            __syncthreads();
-        }
-        slot = __shfl(slot, leader);
-        if (have) {
-            const long long pos = slot + rank_w;
+        int off = 0;
+        if (have && lane == leader) { off = wcnt[wave][d[r]]; wcnt[wave][d[r]] = off + cnt_w; }
+        local[r] = __shfl(off, leader) + rank_w;     // rank among the wave's rows with this digit
+    }
+    // ---- exclusive scan of the bin totals (bins threadIdx.x * PER_T + q, in bin order): per wave, then over the waves
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < PER_T; ++q) mine += tot[q];
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();                                 // wave totals; every wave's counters are final
+    int run = incl - mine;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) run += w < wave ? wave_tot[w] : 0;
+    // first output slot of (wave, bin) = bin start + rows of the blocks before + rows of the waves before
+    int c[PER_T][NWAVE];
+#pragma unroll
+    for (int q = 0; q < PER_T; ++q)
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) c[q][w] = wcnt[w][threadIdx.x * PER_T + q];
+    // (a bin's counters are read and rewritten by the thread that owns the bin: no barrier in between)
+#pragma unroll
+    for (int q = 0; q < PER_T; ++q) {
+        int slot = run + pre[q];
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) { wcnt[w][threadIdx.x * PER_T + q] = slot; slot += c[q][w]; }
+        run += tot[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const long long i = base + r * 64 + lane;
+        if (i < n) {
+            const long long pos = wcnt[wave][d[r]] + local[r];
             const int v = vals_in ? vals_in[i] : (int)i;
             if (coords) {
                 perm[pos] = v;
                 inv[v] = (int)pos;
                 reinterpret_cast<int4*>(sorted)[pos] = reinterpret_cast<const int4*>(coords)[v];
             } else {
-                keys_out[pos] = k;
+                keys_out[pos] = k[r];
                 vals_out[pos] = v;
             }
         }
