@@ -1,3 +1,6 @@
+"""How many (32-row block, kernel offset) units a fine-level convolution has to multiply under different row orders, and
+how large a tile's input window is: the bench scene (80k points), rows in the plan's Z-order.  CPU only.
+    python profiles/conv_order_stats.py"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
