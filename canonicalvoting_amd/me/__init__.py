@@ -740,6 +740,7 @@ def col_sum(x):
 #   while the layer's stream goes on with the BatchNorm backward and the next input gradient) whenever nothing can
 #   touch the gradient earlier - see _ConvFn.backward.
 BACKWARD_OVERLAP = int(os.environ.get("CV_BACKWARD_OVERLAP", "2"))
+LATE_GRAD_LOG = None        # tests: a list that receives (kernel parameter, data_ptr of d_kernel) of every late-joined layer
 _wgrad_streams = {}
 _wgrad_lock = threading.Lock()
 _wgrad_pending = threading.local()
@@ -887,6 +888,8 @@ class _ConvFn(torch.autograd.Function):
                 if nbr is not None:
                     nbr.record_stream(side)
                 _join_at_end_of_backward(cur, side)
+                if LATE_GRAD_LOG is not None:
+                    LATE_GRAD_LOG.append((kernel, d_kernel.data_ptr()))
         if ctx.needs_input_grad[0]:
             nbr_t = transposed_map(nbr, feats.shape[0]) if nbr is not None else None
             d_feats = conv_forward(grad, k3.detach(), nbr_t, feats.shape[0], cache_weights=False, weight_t=True)

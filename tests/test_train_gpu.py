@@ -130,6 +130,32 @@ def test_backward_overlap_changes_no_gradient_bit(cuda, built_lib, monkeypatch):
             assert torch.equal(g, grads[mode][k]), (mode, k)
 
 
+def test_late_joined_weight_gradient_is_the_tensor_the_side_stream_wrote(cuda, built_lib, monkeypatch):
+    """Mode 2 of the backward overlap leaves d_kernel to a side stream until the end of the pass.  That is only sound if
+    the gradient accumulator KEEPS that tensor (no clone or add on the layer's stream): after the pass every late-joined
+    layer's .grad must be the very storage the side stream wrote.  Fails if a torch change (or a layout the predicate
+    misses) makes AccumulateGrad copy instead."""
+    monkeypatch.setattr(ME, "BACKWARD_OVERLAP", 2)
+    log = []
+    monkeypatch.setattr(ME, "LATE_GRAD_LOG", log)
+    coords, feats = scene_coords(23, 1500, batch=2)
+    model = MinkUNet34C(3, 64)
+    model.load_state_dict(so.make_state_dict(3, 64, seed=4))
+    model = model.cuda().train()
+    model.zero_grad(set_to_none=True)
+    x = ME.SparseTensor(torch.from_numpy(feats), torch.from_numpy(coords).int(), device="cuda")
+    model(x).F.square().mean().backward()
+    torch.cuda.synchronize()
+    assert len(log) >= 40, "the late join was not taken (%d layers)" % len(log)
+    for kernel, ptr in log:
+        assert kernel.grad is not None and kernel.grad.data_ptr() == ptr and kernel.grad.is_contiguous()
+    # a second pass accumulates into existing gradients: nothing may be deferred then
+    del log[:]
+    x = ME.SparseTensor(torch.from_numpy(feats), torch.from_numpy(coords).int(), device="cuda")
+    model(x).F.square().mean().backward()
+    assert log == []
+
+
 def test_column_sums_are_the_same_bits_on_every_run(cuda, built_lib):
     """ME.col_sum (bias gradient, cv_sp_col_sum_det_f32): chunk sums added in chunk order - equal bits over repeated
     runs and on another stream with other kernels in flight, and the fp64 column sums to fp32 accuracy; strided rows and
