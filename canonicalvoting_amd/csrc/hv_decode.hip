@@ -37,6 +37,9 @@
 
 namespace {
 
+#ifndef DEC_PROF
+#define DEC_PROF 0      // phase ticks of the greedy walk (thread 0, printed at the end)
+#endif
 constexpr int NCLS = 64;   // class histogram bins (class ids must be in [0, 64))
 
 struct Cand {
@@ -375,6 +378,237 @@ __device__ __forceinline__ void dec_greedy(Geo geo, cv_decode_params prm, List L
     if (threadIdx.x == 0) { n_cand_out[0] = it; n_cand_out[1] = truncated ? 1 : 0; }
 }
 
+// ---- the register-resident walk, second version (round 4).  The first one (dec_greedy<1 / 2>) tests every entry of every
+// thread against every candidate and re-scans them for the maximum: ~44 vector instructions per entry and pass, which is
+// what a 300k-point scene's walk spent its 1.6 ms on (21 000 listed cells x 180 candidates on ONE CU; the 16-entry
+// capacity was also 5 000 cells short, so that scene fell through to the walk over the global arrays).  Here
+//   * a wave owns 64 * E CONSECUTIVE list entries (dec_compact appends in rounds of the grid-stride loop: a stretch of the
+//     list is a window of x slabs) and every thread keeps the bounding box of its own: a candidate's suppression region is
+//     tested against the box first, and a wave whose 64 boxes all miss skips its entries altogether;
+//   * the entries are sorted once (value descending, flat index ascending: the order the walk takes them in), so the
+//     thread's best live entry is the lowest clear bit of `dead`; value / cell / list position of that entry sit in
+//     registers and are re-picked (select chains over the E slots) only when it dies;
+//   * the winner's cell travels through LDS from its owner's registers - no LDS copy of the list (the 80k-point walk's 128 KB),
+//     no by-index global reads except the five geometry words.
+// Same candidates in the same order as the reference loop (eval_joint.py:204-263): the maximum with ties to the lowest flat
+// index, suppression by cube and box exactly as before.  Used for the big grids (dec_greedy_dispatch_big): a 300k-point
+// scene's decode 1.88 -> 1.28 ms.  What is left there (phase ticks, DEC_PROF): the waves that own the cells inside a
+// candidate's region run ~8 kill tests per lane (130 instructions each with the select chains) while the others wait at the
+// barrier - 5 600 of the 13 500 cycles per candidate - and the five geometry words are a trip to the fabric (2 700 cycles).
+// NOT used for the 80k-point lists (3 400 cells, 42 candidates): 0.21 ms against dec_greedy<1>'s 0.18.
+template <int N, class Tv>
+__device__ __forceinline__ Tv pick_slot(const Tv (&r)[N], int j) {
+    Tv x = r[0];
+#pragma unroll
+    for (int q = 1; q < N; ++q) x = j == q ? r[q] : x;
+    return x;
+}
+
+template <int T, int E, int G>
+__device__ __forceinline__ void dec_greedy_sorted(Geo geo, cv_decode_params prm, List L, int n, Cand* __restrict__ cands,
+                                                  Stats* __restrict__ stats, int* __restrict__ n_cand_out) {
+    static_assert(E >= 2 && E <= 32 && T % 64 == 0 && G % 64 == 0 && T % G == 0, "entries per thread live in one 32-bit mask");
+    constexpr int W = T / 64;
+    constexpr unsigned ALL = E == 32 ? 0xffffffffu : ((1u << E) - 1u);
+    __shared__ float s_val[2][W];
+    __shared__ int s_idx[2][W], s_pos[2][W], s_z[2][W];
+    __shared__ unsigned s_xy[2][W];
+    // a group of G threads owns G * E consecutive list entries, dealt to its threads round-robin: the cells a candidate
+    // suppresses sit next to each other in the list, and a thread that owned them all would walk them alone (E consecutive
+    // entries per thread: 0.18 -> 0.30 ms at 80k points; G = 64 at 300k points: the wave that owns the ~500 suppressed cells
+    // takes 9 000 cycles per candidate and the other fifteen wait)
+    const int base = (int)(threadIdx.x / G) * (G * E) + (int)(threadIdx.x % G);
+    float r_val[E];
+    unsigned r_xy[E];
+    int r_zj[E];                                   // z | j << 16: list position = base + G * j
+    int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1, bz0 = 0x7fffffff, bz1 = -1;
+    unsigned dead;
+    {
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const int k = base + G * j;
+            const bool ok = k < n;
+            r_val[j] = ok ? L.val[k] : 0.f;
+            r_xy[j] = ok ? L.xy[k] : 0u;
+            const int z = ok ? L.z[k] : 0;
+            r_zj[j] = z | (j << 16);
+            const int x = (int)(r_xy[j] & 0xffffu), y = (int)(r_xy[j] >> 16);
+            if (ok) {
+                bx0 = min(bx0, x); bx1 = max(bx1, x);
+                by0 = min(by0, y); by1 = max(by1, y);
+                bz0 = min(bz0, z); bz1 = max(bz1, z);
+                ++cnt;
+            }
+        }
+        // odd-even transposition sort of the thread's entries (static register indices): value descending, flat index
+        // ascending (computed only on a tie: no register per entry for it); the slots beyond the list (value 0) end up last
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+#pragma unroll
+            for (int j = r & 1; j + 1 < E; j += 2) {
+                const float v0 = r_val[j], v1 = r_val[j + 1];
+                const unsigned x0 = r_xy[j], x1 = r_xy[j + 1];
+                const int z0 = r_zj[j], z1 = r_zj[j + 1];
+                bool sw = v1 > v0;
+                if (v1 == v0) {
+                    const int i0 = ((int)(x0 & 0xffffu) * geo.Y + (int)(x0 >> 16)) * geo.Z + (z0 & 0xffff);
+                    const int i1 = ((int)(x1 & 0xffffu) * geo.Y + (int)(x1 >> 16)) * geo.Z + (z1 & 0xffff);
+                    sw = i1 < i0;
+                }
+                r_val[j] = sw ? v1 : v0; r_val[j + 1] = sw ? v0 : v1;
+                r_xy[j] = sw ? x1 : x0;  r_xy[j + 1] = sw ? x0 : x1;
+                r_zj[j] = sw ? z1 : z0;  r_zj[j + 1] = sw ? z0 : z1;
+            }
+        }
+        dead = ALL & ~(cnt >= 32 ? 0xffffffffu : ((1u << cnt) - 1u));
+    }
+    const int wave = threadIdx.x >> 6;
+    const float inv_res = 1.0f / geo.res;
+    const int e = prm.elimination, hp = e + (prm.elim_hi_plus1 ? 1 : 0);
+    bool have_cur = false;
+    int cx = 0, cy = 0, cz = 0, clo0 = 0, clo1 = 0, clo2 = 0, chi0 = 0, chi1 = 0, chi2 = 0;
+    int rlo0 = 0, rlo1 = 0, rlo2 = 0, rhi0 = -1, rhi1 = -1, rhi2 = -1;     // conservative region of the current suppression
+    float ccs = 0.f, csn = 0.f, csc[3] = {1.f, 1.f, 1.f};
+    // the thread's best live entry
+    int cur_j = -1, cur_id = 0x7fffffff, cur_pos = -1, cur_z = 0;
+    unsigned cur_xy = 0;
+    float cur_val = -1.f;
+    int it = 0;
+    bool truncated = false;
+#if DEC_PROF
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
+#define DEC_TICK(i) { const unsigned long long t_now = __builtin_readcyclecounter(); pt[i] += t_now - t_prev; t_prev = t_now; }
+    DEC_TICK(7)
+#else
+#define DEC_TICK(i)
+#endif
+    for (;; ++it) {
+        // ---- suppression by the current candidate (:211, :225-229, :243): box against box first
+        const bool hit = have_cur && dead != ALL && bx1 >= rlo0 && bx0 <= rhi0 && by1 >= rlo1 && by0 <= rhi1 &&
+                         bz1 >= rlo2 && bz0 <= rhi2;
+        if (__any(hit)) {
+            if (hit) {
+                unsigned near = 0;
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const int x = (int)(r_xy[j] & 0xffffu), y = (int)(r_xy[j] >> 16), z = r_zj[j] & 0xffff;
+                    const bool in = (unsigned)(x - rlo0) <= (unsigned)(rhi0 - rlo0) && (unsigned)(y - rlo1) <= (unsigned)(rhi1 - rlo1) &&
+                                    (unsigned)(z - rlo2) <= (unsigned)(rhi2 - rlo2);
+                    near |= in ? (1u << j) : 0u;
+                }
+                near &= ~dead;
+                while (near) {
+                    const int j = __ffs(near) - 1;
+                    near &= near - 1;
+                    const unsigned xy = pick_slot<E>(r_xy, j);
+                    const int z = pick_slot<E>(r_zj, j) & 0xffff;
+                    const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+                    bool kill = x >= cx - e && x < cx + hp && y >= cy - e && y < cy + hp && z >= cz - e && z < cz + hp;
+                    if (!kill && x >= clo0 && x <= chi0 && y >= clo1 && y <= chi1 && z >= clo2 && z <= chi2) {
+                        const float v0 = (float)(x - cx) * geo.res, v1 = (float)(y - cy) * geo.res,
+                                    v2 = (float)(z - cz) * geo.res;
+                        kill = inside_box(v0, v1, v2, ccs, csn, csc);
+                    }
+                    if (kill) dead |= 1u << j;
+                }
+            }
+        }
+        DEC_TICK(0)
+        // ---- the thread's best live entry = the first live slot of the sorted order
+        float bv = -1.f;
+        int bid = 0x7fffffff, bpos = -1;
+        {
+            const unsigned alive = ALL & ~dead;
+            if (alive != 0u) {
+                if (cur_j < 0 || ((dead >> cur_j) & 1u)) {
+                    cur_j = __ffs(alive) - 1;
+                    cur_val = pick_slot<E>(r_val, cur_j);
+                    cur_xy = pick_slot<E>(r_xy, cur_j);
+                    const int zj = pick_slot<E>(r_zj, cur_j);
+                    cur_z = zj & 0xffff;
+                    cur_pos = base + G * (zj >> 16);
+                    cur_id = ((int)(cur_xy & 0xffffu) * geo.Y + (int)(cur_xy >> 16)) * geo.Z + cur_z;
+                }
+                bv = cur_val; bid = cur_id; bpos = cur_pos;
+            }
+        }
+        DEC_TICK(1)
+        const float wv = wave_max_f32(bv);
+        const int wid = wave_min_i32(bv == wv ? bid : 0x7fffffff);
+        const int par = it & 1;           // double-buffered: the one barrier also frees the other buffer
+        if (bv == wv && bid == wid) {
+            s_val[par][wave] = bv; s_idx[par][wave] = bid; s_pos[par][wave] = bpos;
+            s_xy[par][wave] = cur_xy; s_z[par][wave] = cur_z;
+        }
+        DEC_TICK(2)
+        lds_barrier();
+        DEC_TICK(3)
+        Best w{s_val[par][0], s_idx[par][0], s_pos[par][0]};
+        int wq = 0;
+#pragma unroll
+        for (int q = 1; q < W; ++q) {
+            const float v = s_val[par][q];
+            const int id = s_idx[par][q];
+            if (v > w.v || (v == w.v && id < w.id)) { w.v = v; w.id = id; w.pos = s_pos[par][q]; wq = q; }
+        }
+        if (!(w.v >= prm.thresh_high)) break;                                   // :208-209
+        if (it >= prm.max_iters) { truncated = true; break; }
+        // ---- the candidate (every thread forms the same values; thread 0 records them)
+        const int id = w.id;
+        {
+            const unsigned wxy = s_xy[par][wq];
+            cx = (int)(wxy & 0xffffu); cy = (int)(wxy >> 16);
+            cz = s_z[par][wq];
+        }
+        ccs = L.geo[0 * L.cap + w.pos];
+        csn = L.geo[1 * L.cap + w.pos];
+        for (int k = 0; k < 3; ++k) csc[k] = L.geo[(2 + k) * L.cap + w.pos];
+        DEC_TICK(4)
+        float hi[3];
+        {
+            const float m00 = ccs * csc[0], m02 = (-csn) * csc[2], m11 = csc[1], m20 = csn * csc[0], m22 = ccs * csc[2];
+            hi[0] = fabsf(m00) + fabsf(m02);
+            hi[1] = fabsf(m11);
+            hi[2] = fabsf(m20) + fabsf(m22);
+        }
+        const int cc[3] = {cx, cy, cz}, shape[3] = {geo.X, geo.Y, geo.Z};
+        int clo[3], chi[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                                             // :220-223
+            const int blo = (int)((-hi[k]) * inv_res), bhi = (int)(hi[k] * inv_res);
+            clo[k] = min(max(cc[k] + blo, 0), shape[k] - 1);
+            chi[k] = min(max(cc[k] + bhi, 0), shape[k] - 1);
+        }
+        clo0 = clo[0]; clo1 = clo[1]; clo2 = clo[2]; chi0 = chi[0]; chi1 = chi[1]; chi2 = chi[2];
+        rlo0 = min(cx - e, clo0); rhi0 = max(cx + hp - 1, chi0);
+        rlo1 = min(cy - e, clo1); rhi1 = max(cy + hp - 1, chi1);
+        rlo2 = min(cz - e, clo2); rhi2 = max(cz + hp - 1, chi2);
+        have_cur = true;
+        if (threadIdx.x == 0) {
+            Cand cd;
+            cd.idx = id;
+            for (int k = 0; k < 3; ++k) {
+                cd.c[k] = cc[k]; cd.clo[k] = clo[k]; cd.chi[k] = chi[k];
+                cd.cw[k] = geo.corner[k] + geo.res * (float)cc[k];                // :206
+                cd.sc[k] = csc[k];
+            }
+            cd.cs = ccs; cd.sn = csn;
+            cands[it] = cd;
+        }
+        // the statistics of this candidate start from zero (the workspace is not cleared by a launch)
+        for (int q = threadIdx.x; q < (int)(sizeof(Stats) / 4); q += T)
+            reinterpret_cast<unsigned*>(&stats[it])[q] = 0u;
+        DEC_TICK(5)
+    }
+#if DEC_PROF
+    if (threadIdx.x == 0)
+        printf("dec_greedy_sorted<%d,%d,%d> n=%d cand=%d ticks: setup %llu | suppress %llu best %llu reduce+write %llu barrier %llu final+geo %llu math+stores %llu\n",
+               T, E, G, n, it, pt[7], pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]);
+#endif
+    if (threadIdx.x == 0) { n_cand_out[0] = it; n_cand_out[1] = truncated ? 1 : 0; }
+}
+
 // the list length is only known on the device: lists up to GREEDY_CAP entries are walked in registers + LDS, longer ones by
 // the same code over the global arrays (L2-resident)
 __global__ __launch_bounds__(GREEDY_T) void dec_greedy_dispatch(Geo geo, cv_decode_params prm, List L,
@@ -384,13 +618,17 @@ __global__ __launch_bounds__(GREEDY_T) void dec_greedy_dispatch(Geo geo, cv_deco
     if (*list_n <= (unsigned)GREEDY_CAP) dec_greedy<1, GREEDY_T>(geo, prm, L, list_n, cands, stats, n_cand_out);
     else dec_greedy<0, GREEDY_T>(geo, prm, L, list_n, cands, stats, n_cand_out);
 }
-// big grids (the host picks this launch from the cell count): 1024 threads, lists up to 16384 cells in registers
+// big grids (the host picks this launch from the cell count): 1024 threads, lists up to 24576 cells in registers (a
+// 300k-point scene lists ~21 000 cells) on the sorted walk
 constexpr int GREEDY_T_BIG = 1024;
+constexpr int GREEDY_E_BIG = 24;
+constexpr int GREEDY_G_BIG = 64;
 __global__ __launch_bounds__(GREEDY_T_BIG) void dec_greedy_dispatch_big(Geo geo, cv_decode_params prm, List L,
                                                                         const unsigned* __restrict__ list_n,
                                                                         Cand* __restrict__ cands, Stats* __restrict__ stats,
                                                                         int* __restrict__ n_cand_out) {
-    if (*list_n <= 16u * GREEDY_T_BIG) dec_greedy<2, GREEDY_T_BIG>(geo, prm, L, list_n, cands, stats, n_cand_out);
+    if (*list_n <= (unsigned)(GREEDY_E_BIG * GREEDY_T_BIG))
+        dec_greedy_sorted<GREEDY_T_BIG, GREEDY_E_BIG, GREEDY_G_BIG>(geo, prm, L, (int)*list_n, cands, stats, n_cand_out);
     else dec_greedy<0, GREEDY_T_BIG>(geo, prm, L, list_n, cands, stats, n_cand_out);
 }
 

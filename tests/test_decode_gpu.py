@@ -2,6 +2,10 @@
 oracle's sequential restatement of eval_joint.py:195-263.  Integer outputs (candidate cells,
 verdicts, box count, classes) must be exact; boxes/scores are bit-identical by construction
 (shared fp32 conventions), asserted to 1e-6."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -152,3 +156,17 @@ def test_hip_path_matches_reference_lines_executed_on_cpu(cuda, built_lib, name)
     np.testing.assert_allclose(raw["scores"], z["scores"], rtol=1e-6)
     zeroed = np.flatnonzero((before != 0) & (g[0].cpu().numpy() == 0))
     assert np.array_equal(zeroed, z["zeroed"].astype(zeroed.dtype))
+
+
+def test_sorted_walker_of_the_big_grids_on_the_small_cases(cuda, built_lib):
+    """Grids beyond 4 M cells (300k-point scenes) take dec_greedy_dispatch_big: the sorted register-resident walk
+    (dec_greedy_sorted).  The oracle / planted-tie / iteration-cap / reference-line cases of this file are run through it
+    too: CV_DEC_BIG_CELLS=1 sends every grid that way (read once per process, hence a fresh interpreter).  The 300k-point
+    scene itself is compared with the oracle in test_production_size_gpu.py."""
+    env = dict(os.environ, CV_DEC_BIG_CELLS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "oracle_grids or planted_ties or iteration_cap or reference_lines or end_to_end_80k"],
+                       env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
