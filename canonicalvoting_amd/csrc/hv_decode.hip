@@ -393,15 +393,25 @@ __device__ __forceinline__ void dec_greedy(Geo geo, cv_decode_params prm, List L
 // Same candidates in the same order as the reference loop (eval_joint.py:204-263): the maximum with ties to the lowest flat
 // index, suppression by cube and box exactly as before.  Used for the big grids (dec_greedy_dispatch_big): a 300k-point
 // scene's decode 1.88 -> 1.28 ms.  What is left there (phase ticks, DEC_PROF): the waves that own the cells inside a
-// candidate's region run ~8 kill tests per lane (130 instructions each with the select chains) while the others wait at the
-// barrier - 5 600 of the 13 500 cycles per candidate - and the five geometry words are a trip to the fabric (2 700 cycles).
+// candidate's region run ~6 kill tests per lane (~100 instructions each with the select trees) in nearly every wave - the four
+// waves of a SIMD keep it busy for ~13 000 cycles per candidate - and the five geometry words cost 2 700 cycles (requesting them
+// before the barrier, by every wave's best lane, did not shorten that).
 // NOT used for the 80k-point lists (3 400 cells, 42 candidates): 0.21 ms against dec_greedy<1>'s 0.18.
 template <int N, class Tv>
 __device__ __forceinline__ Tv pick_slot(const Tv (&r)[N], int j) {
-    Tv x = r[0];
+    // slot j of a register array (a dynamic index has to become selects): a binary tree over the bits of j - N - 1 selects
+    // and five bit tests, which two picks of the same j share, instead of N compares + N selects each
+    static_assert(N <= 32, "five index bits");
+    Tv t[32];
 #pragma unroll
-    for (int q = 1; q < N; ++q) x = j == q ? r[q] : x;
-    return x;
+    for (int i = 0; i < 32; ++i) t[i] = r[i < N ? i : N - 1];
+#pragma unroll
+    for (int bit = 0; bit < 5; ++bit) {
+        const bool b = (j >> bit) & 1;
+#pragma unroll
+        for (int i = 0; i < (32 >> (bit + 1)); ++i) t[i] = b ? t[2 * i + 1] : t[2 * i];
+    }
+    return t[0];
 }
 
 template <int T, int E, int G>
@@ -602,6 +612,9 @@ __device__ __forceinline__ void dec_greedy_sorted(Geo geo, cv_decode_params prm,
         DEC_TICK(5)
     }
 #if DEC_PROF
+    if ((threadIdx.x & 63) == 0)
+        printf("  wave %2d: suppress %llu best %llu reduce+write %llu barrier %llu final+geo %llu math+stores %llu\n", (int)(threadIdx.x >> 6),
+               pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]);
     if (threadIdx.x == 0)
         printf("dec_greedy_sorted<%d,%d,%d> n=%d cand=%d ticks: setup %llu | suppress %llu best %llu reduce+write %llu barrier %llu final+geo %llu math+stores %llu\n",
                T, E, G, n, it, pt[7], pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]);
