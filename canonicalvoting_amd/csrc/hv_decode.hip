@@ -165,8 +165,13 @@ __device__ __forceinline__ void take_better(Best& b, float v, int id, int pos) {
     if (v > b.v || (v == b.v && id < b.id)) { b.v = v; b.id = id; b.pos = pos; }
 }
 
-constexpr int GREEDY_T = 256;        // threads of the greedy workgroup: one wave per SIMD (the per-candidate part that
-                                     // every wave repeats - reduction, candidate set-up - then runs once per SIMD)
+#ifndef DEC_SMALL_T
+#define DEC_SMALL_T 512     // 256: 0.180 ms, 512: 0.158 ms, 1024: 0.181 ms decode stage at 80k points (profiles/r4/dec_small_t.txt)
+#endif
+constexpr int GREEDY_T = DEC_SMALL_T;        // threads of the greedy workgroup: two waves per SIMD.  One wave per SIMD (256, rounds
+                                     // 2-3) runs the per-candidate part every wave repeats - reduction, candidate set-up -
+                                     // once per SIMD, but leaves the LDS round trips of a region's box tests (~1 000 per
+                                     // candidate at 80k points, 4 per thread) with nothing to hide behind
 constexpr int GREEDY_W = GREEDY_T / 64;
 constexpr int GREEDY_CAP = 4096;     // list entries held in LDS (32 bytes each)
 
@@ -203,7 +208,7 @@ __device__ __forceinline__ void dec_greedy(Geo geo, cv_decode_params prm, List L
                                            const unsigned* __restrict__ list_n, Cand* __restrict__ cands,
                                            Stats* __restrict__ stats, int* __restrict__ n_cand_out) {
     constexpr bool IN_REG = MODE != 0, IN_LDS = MODE == 1;
-    constexpr int GREEDY_E = 16;                         // entries per thread of the register-resident walk
+    constexpr int GREEDY_E = (MODE == 1 ? GREEDY_CAP / T : 16);      // entries per thread of the register-resident walk
     constexpr int CAP = IN_LDS ? GREEDY_E * T : 1;
     constexpr int GREEDY_T = T, GREEDY_W = T / 64;
     __shared__ unsigned l_xy[CAP];
