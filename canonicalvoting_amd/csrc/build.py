@@ -33,6 +33,7 @@ SOURCES = {
     "hv_decode.hip": STRICT + os.environ.get("CV_DEC_DEFS", "").split(),  # greedy-walk experiments (-DDEC_BLOCKED=0)
     "sparse_coords.hip": [],
     "sparse_conv.hip": os.environ.get("CV_SC_DEFS", "").split(),          # kernel experiments (-DCV_WP_CLAMPED_GATHER=1)
+    "sparse_win.hip": os.environ.get("CV_WIN_DEFS", "").split(),          # conv_win ablations (-DCV_WIN_ABL=2)
     "net_exec.cpp": [],
     "scene_exec.cpp": [],
 }

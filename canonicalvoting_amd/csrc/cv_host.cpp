@@ -66,7 +66,7 @@ void cv_set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int cv_abi_version(void) { return 1; }
+int cv_abi_version(void) { return CV_ABI_VERSION; }
 const char* cv_last_error(void) { return g_err; }
 
 // utils/calc_map.py:6-21.  Rows 0..3 of a box are its top face (the xz polygon),

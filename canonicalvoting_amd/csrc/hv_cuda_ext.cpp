@@ -191,5 +191,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("backward", &hv_backward, "hv backward (HIP, gfx950)", py::arg("grad_grid"), py::arg("points"), py::arg("xyz_labels"),
           py::arg("scale_labels"), py::arg("obj_labels"), py::arg("res"), py::arg("num_rots"), py::arg("corners") = py::none());
     m.def("set_algorithm", [](int a) { g_algo = a; }, "0 auto, 1 direct global atomics, 2 LDS tiles (A/B measurements)");
-    m.def("abi_version", []() { return cv_abi_version(); });
+    // the header this module was compiled against vs the libcvhip.so the loader found: a stale pair must not run
+    TORCH_CHECK(cv_abi_version() == CV_ABI_VERSION, "hv_cuda: libcvhip.so has ABI version ", cv_abi_version(),
+                ", this extension was compiled against ", CV_ABI_VERSION, " - rebuild (python -m canonicalvoting_amd.csrc.build --force)");
+    m.def("abi_version", []() { return CV_ABI_VERSION; }, "CV_ABI_VERSION of the header this extension was compiled against");
+    m.def("library_abi_version", []() { return cv_abi_version(); }, "cv_abi_version() of the loaded libcvhip.so");
 }

@@ -819,13 +819,6 @@ __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : NB == 2 ? 4 : 5)) void conv
 #ifndef CV_HL_ABL
 #define CV_HL_ABL 0       // timing ablations of conv_hl (wrong results): 1 no gathers, 2 no MFMA, 4 no weight tile, 8 no epilogue, 16 no map reads
 #endif
-template <int... I, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
-
 // NS = unit slots (registers for the A fragments and this thread's share of the weight tile, one LDS weight tile each):
 // the loads of unit u + NS - 1 are requested while unit u multiplies.  Workgroups of the split coarse levels have no more
 // than NS units: all their loads are in flight after the prologue (two dependent round trips - map entries, fragments -
@@ -1210,61 +1203,9 @@ __launch_bounds__(NW * 64, hl_blocks(NB, NS, NW)) void conv_hl(ConvArgs a) {
 //    vmcnt (the LDS-DMA instructions a wave issued for the units behind the one it needs stay in flight);
 //  * the accumulators are the only long-lived registers: one workgroup of 8 waves per CU (LDS-bound), two waves per SIMD.
 // Dead rows of a live wave fetch a row of zeros (one line, all lanes); dead waves issue nothing for the unit.
-__device__ __attribute__((aligned(128))) unsigned char g_zero_chunk[128];
 #ifndef CV_HD_ABL
 #define CV_HD_ABL 0
 #endif
-template <int N>
-__device__ __forceinline__ void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {      // n is wave-uniform, 0 ... 8
-    switch (n) {
-        case 0: wait_vmcnt_le<0>(); break;
-        case 1: wait_vmcnt_le<1>(); break;
-        case 2: wait_vmcnt_le<2>(); break;
-        case 3: wait_vmcnt_le<3>(); break;
-        case 4: wait_vmcnt_le<4>(); break;
-        case 5: wait_vmcnt_le<5>(); break;
-        case 6: wait_vmcnt_le<6>(); break;
-        case 7: wait_vmcnt_le<7>(); break;
-        default: wait_vmcnt_le<8>(); break;
-    }
-}
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-// one LDS-DMA request: every lane's 16 bytes at g land at l + 16 * lane (l wave-uniform).  A plain device function: inside a
-// generic lambda the builtin keeps hipcc's host pass from emitting the kernel's launch stub.
-__device__ __forceinline__ void lds_dma16(const void* g, unsigned char* l) {
-    __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)l, 16, 0, 0);
-}
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-// MFMA fragments of one k-step out of a ring stage: A high / low piece of the lane's row, NB x (high, low) weight pieces.
-// Inline asm (and a plain device function, not a lambda: the host pass must not meet the register constraints): hipcc
-// orders every LDS read that may alias an LDS-DMA destination behind vmcnt(0) - it would drain the requests of units k + 1
-// and k + 2 in front of unit k's MFMAs.  The waits that matter are conv_hd's counted vmcnt and its workgroup barrier.
-template <int NB>
-__device__ __forceinline__ void hd_read_frags(unsigned aa0, unsigned aa1, unsigned ab, u32x4v& A0, u32x4v& A1,
-                                              u32x4v (&B0)[NB], u32x4v (&B1)[NB]) {
-    constexpr int P1 = NB * 32 * 64;                            // low-piece plane of the weight tile
-    if constexpr (NB == 1) {
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %6 offset:%7\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(A0), "=&v"(A1), "=&v"(B0[0]), "=&v"(B1[0])
-                     : "v"(aa0), "v"(aa1), "v"(ab), "i"(P1) : "memory");
-    } else if constexpr (NB == 2) {
-        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %8 offset:%9\n\t"
-                     "ds_read_b128 %4, %8 offset:%10\n\tds_read_b128 %5, %8 offset:%11\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(A0), "=&v"(A1), "=&v"(B0[0]), "=&v"(B1[0]), "=&v"(B0[1]), "=&v"(B1[1])
-                     : "v"(aa0), "v"(aa1), "v"(ab), "i"(P1), "i"(2048), "i"(P1 + 2048) : "memory");
-    } else {
-        static_assert(NB == 3, "conv_hd: 32, 64 or 96 columns per workgroup");
-        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %10 offset:%11\n\t"
-                     "ds_read_b128 %4, %10 offset:%12\n\tds_read_b128 %5, %10 offset:%13\n\t"
-                     "ds_read_b128 %6, %10 offset:%14\n\tds_read_b128 %7, %10 offset:%15\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(A0), "=&v"(A1), "=&v"(B0[0]), "=&v"(B1[0]), "=&v"(B0[1]), "=&v"(B1[1]), "=&v"(B0[2]), "=&v"(B1[2])
-                     : "v"(aa0), "v"(aa1), "v"(ab), "i"(P1), "i"(2048), "i"(P1 + 2048), "i"(4096), "i"(P1 + 4096) : "memory");
-    }
-}
 // LDS of one workgroup: NSTG ring stages (gathered rows of NW waves + the weight tile), the tile's row / map tables, unit list
 constexpr int hd_lds_bytes(int NB, int NW, int NSTG) {
     return NSTG * (NW * 4096 + 2 * NB * 32 * 64) + NW * 32 * 4 + (WP_NPRE + 1) * NW * 32 * 4 + NW * 4 + (HL_MAX_UNITS + 4) * 2;
@@ -2892,9 +2833,10 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
 
 int cv_sp_set_option(const char* name, long long value, long long* previous) {
     CV_REQUIRE(name, CV_EINVAL, "null option name");
+    if (cvsc::win_option(name, value, previous)) return CV_OK;
     std::atomic<long long>* o = !strcmp(name, "hd_mask") ? &g_opt_hd_mask : !strcmp(name, "hd_min_rows") ? &g_opt_hd_min_rows :
                                 !strcmp(name, "hd_shape") ? &g_opt_hd_shape : nullptr;
-    CV_REQUIRE(o, CV_EINVAL, "unknown option '%s' (hd_mask, hd_min_rows, hd_shape)", name);
+    CV_REQUIRE(o, CV_EINVAL, "unknown option '%s' (hd_mask, hd_min_rows, hd_shape, win, win_xcd)", name);
     const long long before = o->exchange(value, std::memory_order_relaxed);
     if (previous) *previous = before;
     return CV_OK;
@@ -3046,6 +2988,8 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         CV_LAUNCH_CHECK();
         return CV_OK;
     }
+    a.win = d->win;
+    if (a.win && cvsc::win_enabled() && cvsc::win_eligible(a)) return cvsc::launch_win(a, st);
     if (d->perm_groups > 1) {
         // offsets split into perm_groups contiguous groups, each processed in its own row order, all in
         // one launch (grid.z); partial tiles are reduced by conv_finish

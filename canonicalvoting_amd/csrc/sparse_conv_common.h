@@ -48,6 +48,7 @@ struct ConvArgs {
     int in_hl, out_hl, res_hl;   // 1: the operand is in the hl format (fp16 pairs in place, see below) instead of fp32
     int xcd_tiles;               // conv_rows_wp / conv_hl: XCD-aware tile numbering (xcd_tile)
     int* tickets;                // conv_hl split-K: arrival counters per output tile (zero; the last arriver reduces, see there)
+    const int* win;              // conv_win: the window block of the kernel map (cv_sp_build_windows), see sparse_win.hip
 };
 
 // ---- hl format: activations stored as the fp16 pairs the matrix cores multiply --------------------------------------
@@ -233,7 +234,94 @@ __device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigne
 __device__ __forceinline__ void hl_split2(float x0, float x1, unsigned& h, unsigned& l) { split2h(x0, x1, h, l); }
 
 
+// ---- shared by the LDS-DMA kernels (conv_hd in sparse_conv.hip, conv_win in sparse_win.hip) -----------------------------
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+static __device__ __attribute__((aligned(128))) unsigned char g_zero_chunk[128];
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {      // n is wave-uniform, 0 ... 8
+    switch (n) {
+        case 0: wait_vmcnt_le<0>(); break;
+        case 1: wait_vmcnt_le<1>(); break;
+        case 2: wait_vmcnt_le<2>(); break;
+        case 3: wait_vmcnt_le<3>(); break;
+        case 4: wait_vmcnt_le<4>(); break;
+        case 5: wait_vmcnt_le<5>(); break;
+        case 6: wait_vmcnt_le<6>(); break;
+        case 7: wait_vmcnt_le<7>(); break;
+        default: wait_vmcnt_le<8>(); break;
+    }
+}
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// one LDS-DMA request: every lane's 16 bytes at g land at l + 16 * lane (l wave-uniform).  A plain device function: inside a
+// generic lambda the builtin keeps hipcc's host pass from emitting the kernel's launch stub.
+__device__ __forceinline__ void lds_dma16(const void* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds(g, (lds_ptr_t)l, 16, 0, 0);
+}
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+// MFMA fragments of one k-step out of a ring stage: A high / low piece of the lane's row, NB x (high, low) weight pieces.
+// Inline asm (and a plain device function, not a lambda: the host pass must not meet the register constraints): hipcc
+// orders every LDS read that may alias an LDS-DMA destination behind vmcnt(0) - it would drain the requests of units k + 1
+// and k + 2 in front of unit k's MFMAs.  The waits that matter are conv_hd's counted vmcnt and its workgroup barrier.
+template <int NB>
+__device__ __forceinline__ void hd_read_frags(unsigned aa0, unsigned aa1, unsigned ab, u32x4v& A0, u32x4v& A1,
+                                              u32x4v (&B0)[NB], u32x4v (&B1)[NB]) {
+    constexpr int P1 = NB * 32 * 64;                            // low-piece plane of the weight tile
+    if constexpr (NB == 1) {
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %6 offset:%7\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(A0), "=&v"(A1), "=&v"(B0[0]), "=&v"(B1[0])
+                     : "v"(aa0), "v"(aa1), "v"(ab), "i"(P1) : "memory");
+    } else if constexpr (NB == 2) {
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %8 offset:%9\n\t"
+                     "ds_read_b128 %4, %8 offset:%10\n\tds_read_b128 %5, %8 offset:%11\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(A0), "=&v"(A1), "=&v"(B0[0]), "=&v"(B1[0]), "=&v"(B0[1]), "=&v"(B1[1])
+                     : "v"(aa0), "v"(aa1), "v"(ab), "i"(P1), "i"(2048), "i"(P1 + 2048) : "memory");
+    } else {
+        static_assert(NB == 3, "conv_hd: 32, 64 or 96 columns per workgroup");
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %10 offset:%11\n\t"
+                     "ds_read_b128 %4, %10 offset:%12\n\tds_read_b128 %5, %10 offset:%13\n\t"
+                     "ds_read_b128 %6, %10 offset:%14\n\tds_read_b128 %7, %10 offset:%15\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(A0), "=&v"(A1), "=&v"(B0[0]), "=&v"(B1[0]), "=&v"(B0[1]), "=&v"(B1[1]), "=&v"(B0[2]), "=&v"(B1[2])
+                     : "v"(aa0), "v"(aa1), "v"(ab), "i"(P1), "i"(2048), "i"(P1 + 2048), "i"(4096), "i"(P1 + 4096) : "memory");
+    }
+}
+
+// the weight fragments alone (A fragments already in registers)
+template <int NB>
+__device__ __forceinline__ void hd_read_b(unsigned ab, u32x4v (&B0)[NB], u32x4v (&B1)[NB]) {
+    constexpr int P1 = NB * 32 * 64;
+    if constexpr (NB == 1) {
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(B0[0]), "=&v"(B1[0]) : "v"(ab), "i"(P1) : "memory");
+    } else if constexpr (NB == 2) {
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\t"
+                     "ds_read_b128 %3, %4 offset:%7\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(B0[0]), "=&v"(B1[0]), "=&v"(B0[1]), "=&v"(B1[1])
+                     : "v"(ab), "i"(P1), "i"(2048), "i"(P1 + 2048) : "memory");
+    } else {
+        static_assert(NB == 3, "32, 64 or 96 columns per workgroup");
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:%7\n\tds_read_b128 %2, %6 offset:%8\n\t"
+                     "ds_read_b128 %3, %6 offset:%9\n\tds_read_b128 %4, %6 offset:%10\n\tds_read_b128 %5, %6 offset:%11\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(B0[0]), "=&v"(B1[0]), "=&v"(B0[1]), "=&v"(B1[1]), "=&v"(B0[2]), "=&v"(B1[2])
+                     : "v"(ab), "i"(P1), "i"(2048), "i"(P1 + 2048), "i"(4096), "i"(P1 + 4096) : "memory");
+    }
+}
+
 // ---- across the two translation units
 int launch_finish(const ConvArgs& a, hipStream_t st);                  // sparse_conv.hip: reduce the partial tiles + epilogue
 int nb_full(int cout);                                                 // sparse_conv.hip
+bool win_eligible(const ConvArgs& a);                                  // sparse_win.hip: conv_win takes this launch
+int launch_win(const ConvArgs& a, hipStream_t st);                     // sparse_win.hip
+bool win_option(const char* name, long long value, long long* previous);   // sparse_win.hip: "win", "win_xcd" of cv_sp_set_option
+bool win_enabled();
 }  // namespace cvsc

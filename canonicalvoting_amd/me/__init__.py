@@ -197,21 +197,39 @@ class CoordinateManager:
     MASK_GROUPS = int(os.environ.get("CV_NET_MASK_GROUPS", "3"))
     MASKED_MIN_ROWS = int(os.environ.get("CV_MASKED_MIN_ROWS", "16384"))
 
-    def fused_fast(self, stem_k=5):
+    def windows(self, ts=1):
+        """neighbour windows of the 3x3x3 map at tensor stride ts (cv_sp_build_windows; int32 block, cached): hand it to
+        conv_forward(win=...) - the rows of this manager must be in spatial order (a sorted twin from fused_plan)"""
+        key = ("win", ts)
+        m = self._maps.get(key)
+        if m is None:
+            L = _lib.lib()
+            nbr = self.kernel_map(3, ts)
+            n = nbr.shape[0]
+            if not L.cv_sp_windows_supported(n):
+                raise RuntimeError("coordinate set too large for the window plan (%d rows)" % n)
+            m = torch.empty(int(L.cv_sp_windows_words(n)), dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(L.cv_sp_build_windows(_ptr(nbr), n, _ptr(m), _stream(self.device)), "cv_sp_build_windows")
+            self._maps[key] = m
+        return m
+
+    def fused_fast(self, stem_k=5, win_levels=0):
         """The coordinate plan of the fused network as raw device pointers (what MinkUNet.program_forward hands to the
         C executor): .counts rows per level, .map_ptrs [stem, down 0-3, k3 0-4, up 0-3, out], .perm_ptrs [mask orders of
         levels 0-4 (None where a level is not mask-sorted), octant orders of the four transposed convs].
         ONE C call (cv_sp_scene_plan: spatial row sort, the five levels of the sorted set, every map and order) into
         three allocations; the tensor views of the plan (fused_plan) are only made when somebody asks for them."""
-        if self._fused is not None and self._fused_k == stem_k:
-            return self._fused
+        cache = self.__dict__.setdefault("_fused_cache", {})
+        if (stem_k, win_levels) in cache:
+            return cache[(stem_k, win_levels)]
         L = _lib.lib()
         dev = self.device
         n = self._input.shape[0]
         NL = CoordinateManager.NUM_LEVELS
         G = self.MASK_GROUPS if (27 + self.MASK_GROUPS - 1) // self.MASK_GROUPS <= 10 else 0   # wide groups: lazily
         cap = int(L.cv_sp_table_capacity(n))
-        words = int(L.cv_sp_scene_plan_words(n, stem_k, G, self.MASKED_MIN_ROWS))
+        words = int(L.cv_sp_scene_plan_words(n, stem_k, G, self.MASKED_MIN_ROWS, win_levels))
         up64 = lambda v: (v + 63) // 64 * 64
         # int32 buffer: perm | inv | coords of the 5 levels | table values of the 5 levels | counts | arena (sized for
         # the worst case, every coarse level bounded by n: the call does not come back between the levels and the maps)
@@ -234,7 +252,7 @@ class CoordinateManager:
         with torch.cuda.device(dev):
             _lib.check(L.cv_sp_scene_plan(_ptr(self._input), n, vp(ib + 4 * o_perm), vp(ib + 4 * o_inv), c_coords, c_keys,
                                           c_vals, cap, vp(ib + 4 * o_counts), counts_h, stem_k, G, self.MASKED_MIN_ROWS,
-                                          vp(ib + 4 * o_arena), words, ctypes.byref(off), vp(wb), sws_b, vp(wb + up64(sws_b)),
+                                          win_levels, vp(ib + 4 * o_arena), words, ctypes.byref(off), vp(wb), sws_b, vp(wb + up64(sws_b)),
                                           lws_b, _stream(dev)), "cv_sp_scene_plan")
         self._raise_on_dups(counts_h[5], counts_h[6])
         plan = _FusedPlan()
@@ -247,7 +265,9 @@ class CoordinateManager:
                         [ap(off.up[i]) for i in range(4)] + [ib + 4 * o_inv]
         plan.perm_ptrs = [ap(off.mask_perm[i]) if off.mask_perm[i] >= 0 else None for i in range(5)] + \
                          [ap(off.up_perm[i]) for i in range(4)]
+        plan.win_ptrs = [ap(off.win[i]) if off.win[i] >= 0 else None for i in range(5)]
         plan.views = None
+        cache[(stem_k, win_levels)] = plan
         self._fused = plan
         self._fused_k = stem_k
         return plan
@@ -423,7 +443,7 @@ def range_flag(dev):
 def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=None, relu=False,
                  out=None, flavour=0, row_perm=None, j_begin=0, j_end=0, acc_in=None, perm_groups=0,
                  cache_weights=True, pieces=None, in_hl=False, out_hl=False, res_hl=False, stem_mfma=False,
-                 split_tickets=None, weight_t=False):
+                 split_tickets=None, weight_t=False, win=None):
     """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout].
     in_hl / out_hl / res_hl: the operand is in the hl format (to_hl / from_hl; cv_conv_desc.in_hl), pieces=2 only.
     pieces=2: fp16-pair products (weights packed per call; the caller reads range_flag(dev) after synchronising);
@@ -498,7 +518,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
                       None, None, None, p(wp6), None, 0, 0, None,
                       1 if (perm_groups > 1 and getattr(row_perm, "_cv_has_map", False)) else 0,
                       2 if flag is not None else (1 if (pieces == 1 and wp6 is not None) else 0), acc_scale, p(flag),
-                      1 if in_hl else 0, 1 if out_hl else 0, 1 if res_hl else 0, p(split_tickets))
+                      1 if in_hl else 0, 1 if out_hl else 0, 1 if res_hl else 0, p(split_tickets), p(win))
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
     return out
@@ -516,6 +536,13 @@ def set_option(name, value):
     prev = ctypes.c_longlong(0)
     _lib.check(_lib.lib().cv_sp_set_option(name.encode(), int(value), ctypes.byref(prev)), "cv_sp_set_option")
     return int(prev.value)
+
+
+def option(name):
+    """current value of a cv_sp_set_option knob"""
+    v = set_option(name, 0)
+    set_option(name, v)
+    return v
 
 
 def to_hl(x):

@@ -143,6 +143,7 @@ def detect_scene_c(model, hv, coords4, feats, res, nclasses=9, log_scale=True, s
     d.d_points, d.res, d.num_rots = vp(scan_points.data_ptr()), float(res), hv_cuda._scalar(hv.num_rots, "i")
     d.ops, d.n_ops, d.bufs, d.n_bufs = ctypes.cast(c_ops, vp), len(c_ops), ctypes.cast(c_bufs, vp), len(c_bufs)
     d.stem_k, d.mask_groups, d.masked_min_rows = model.conv0p1s1.kernel_size, G, cm_cls.MASKED_MIN_ROWS
+    d.win_levels = int(L.cv_net_win_levels(c_ops, len(c_ops), c_bufs, len(c_bufs))) if ME.option("win") else 0
     d.max_channels, d.use_range_flag = max(model.PLANES), 1 if pieces == 2 else 0
     d.d_out_feats, d.out_ld, d.out_channels = vp(y.data_ptr()), y.stride(0), y.shape[1]
     d.nclasses, d.log_scale = nclasses, 1 if log_scale else 0
@@ -186,6 +187,8 @@ def detect_scene_c(model, hv, coords4, feats, res, nclasses=9, log_scale=True, s
             continue
         _lib.check(rc, "cv_detect_scene_f32")
         break
+    else:
+        _lib.check(rc, "cv_detect_scene_f32")          # still CV_ENOMEM after four growing attempts: not an empty scene
     host.ws_hint = max(host.ws_hint, int(r.needed_ws_bytes))
     host.grid_hint = max(host.grid_hint, int(r.needed_grid_floats) * 9 // 8)
     if r.range_flag or r.truncated:

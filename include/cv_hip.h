@@ -30,6 +30,11 @@ extern "C" {
 #define CV_EHIP (-5)      /* a HIP runtime call or kernel launch failed */
 #define CV_ERANGE (-34)   /* result does not fit the caller's buffers */
 
+/* Version of this header.  cv_abi_version() returns the value the LIBRARY was built with: a binding compiled against
+ * this header compares the two (csrc/hv_cuda_ext.cpp does at import) and refuses a stale pair.
+ * 2 (round 5): neighbour windows (cv_sp_build_windows, cv_conv_desc.win, cv_scene_maps.win, win_levels arguments of the
+ *    scene-plan calls, `wins` of cv_net_run_f32); the round 1-3 tile-plan symbols are gone. */
+#define CV_ABI_VERSION 2
 int cv_abi_version(void);
 const char* cv_last_error(void);
 
@@ -235,6 +240,11 @@ typedef struct cv_conv_desc {
                                stream.  A split launch then reduces its partial tiles in the last-arriving workgroup of every
                                output tile (same summation order as the finish launch: bit-identical) instead of a second
                                launch; the library leaves the counters at zero.  NULL: two launches. */
+    const int32_t* win;     /* optional: neighbour windows of `nbr` (cv_sp_build_windows; K == 27, n_in == n_out rows in spatial
+                               order).  With hl-format input, fp16-pair weights and Cout 32 / 64 / 96 the convolution then runs as
+                               conv_win: every 256-row tile lands its window of input rows in LDS once and multiplies all 27
+                               offsets out of it - no mask groups, no partial tiles, no finish launch (row_perm / perm_groups
+                               are ignored).  Other shapes ignore it. */
 } cv_conv_desc;
 #define CV_SPLIT_TICKETS 4096
 
@@ -272,6 +282,16 @@ int cv_sp_pack_weights_stem_h2_f32(const float* d_w, int K, int cin, const float
 
 size_t cv_sp_conv_workspace_bytes(long long n_out, int cout, int K);
 int cv_sp_conv_f32(const cv_conv_desc* desc, void* stream);
+
+/* Neighbour windows of a 3x3x3 kernel map d_nbr[n][27] whose rows are in spatial order (cv_sp_sort_rows): for every tile of
+ * 256 consecutive rows the ascending list of distinct input rows it touches (the first 448 of them: the window) and the
+ * map rewritten to 16-bit window slots.  d_win: cv_sp_windows_words(n) int32 words, 256-byte aligned.  Built once per
+ * coordinate level, shared by every convolution on that map (cv_conv_desc.win).  cv_sp_windows_supported: the plan kernel
+ * ranks a tile's rows with a bitmap over the level's rows in LDS - levels beyond ~800k rows keep the mask-sorted path.
+ * (No reference counterpart: MinkowskiEngine's kernel maps are internal.)  Asynchronous. */
+int cv_sp_windows_supported(long long n);
+size_t cv_sp_windows_words(long long n);
+int cv_sp_build_windows(const int32_t* d_nbr, long long n, int32_t* d_win, void* stream);
 /* Launch sizing of the convolutions whose output tiles alone do not fill the chip (the coarse levels): the number of
  * workgroups a launch is split up to (over the kernel offsets; partial tiles, then a finish pass).  Default 512
  * (or CV_SPLIT_TARGET) - best for ONE scene in flight; a host that keeps several scenes in flight on separate streams
@@ -308,12 +328,16 @@ typedef struct cv_scene_maps {
     long long stem, out, down[4], k3[5], up[4], mask_perm[5], up_perm[4], scratch;
     long long bitmap;       /* 2^20 words: occupancy bits of the level-0 set over its bounding box (cv_sp_scene_plan puts
                                them in front of the hash probes of the level-0 maps: 87 % of the lookups are misses) */
+    long long win[5];       /* neighbour windows of k3[i] (cv_sp_build_windows) for the levels of `win_levels` with at least
+                               masked_min_rows rows; such a level has no mask_perm */
 } cv_scene_maps;
+/* win_levels: bit i set = level i runs its 3x3x3 convolutions on neighbour windows (cv_net_win_levels of the program) */
 size_t cv_sp_scene_maps_words(const long long* level_rows, long long n_orig, int stem_k, int mask_groups,
-                              long long masked_min_rows, cv_scene_maps* offsets);
+                              long long masked_min_rows, int win_levels, cv_scene_maps* offsets);
 int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
                      long long cap, const long long* level_rows, const int32_t* d_perm, long long n_orig, int stem_k,
-                     int mask_groups, long long masked_min_rows, int32_t* d_arena, size_t arena_words, void* stream);
+                     int mask_groups, long long masked_min_rows, int win_levels, int32_t* d_arena, size_t arena_words,
+                     void* stream);
 
 /* The whole coordinate plan of a scene in ONE call (replaces cv_sp_sort_rows + cv_sp_build_levels + cv_sp_scene_maps
  * issued by the caller): spatial row sort of d_input[n][4] into d_coords[0], the five levels with their tables, every
@@ -322,10 +346,10 @@ int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* 
  * filled on return.  The level counts are copied to pinned host memory behind the levels and the call waits for that copy
  * only (an event), while `stream` goes on with the level-0 maps queued behind it.  When h_counts[5] (duplicates) or h_counts[6] (rows
  * outside the key window) is non-zero nothing beyond the level-0 maps is built and the caller must reject the input. */
-size_t cv_sp_scene_plan_words(long long n, int stem_k, int mask_groups, long long masked_min_rows);
+size_t cv_sp_scene_plan_words(long long n, int stem_k, int mask_groups, long long masked_min_rows, int win_levels);
 int cv_sp_scene_plan(const int32_t* d_input, long long n, int32_t* d_perm, int32_t* d_inv, int32_t* const* d_coords,
                      unsigned long long* const* d_keys, int32_t* const* d_vals, long long cap, int32_t* d_counts,
-                     int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int32_t* d_arena,
+                     int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int win_levels, int32_t* d_arena,
                      size_t arena_words, cv_scene_maps* offsets, void* d_sort_ws, size_t sort_ws_bytes, void* d_levels_ws,
                      size_t levels_ws_bytes, void* stream);
 
@@ -360,11 +384,15 @@ typedef struct cv_net_op {
     float acc_scale;
 } cv_net_op;
 size_t cv_net_arena_bytes(const cv_net_buf* bufs, int n_bufs, const long long* level_rows, int n_levels);
+/* wins[n_wins] (may be NULL): window blocks indexed like the first entries of perms (the level of a mask-grouped 3x3x3
+ * op's order slot): a non-NULL entry hands the op cv_conv_desc.win.  cv_net_win_levels: the levels of a program whose
+ * mask-grouped ops can ALL take windows (what the scene plan is then asked to build instead of mask orders). */
+int cv_net_win_levels(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int n_bufs);
 int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int n_bufs, const long long* level_rows,
                    int n_levels, void* d_arena, size_t arena_bytes, const void* const* ext_ptr, const int* ext_ld,
-                   const int32_t* const* maps, int n_maps, const int32_t* const* perms, int n_perms, void* d_ws,
-                   size_t ws_bytes, int32_t* range_flag, void* stream);   /* range_flag: cv_conv_desc.range_flag of
-                                                                             every fp16-pair op, or NULL */
+                   const int32_t* const* maps, int n_maps, const int32_t* const* perms, int n_perms,
+                   const int32_t* const* wins, int n_wins, void* d_ws, size_t ws_bytes, int32_t* range_flag,
+                   void* stream);   /* range_flag: cv_conv_desc.range_flag of every fp16-pair op, or NULL */
 
 /* d_keys[n] (int64) = bit mask of the valid neighbours among offsets [j_begin, j_end) of every row of a
  * kernel map; argsort of it is a row_perm for cv_conv_desc.  Asynchronous. */
@@ -454,6 +482,7 @@ typedef struct cv_scene_desc {
     const cv_net_buf* bufs; int n_bufs;
     int stem_k, mask_groups;
     long long masked_min_rows;
+    int win_levels;               /* cv_net_win_levels(ops, ...): levels whose 3x3x3 convolutions run on neighbour windows (0: none) */
     int max_channels;             /* widest convolution output (workspace sizing) */
     int use_range_flag;           /* 1: the program runs on fp16 pairs; result.range_flag reports an input beyond the fp16 range */
     float* d_out_feats;           /* [n][out_ld] network output, caller's buffer, caller's row order */

@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol(built_lib):
         assert hasattr(L, s), "libcvhip.so does not export %s" % s
         assert s in _lib.SIGNATURES, "no ctypes signature for %s" % s
     assert sorted(_lib.SIGNATURES) == syms
-    assert _lib.lib().cv_abi_version() == 1
+    header_version = int(re.search(r"#define\s+CV_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "cv_hip.h")).read()).group(1))
+    assert _lib.lib().cv_abi_version() == header_version == _lib.ABI_VERSION       # library, header and ctypes signatures agree
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -111,21 +112,29 @@ def test_host_side_layout_functions(built_lib):
     L = _lib.lib()
     rows = (ctypes.c_int64 * 5)(80000, 36822, 9929, 2349, 494)
     off = _lib.SceneMaps()
-    words = L.cv_sp_scene_maps_words(rows, 80000, 5, 4, 16384, ctypes.byref(off))
-    assert off.out == -1          # the caller's rows <- sorted rows map is cv_sp_sort_rows' inverse permutation
-    spans = [(off.stem, 80000 * 125)] + [(off.down[i], rows[i + 1] * 8) for i in range(4)] + \
-            [(off.k3[i], rows[i] * 27) for i in range(5)] + [(off.up[i], rows[3 - i] * 8) for i in range(4)] + \
-            [(off.up_perm[i], rows[3 - i]) for i in range(4)] + [(off.scratch, (5 * 4 + 4) * 1024), (off.bitmap, 1 << 20)]
-    for i in range(5):
-        if rows[i] >= 16384:
-            assert off.mask_perm[i] >= 0
-            spans.append((off.mask_perm[i], 4 * rows[i] * (1 + 7)))          # orders + map rows in processing order
-        else:
-            assert off.mask_perm[i] == -1
-    spans.sort()
-    for (a, la), (b, _) in zip(spans[:-1], spans[1:]):
-        assert a % 64 == 0 and a + la <= b                                   # aligned, non-overlapping
-    assert spans[-1][0] + spans[-1][1] <= words
+    for win_levels in (0, 3, 31):
+        words = L.cv_sp_scene_maps_words(rows, 80000, 5, 4, 16384, win_levels, ctypes.byref(off))
+        assert off.out == -1          # the caller's rows <- sorted rows map is cv_sp_sort_rows' inverse permutation
+        spans = [(off.stem, 80000 * 125)] + [(off.down[i], rows[i + 1] * 8) for i in range(4)] + \
+                [(off.k3[i], rows[i] * 27) for i in range(5)] + [(off.up[i], rows[3 - i] * 8) for i in range(4)] + \
+                [(off.up_perm[i], rows[3 - i]) for i in range(4)] + [(off.scratch, (5 * 4 + 4) * 1024), (off.bitmap, 1 << 20)]
+        for i in range(5):
+            windows = rows[i] >= 16384 and (win_levels >> i) & 1          # a level has windows OR mask orders
+            if windows:
+                assert off.win[i] >= 0 and off.mask_perm[i] == -1
+                spans.append((off.win[i], L.cv_sp_windows_words(rows[i])))
+                assert L.cv_sp_windows_words(rows[i]) >= -(-rows[i] // 256) * (448 + 256 * 14)
+            elif rows[i] >= 16384:
+                assert off.mask_perm[i] >= 0 and off.win[i] == -1
+                spans.append((off.mask_perm[i], 4 * rows[i] * (1 + 7)))      # orders + map rows in processing order
+            else:
+                assert off.mask_perm[i] == -1 and off.win[i] == -1
+        spans.sort()
+        for (a, la), (b, _) in zip(spans[:-1], spans[1:]):
+            assert a % 64 == 0 and a + la <= b                               # aligned, non-overlapping
+        assert spans[-1][0] + spans[-1][1] <= words
+        assert words <= L.cv_sp_scene_plan_words(80000, 5, 4, 16384, win_levels)      # the pre-count sizing covers it
+    assert L.cv_sp_windows_supported(80000) == 1 and L.cv_sp_windows_supported(5_000_000) == 0
     # arena of a two-buffer program: one external, one level-1 buffer of 96 channels
     bufs = (_lib.NetBuf * 2)(_lib.NetBuf(-1, 3, 0), _lib.NetBuf(1, 96, 1))
     assert L.cv_net_arena_bytes(bufs, 2, rows, 5) >= 36822 * 96 * 4
