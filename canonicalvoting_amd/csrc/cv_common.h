@@ -87,7 +87,7 @@ int cv_sp_mask_perms_batch(const CvPermJob* jobs, int n_jobs, void* d_ws, size_t
 
 // ---- neighbour windows of the 3x3x3 kernel maps (sparse_win.hip): one launch for the levels of a scene
 #ifndef CV_WIN_CAP
-#define CV_WIN_CAP 448       // window rows a tile keeps in LDS (see conv_win's LDS budget)
+#define CV_WIN_CAP 512       // window rows a tile keeps in LDS (see conv_win's LDS budget)
 #endif
 struct CvWinJob { const int32_t* nbr; long long n; int32_t* win; };      // nbr[n][27] -> win[cv_sp_windows_words(n)]
 constexpr int CV_MAX_WIN_JOBS = 5;

@@ -45,9 +45,8 @@ namespace {
 
 constexpr int WIN_T = 256;                 // rows per tile
 constexpr int WIN_CAP = CV_WIN_CAP;        // window rows held in LDS (multiple of 64: 8 rows per LDS-DMA instruction x 8 waves)
-constexpr int WIN_LM = 28;                 // 16-bit map entries per row (27 offsets + 1 pad: 56 bytes, 8-byte aligned)
 constexpr unsigned WIN_NONE = 0xFFFFu, WIN_OUT = 0xFFFEu;
-static_assert(WIN_CAP % 64 == 0 && WIN_CAP < 0xFFFE, "window capacity");
+static_assert(WIN_CAP % 128 == 0 && WIN_CAP < 0xFFFE, "window capacity");
 
 // ------------------------------------------------------------------ plan: windows of a 27-offset kernel map
 struct WinJobsDev {
@@ -71,8 +70,8 @@ __global__ __launch_bounds__(256) void build_windows(const WinJobsDev jobs, int 
     const long long ntiles = (n + WIN_T - 1) / WIN_T;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int* __restrict__ wrows = jobs.win[job] + (long long)tile * WIN_CAP;
-    unsigned* __restrict__ lm_out = reinterpret_cast<unsigned*>(jobs.win[job] + ntiles * WIN_CAP) +
-                                    ((long long)tile * WIN_T + t) * (WIN_LM / 2);
+    unsigned short* __restrict__ lm_out = reinterpret_cast<unsigned short*>(jobs.win[job] + ntiles * WIN_CAP) +
+                                          (long long)tile * (27 * WIN_T) + t;            // [tile][27][256]
     unsigned* bits = win_lds;
     unsigned short* wpre = reinterpret_cast<unsigned short*>(win_lds + cap_words);
     const long long row = (long long)tile * WIN_T + t;
@@ -125,9 +124,6 @@ __global__ __launch_bounds__(256) void build_windows(const WinJobsDev jobs, int 
     }
     for (int r = total + t; r < WIN_CAP; r += 256) wrows[r] = -1;
     __syncthreads();
-    unsigned out[WIN_LM / 2];
-#pragma unroll
-    for (int q = 0; q < WIN_LM / 2; ++q) out[q] = 0xFFFFFFFFu;
 #pragma unroll
     for (int j = 0; j < 27; ++j) {
         unsigned v = WIN_NONE;
@@ -136,10 +132,8 @@ __global__ __launch_bounds__(256) void build_windows(const WinJobsDev jobs, int 
             const unsigned rank = (unsigned)wpre[w] + (unsigned)__popc(bits[w] & ((1u << (e[j] & 31)) - 1u));
             v = rank < (unsigned)WIN_CAP ? rank : WIN_OUT;
         }
-        out[j >> 1] = (j & 1) ? ((out[j >> 1] & 0x0000FFFFu) | (v << 16)) : ((out[j >> 1] & 0xFFFF0000u) | v);
+        lm_out[j * WIN_T] = (unsigned short)v;
     }
-#pragma unroll
-    for (int q = 0; q < WIN_LM / 2; ++q) lm_out[q] = out[q];
 }
 
 // ------------------------------------------------------------------ the convolution
@@ -147,21 +141,114 @@ __global__ __launch_bounds__(256) void build_windows(const WinJobsDev jobs, int 
 #define CV_WIN_ABL 0      // timing ablations (wrong results): 1 no window DMA, 2 no MFMA, 4 no weight DMA, 8 no fragment reads
 #endif
 
+// MFMA operand fragments of one unit: per offset g of the unit the lane's row (high piece, low piece), per (g, plane, nb)
+// the weight pieces.  One asm statement reads them all and waits (see hd_read_frags for why it is asm and a plain function).
+template <int NB, int G>
+struct WinFrags {
+    u32x4v a[2 * G];            // [g][h | l]
+    u32x4v b[2 * G * NB];       // [(g * 2 + plane) * NB + nb]
+};
+// request every fragment of a unit (no wait: the MFMAs of the previous unit run while they travel) ...
+__device__ __forceinline__ void win_read_issue(WinFrags<3, 1>& f, const unsigned (&aa)[2], unsigned ab) {
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\t"
+                 "ds_read_b128 %2, %10\n\tds_read_b128 %3, %10 offset:1024\n\tds_read_b128 %4, %10 offset:2048\n\t"
+                 "ds_read_b128 %5, %10 offset:3072\n\tds_read_b128 %6, %10 offset:4096\n\tds_read_b128 %7, %10 offset:5120"
+                 : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.b[0]), "=&v"(f.b[1]), "=&v"(f.b[2]), "=&v"(f.b[3]), "=&v"(f.b[4]), "=&v"(f.b[5])
+                 : "v"(aa[0]), "v"(aa[1]), "v"(ab) : "memory");
+}
+__device__ __forceinline__ void win_read_issue(WinFrags<2, 1>& f, const unsigned (&aa)[2], unsigned ab) {
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\t"
+                 "ds_read_b128 %2, %8\n\tds_read_b128 %3, %8 offset:1024\n\tds_read_b128 %4, %8 offset:2048\n\t"
+                 "ds_read_b128 %5, %8 offset:3072"
+                 : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.b[0]), "=&v"(f.b[1]), "=&v"(f.b[2]), "=&v"(f.b[3])
+                 : "v"(aa[0]), "v"(aa[1]), "v"(ab) : "memory");
+}
+__device__ __forceinline__ void win_read_issue(WinFrags<1, 3>& f, const unsigned (&aa)[6], unsigned ab) {
+    asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %13\n\tds_read_b128 %2, %14\n\tds_read_b128 %3, %15\n\t"
+                 "ds_read_b128 %4, %16\n\tds_read_b128 %5, %17\n\t"
+                 "ds_read_b128 %6, %18\n\tds_read_b128 %7, %18 offset:1024\n\tds_read_b128 %8, %18 offset:2048\n\t"
+                 "ds_read_b128 %9, %18 offset:3072\n\tds_read_b128 %10, %18 offset:4096\n\tds_read_b128 %11, %18 offset:5120"
+                 : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.a[2]), "=&v"(f.a[3]), "=&v"(f.a[4]), "=&v"(f.a[5]),
+                   "=&v"(f.b[0]), "=&v"(f.b[1]), "=&v"(f.b[2]), "=&v"(f.b[3]), "=&v"(f.b[4]), "=&v"(f.b[5])
+                 : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(aa[4]), "v"(aa[5]), "v"(ab) : "memory");
+}
+// ... and the wait that hands them (and the prefetched window slots) over: the operands tie the registers to the wait, nothing
+// that uses them may be scheduled in front of it
+__device__ __forceinline__ void win_read_wait(WinFrags<3, 1>& f, unsigned (&sl)[1]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3]), "+v"(f.b[4]), "+v"(f.b[5]), "+v"(sl[0])
+                 :: "memory");
+}
+__device__ __forceinline__ void win_read_wait(WinFrags<2, 1>& f, unsigned (&sl)[1]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3]), "+v"(sl[0]) :: "memory");
+}
+__device__ __forceinline__ void win_read_wait(WinFrags<1, 3>& f, unsigned (&sl)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.a[4]), "+v"(f.a[5]), "+v"(f.b[0]), "+v"(f.b[1]),
+                   "+v"(f.b[2]), "+v"(f.b[3]), "+v"(f.b[4]), "+v"(f.b[5]), "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2])
+                 :: "memory");
+}
+// window slots of a unit's G offsets (16-bit LDS reads, no wait)
+template <int G>
+__device__ __forceinline__ void win_slots_issue(unsigned (&sl)[G], unsigned addr) {
+    if constexpr (G == 1) {
+        asm volatile("ds_read_u16 %0, %1" : "=&v"(sl[0]) : "v"(addr) : "memory");
+    } else {
+        static_assert(G == 3, "one or three offsets per unit");
+        asm volatile("ds_read_u16 %0, %3\n\tds_read_u16 %1, %3 offset:512\n\tds_read_u16 %2, %3 offset:1024"
+                     : "=&v"(sl[0]), "=&v"(sl[1]), "=&v"(sl[2]) : "v"(addr) : "memory");
+    }
+}
+// the weight pieces of a one-offset unit alone (extra units: the A fragments come from global memory)
 template <int NB>
+__device__ __forceinline__ void win_read_b(u32x4v (&b)[2 * NB], unsigned ab) {
+    if constexpr (NB == 1) {
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(b[0]), "=&v"(b[1]) : "v"(ab) : "memory");
+    } else if constexpr (NB == 2) {
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                     "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(ab) : "memory");
+    } else {
+        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:1024\n\tds_read_b128 %2, %6 offset:2048\n\t"
+                     "ds_read_b128 %3, %6 offset:3072\n\tds_read_b128 %4, %6 offset:4096\n\tds_read_b128 %5, %6 offset:5120\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]) : "v"(ab) : "memory");
+    }
+}
+
+// Units.  A unit = G kernel offsets x one 16-channel k-step x NB column blocks = 3 NB G MFMAs per wave and NB G 2 KB of
+// weights (6 KB for the two shapes the network has: <3, 1> 96 columns, <1, 3> 32 columns).  They run k-step-major: for each
+// HALF chunk h = 2 c + ks (16 channels: 32 B of high and 32 B of low pieces = a 64-byte window row) the 27 / G units of
+// its offsets; the window of half chunk h + 1 lands in the other buffer meanwhile.  Weight tiles travel through a ring of
+// D = 9 stages (27 / G is a multiple of 9: a unit's stage is its index in the half chunk mod 9, a compile-time number in
+// the 9-fold unrolled loop) requested P = 6 units ahead.
+//
+// Software pipeline inside every wave (profiles/r5/win_v1_v2.txt: with "read fragments -> wait -> multiply" behind a per-unit
+// barrier a 32-channel unit took 2100 cycles where its MFMAs need 1152; with the two waves of a SIMD in ping-pong still
+// ~1300 per 16-channel unit, each wave's own chain of LDS round trips being longer than its MFMAs): step s requests the
+// fragments of unit s + 1 into the second register set (and the window slots of unit s + 2), multiplies unit s out of the
+// first, then waits.  Barrier s therefore guarantees the weight tile of unit s + 1 (and the window it needs).
+template <int NB, int G>
 __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
-    constexpr int NW = 8, NSTG = 3;
-    constexpr int WBUF = (WIN_CAP + 1) * 128;                       // one window buffer: WIN_CAP rows + the row of zeros
-    constexpr int B_BYTES = 2 * NB * 32 * 64;                       // weight tile of a unit: [plane][col][64 B]
-    constexpr int B_INSTR = B_BYTES / 1024, B_PER_WAVE = (B_INSTR + NW - 1) / NW;
-    constexpr int WIN_INSTR = WIN_CAP / 8, WIN_PER_WAVE = WIN_INSTR / NW;          // LDS-DMA instructions of one window chunk
-    constexpr int OFF_B = 2 * WBUF, OFF_ROWS = OFF_B + NSTG * B_BYTES, OFF_OM = OFF_ROWS + WIN_T * 4, LDS_TOTAL = OFF_OM + NW * 4;
+    static_assert((NB == 3 && G == 1) || (NB == 2 && G == 1) || (NB == 1 && G == 3), "unit shapes");
+    constexpr int NW = 8, D = 9, P = 6;
+    constexpr int UPH = 27 / G;                                     // units per half chunk
+    constexpr int WBUF = (WIN_CAP + 1) * 64;                        // one window buffer: WIN_CAP rows of 64 B + the row of zeros
+    constexpr int B_UNIT = NB * G * 2048;                           // weight tile of a unit: [g][plane][col][32 B]
+    constexpr int B_INSTR = B_UNIT / 1024;                          // <= 6: wave t requests KB t of the tile
+    constexpr int WIN_PER_WAVE = WIN_CAP / 16 / NW;                 // LDS-DMA instructions (16 rows each) per wave and half chunk
+    constexpr int OFF_B = 2 * WBUF, OFF_LM = OFF_B + D * B_UNIT, OFF_ROWS = OFF_LM + 27 * WIN_T * 2,
+                  OFF_OM = OFF_ROWS + WIN_T * 4, LDS_TOTAL = OFF_OM + NW * 4;
     constexpr int EP_BYTES = NW * 32 * EP_LD * 4;
-    static_assert(EP_BYTES <= WBUF, "the epilogue tile aliases the first window buffer");
-    static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
-    static_assert(WIN_PER_WAVE * NW * 8 == WIN_CAP, "window instructions are dealt evenly to the waves");
+    static_assert(EP_BYTES <= 2 * WBUF, "the epilogue tile aliases the window buffers");
+    static_assert(LDS_TOTAL <= 160 * 1024 && B_INSTR <= NW && UPH % D == 0 && D >= P + 1, "LDS budget / ring");
+    static_assert(WIN_PER_WAVE * NW * 16 == WIN_CAP && WIN_PER_WAVE <= P - 2, "window instructions are dealt evenly to the waves");
     // ONE __shared__ object (a second one makes hipcc drain vmcnt in front of the LDS reads of an LDS-DMA pipeline)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_TOTAL];
     int* const rows_s = reinterpret_cast<int*>(lds + OFF_ROWS);
+    const unsigned short* const lm_s = reinterpret_cast<const unsigned short*>(lds + OFF_LM);      // [27][256] window slots
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const long long ntiles = (a.n_out + WIN_T - 1) / WIN_T;
@@ -171,48 +258,53 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
     if (tile >= ntiles) return;
     const long long row0 = tile * WIN_T;
     const int nch = a.cin / KC, nch2 = a.in2 ? a.cin2 / KC : 0;
-    const int U = 27 * nch;
+    const int NH = 2 * nch, U = NH * UPH;                           // half chunks, main units
 
-    // ---- tile set-up: the lane's 27 window slots, this wave's share of the window rows
-    unsigned lm[WIN_LM / 2];
-    const unsigned short* const lm16 = reinterpret_cast<const unsigned short*>(a.win + ntiles * WIN_CAP) +
-                                       (row0 + wave * 32 + l31) * WIN_LM;        // the same 27 slots in memory (extra units)
+    // ---- tile set-up: the tile's window slots -> LDS, this wave's share of the window rows
     {
-        const uint2* p = reinterpret_cast<const uint2*>(lm16);
-#pragma unroll
-        for (int q = 0; q < WIN_LM / 4; ++q) { const uint2 v = p[q]; lm[2 * q] = v.x; lm[2 * q + 1] = v.y; }
+        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(a.win + ntiles * WIN_CAP) +
+                                                          tile * (27 * WIN_T));
+        for (int f = tid; f < 27 * WIN_T * 2 / 16; f += NW * 64) reinterpret_cast<uint4*>(lds + OFF_LM)[f] = src[f];
     }
     const unsigned in_row_bytes = (unsigned)a.in_ld * 4u, in2_row_bytes = (unsigned)a.in2_ld * 4u;
     const unsigned char* const in_b = reinterpret_cast<const unsigned char*>(a.in);
     const unsigned char* const in2_b = reinterpret_cast<const unsigned char*>(a.in2);
-    // window instruction q = wave + 8 i covers window rows 8 q + (lane >> 3); LDS slot lane & 7 of row w receives the
-    // row's piece (lane & 7) ^ ((w >> 1) & 7) - and (w >> 1) & 7 = (4 q + (lane >> 4)) & 7 = (4 (wave & 1) + (lane >> 4)) & 7
-    const int a_row = lane >> 3;
-    const unsigned w_piece = (unsigned)(((lane & 7) ^ ((4 * (wave & 1) + (a_row >> 1)) & 7)) << 4);
+    // window instruction q = wave + 8 i covers window rows 16 q + (lane >> 2); LDS slot lane & 3 of row w receives the row's
+    // piece (lane & 3) ^ ((w >> 2) & 3) of the half chunk's four [h lo-half, h hi-half, l lo-half, l hi-half] - and
+    // (w >> 2) & 3 = (4 q + (lane >> 4)) & 3 = (lane >> 4) & 3
+    const unsigned w_sp = (unsigned)((lane & 3) ^ ((lane >> 4) & 3));
+    const unsigned w_piece = (w_sp >> 1) * 64u + (w_sp & 1u) * 16u;            // byte offset inside the 128-byte chunk, k-step 0
     unsigned woff[WIN_PER_WAVE];
     {
         const int* wr = a.win + tile * WIN_CAP;
 #pragma unroll
         for (int i = 0; i < WIN_PER_WAVE; ++i) {
-            const int r = wr[8 * (wave + NW * i) + a_row];
+            const int r = wr[16 * (wave + NW * i) + (lane >> 2)];
             woff[i] = r >= 0 ? (unsigned)r * in_row_bytes : 0xFFFFFFFFu;
         }
     }
     if (tid < WIN_T) rows_s[tid] = row0 + tid < a.n_out ? (int)(row0 + tid) : -1;
-    if (tid < 16) *reinterpret_cast<uint4*>(lds + (tid >> 3) * WBUF + WIN_CAP * 128 + (tid & 7) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 8) *reinterpret_cast<uint4*>(lds + (tid >> 2) * WBUF + WIN_CAP * 64 + (tid & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    const int my_t = wave * 32 + l31;
     unsigned jmask = 0u, omask = 0u;                                // offsets this wave has a neighbour at / an outside-window pair at
-    static_for<27>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        const unsigned v = (lm[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+#pragma unroll
+    for (int j = 0; j < 27; ++j) {
+        const unsigned v = lm_s[j * WIN_T + my_t];
         if (__any(v != WIN_NONE)) jmask |= 1u << j;
         if (__any(v == WIN_OUT)) omask |= 1u << j;
-    });
+    }
     if (lane == 0) reinterpret_cast<unsigned*>(lds + OFF_OM)[wave] = omask;
     __syncthreads();
     unsigned omask_wg = 0u;                                         // offsets with an outside-window pair in ANY wave of the tile
 #pragma unroll
     for (int w = 0; w < NW; ++w) omask_wg |= reinterpret_cast<const unsigned*>(lds + OFF_OM)[w];
     omask_wg = __builtin_amdgcn_readfirstlane(omask_wg);
+    jmask = __builtin_amdgcn_readfirstlane(jmask);
+    unsigned umask = 0u;                                            // units with a live offset
+#pragma unroll
+    for (int u = 0; u < UPH; ++u)
+        if ((jmask >> (u * G)) & ((1u << G) - 1u)) umask |= 1u << u;
 
     f32x16 acc[NB];
 #pragma unroll
@@ -220,60 +312,65 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
-    // ---- per-thread invariants of the weight tile requests (conv_hd's layout: slot s of column col holds the slab's
-    // 16-byte piece s ^ ((col >> 2) & 3))
-    int b_src[B_PER_WAVE];
-#pragma unroll
-    for (int i = 0; i < B_PER_WAVE; ++i) {
-        const int f = (wave + i * NW) * 64 + lane;
-        const int pl = f / (NB * 32 * 4), rem = f - pl * (NB * 32 * 4);
-        const int col = rem >> 2, slot = rem & 3;
-        b_src[i] = (pl * a.cout + min(col, a.cout - 1)) * 32 + ((slot ^ ((col >> 2) & 3)) << 3);
-    }
+    // ---- weight tile requests: wave t < B_INSTR requests KB t = (g, plane, nb) of every unit's tile: lane f -> column f >> 1,
+    // LDS slot f & 1 of the column's 32 bytes, which receives the 16-byte piece (f & 1) ^ ((col >> 4) & 1) (conflict-free reads)
+    const int bt_g = wave / (2 * NB), bt_pl = (wave / NB) & 1, bt_nb = wave % NB;
+    const unsigned b_src = (unsigned)((bt_pl * a.cout + bt_nb * 32 + (lane >> 1)) * 32 + (((lane & 1) ^ ((lane >> 5) & 1)) << 3));
     const unsigned slab_words = 2u * (unsigned)a.cout * 32u;
-    // weight tile of a unit -> ring stage: main unit (offset j, chunk c) has stage j % 3 (27 % 3 == 0), second-source unit k
-    // stage k % 3 (the main units are a multiple of three)
-    auto issue_slab = [&](const unsigned short* slab, int stage) {
-        unsigned char* dst = lds + OFF_B + stage * B_BYTES;
-#pragma unroll
-        for (int i = 0; i < B_PER_WAVE; ++i) {
-            const int t = wave + i * NW;
-            if (t < B_INSTR && !(CV_WIN_ABL & 4)) lds_dma16(slab + b_src[i], dst + t * 1024);
-        }
+    const bool has_w = wave < B_INSTR;
+    auto issue_slab = [&](const unsigned short* slab, int ks, int stage) {
+        if (has_w && !(CV_WIN_ABL & 4)) lds_dma16(slab + b_src + ks * 16, lds + OFF_B + stage * B_UNIT + wave * 1024);
     };
-    auto issue_w = [&](int j, int c) {                              // unit (j, c); c == nch: second-source unit j
+    auto issue_main = [&](int h, int u, int stage) {                // unit u of half chunk h
         int nch_l = nch;
-        asm volatile("" : "+s"(nch_l));                             // (keeps 27 hoisted slab offsets out of the scalar registers)
-        if (c < nch_l) issue_slab(a.wp6 + (size_t)(unsigned)(j * nch_l + c) * slab_words, j % NSTG);
-        else issue_slab(a.wp6_2 + (size_t)(unsigned)j * slab_words, j % NSTG);
+        asm volatile("" : "+s"(nch_l));                             // (keeps hoisted slab offsets out of the scalar registers)
+        issue_slab(a.wp6 + (size_t)(unsigned)((u * G + bt_g) * nch_l + (h >> 1)) * slab_words, h & 1, stage);
     };
-    // instruction i of this wave's share of window chunk c.  ALWAYS one instruction (rows beyond the window - and a whole
-    // chunk beyond the last, `dummy` - fetch the line of zeros): the counted waits below then know the queue at compile time
-    auto issue_win = [&](int c, int i, bool dummy) {
+    // instruction i of this wave's share of the window of half chunk h.  ALWAYS one instruction (rows beyond the window - and a
+    // whole half chunk beyond the last, `dummy` - fetch the line of zeros): the counted waits know the queue at compile time
+    auto issue_win = [&](int h, int i, bool dummy) {
         if (CV_WIN_ABL & 1) dummy = true;
-        const unsigned char* g = (!dummy && woff[i] != 0xFFFFFFFFu) ? in_b + ((size_t)woff[i] + (size_t)(c * 128) + w_piece)
-                                                                    : g_zero_chunk + w_piece;
-        lds_dma16(g, lds + (c & 1) * WBUF + (wave + NW * i) * 1024);
+        const unsigned char* g = (!dummy && woff[i] != 0xFFFFFFFFu)
+                                     ? in_b + ((size_t)woff[i] + (size_t)((h >> 1) * 128 + (h & 1) * 32) + w_piece)
+                                     : g_zero_chunk + w_piece;
+        lds_dma16(g, lds + (h & 1) * WBUF + (wave + NW * i) * 1024);
     };
-    // vmcnt wait that leaves `base` + this wave's weight instructions of one unit in flight (nWw is 1 or 2 / 0 or 1 by wave half)
-    auto wait_keep = [&](auto BASE, bool plus_w) {
+    // vmcnt wait that leaves BASE instructions + this wave's weight requests of P - 2 units in flight
+    auto wait_keep = [&](auto BASE) {
         constexpr int base = decltype(BASE)::value;
-        if (!plus_w) wait_vmcnt_le<base>();
-        else if (B_INSTR % NW == 0 || wave < B_INSTR % NW) wait_vmcnt_le<base + B_PER_WAVE>();
-        else wait_vmcnt_le<base + B_PER_WAVE - 1>();
+        if (has_w) wait_vmcnt_le<base + (P - 2)>();
+        else wait_vmcnt_le<base>();
     };
 
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)lds;
-    const unsigned bswz = (unsigned)((l31 >> 2) & 3);
-    const unsigned b_rd[2] = {lds0 + (unsigned)(OFF_B + l31 * 64) + (((0u + half) ^ bswz) << 4),
-                              lds0 + (unsigned)(OFF_B + l31 * 64) + (((2u + half) ^ bswz) << 4)};
-    const long long my_row = row0 + wave * 32 + l31;
+    const unsigned b_rd = lds0 + (unsigned)(OFF_B + l31 * 32) + (unsigned)((half ^ ((l31 >> 4) & 1)) << 4);
+    const long long my_row = row0 + my_t;
 
-    auto mfma_step = [&](const u32x4v& A0, const u32x4v& A1, const u32x4v (&B0)[NB], const u32x4v (&B1)[NB]) {
-        const f16x8 a0 = __builtin_bit_cast(f16x8, A0), a1 = __builtin_bit_cast(f16x8, A1);
+    constexpr int UPC = 2 * UPH;                                     // units per 32-channel chunk: k-step 0, then k-step 1
+    static_assert(UPC % 18 == 0, "the unit loop is unrolled 18-fold: ring stage and register set are compile-time numbers");
+    WinFrags<NB, G> F[2];                                           // fragments of the unit that multiplies / of the next one
+    unsigned SL[G];                                                 // window slots of the lane's row for the next unit's offsets
+    const unsigned lm_rd = lds0 + (unsigned)(OFF_LM + my_t * 2);
+    // unit w of chunk c = unit u of half chunk h
+    auto slots_issue = [&](int u) { win_slots_issue<G>(SL, lm_rd + (unsigned)(u * G * WIN_T * 2)); };
+    auto read_issue = [&](auto PAR, int h, int stage) {             // fragments of the unit whose slots are in SL -> F[PAR]
+        constexpr int par = decltype(PAR)::value;
+        unsigned aa[2 * G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const unsigned v = SL[g];
+            const unsigned li = v >= WIN_OUT ? (unsigned)WIN_CAP : v;     // no neighbour / outside the window: the row of zeros
+            const unsigned base = lds0 + (unsigned)((h & 1) * WBUF) + li * 64u, sw = (li >> 2) & 3u;
+            aa[2 * g] = base + (((unsigned)half ^ sw) << 4);
+            aa[2 * g + 1] = base + (((2u + (unsigned)half) ^ sw) << 4);
+        }
+        if (!(CV_WIN_ABL & 8)) win_read_issue(F[par], aa, b_rd + (unsigned)(stage * B_UNIT));
+    };
+    auto mfma_frags = [&](const u32x4v& Ah, const u32x4v& Al, const u32x4v* Bh, const u32x4v* Bl) {
+        const f16x8 a0 = __builtin_bit_cast(f16x8, Ah), a1 = __builtin_bit_cast(f16x8, Al);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const f16x8 b0 = __builtin_bit_cast(f16x8, B0[nb]), b1 = __builtin_bit_cast(f16x8, B1[nb]);
+            const f16x8 b0 = __builtin_bit_cast(f16x8, Bh[nb]), b1 = __builtin_bit_cast(f16x8, Bl[nb]);
             if (!(CV_WIN_ABL & 2)) {
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[nb], 0, 0, 0);
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[nb], 0, 0, 0);
@@ -281,108 +378,127 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
             }
         }
     };
-    // main units: window slot -> fragment addresses -> asm fragment reads -> MFMAs.  A lane without a neighbour - or whose
-    // neighbour is outside the window (those pairs are added by the extra units below) - reads the row of zeros.
-    auto compute_fast = [&](unsigned v, int c, int stage) {
-        const unsigned li = v >= WIN_OUT ? (unsigned)WIN_CAP : v;
-        const unsigned base = lds0 + (unsigned)((c & 1) * WBUF) + li * 128u, sw = (li >> 1) & 7u;
-        unsigned aa[4];
+    auto mfma_unit = [&](auto PAR) {
+        constexpr int par = decltype(PAR)::value;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) aa[k] = base + (((unsigned)(2 * k + half) ^ sw) << 4);
-        if (CV_WIN_ABL & 8) return;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4v A0, A1, B0[NB], B1[NB];
-            hd_read_frags<NB>(aa[ks], aa[2 + ks], b_rd[ks] + (unsigned)(stage * B_BYTES), A0, A1, B0, B1);
-            mfma_step(A0, A1, B0, B1);
-        }
+        for (int g = 0; g < G; ++g)
+            mfma_frags(F[par].a[2 * g], F[par].a[2 * g + 1], &F[par].b[(2 * g) * NB], &F[par].b[(2 * g + 1) * NB]);
     };
-    // Extra units, behind the main ones (ONE code instance, a run-time loop - a second path inside the unrolled steps made
-    // hipcc shuttle the accumulators between two register sets): e < nch2: chunk e of the second source (A = the output row
-    // itself); then, for every offset at which ANY wave of the tile has a pair outside its window, the offset's nch chunks
-    // with A = the outside neighbours only.  Their A fragments come straight from global memory, the weight tiles through
-    // the ring like every unit's.
+
+    // Extra units behind the main ones (ONE code instance, a run-time loop): one offset x one k-step each.  e < 2 nch2: the
+    // second source (A = the output row itself, chunk e / 2); then, for every offset at which ANY wave of the tile has a
+    // pair outside its window, the offset's 2 nch half chunks with A = the outside neighbours only.  Their A fragments
+    // come straight from global memory, the weight tiles (KB (plane, nb) of a G = 1 tile) through the ring.
     const int n_fix = __popc(omask_wg);
-    const int E = nch2 + n_fix * nch, S = U + E;
-    auto extra_decode = [&](int e, int& j, int& c) -> bool {         // true: second-source unit
-        if (e < nch2) { j = 0; c = e; return true; }
-        const int f = e - nch2, idx = f / nch;
-        c = f - idx * nch;
+    const int E = 2 * nch2 + n_fix * NH;
+    const bool has_we = wave < 2 * NB;
+    const unsigned be_src = (unsigned)(((wave / NB) * a.cout + (wave % NB) * 32 + (lane >> 1)) * 32 + (((lane & 1) ^ ((lane >> 5) & 1)) << 3));
+    auto extra_decode = [&](int e, int& j, int& h) -> bool {        // true: second-source unit
+        if (e < 2 * nch2) { j = 0; h = e; return true; }
+        const int f = e - 2 * nch2, idx = f / NH;
+        h = f - idx * NH;
         unsigned m = omask_wg;
         for (int q = 0; q < idx; ++q) m &= m - 1u;
         j = __ffs(m) - 1;
         return false;
     };
     auto issue_extra = [&](int e) {
-        int j, c;
-        if (extra_decode(e, j, c)) issue_slab(a.wp6_2 + (size_t)(unsigned)c * slab_words, e % NSTG);
-        else issue_slab(a.wp6 + (size_t)(unsigned)(j * nch + c) * slab_words, e % NSTG);
+        int j, h;
+        const bool second = extra_decode(e, j, h);
+        const unsigned short* slab = second ? a.wp6_2 + (size_t)(unsigned)(h >> 1) * slab_words
+                                            : a.wp6 + (size_t)(unsigned)(j * nch + (h >> 1)) * slab_words;
+        if (has_we && !(CV_WIN_ABL & 4)) lds_dma16(slab + be_src + (h & 1) * 16, lds + OFF_B + (e % D) * B_UNIT + wave * 1024);
     };
+    // (a wave that requests main tiles but no extra tiles - G = 3 - or the reverse would break the counted waits: the extra
+    // loop below drains the queue instead of counting)
 
-    // ---- prologue: window chunk 0, weight tiles of units 0 and 1
+    // ---- prologue: the window of half chunk 0, the weight tiles of units 0 ... P - 1
 #pragma unroll
     for (int i = 0; i < WIN_PER_WAVE; ++i) issue_win(0, i, false);
-    issue_w(0, 0);
-    issue_w(1, 0);
-    // Step s: this wave's requests up to the weight tile of unit s have landed (behind it in the queue, allowed to stay in
-    // flight: the window instruction issued at step s - 1 and the weight tile of unit s + 1); barrier = everybody's have, and
-    // everybody is past the MFMAs of unit s - 1, whose ring stage takes unit s + 2.  The window of chunk c + 1 is requested
-    // one instruction per step behind the barriers of chunk c's first steps (its buffer was last read by chunk c - 1).
+#pragma unroll
+    for (int u = 0; u < P; ++u) issue_main(0, u, u);                // (U >= 18 > P)
+    if (has_w) wait_vmcnt_le<P - 1>(); else wait_vmcnt_le<0>();
+    __builtin_amdgcn_s_barrier();                                   // unit 0's tile and window are there
+    typedef std::integral_constant<int, 0> P0;
+    typedef std::integral_constant<int, 1> P1;
+    slots_issue(0);
+    win_read_wait(F[1], SL);                                        // (the register set is a dummy here: only the slots travel)
+    read_issue(P0{}, 0, 0);
+    slots_issue(1);
+    win_read_wait(F[0], SL);                                        // fragments of unit 0 in F[0], slots of unit 1 in SL
+    // Step s = unit w of chunk c = unit u of half chunk h:
+    // [wait: this wave's requests up to the weight tile of unit s + 1 have landed; behind it in the queue, allowed to stay in
+    //  flight: the tiles of units s + 2 ... s + P - 1 and the window instructions issued at steps s + 2 - P ... s - 1]
+    // -> barrier (everybody's have; everybody is past unit s - 1) -> this step's requests: one window instruction of half
+    // chunk h + 1 at u < WIN_PER_WAVE (its buffer was last read at the end of half chunk h - 1), the tile of unit s + P
+    // -> request the fragments of unit s + 1 and the slots of unit s + 2 -> multiply unit s -> wait for the requests.
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
-        static_for<27>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            constexpr int stage = j % NSTG, j2 = (j + 2) % 27;
-            // in flight behind the weight tile of this unit: the window instruction of step j - 1 (steps 0 ... WIN_PER_WAVE - 1
-            // issue one each) and the weight tile of the next unit (none behind the very last unit)
-            wait_keep(std::integral_constant<int, (j >= 1 && j - 1 < WIN_PER_WAVE) ? 1 : 0>{}, j < 26 || c * 27 + j + 1 < S);
-            __builtin_amdgcn_s_barrier();
-            if constexpr (j < WIN_PER_WAVE) issue_win(c + 1, j, c + 1 >= nch);
-            if constexpr (j + 2 < 27) {
-                issue_w(j2, c);
-            } else {
-                if (c + 1 < nch) issue_w(j2, c + 1);
-                else if (j2 < E) issue_extra(j2);
-            }
-            if ((jmask >> j) & 1u) {
-                unsigned v = (lm[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-                asm volatile("" : "+v"(v));                         // (the slot's LDS addresses are formed here, not hoisted for all 27 offsets)
-                compute_fast(v, c, stage);
-            }
-        });
+#pragma unroll 1
+        for (int jj = 0; jj < UPC / 18; ++jj) {
+            static_for<18>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                constexpr int kd = k % D;                           // ring stage of this unit
+                typedef std::integral_constant<int, k & 1> PAR;
+                typedef std::integral_constant<int, (k + 1) & 1> PARN;
+                const int w = jj * 18 + k, ks = w >= UPH ? 1 : 0, u = w - ks * UPH, h = 2 * c + ks, s = c * UPC + w;
+                // window instructions among the P - 2 steps in front of this one (steps 0 ... WIN_PER_WAVE - 1 of a half chunk);
+                // u < D means u == kd (the half chunk and the unroll are multiples of the ring)
+                constexpr int lo = kd - (P - 2) > 0 ? kd - (P - 2) : 0, hi = kd - 1 < WIN_PER_WAVE - 1 ? kd - 1 : WIN_PER_WAVE - 1;
+                constexpr int nwin = hi >= lo ? hi - lo + 1 : 0;
+                if (s + P - 1 < U) {
+                    if (u < D) wait_keep(std::integral_constant<int, nwin>{});
+                    else wait_keep(std::integral_constant<int, 0>{});
+                } else {
+                    wait_vmcnt_le<0>();                             // the last main units: fewer (or other waves') requests behind them
+                }
+                __builtin_amdgcn_s_barrier();
+                if constexpr (kd < WIN_PER_WAVE) {
+                    if (u < D) issue_win(h + 1, kd, h + 1 >= NH);
+                }
+                {
+                    const int up = u + P;                           // unit s + P: in this half chunk, the next one, or an extra unit
+                    if (up < UPH) issue_main(h, up, (kd + P) % D);
+                    else if (h + 1 < NH) issue_main(h + 1, up - UPH, (kd + P) % D);
+                    else if (up - UPH < E) issue_extra(up - UPH);
+                }
+                const int un = u + 1 < UPH ? u + 1 : 0, hn = u + 1 < UPH ? h : h + 1;        // unit s + 1
+                const int un2 = un + 1 < UPH ? un + 1 : 0;                                    // unit s + 2 (its slots only)
+                if (hn < NH && ((umask >> un) & 1u)) read_issue(PARN{}, hn, (kd + 1) % D);
+                slots_issue(un2);
+                if ((umask >> u) & 1u) mfma_unit(PAR{});
+                win_read_wait(F[(k + 1) & 1], SL);
+            });
+        }
     }
 #pragma unroll 1
     for (int e = 0; e < E; ++e) {
-        wait_keep(std::integral_constant<int, 0>{}, e + 1 < E);
+        wait_vmcnt_le<0>();
         __builtin_amdgcn_s_barrier();
-        if (e + 2 < E) issue_extra(e + 2);
-        int j, c;
-        const bool second = extra_decode(e, j, c);
+        if (e + P < E) issue_extra(e + P);
+        int j, h;
+        const bool second = extra_decode(e, j, h);
         long long src = -1;
         if (my_row < a.n_out) {
             if (second) src = my_row;
-            else if (lm16[j] == WIN_OUT) src = a.nbr[my_row * 27 + j];
+            else if (lm_s[j * WIN_T + my_t] == WIN_OUT) src = a.nbr[my_row * 27 + j];
         }
         if (!__any(src >= 0)) continue;
-        uint4 fa[4];
+        uint4 fa[2];
         if (src >= 0) {
             const unsigned char* p = (second ? in2_b + (size_t)src * in2_row_bytes : in_b + (size_t)src * in_row_bytes) +
-                                     (size_t)(c * 128 + half * 16);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) fa[k] = *reinterpret_cast<const uint4*>(p + 32 * k);
+                                     (size_t)((h >> 1) * 128 + (h & 1) * 32 + half * 16);
+            fa[0] = *reinterpret_cast<const uint4*>(p);
+            fa[1] = *reinterpret_cast<const uint4*>(p + 64);
         } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) fa[k] = make_uint4(0u, 0u, 0u, 0u);
+            fa[0] = fa[1] = make_uint4(0u, 0u, 0u, 0u);
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4v B0[NB], B1[NB];
-            hd_read_b<NB>(b_rd[ks] + (unsigned)((e % NSTG) * B_BYTES), B0, B1);
-            mfma_step(__builtin_bit_cast(u32x4v, fa[ks]), __builtin_bit_cast(u32x4v, fa[2 + ks]), B0, B1);
-        }
+        u32x4v B[2 * NB];
+        win_read_b<NB>(B, b_rd + (unsigned)((e % D) * B_UNIT));
+        mfma_frags(__builtin_bit_cast(u32x4v, fa[0]), __builtin_bit_cast(u32x4v, fa[1]), &B[0], &B[NB]);
     }
     wait_vmcnt_le<0>();
-    __syncthreads();                                                // the window buffers are dead: the epilogue tile reuses the first
+    __syncthreads();                                                // the window buffers are dead: the epilogue tile reuses them
     {
         const float sc = a.acc_scale;
 #pragma unroll
@@ -430,9 +546,9 @@ int launch_win(const ConvArgs& a, hipStream_t st) {
         per = (int)((ntiles + 7) / 8);
         grid = (unsigned)per * 8u;
     }
-    if (a.cout == 32) conv_win<1><<<grid, 512, 0, st>>>(a, per);
-    else if (a.cout == 64) conv_win<2><<<grid, 512, 0, st>>>(a, per);
-    else conv_win<3><<<grid, 512, 0, st>>>(a, per);
+    if (a.cout == 32) conv_win<1, 3><<<grid, 512, 0, st>>>(a, per);
+    else if (a.cout == 64) conv_win<2, 1><<<grid, 512, 0, st>>>(a, per);
+    else conv_win<3, 1><<<grid, 512, 0, st>>>(a, per);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }
@@ -471,7 +587,7 @@ int cv_sp_windows_supported(long long n) { return n > 0 && win_lds_bytes(n) <= (
 size_t cv_sp_windows_words(long long n) {
     if (n <= 0) return 0;
     const size_t ntiles = (size_t)((n + WIN_T - 1) / WIN_T);
-    return cv_align_up(ntiles * (size_t)(WIN_CAP + WIN_T * WIN_LM / 2), 64);
+    return cv_align_up(ntiles * (size_t)(WIN_CAP + 27 * WIN_T / 2), 64);
 }
 
 int cv_sp_build_windows(const int32_t* d_nbr, long long n, int32_t* d_win, void* stream) {

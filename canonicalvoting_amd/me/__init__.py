@@ -40,7 +40,7 @@ def _stream(dev):
 
 class _FusedPlan:
     """what CoordinateManager.fused_fast() returns"""
-    __slots__ = ("keep", "counts", "cap", "stem_k", "groups", "off", "layout", "map_ptrs", "perm_ptrs", "views")
+    __slots__ = ("keep", "counts", "cap", "stem_k", "groups", "off", "layout", "map_ptrs", "perm_ptrs", "win_ptrs", "views")
 
 
 class CoordinateManager:

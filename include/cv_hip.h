@@ -284,7 +284,7 @@ size_t cv_sp_conv_workspace_bytes(long long n_out, int cout, int K);
 int cv_sp_conv_f32(const cv_conv_desc* desc, void* stream);
 
 /* Neighbour windows of a 3x3x3 kernel map d_nbr[n][27] whose rows are in spatial order (cv_sp_sort_rows): for every tile of
- * 256 consecutive rows the ascending list of distinct input rows it touches (the first 448 of them: the window) and the
+ * 256 consecutive rows the ascending list of distinct input rows it touches (the first 512 of them: the window) and the
  * map rewritten to 16-bit window slots.  d_win: cv_sp_windows_words(n) int32 words, 256-byte aligned.  Built once per
  * coordinate level, shared by every convolution on that map (cv_conv_desc.win).  cv_sp_windows_supported: the plan kernel
  * ranks a tile's rows with a bitmap over the level's rows in LDS - levels beyond ~800k rows keep the mask-sorted path.

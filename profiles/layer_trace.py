@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: re.sub(r"\(anonymous namespace\)::|cvsc::|void ", "", r["Kernel_Name"]).split("(")[0]
 starts = [i for i, r in enumerate(rows) if "sort_minmax" in r["Kernel_Name"]]        # first launch of a scene's coordinate plan
-assert len(starts) >= 3, "expected several scenes in the trace"
+assert len(starts) >= 3, "expected several scenes in the trace (found %d sort_minmax launches)" % len(starts)
 a, b = starts[-2], starts[-1]
 scene = rows[a:b]
 t0 = int(scene[0]["Start_Timestamp"])

@@ -123,7 +123,7 @@ def test_host_side_layout_functions(built_lib):
             if windows:
                 assert off.win[i] >= 0 and off.mask_perm[i] == -1
                 spans.append((off.win[i], L.cv_sp_windows_words(rows[i])))
-                assert L.cv_sp_windows_words(rows[i]) >= -(-rows[i] // 256) * (448 + 256 * 14)
+                assert L.cv_sp_windows_words(rows[i]) >= -(-rows[i] // 256) * (512 + 27 * 128)
             elif rows[i] >= 16384:
                 assert off.mask_perm[i] >= 0 and off.win[i] == -1
                 spans.append((off.mask_perm[i], 4 * rows[i] * (1 + 7)))      # orders + map rows in processing order

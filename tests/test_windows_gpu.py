@@ -13,7 +13,7 @@ from canonicalvoting_amd.synth import make_scene
 
 pytestmark = pytest.mark.gpu
 
-WIN_T, WIN_CAP, WIN_LM = 256, 448, 28
+WIN_T, WIN_CAP = 256, 512
 
 
 def sorted_manager(cuda, coords4):
@@ -37,8 +37,8 @@ def split_windows(win, n):
     ntiles = (n + WIN_T - 1) // WIN_T
     w = win.cpu().numpy()
     rows = w[:ntiles * WIN_CAP].reshape(ntiles, WIN_CAP)
-    lm = w[ntiles * WIN_CAP:ntiles * (WIN_CAP + WIN_T * WIN_LM // 2)].view(np.uint16).reshape(ntiles, WIN_T, WIN_LM)
-    return rows, lm
+    lm = w[ntiles * WIN_CAP:ntiles * (WIN_CAP + 27 * WIN_T // 2)].view(np.uint16).reshape(ntiles, 27, WIN_T)
+    return rows, lm.transpose(0, 2, 1)                                   # [tile][row][offset]
 
 
 @pytest.mark.parametrize("seed,n,ts,dense", [(0, 700, 1, False), (1, 40000, 1, False), (2, 40000, 2, False),
@@ -56,8 +56,8 @@ def test_window_plan_resolves_every_map_entry(cuda, built_lib, seed, n, ts, dens
         w = rows[t]
         k = min(len(want), WIN_CAP)
         assert np.array_equal(w[:k], want[:k]) and (w[k:] == -1).all()
-        e = lm[t, :len(m), :27].astype(np.int64)
-        assert (lm[t, len(m):, :27] == 0xFFFF).all()                    # rows beyond the level in the last tile
+        e = lm[t, :len(m)].astype(np.int64)
+        assert (lm[t, len(m):] == 0xFFFF).all()                    # rows beyond the level in the last tile
         assert np.array_equal(e == 0xFFFF, m < 0)
         inside = (m >= 0) & (e < 0xFFFE)
         assert np.array_equal(w[e[inside]], m[inside])                  # the slot holds exactly the neighbour's row
