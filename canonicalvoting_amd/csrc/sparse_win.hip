@@ -221,30 +221,33 @@ __device__ __forceinline__ void win_read_b(u32x4v (&b)[2 * NB], unsigned ab) {
 // Units.  A unit = G kernel offsets x one 16-channel k-step x NB column blocks = 3 NB G MFMAs per wave and NB G 2 KB of
 // weights (6 KB for the two shapes the network has: <3, 1> 96 columns, <1, 3> 32 columns).  They run k-step-major: for each
 // HALF chunk h = 2 c + ks (16 channels: 32 B of high and 32 B of low pieces = a 64-byte window row) the 27 / G units of
-// its offsets; the window of half chunk h + 1 lands in the other buffer meanwhile.  Weight tiles travel through a ring of
-// D = 9 stages (27 / G is a multiple of 9: a unit's stage is its index in the half chunk mod 9, a compile-time number in
-// the 9-fold unrolled loop) requested P = 6 units ahead.
+// its offsets; the window of half chunk h + 1 lands in the other buffer meanwhile.
 //
-// Software pipeline inside every wave (profiles/r5/win_v1_v2.txt: with "read fragments -> wait -> multiply" behind a per-unit
-// barrier a 32-channel unit took 2100 cycles where its MFMAs need 1152; with the two waves of a SIMD in ping-pong still
-// ~1300 per 16-channel unit, each wave's own chain of LDS round trips being longer than its MFMAs): step s requests the
-// fragments of unit s + 1 into the second register set (and the window slots of unit s + 2), multiplies unit s out of the
-// first, then waits.  Barrier s therefore guarantees the weight tile of unit s + 1 (and the window it needs).
+// What the first three versions measured (profiles/r5/win_v*_*.txt): a barrier per unit with "read fragments -> wait ->
+// multiply" 2100 cycles per 32-channel unit where the MFMAs need 1152; ping-pong between the two waves of a SIMD, then a
+// software pipeline inside every wave: ~1300 cycles per 16-channel unit either way - and 1000 of them with the DMA, the
+// fragment reads AND the MFMAs compiled out: the per-unit skeleton (barrier, counted wait, ~36 scalar instructions per wave
+// through the CU's one scalar unit, a dozen branches) was the kernel.  Hence:
+//  * steps of THREE units (27 MFMAs per wave) behind one barrier and one counted wait; their weight tiles are requested
+//    three steps ahead into a ring of R = 12 unit tiles (a tile has two steps = six units of MFMA time to land);
+//  * run-time cursors that advance by additions (ring stage, slab pointer, slot row) instead of index arithmetic per unit;
+//  * inside a step the wave's own software pipeline: request the fragments of unit s + 1 (second register set) and the
+//    window slots of unit s + 2, multiply unit s, wait.  The barrier of step T therefore guarantees the tiles of step T + 1.
 template <int NB, int G>
 __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
     static_assert((NB == 3 && G == 1) || (NB == 2 && G == 1) || (NB == 1 && G == 3), "unit shapes");
-    constexpr int NW = 8, D = 9, P = 6;
+    constexpr int NW = 8, R = 12, BU = 3;                           // ring tiles, units per step (barrier)
     constexpr int UPH = 27 / G;                                     // units per half chunk
     constexpr int WBUF = (WIN_CAP + 1) * 64;                        // one window buffer: WIN_CAP rows of 64 B + the row of zeros
     constexpr int B_UNIT = NB * G * 2048;                           // weight tile of a unit: [g][plane][col][32 B]
     constexpr int B_INSTR = B_UNIT / 1024;                          // <= 6: wave t requests KB t of the tile
     constexpr int WIN_PER_WAVE = WIN_CAP / 16 / NW;                 // LDS-DMA instructions (16 rows each) per wave and half chunk
-    constexpr int OFF_B = 2 * WBUF, OFF_LM = OFF_B + D * B_UNIT, OFF_ROWS = OFF_LM + 27 * WIN_T * 2,
+    constexpr int OFF_B = 2 * WBUF, OFF_LM = OFF_B + R * B_UNIT, OFF_ROWS = OFF_LM + 27 * WIN_T * 2,
                   OFF_OM = OFF_ROWS + WIN_T * 4, LDS_TOTAL = OFF_OM + NW * 4;
     constexpr int EP_BYTES = NW * 32 * EP_LD * 4;
     static_assert(EP_BYTES <= 2 * WBUF, "the epilogue tile aliases the window buffers");
-    static_assert(LDS_TOTAL <= 160 * 1024 && B_INSTR <= NW && UPH % D == 0 && D >= P + 1, "LDS budget / ring");
-    static_assert(WIN_PER_WAVE * NW * 16 == WIN_CAP && WIN_PER_WAVE <= P - 2, "window instructions are dealt evenly to the waves");
+    static_assert(LDS_TOTAL <= 160 * 1024 && B_INSTR <= NW && UPH % BU == 0 && R == 4 * BU, "LDS budget / ring");
+    static_assert(WIN_PER_WAVE * NW * 16 == WIN_CAP, "window instructions are dealt evenly to the waves");
     // ONE __shared__ object (a second one makes hipcc drain vmcnt in front of the LDS reads of an LDS-DMA pipeline)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_TOTAL];
     int* const rows_s = reinterpret_cast<int*>(lds + OFF_ROWS);
@@ -318,14 +321,6 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
     const unsigned b_src = (unsigned)((bt_pl * a.cout + bt_nb * 32 + (lane >> 1)) * 32 + (((lane & 1) ^ ((lane >> 5) & 1)) << 3));
     const unsigned slab_words = 2u * (unsigned)a.cout * 32u;
     const bool has_w = wave < B_INSTR;
-    auto issue_slab = [&](const unsigned short* slab, int ks, int stage) {
-        if (has_w && !(CV_WIN_ABL & 4)) lds_dma16(slab + b_src + ks * 16, lds + OFF_B + stage * B_UNIT + wave * 1024);
-    };
-    auto issue_main = [&](int h, int u, int stage) {                // unit u of half chunk h
-        int nch_l = nch;
-        asm volatile("" : "+s"(nch_l));                             // (keeps hoisted slab offsets out of the scalar registers)
-        issue_slab(a.wp6 + (size_t)(unsigned)((u * G + bt_g) * nch_l + (h >> 1)) * slab_words, h & 1, stage);
-    };
     // instruction i of this wave's share of the window of half chunk h.  ALWAYS one instruction (rows beyond the window - and a
     // whole half chunk beyond the last, `dummy` - fetch the line of zeros): the counted waits know the queue at compile time
     auto issue_win = [&](int h, int i, bool dummy) {
@@ -334,12 +329,6 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
                                      ? in_b + ((size_t)woff[i] + (size_t)((h >> 1) * 128 + (h & 1) * 32) + w_piece)
                                      : g_zero_chunk + w_piece;
         lds_dma16(g, lds + (h & 1) * WBUF + (wave + NW * i) * 1024);
-    };
-    // vmcnt wait that leaves BASE instructions + this wave's weight requests of P - 2 units in flight
-    auto wait_keep = [&](auto BASE) {
-        constexpr int base = decltype(BASE)::value;
-        if (has_w) wait_vmcnt_le<base + (P - 2)>();
-        else wait_vmcnt_le<base>();
     };
 
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)lds;
@@ -352,8 +341,7 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
     unsigned SL[G];                                                 // window slots of the lane's row for the next unit's offsets
     const unsigned lm_rd = lds0 + (unsigned)(OFF_LM + my_t * 2);
     // unit w of chunk c = unit u of half chunk h
-    auto slots_issue = [&](int u) { win_slots_issue<G>(SL, lm_rd + (unsigned)(u * G * WIN_T * 2)); };
-    auto read_issue = [&](auto PAR, int h, int stage) {             // fragments of the unit whose slots are in SL -> F[PAR]
+    auto read_issue = [&](auto PAR, int h, unsigned stage_off) {    // fragments of the unit whose slots are in SL -> F[PAR]
         constexpr int par = decltype(PAR)::value;
         unsigned aa[2 * G];
 #pragma unroll
@@ -364,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
             aa[2 * g] = base + (((unsigned)half ^ sw) << 4);
             aa[2 * g + 1] = base + (((2u + (unsigned)half) ^ sw) << 4);
         }
-        if (!(CV_WIN_ABL & 8)) win_read_issue(F[par], aa, b_rd + (unsigned)(stage * B_UNIT));
+        if (!(CV_WIN_ABL & 8)) win_read_issue(F[par], aa, b_rd + stage_off);
     };
     auto mfma_frags = [&](const u32x4v& Ah, const u32x4v& Al, const u32x4v* Bh, const u32x4v* Bl) {
         const f16x8 a0 = __builtin_bit_cast(f16x8, Ah), a1 = __builtin_bit_cast(f16x8, Al);
@@ -407,75 +395,109 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
         const bool second = extra_decode(e, j, h);
         const unsigned short* slab = second ? a.wp6_2 + (size_t)(unsigned)(h >> 1) * slab_words
                                             : a.wp6 + (size_t)(unsigned)(j * nch + (h >> 1)) * slab_words;
-        if (has_we && !(CV_WIN_ABL & 4)) lds_dma16(slab + be_src + (h & 1) * 16, lds + OFF_B + (e % D) * B_UNIT + wave * 1024);
+        if (has_we && !(CV_WIN_ABL & 4)) lds_dma16(slab + be_src + (h & 1) * 16, lds + OFF_B + ((U + e) % R) * B_UNIT + wave * 1024);
     };
     // (a wave that requests main tiles but no extra tiles - G = 3 - or the reverse would break the counted waits: the extra
     // loop below drains the queue instead of counting)
 
-    // ---- prologue: the window of half chunk 0, the weight tiles of units 0 ... P - 1
+    // ---- request cursor: the next MAIN unit whose weight tile goes out (half chunk, unit, ring stage, this wave's source
+    // pointer); everything advances by additions - no index arithmetic in the steps
+    const size_t w_step = (size_t)(G * nch) * slab_words;           // from a unit's slab to the next unit's (16-bit words)
+    int q_h = 0, q_u = 0;
+    unsigned q_stage_off = 0u;
+    const unsigned short* q_base = a.wp6 + (size_t)(bt_g * nch) * slab_words + b_src;      // unit 0 of half chunk q_h
+    const unsigned short* q_ptr = q_base;
+    auto issue_next = [&]() {
+        if (q_h < NH) {
+            if (has_w && !(CV_WIN_ABL & 4)) lds_dma16(q_ptr, lds + OFF_B + wave * 1024 + q_stage_off);
+            q_ptr += w_step;
+            if (++q_u == UPH) {                                     // next half chunk: k-step 1 of the same chunk, or the next chunk
+                q_u = 0;
+                q_base += (q_h & 1) ? (size_t)slab_words - 16 : (size_t)16;
+                ++q_h;
+                q_ptr = q_base;
+            }
+        }
+        q_stage_off = q_stage_off + (unsigned)B_UNIT == (unsigned)(R * B_UNIT) ? 0u : q_stage_off + (unsigned)B_UNIT;
+    };
+    // ---- prologue: the window of half chunk 0, the weight tiles of the first three steps
 #pragma unroll
     for (int i = 0; i < WIN_PER_WAVE; ++i) issue_win(0, i, false);
 #pragma unroll
-    for (int u = 0; u < P; ++u) issue_main(0, u, u);                // (U >= 18 > P)
-    if (has_w) wait_vmcnt_le<P - 1>(); else wait_vmcnt_le<0>();
-    __builtin_amdgcn_s_barrier();                                   // unit 0's tile and window are there
+    for (int u = 0; u < 3 * BU; ++u) issue_next();                  // (U >= 18 > 9)
+    wait_vmcnt_le<0>();
+    __builtin_amdgcn_s_barrier();                                   // the first three steps' tiles and the window are there
     typedef std::integral_constant<int, 0> P0;
-    typedef std::integral_constant<int, 1> P1;
-    slots_issue(0);
+    unsigned r_stage_off = 0u;                                      // ring stage of the unit that multiplies, in bytes
+    unsigned um = umask;                                            // live bits of the units from the current one on (this half chunk)
+    unsigned sl_addr = lm_rd;                                       // slot row of the unit whose slots are requested next
+    auto slots_next = [&](int u_next) {                             // request the slots of unit u_next of a half chunk
+        win_slots_issue<G>(SL, sl_addr);
+        sl_addr = u_next + 1 == UPH ? lm_rd : sl_addr + (unsigned)(G * WIN_T * 2);
+    };
+    slots_next(0);
     win_read_wait(F[1], SL);                                        // (the register set is a dummy here: only the slots travel)
-    read_issue(P0{}, 0, 0);
-    slots_issue(1);
+    read_issue(P0{}, 0, 0u);
+    slots_next(1);
     win_read_wait(F[0], SL);                                        // fragments of unit 0 in F[0], slots of unit 1 in SL
-    // Step s = unit w of chunk c = unit u of half chunk h:
-    // [wait: this wave's requests up to the weight tile of unit s + 1 have landed; behind it in the queue, allowed to stay in
-    //  flight: the tiles of units s + 2 ... s + P - 1 and the window instructions issued at steps s + 2 - P ... s - 1]
-    // -> barrier (everybody's have; everybody is past unit s - 1) -> this step's requests: one window instruction of half
-    // chunk h + 1 at u < WIN_PER_WAVE (its buffer was last read at the end of half chunk h - 1), the tile of unit s + P
-    // -> request the fragments of unit s + 1 and the slots of unit s + 2 -> multiply unit s -> wait for the requests.
+    // Step T = units 3 T ... 3 T + 2 (w = 18 jj + k inside chunk c; u inside half chunk h):
+    // [wait: everything this wave requested up to step T - 2 has landed - the tiles of step T + 1 among it; what it requested at
+    //  step T - 1 (three tiles, and the four window instructions when that was the first step of a half chunk) stays in flight]
+    // -> barrier (everybody's have landed; everybody is past step T - 1) -> requests: the window of half chunk h + 1 at the
+    // first step of half chunk h (its buffer was last read in half chunk h - 1), the tiles of step T + 3 (the ring slots of
+    // step T - 1) -> three times: request the fragments of the next unit and the slots of the one behind it, multiply, wait.
+    bool prev_first = false, tail = false;
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
 #pragma unroll 1
         for (int jj = 0; jj < UPC / 18; ++jj) {
             static_for<18>([&](auto K) {
                 constexpr int k = decltype(K)::value;
-                constexpr int kd = k % D;                           // ring stage of this unit
                 typedef std::integral_constant<int, k & 1> PAR;
                 typedef std::integral_constant<int, (k + 1) & 1> PARN;
-                const int w = jj * 18 + k, ks = w >= UPH ? 1 : 0, u = w - ks * UPH, h = 2 * c + ks, s = c * UPC + w;
-                // window instructions among the P - 2 steps in front of this one (steps 0 ... WIN_PER_WAVE - 1 of a half chunk);
-                // u < D means u == kd (the half chunk and the unroll are multiples of the ring)
-                constexpr int lo = kd - (P - 2) > 0 ? kd - (P - 2) : 0, hi = kd - 1 < WIN_PER_WAVE - 1 ? kd - 1 : WIN_PER_WAVE - 1;
-                constexpr int nwin = hi >= lo ? hi - lo + 1 : 0;
-                if (s + P - 1 < U) {
-                    if (u < D) wait_keep(std::integral_constant<int, nwin>{});
-                    else wait_keep(std::integral_constant<int, 0>{});
-                } else {
-                    wait_vmcnt_le<0>();                             // the last main units: fewer (or other waves') requests behind them
+                const int w = jj * 18 + k, ks = w >= UPH ? 1 : 0, u = w - ks * UPH, h = 2 * c + ks;
+                if constexpr (k % BU == 0) {
+                    if (tail) wait_vmcnt_le<0>();
+                    else if (prev_first) { if (has_w) wait_vmcnt_le<BU + WIN_PER_WAVE>(); else wait_vmcnt_le<WIN_PER_WAVE>(); }
+                    else { if (has_w) wait_vmcnt_le<BU>(); else wait_vmcnt_le<0>(); }
+                    __builtin_amdgcn_s_barrier();
+                    prev_first = u == 0;
+                    if (prev_first) {
+#pragma unroll
+                        for (int i = 0; i < WIN_PER_WAVE; ++i) issue_win(h + 1, i, h + 1 >= NH);
+                    }
+                    tail = q_h >= NH;                               // nothing is requested from here on
+#pragma unroll
+                    for (int i = 0; i < BU; ++i) issue_next();
                 }
-                __builtin_amdgcn_s_barrier();
-                if constexpr (kd < WIN_PER_WAVE) {
-                    if (u < D) issue_win(h + 1, kd, h + 1 >= NH);
+                if constexpr (k == 0 || k == 9) {
+                    if (u == 0) um = umask;                         // a half chunk starts
                 }
-                {
-                    const int up = u + P;                           // unit s + P: in this half chunk, the next one, or an extra unit
-                    if (up < UPH) issue_main(h, up, (kd + P) % D);
-                    else if (h + 1 < NH) issue_main(h + 1, up - UPH, (kd + P) % D);
-                    else if (up - UPH < E) issue_extra(up - UPH);
-                }
-                const int un = u + 1 < UPH ? u + 1 : 0, hn = u + 1 < UPH ? h : h + 1;        // unit s + 1
-                const int un2 = un + 1 < UPH ? un + 1 : 0;                                    // unit s + 2 (its slots only)
-                if (hn < NH && ((umask >> un) & 1u)) read_issue(PARN{}, hn, (kd + 1) % D);
-                slots_issue(un2);
-                if ((umask >> u) & 1u) mfma_unit(PAR{});
+                const bool last_u = u + 1 == UPH;
+                const bool live_next = last_u ? (h + 1 < NH && (umask & 1u)) : ((um >> 1) & 1u);
+                const unsigned n_stage_off = r_stage_off + (unsigned)B_UNIT == (unsigned)(R * B_UNIT) ? 0u : r_stage_off + (unsigned)B_UNIT;
+                if (live_next) read_issue(PARN{}, last_u ? h + 1 : h, n_stage_off);
+                slots_next(last_u ? 1 : (u + 2 < UPH ? u + 2 : 0));
+                if (um & 1u) mfma_unit(PAR{});
                 win_read_wait(F[(k + 1) & 1], SL);
+                um >>= 1;
+                r_stage_off = n_stage_off;
             });
         }
     }
-#pragma unroll 1
-    for (int e = 0; e < E; ++e) {
+    // extra units: the main units are consumed (every ring slot is free behind a barrier): up to PE tiles ahead
+    constexpr int PE = 6;
+    int q_e = 0;
+    if (E > 0) {
         wait_vmcnt_le<0>();
         __builtin_amdgcn_s_barrier();
-        if (e + P < E) issue_extra(e + P);
+        for (; q_e < E && q_e < PE; ++q_e) issue_extra(q_e);
+    }
+#pragma unroll 1
+    for (int e = 0; e < E; ++e) {
+        wait_vmcnt_dyn(__builtin_amdgcn_readfirstlane(has_we ? q_e - 1 - e : 0));       // the tiles behind unit e's stay in flight
+        __builtin_amdgcn_s_barrier();
+        if (q_e < E) issue_extra(q_e++);                            // (its ring slot held extra unit q_e - 12 or a main unit)
         int j, h;
         const bool second = extra_decode(e, j, h);
         long long src = -1;
@@ -494,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
             fa[0] = fa[1] = make_uint4(0u, 0u, 0u, 0u);
         }
         u32x4v B[2 * NB];
-        win_read_b<NB>(B, b_rd + (unsigned)((e % D) * B_UNIT));
+        win_read_b<NB>(B, b_rd + (unsigned)(((U + e) % R) * B_UNIT));
         mfma_frags(__builtin_bit_cast(u32x4v, fa[0]), __builtin_bit_cast(u32x4v, fa[1]), &B[0], &B[NB]);
     }
     wait_vmcnt_le<0>();
