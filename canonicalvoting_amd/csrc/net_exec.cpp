@@ -265,7 +265,9 @@ size_t cv_net_arena_bytes(const cv_net_buf* bufs, int n_bufs, const long long* l
 // neighbour windows: hl-format input, fp16-pair weights, Cout 32 / 64 / 96, channels % 32 == 0.
 int cv_net_win_levels(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int n_bufs) {
     if (!ops || !bufs || n_ops <= 0) return 0;
-    static const bool on = !(getenv("CV_WIN") && atoi(getenv("CV_WIN")) == 0);
+    long long on = 0;
+    cv_sp_set_option("win", 0, &on);            // (read the switch: set it back)
+    cv_sp_set_option("win", on, nullptr);
     if (!on) return 0;
     int yes = 0, no = 0;
     for (int k = 0; k < n_ops; ++k) {

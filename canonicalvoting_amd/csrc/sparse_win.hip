@@ -45,8 +45,12 @@ namespace {
 
 constexpr int WIN_T = 256;                 // rows per tile
 constexpr int WIN_CAP = CV_WIN_CAP;        // window rows held in LDS (multiple of 64: 8 rows per LDS-DMA instruction x 8 waves)
-constexpr unsigned WIN_NONE = 0xFFFFu, WIN_OUT = 0xFFFEu;
-static_assert(WIN_CAP % 128 == 0 && WIN_CAP < 0xFFFE, "window capacity");
+// a window slot as the kernel map stores it: byte offset of the slot's 64-byte row in a window buffer, with the row's
+// read swizzle (slot >> 2) & 3 in bits 4-5: the fragment address of piece p is (entry ^ (p << 4)) + buffer.  The two rows
+// behind the window are zeros: WIN_NONE (no neighbour) and WIN_OUT (neighbour beyond the window: added by the extra units).
+constexpr unsigned WIN_NONE = (unsigned)CV_WIN_CAP * 64u, WIN_OUT = WIN_NONE + 64u;
+__host__ __device__ constexpr unsigned win_entry(unsigned slot) { return slot * 64u + (((slot >> 2) & 3u) << 4); }
+static_assert(WIN_CAP % 128 == 0 && (WIN_CAP + 2) * 64 <= 0xFFFF, "window capacity");
 
 // ------------------------------------------------------------------ plan: windows of a 27-offset kernel map
 struct WinJobsDev {
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void build_windows(const WinJobsDev jobs, int 
         if (e[j] >= 0) {
             const int w = (e[j] >> 5) - lo_w;
             const unsigned rank = (unsigned)wpre[w] + (unsigned)__popc(bits[w] & ((1u << (e[j] & 31)) - 1u));
-            v = rank < (unsigned)WIN_CAP ? rank : WIN_OUT;
+            v = rank < (unsigned)WIN_CAP ? win_entry(rank) : WIN_OUT;
         }
         lm_out[j * WIN_T] = (unsigned short)v;
     }
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void build_windows(const WinJobsDev jobs, int 
 
 // ------------------------------------------------------------------ the convolution
 #ifndef CV_WIN_ABL
-#define CV_WIN_ABL 0      // timing ablations (wrong results): 1 no window DMA, 2 no MFMA, 4 no weight DMA, 8 no fragment reads
+#define CV_WIN_ABL 0      // timing ablations (wrong results): 1 no window DMA, 2 no MFMA, 4 no weight DMA, 8 no fragment reads, 16 no step barriers, 32 no liveness tests, 64 no counted waits
 #endif
 
 // MFMA operand fragments of one unit: per offset g of the unit the lane's row (high piece, low piece), per (g, plane, nb)
@@ -148,29 +152,35 @@ struct WinFrags {
     u32x4v a[2 * G];            // [g][h | l]
     u32x4v b[2 * G * NB];       // [(g * 2 + plane) * NB + nb]
 };
-// request every fragment of a unit (no wait: the MFMAs of the previous unit run while they travel) ...
+// request every fragment of a unit (no wait: the MFMAs of the previous unit run while they travel); OFF = the unit's ring
+// tile relative to the base register ...
+template <int OFF>
 __device__ __forceinline__ void win_read_issue(WinFrags<3, 1>& f, const unsigned (&aa)[2], unsigned ab) {
     asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\t"
-                 "ds_read_b128 %2, %10\n\tds_read_b128 %3, %10 offset:1024\n\tds_read_b128 %4, %10 offset:2048\n\t"
-                 "ds_read_b128 %5, %10 offset:3072\n\tds_read_b128 %6, %10 offset:4096\n\tds_read_b128 %7, %10 offset:5120"
+                 "ds_read_b128 %2, %10 offset:%11\n\tds_read_b128 %3, %10 offset:%12\n\tds_read_b128 %4, %10 offset:%13\n\t"
+                 "ds_read_b128 %5, %10 offset:%14\n\tds_read_b128 %6, %10 offset:%15\n\tds_read_b128 %7, %10 offset:%16"
                  : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.b[0]), "=&v"(f.b[1]), "=&v"(f.b[2]), "=&v"(f.b[3]), "=&v"(f.b[4]), "=&v"(f.b[5])
-                 : "v"(aa[0]), "v"(aa[1]), "v"(ab) : "memory");
+                 : "v"(aa[0]), "v"(aa[1]), "v"(ab), "i"(OFF), "i"(OFF + 1024), "i"(OFF + 2048), "i"(OFF + 3072), "i"(OFF + 4096),
+                   "i"(OFF + 5120) : "memory");
 }
+template <int OFF>
 __device__ __forceinline__ void win_read_issue(WinFrags<2, 1>& f, const unsigned (&aa)[2], unsigned ab) {
     asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\t"
-                 "ds_read_b128 %2, %8\n\tds_read_b128 %3, %8 offset:1024\n\tds_read_b128 %4, %8 offset:2048\n\t"
-                 "ds_read_b128 %5, %8 offset:3072"
+                 "ds_read_b128 %2, %8 offset:%9\n\tds_read_b128 %3, %8 offset:%10\n\tds_read_b128 %4, %8 offset:%11\n\t"
+                 "ds_read_b128 %5, %8 offset:%12"
                  : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.b[0]), "=&v"(f.b[1]), "=&v"(f.b[2]), "=&v"(f.b[3])
-                 : "v"(aa[0]), "v"(aa[1]), "v"(ab) : "memory");
+                 : "v"(aa[0]), "v"(aa[1]), "v"(ab), "i"(OFF), "i"(OFF + 1024), "i"(OFF + 2048), "i"(OFF + 3072) : "memory");
 }
+template <int OFF>
 __device__ __forceinline__ void win_read_issue(WinFrags<1, 3>& f, const unsigned (&aa)[6], unsigned ab) {
     asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %13\n\tds_read_b128 %2, %14\n\tds_read_b128 %3, %15\n\t"
                  "ds_read_b128 %4, %16\n\tds_read_b128 %5, %17\n\t"
-                 "ds_read_b128 %6, %18\n\tds_read_b128 %7, %18 offset:1024\n\tds_read_b128 %8, %18 offset:2048\n\t"
-                 "ds_read_b128 %9, %18 offset:3072\n\tds_read_b128 %10, %18 offset:4096\n\tds_read_b128 %11, %18 offset:5120"
+                 "ds_read_b128 %6, %18 offset:%19\n\tds_read_b128 %7, %18 offset:%20\n\tds_read_b128 %8, %18 offset:%21\n\t"
+                 "ds_read_b128 %9, %18 offset:%22\n\tds_read_b128 %10, %18 offset:%23\n\tds_read_b128 %11, %18 offset:%24"
                  : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.a[2]), "=&v"(f.a[3]), "=&v"(f.a[4]), "=&v"(f.a[5]),
                    "=&v"(f.b[0]), "=&v"(f.b[1]), "=&v"(f.b[2]), "=&v"(f.b[3]), "=&v"(f.b[4]), "=&v"(f.b[5])
-                 : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(aa[4]), "v"(aa[5]), "v"(ab) : "memory");
+                 : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(aa[4]), "v"(aa[5]), "v"(ab), "i"(OFF), "i"(OFF + 1024),
+                   "i"(OFF + 2048), "i"(OFF + 3072), "i"(OFF + 4096), "i"(OFF + 5120) : "memory");
 }
 // ... and the wait that hands them (and the prefetched window slots) over: the operands tie the registers to the wait, nothing
 // that uses them may be scheduled in front of it
@@ -189,15 +199,15 @@ __device__ __forceinline__ void win_read_wait(WinFrags<1, 3>& f, unsigned (&sl)[
                    "+v"(f.b[2]), "+v"(f.b[3]), "+v"(f.b[4]), "+v"(f.b[5]), "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2])
                  :: "memory");
 }
-// window slots of a unit's G offsets (16-bit LDS reads, no wait)
-template <int G>
+// window slots of a unit's G offsets (16-bit LDS reads at an immediate offset from the lane's slot column, no wait)
+template <int G, int OFF>
 __device__ __forceinline__ void win_slots_issue(unsigned (&sl)[G], unsigned addr) {
     if constexpr (G == 1) {
-        asm volatile("ds_read_u16 %0, %1" : "=&v"(sl[0]) : "v"(addr) : "memory");
+        asm volatile("ds_read_u16 %0, %1 offset:%2" : "=&v"(sl[0]) : "v"(addr), "i"(OFF) : "memory");
     } else {
         static_assert(G == 3, "one or three offsets per unit");
-        asm volatile("ds_read_u16 %0, %3\n\tds_read_u16 %1, %3 offset:512\n\tds_read_u16 %2, %3 offset:1024"
-                     : "=&v"(sl[0]), "=&v"(sl[1]), "=&v"(sl[2]) : "v"(addr) : "memory");
+        asm volatile("ds_read_u16 %0, %3 offset:%4\n\tds_read_u16 %1, %3 offset:%5\n\tds_read_u16 %2, %3 offset:%6"
+                     : "=&v"(sl[0]), "=&v"(sl[1]), "=&v"(sl[2]) : "v"(addr), "i"(OFF), "i"(OFF + 512), "i"(OFF + 1024) : "memory");
     }
 }
 // the weight pieces of a one-offset unit alone (extra units: the A fragments come from global memory)
@@ -223,22 +233,27 @@ __device__ __forceinline__ void win_read_b(u32x4v (&b)[2 * NB], unsigned ab) {
 // HALF chunk h = 2 c + ks (16 channels: 32 B of high and 32 B of low pieces = a 64-byte window row) the 27 / G units of
 // its offsets; the window of half chunk h + 1 lands in the other buffer meanwhile.
 //
-// What the first three versions measured (profiles/r5/win_v*_*.txt): a barrier per unit with "read fragments -> wait ->
-// multiply" 2100 cycles per 32-channel unit where the MFMAs need 1152; ping-pong between the two waves of a SIMD, then a
-// software pipeline inside every wave: ~1300 cycles per 16-channel unit either way - and 1000 of them with the DMA, the
-// fragment reads AND the MFMAs compiled out: the per-unit skeleton (barrier, counted wait, ~36 scalar instructions per wave
-// through the CU's one scalar unit, a dozen branches) was the kernel.  Hence:
+// What the first versions measured (profiles/r5/win_v*_*.txt): a barrier per unit with "read fragments -> wait -> multiply":
+// 2100 cycles per 32-channel unit where the MFMAs need 1152; ping-pong between the two waves of a SIMD, a software pipeline
+// inside every wave, steps of three units behind one barrier: 1340 cycles per 16-channel unit - of which 480 remain with
+// the DMA, the fragment reads AND the MFMAs compiled out.  The run-time bookkeeping of a unit (ring stage, slab pointer, slot
+// row, liveness, ~60 scalar instructions and a dozen branches through the CU's one scalar unit) was a third of the kernel and
+// added to the rest.  Hence this version:
+//  * the 54 / G units of a 32-channel chunk are unrolled: unit, k-step, window buffer, ring tile and slot row are
+//    immediates of the instructions; what remains at run time is the chunk loop, one slab pointer and the live-unit mask;
 //  * steps of THREE units (27 MFMAs per wave) behind one barrier and one counted wait; their weight tiles are requested
-//    three steps ahead into a ring of R = 12 unit tiles (a tile has two steps = six units of MFMA time to land);
-//  * run-time cursors that advance by additions (ring stage, slab pointer, slot row) instead of index arithmetic per unit;
+//    three steps ahead into a ring of R = 12 unit tiles (a tile has two steps = six units of MFMA time to land; the ring
+//    position of a chunk's first unit alternates between tile 0 and tile 6: two base registers per chunk);
 //  * inside a step the wave's own software pipeline: request the fragments of unit s + 1 (second register set) and the
-//    window slots of unit s + 2, multiply unit s, wait.  The barrier of step T therefore guarantees the tiles of step T + 1.
+//    window slots of unit s + 2, multiply unit s, wait.  The barrier of step T therefore guarantees the tiles of step T + 1;
+//  * the plan stores a slot as its row's byte offset with the read swizzle folded in (win_entry): a fragment address is one
+//    xor-add.
 template <int NB, int G>
 __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
     static_assert((NB == 3 && G == 1) || (NB == 2 && G == 1) || (NB == 1 && G == 3), "unit shapes");
     constexpr int NW = 8, R = 12, BU = 3;                           // ring tiles, units per step (barrier)
     constexpr int UPH = 27 / G;                                     // units per half chunk
-    constexpr int WBUF = (WIN_CAP + 1) * 64;                        // one window buffer: WIN_CAP rows of 64 B + the row of zeros
+    constexpr int WBUF = (WIN_CAP + 2) * 64;                        // one window buffer: WIN_CAP rows of 64 B + two rows of zeros
     constexpr int B_UNIT = NB * G * 2048;                           // weight tile of a unit: [g][plane][col][32 B]
     constexpr int B_INSTR = B_UNIT / 1024;                          // <= 6: wave t requests KB t of the tile
     constexpr int WIN_PER_WAVE = WIN_CAP / 16 / NW;                 // LDS-DMA instructions (16 rows each) per wave and half chunk
@@ -287,14 +302,14 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
         }
     }
     if (tid < WIN_T) rows_s[tid] = row0 + tid < a.n_out ? (int)(row0 + tid) : -1;
-    if (tid < 8) *reinterpret_cast<uint4*>(lds + (tid >> 2) * WBUF + WIN_CAP * 64 + (tid & 3) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 16) *reinterpret_cast<uint4*>(lds + (tid >> 3) * WBUF + WIN_CAP * 64 + (tid & 7) * 16) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     const int my_t = wave * 32 + l31;
     unsigned jmask = 0u, omask = 0u;                                // offsets this wave has a neighbour at / an outside-window pair at
 #pragma unroll
     for (int j = 0; j < 27; ++j) {
         const unsigned v = lm_s[j * WIN_T + my_t];
-        if (__any(v != WIN_NONE)) jmask |= 1u << j;
+        if (__any(v != WIN_NONE)) jmask |= 1u << j;          // (an outside-window pair makes the offset live too: harmless)
         if (__any(v == WIN_OUT)) omask |= 1u << j;
     }
     if (lane == 0) reinterpret_cast<unsigned*>(lds + OFF_OM)[wave] = omask;
@@ -336,23 +351,22 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
     const long long my_row = row0 + my_t;
 
     constexpr int UPC = 2 * UPH;                                     // units per 32-channel chunk: k-step 0, then k-step 1
-    static_assert(UPC % 18 == 0, "the unit loop is unrolled 18-fold: ring stage and register set are compile-time numbers");
+    static_assert(UPC % (2 * BU) == 0 && (UPC % R == 0 || UPC % R == R / 2), "chunk = whole steps; ring position alternates 0 / 6");
     WinFrags<NB, G> F[2];                                           // fragments of the unit that multiplies / of the next one
-    unsigned SL[G];                                                 // window slots of the lane's row for the next unit's offsets
+    unsigned SL[G];                                                 // window-slot entries of the lane's row for the next unit's offsets
     const unsigned lm_rd = lds0 + (unsigned)(OFF_LM + my_t * 2);
-    // unit w of chunk c = unit u of half chunk h
-    auto read_issue = [&](auto PAR, int h, unsigned stage_off) {    // fragments of the unit whose slots are in SL -> F[PAR]
-        constexpr int par = decltype(PAR)::value;
+    const unsigned k_h = (unsigned)half << 4, k_l = (2u + (unsigned)half) << 4;          // piece selectors of the lane: high, low
+    unsigned b_lo = b_rd, b_hi = b_rd + (unsigned)(R / 2 * B_UNIT);  // ring tiles 0-5 / 6-11 of the CHUNK's numbering (see below)
+    // fragments of unit w (k-step KS, ring tile TL of the chunk's numbering) whose slot entries are in SL -> F[PAR]
+    auto read_issue = [&](auto PAR, auto KS, auto TL) {
+        constexpr int par = decltype(PAR)::value, ks = decltype(KS)::value, tl = decltype(TL)::value;
         unsigned aa[2 * G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const unsigned v = SL[g];
-            const unsigned li = v >= WIN_OUT ? (unsigned)WIN_CAP : v;     // no neighbour / outside the window: the row of zeros
-            const unsigned base = lds0 + (unsigned)((h & 1) * WBUF) + li * 64u, sw = (li >> 2) & 3u;
-            aa[2 * g] = base + (((unsigned)half ^ sw) << 4);
-            aa[2 * g + 1] = base + (((2u + (unsigned)half) ^ sw) << 4);
+            aa[2 * g] = (SL[g] ^ k_h) + (lds0 + (unsigned)(ks * WBUF));
+            aa[2 * g + 1] = (SL[g] ^ k_l) + (lds0 + (unsigned)(ks * WBUF));
         }
-        if (!(CV_WIN_ABL & 8)) win_read_issue(F[par], aa, b_rd + stage_off);
+        if (!(CV_WIN_ABL & 8)) win_read_issue<(tl % (R / 2)) * B_UNIT>(F[par], aa, tl < R / 2 ? b_lo : b_hi);
     };
     auto mfma_frags = [&](const u32x4v& Ah, const u32x4v& Al, const u32x4v* Bh, const u32x4v* Bl) {
         const f16x8 a0 = __builtin_bit_cast(f16x8, Ah), a1 = __builtin_bit_cast(f16x8, Al);
@@ -400,89 +414,97 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
     // (a wave that requests main tiles but no extra tiles - G = 3 - or the reverse would break the counted waits: the extra
     // loop below drains the queue instead of counting)
 
-    // ---- request cursor: the next MAIN unit whose weight tile goes out (half chunk, unit, ring stage, this wave's source
-    // pointer); everything advances by additions - no index arithmetic in the steps
-    const size_t w_step = (size_t)(G * nch) * slab_words;           // from a unit's slab to the next unit's (16-bit words)
-    int q_h = 0, q_u = 0;
-    unsigned q_stage_off = 0u;
-    const unsigned short* q_base = a.wp6 + (size_t)(bt_g * nch) * slab_words + b_src;      // unit 0 of half chunk q_h
-    const unsigned short* q_ptr = q_base;
-    auto issue_next = [&]() {
-        if (q_h < NH) {
-            if (has_w && !(CV_WIN_ABL & 4)) lds_dma16(q_ptr, lds + OFF_B + wave * 1024 + q_stage_off);
-            q_ptr += w_step;
-            if (++q_u == UPH) {                                     // next half chunk: k-step 1 of the same chunk, or the next chunk
-                q_u = 0;
-                q_base += (q_h & 1) ? (size_t)slab_words - 16 : (size_t)16;
-                ++q_h;
-                q_ptr = q_base;
-            }
+    // ---- weight tile requests.  q_ptr: this wave's source of the next main unit to request (uniform part; b_src is the
+    // lane's); it moves by one of three constants per unit.  q_lo / q_hi: LDS destination of ring tiles 0-5 / 6-11 of the
+    // chunk's numbering (with the wave's KB).
+    const ptrdiff_t w_step = (ptrdiff_t)(G * nch) * (ptrdiff_t)slab_words;      // 16-bit words: a unit's slab -> the next unit's
+    const ptrdiff_t w_to_ks1 = 16 - (UPH - 1) * w_step;             // last unit of k-step 0 -> first of k-step 1
+    const ptrdiff_t w_to_next_c = (ptrdiff_t)slab_words - 16 - (UPH - 1) * w_step;        // last unit of a chunk -> next chunk
+    const unsigned short* q_ptr = a.wp6 + (size_t)(bt_g * nch) * slab_words;
+    unsigned q_lo = (unsigned)(OFF_B + wave * 1024), q_hi = q_lo + (unsigned)(R / 2 * B_UNIT);
+    // request unit x of the current chunk's numbering (x >= UPC: a unit of the next chunk, when there is one)
+    auto issue_unit = [&](auto X, bool exists) {
+        constexpr int x = decltype(X)::value, tl = x % R;
+        if (exists) {
+            if (has_w && !(CV_WIN_ABL & 4)) lds_dma16(q_ptr + b_src, lds + ((tl < R / 2 ? q_lo : q_hi) + (unsigned)((tl % (R / 2)) * B_UNIT)));
+            q_ptr += (x + 1) % UPC == 0 ? w_to_next_c : (x + 1) % UPC == UPH ? w_to_ks1 : w_step;
         }
-        q_stage_off = q_stage_off + (unsigned)B_UNIT == (unsigned)(R * B_UNIT) ? 0u : q_stage_off + (unsigned)B_UNIT;
     };
+    // the window of the half chunk that follows k-step KS of chunk c, this wave's WIN_PER_WAVE instructions.  ALWAYS that many
+    // (rows beyond the window - and a whole half chunk beyond the last - fetch the line of zeros): the counted waits below
+    // know the queue at compile time
+    auto issue_window = [&](auto KS, int c) {
+        constexpr int ks = decltype(KS)::value;                    // the window goes to the buffer the CURRENT k-step does not use
+        const bool dummy = (CV_WIN_ABL & 1) || (ks == 1 && c + 1 >= nch);
+        const size_t off = ks == 0 ? (size_t)(c * 128 + 32) : (size_t)((c + 1) * 128);
+#pragma unroll
+        for (int i = 0; i < WIN_PER_WAVE; ++i) {
+            const unsigned char* g = (!dummy && woff[i] != 0xFFFFFFFFu) ? in_b + ((size_t)woff[i] + off + w_piece) : g_zero_chunk + w_piece;
+            lds_dma16(g, lds + (1 - ks) * WBUF + (wave + NW * i) * 1024);
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
     // ---- prologue: the window of half chunk 0, the weight tiles of the first three steps
+    {
+        const bool dummy = CV_WIN_ABL & 1;
 #pragma unroll
-    for (int i = 0; i < WIN_PER_WAVE; ++i) issue_win(0, i, false);
-#pragma unroll
-    for (int u = 0; u < 3 * BU; ++u) issue_next();                  // (U >= 18 > 9)
+        for (int i = 0; i < WIN_PER_WAVE; ++i) {
+            const unsigned char* g = (!dummy && woff[i] != 0xFFFFFFFFu) ? in_b + ((size_t)woff[i] + w_piece) : g_zero_chunk + w_piece;
+            lds_dma16(g, lds + (wave + NW * i) * 1024);
+        }
+    }
+    static_for<3 * BU>([&](auto X) { issue_unit(X, true); });       // (a chunk has at least 18 units)
     wait_vmcnt_le<0>();
     __builtin_amdgcn_s_barrier();                                   // the first three steps' tiles and the window are there
-    typedef std::integral_constant<int, 0> P0;
-    unsigned r_stage_off = 0u;                                      // ring stage of the unit that multiplies, in bytes
-    unsigned um = umask;                                            // live bits of the units from the current one on (this half chunk)
-    unsigned sl_addr = lm_rd;                                       // slot row of the unit whose slots are requested next
-    auto slots_next = [&](int u_next) {                             // request the slots of unit u_next of a half chunk
-        win_slots_issue<G>(SL, sl_addr);
-        sl_addr = u_next + 1 == UPH ? lm_rd : sl_addr + (unsigned)(G * WIN_T * 2);
-    };
-    slots_next(0);
+    win_slots_issue<G, 0>(SL, lm_rd);
     win_read_wait(F[1], SL);                                        // (the register set is a dummy here: only the slots travel)
-    read_issue(P0{}, 0, 0u);
-    slots_next(1);
-    win_read_wait(F[0], SL);                                        // fragments of unit 0 in F[0], slots of unit 1 in SL
-    // Step T = units 3 T ... 3 T + 2 (w = 18 jj + k inside chunk c; u inside half chunk h):
+    read_issue(I0{}, I0{}, I0{});
+    win_slots_issue<G, G * WIN_T * 2>(SL, lm_rd);
+    win_read_wait(F[0], SL);                                        // fragments of unit 0 in F[0], slot entries of unit 1 in SL
+    // Step T = units 3 T ... 3 T + 2 of chunk c (unit w: k-step w / UPH, unit u = w % UPH of its half chunk):
     // [wait: everything this wave requested up to step T - 2 has landed - the tiles of step T + 1 among it; what it requested at
-    //  step T - 1 (three tiles, and the four window instructions when that was the first step of a half chunk) stays in flight]
-    // -> barrier (everybody's have landed; everybody is past step T - 1) -> requests: the window of half chunk h + 1 at the
-    // first step of half chunk h (its buffer was last read in half chunk h - 1), the tiles of step T + 3 (the ring slots of
-    // step T - 1) -> three times: request the fragments of the next unit and the slots of the one behind it, multiply, wait.
-    bool prev_first = false, tail = false;
+    //  step T - 1 (three tiles, and the window instructions when that was the first step of a half chunk) stays in flight]
+    // -> barrier (everybody's have landed; everybody is past step T - 1) -> requests: at the first step of a half chunk the
+    // window of the next one (its buffer was last read in the half chunk before), the tiles of step T + 3 (the ring slots of
+    // step T - 1) -> three times: request the fragments of the next unit and the slot entries of the one behind it, multiply,
+    // wait.  Ring tiles are numbered from the chunk's first unit; UPC % 12 == 6: the chunk's tile 0 is ring tile 0 or 6.
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
-#pragma unroll 1
-        for (int jj = 0; jj < UPC / 18; ++jj) {
-            static_for<18>([&](auto K) {
-                constexpr int k = decltype(K)::value;
-                typedef std::integral_constant<int, k & 1> PAR;
-                typedef std::integral_constant<int, (k + 1) & 1> PARN;
-                const int w = jj * 18 + k, ks = w >= UPH ? 1 : 0, u = w - ks * UPH, h = 2 * c + ks;
-                if constexpr (k % BU == 0) {
-                    if (tail) wait_vmcnt_le<0>();
-                    else if (prev_first) { if (has_w) wait_vmcnt_le<BU + WIN_PER_WAVE>(); else wait_vmcnt_le<WIN_PER_WAVE>(); }
-                    else { if (has_w) wait_vmcnt_le<BU>(); else wait_vmcnt_le<0>(); }
-                    __builtin_amdgcn_s_barrier();
-                    prev_first = u == 0;
-                    if (prev_first) {
-#pragma unroll
-                        for (int i = 0; i < WIN_PER_WAVE; ++i) issue_win(h + 1, i, h + 1 >= NH);
-                    }
-                    tail = q_h >= NH;                               // nothing is requested from here on
-#pragma unroll
-                    for (int i = 0; i < BU; ++i) issue_next();
+        const bool more = c + 1 < nch;
+        static_for<UPC>([&](auto W) {
+            constexpr int w = decltype(W)::value, ks = w / UPH, u = w % UPH;
+            constexpr int wn = (w + 1) % UPC, ksn = wn / UPH, un = wn % UPH;              // unit s + 1
+            constexpr int un2 = ((w + 2) % UPC) % UPH;                                   // unit s + 2: its slot entries only
+            typedef std::integral_constant<int, w & 1> PAR;
+            typedef std::integral_constant<int, (w + 1) & 1> PARN;
+            if constexpr (w % BU == 0) {
+                constexpr int T = w / BU;
+                // what step T - 1 requested: tiles unless it was beyond the last chunk's units; the window at T - 1 == 0 or UPH / BU
+                constexpr bool prev_win = T - 1 == 0 || T - 1 == UPH / BU;
+                constexpr bool prev_next_chunk = T >= 1 && (T - 1) * BU + 3 * BU >= UPC;  // step T - 1 requested units of chunk c + 1
+                const bool prev_tiles = T == 0 ? true : (prev_next_chunk ? more : true);    // (T == 0: the previous chunk's last step requested this chunk's)
+                if (!(CV_WIN_ABL & 64)) {
+                    if (!prev_tiles) wait_vmcnt_le<prev_win ? WIN_PER_WAVE : 0>();
+                    else if (has_w) wait_vmcnt_le<BU + (prev_win ? WIN_PER_WAVE : 0)>();
+                    else wait_vmcnt_le<prev_win ? WIN_PER_WAVE : 0>();
                 }
-                if constexpr (k == 0 || k == 9) {
-                    if (u == 0) um = umask;                         // a half chunk starts
-                }
-                const bool last_u = u + 1 == UPH;
-                const bool live_next = last_u ? (h + 1 < NH && (umask & 1u)) : ((um >> 1) & 1u);
-                const unsigned n_stage_off = r_stage_off + (unsigned)B_UNIT == (unsigned)(R * B_UNIT) ? 0u : r_stage_off + (unsigned)B_UNIT;
-                if (live_next) read_issue(PARN{}, last_u ? h + 1 : h, n_stage_off);
-                slots_next(last_u ? 1 : (u + 2 < UPH ? u + 2 : 0));
-                if (um & 1u) mfma_unit(PAR{});
-                win_read_wait(F[(k + 1) & 1], SL);
-                um >>= 1;
-                r_stage_off = n_stage_off;
-            });
+                if (!(CV_WIN_ABL & 16)) __builtin_amdgcn_s_barrier();
+                if constexpr (u == 0) issue_window(std::integral_constant<int, ks>{}, c);
+                static_for<BU>([&](auto I) {
+                    constexpr int x = w + 3 * BU + decltype(I)::value;
+                    issue_unit(std::integral_constant<int, x>{}, x < UPC ? true : more);
+                });
+            }
+            const bool live_next = (CV_WIN_ABL & 32) ? (wn != 0 || more) : wn == 0 ? (more && (umask & 1u)) : ((umask >> un) & 1u);
+            if (live_next) read_issue(PARN{}, std::integral_constant<int, ksn>{}, std::integral_constant<int, (wn == 0 ? UPC : wn) % R>{});
+            win_slots_issue<G, un2 * G * WIN_T * 2>(SL, lm_rd);
+            if ((CV_WIN_ABL & 32) || ((umask >> u) & 1u)) mfma_unit(PAR{});
+            win_read_wait(F[(w + 1) & 1], SL);
+        });
+        if (UPC % R != 0) {                                         // the next chunk's tile 0 is half a ring further
+            const unsigned t0 = b_lo; b_lo = b_hi; b_hi = t0;
+            const unsigned t1 = q_lo; q_lo = q_hi; q_hi = t1;
         }
     }
     // extra units: the main units are consumed (every ring slot is free behind a barrier): up to PE tiles ahead
@@ -536,7 +558,9 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
     for (int nb = 0; nb < NB; ++nb) epilogue_store_wide(ae, acc[nb], rows_s + wave * 32, nb * 32, lane, ep);
 }
 
-std::atomic<long long> g_win_on{getenv("CV_WIN") ? atoll(getenv("CV_WIN")) : 1};
+// OFF by default: measured slower than the mask-sorted kernels on MI355X (profiles/r5/win_*.txt):
+// 80 us against 63 us per 96 -> 96 layer at tensor stride 2, 161 us against 93 us at stride 1 (313 tiles on 256 CUs: two rounds)
+std::atomic<long long> g_win_on{getenv("CV_WIN") ? atoll(getenv("CV_WIN")) : 0};
 std::atomic<long long> g_win_xcd{getenv("CV_WIN_XCD") ? atoll(getenv("CV_WIN_XCD")) : 1};
 
 size_t win_lds_bytes(long long n) { return (size_t)((n + 31) / 32) * 6 + 64; }

@@ -19,6 +19,7 @@ N = nbr.shape[0]
 x = ME.to_hl(torch.randn(N, cin, device=dev))
 w = torch.randn(27, cin, cout, device=dev) * 0.02
 win = cm.windows(ts)
+ME.set_option('win', 1)          # (off by default)
 for _ in range(3):
     y = ME.conv_forward(x, w, nbr, N, relu=True, pieces=2, in_hl=True, out_hl=True, win=win)
 torch.cuda.synchronize()

@@ -14,6 +14,7 @@ from canonicalvoting_amd.synth import make_scene
 pytestmark = pytest.mark.gpu
 
 WIN_T, WIN_CAP = 256, 512
+NONE, OUT = WIN_CAP * 64, WIN_CAP * 64 + 64       # no neighbour / neighbour beyond the window (two rows of zeros)
 
 
 def sorted_manager(cuda, coords4):
@@ -56,12 +57,14 @@ def test_window_plan_resolves_every_map_entry(cuda, built_lib, seed, n, ts, dens
         w = rows[t]
         k = min(len(want), WIN_CAP)
         assert np.array_equal(w[:k], want[:k]) and (w[k:] == -1).all()
-        e = lm[t, :len(m)].astype(np.int64)
-        assert (lm[t, len(m):] == 0xFFFF).all()                    # rows beyond the level in the last tile
-        assert np.array_equal(e == 0xFFFF, m < 0)
-        inside = (m >= 0) & (e < 0xFFFE)
-        assert np.array_equal(w[e[inside]], m[inside])                  # the slot holds exactly the neighbour's row
-        out = (m >= 0) & (e == 0xFFFE)
+        e = lm[t, :len(m)].astype(np.int64)                              # entry = slot * 64 + ((slot >> 2) & 3) * 16
+        assert (lm[t, len(m):] == NONE).all()                            # rows beyond the level in the last tile
+        assert np.array_equal(e == NONE, m < 0)
+        inside = (m >= 0) & (e < NONE)
+        slot = e[inside] >> 6
+        assert np.array_equal(e[inside] & 63, ((slot >> 2) & 3) << 4)    # the row's read swizzle rides in bits 4-5
+        assert np.array_equal(w[slot], m[inside])                        # the slot holds exactly the neighbour's row
+        out = (m >= 0) & (e == OUT)
         assert np.isin(m[out], want[k:]).all()                          # only rows beyond the capacity are left outside
         outside += int(out.sum())
         pairs += int((m >= 0).sum())
@@ -105,10 +108,13 @@ def test_conv_win_matches_conv_hl_and_float64(cuda, built_lib, cin, cout, n, ts,
                         out=out, out_hl=True, res_hl=True, **kw)
         return plain, ME.from_hl(out)
 
-    got = run(win=win)
-    prev = ME.set_option("win", 0)
+    prev = ME.set_option("win", 1)
     try:
+        got = run(win=win)
+        ME.set_option("win", 0)
         want = run(win=win)              # the switch off: the same call takes the mask-sorted / split kernels
+        ME.set_option("win", 1)
+        again = run(win=win)
     finally:
         ME.set_option("win", prev)
     nb = nbr.cpu().numpy()
@@ -118,12 +124,11 @@ def test_conv_win_matches_conv_hl_and_float64(cuda, built_lib, cin, cout, n, ts,
         assert float((g - h).abs().max()) < tol
         assert np.abs(g.cpu().numpy() - r).max() < tol
     assert float(got[0].abs().max()) > 0.1
-    again = run(win=win)
     assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])          # the same bits on every run
 
 
 def test_program_forward_on_windows_matches_mask_sorted_program(cuda, built_lib):
-    """The fused network with the fine levels on neighbour windows (the default) against the same program with the option
+    """The fused network with the fine levels on neighbour windows (option "win" on) against the same program with the option
     off (mask-sorted conv_hl / conv_hd + finish launches): per-point outputs agree within the north_star tolerance; the
     plan built windows for exactly the levels cv_net_win_levels names and no mask orders there."""
     from canonicalvoting_amd.minkunet import MinkUNet34C
@@ -133,18 +138,19 @@ def test_program_forward_on_windows_matches_mask_sorted_program(cuda, built_lib)
     f = torch.from_numpy((sc.feats * 2 - 1).astype(np.float32)).to(cuda)
     torch.manual_seed(0)
     model = MinkUNet34C(3, 64).to(cuda).eval()
-    with torch.no_grad():
-        x = ME.SparseTensor(f, c4, device=cuda)
-        y_win = model.program_forward(x).F
-        plan = x.coordinate_manager.fused_fast(5, 3)
-        assert [p is not None for p in plan.win_ptrs] == [True, plan.counts[1] >= ME.CoordinateManager.MASKED_MIN_ROWS, False, False, False]
-        assert plan.perm_ptrs[0] is None
-        prev = ME.set_option("win", 0)
-        try:
+    prev = ME.set_option("win", 1)
+    try:
+        with torch.no_grad():
+            x = ME.SparseTensor(f, c4, device=cuda)
+            y_win = model.program_forward(x).F
+            plan = x.coordinate_manager.fused_fast(5, 3)
+            assert [p is not None for p in plan.win_ptrs] == [True, plan.counts[1] >= ME.CoordinateManager.MASKED_MIN_ROWS, False, False, False]
+            assert plan.perm_ptrs[0] is None
+            ME.set_option("win", 0)
             x2 = ME.SparseTensor(f, c4, device=cuda)
             y_old = model.program_forward(x2).F
             assert all(p is None for p in x2.coordinate_manager.fused_fast(5, 0).win_ptrs)
-        finally:
-            ME.set_option("win", prev)
+    finally:
+        ME.set_option("win", prev)
     assert float((y_win - y_old).abs().max()) < 1e-4 * max(1.0, float(y_old.abs().max()))
     assert float(y_old.abs().max()) > 1e-3
