@@ -64,8 +64,10 @@ def parse():
     ap.add_argument("--points", type=int, default=N_POINTS)
     ap.add_argument("--algo", type=int, default=0, help="vote algorithm: 0 auto, 1 direct, 2 tiles")
     ap.add_argument("--cpu-scenes", type=int, default=1, help="scenes timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--cpu-reps", type=int, default=3, help="all-thread repetitions of the CPU oracle after one warm-up "
-                                                            "(best is reported)")
+    ap.add_argument("--cpu-reps", type=int, default=None,
+                    help="repetitions of the CPU oracle at its best torch thread count (after a warm-up and one run per "
+                         "thread count; best is reported).  Default 3, or 1 with WORLD_SIZE > 1 - the other ranks wait "
+                         "for rank 0 behind the final barrier")
     ap.add_argument("--stage", default="full", choices=["vote_decode", "full"],
                     help="full = MinkUNet34C forward + head + vote + decode + NMS (eval_joint.py path)")
     ap.add_argument("--min-warm-seconds", type=float, default=1.5,
@@ -93,6 +95,16 @@ def parse():
                     help="scene thread i takes its first timed step i x this many microseconds after the clock started: scenes that "
                          "start together stay in the same stage (all in the convolutions, then all in the vote) and share the chip "
                          "worse than scenes a fraction of a scene apart")
+    ap.add_argument("--measure-traffic", type=int, default=-1,
+                    help="roofline.traffic from the PMC counters IN this run (rank 0, single process, default 80k workload): "
+                         "two child runs of `bench.py --stage vote_decode` under rocprofv3 (--kernel-trace --pmc FETCH_SIZE, "
+                         "then WRITE_SIZE: separate passes), after the timed region.  -1 = when rocprofv3 is on PATH; 0 = "
+                         "never (the value of profiles/r*/vote_hbm_traffic.json is reported, labelled as read from a file)")
+    ap.add_argument("--tail-priority", type=int, default=0,
+                    help="the last N steps of the timed region run on high-priority HIP streams (one per scene thread, "
+                         "hipStreamCreateWithPriority): the scenes that start last have the most work left when the ticket "
+                         "counter runs out, so favouring them shortens the drain of a short region (longest remaining work "
+                         "first); fill and drain stay inside the timed region, results are bit-identical.  0 = off")
     ap.add_argument("--mode", default="eval", choices=["eval", "train", "separate"],
                     help="eval (default, the BASELINE metric): eval_joint.py path.  train: train_joint.py step "
                          "(fwd + bwd + Adam, fp32) on --train-batch scenes per GPU-step, DDP gradient all-reduce over "
@@ -104,9 +116,9 @@ def parse():
                          "bf16, one product, fp32 accumulation and storage (BASELINE configs 3-4 name bf16 for "
                          "training; outside the 1e-4 parity bar, reported as dtype bf16)")
     ap.add_argument("--train-batch", type=int, default=3, help="scenes per GPU-step in --mode train (config.yaml:15)")
-    ap.add_argument("--train-steps", type=int, default=5,
+    ap.add_argument("--train-steps", type=int, default=None,
                     help="eval mode, rank 0: train_joint.py steps timed AFTER the timed region for the `train_step_ms` side "
-                         "field (0 = skip)")
+                         "field (0 = skip).  Default 5, or 0 with WORLD_SIZE > 1")
     ap.add_argument("--sync-bn", action="store_true", help="--mode train: BatchNorm statistics over all ranks' rows "
                                                            "(the reference's batch-of-3 semantics under scene-parallel DDP)")
     ap.add_argument("--large", action="store_true",
@@ -153,7 +165,66 @@ def check_world(a):
     if a.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (launch with python -m torch.distributed.run "
                          "--nproc-per-node %d ... bench.py --gpus %d)" % (a.gpus, world, a.gpus, a.gpus))
+    # rank 0's side legs run while the other ranks idle: a cheap tail on a multi-GPU launch unless the caller asks otherwise
+    if a.cpu_reps is None:
+        a.cpu_reps = 3 if world == 1 else 1
+    if a.train_steps is None:
+        a.train_steps = 5 if world == 1 else 0
     return world, rank, local
+
+
+def measure_vote_traffic(a):
+    """HBM bytes per launch of hv_fwd_tiles from the PMC counters, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
+    WRITE_SIZE in SEPARATE rocprofv3 passes with --kernel-trace only; FETCH_SIZE (KB) doubled (gfx950 tallies the 128-byte
+    requests of a wide coalesced read at 64 B), WRITE_SIZE taken as is.  Returns (bytes per launch, description) or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None or os.environ.get("CV_BENCH_CHILD"):
+        return None
+    vals = {}
+    env = dict(os.environ, CV_BENCH_CHILD="1", TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="cv_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "--output-format", "csv", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--streams", "1", "--stage", "vote_decode", "--steps", "6", "--warmup", "2",
+                   "--cpu-scenes", "0", "--train-steps", "0", "--measure-traffic", "0", "--points", str(a.points),
+                   "--algo", str(a.algo)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                 if "hv_fwd_tiles" in row["Kernel_Name"] and row["Counter_Name"] == counter]
+            if not v:
+                return None
+            vals[counter] = (sum(v) / len(v), len(v))
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    f, w = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+    return (2.0 * f[0] + w[0]) * 1024.0, ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in two "
+                                          "separate child passes of `bench.py --streams 1 --stage vote_decode` (%d / %d launches of "
+                                          "hv_fwd_tiles); FETCH_SIZE %.0f KB doubled (gfx950 wide-read correction), WRITE_SIZE %.0f KB "
+                                          "as is" % (f[1], w[1], f[0], w[0]))
+
+
+def collective_info():
+    """what aligned the timed region: backend of the process group (None for a single process without one) and whether
+    librccl is mapped into this process"""
+    import torch.distributed as tdist
+    backend = tdist.get_backend() if tdist.is_initialized() else None
+    try:
+        rccl = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln})
+    except OSError:
+        rccl = []
+    return {"backend": backend, "world_size": tdist.get_world_size() if tdist.is_initialized() else 1,
+            "librccl_mapped": bool(rccl), "librccl": rccl[:1]}
 
 
 class ResidentScene:
@@ -331,19 +402,30 @@ def cpu_baseline(a, scenes, model, hv, full, teacher):
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()} if full else None
     s = scenes[0]
     nthreads = torch.get_num_threads()
-    runs, ref = [], None
-    for rep in range(a.cpu_reps + 1):                 # first one is the warm-up
-        t, ref = cpu_oracle_scene(s, sd, full, teacher)
-        if rep > 0 or a.cpu_reps == 0:
-            runs.append(t)
-    best = min(runs, key=lambda t: t["total"])
+    # torch-CPU thread sweep ("128 cores" ran 2.2 x slower than one thread - oversubscription of the oracle's many
+    # small ops): one run per thread count after one warm-up, then --cpu-reps - 1 more at the best count; `cores` = the count
+    # that gave the best time, the one-thread figure stays beside it
+    sweep = sorted({t for t in ((1, 8, 16, 32, nthreads) if a.cpu_reps > 1 else (1, 16)) if t <= nthreads}) if full else [1]
+    by_threads, ref = {}, None
     one = None
-    if full:
-        torch.set_num_threads(1)
-        try:
-            one, _ = cpu_oracle_scene(s, sd, full, teacher)
-        finally:
-            torch.set_num_threads(nthreads)
+    try:
+        torch.set_num_threads(min(8, nthreads))
+        _, ref = cpu_oracle_scene(s, sd, full, teacher)          # warm-up (code paths, allocator)
+        for t_n in sweep:
+            torch.set_num_threads(t_n)
+            t, ref = cpu_oracle_scene(s, sd, full, teacher)
+            by_threads[t_n] = [t]
+        best_n = min(by_threads, key=lambda n_: by_threads[n_][0]["total"])
+        torch.set_num_threads(best_n)
+        for _ in range(max(0, a.cpu_reps - 1)):
+            t, ref = cpu_oracle_scene(s, sd, full, teacher)
+            by_threads[best_n].append(t)
+    finally:
+        torch.set_num_threads(nthreads)
+    runs = [t for v in by_threads.values() for t in v]
+    best = min(by_threads[best_n], key=lambda t: t["total"])
+    if full and 1 in by_threads:
+        one = by_threads[1][0]
     keep = {}
     run_step(model, hv, s, teacher=teacher, keep=keep)
     torch.cuda.synchronize()
@@ -358,16 +440,18 @@ def cpu_baseline(a, scenes, model, hv, full, teacher):
     corner, _, _ = oracle.grid_geometry(sc.points, RES)
     dec_ref = oracle.decode(*[t.cpu().numpy() for t in keep["grids"]], corner, RES, sc.points, hx, hp, hc)
     par = parity_flags(keep, ref, s, dec_ref)
-    base = {"value": 1.0 / best["total"], "unit": "scenes/s", "cores": nthreads if full else 1, "kind": "port",
+    base = {"value": 1.0 / best["total"], "unit": "scenes/s", "cores": best_n if full else 1, "kind": "port",
+            "host_threads_available": nthreads,
+            "thread_sweep_s": {str(n_): round(min(t["total"] for t in v), 4) for n_, v in sorted(by_threads.items())},
             "stage_s": {k: round(v, 4) for k, v in best.items()},
             "one_thread": None if one is None else {"value": 1.0 / one["total"], "cores": 1,
                                                     "stage_s": {k: round(v, 4) for k, v in one.items()}},
-            "sample": "1 of the same %d-point scenes through the CPU oracle (%s): 1 warm-up + best of %d, %.1f s of CPU "
-                      "work in total; build CPU oracle, not reference code (the reference has no CPU vote and "
-                      "MinkowskiEngine is absent)"
-                      % (a.points, "torch-CPU sparse MinkUNet34C on all host threads + C vote/decode/NMS on 1 thread"
-                         if full else "C vote/decode/NMS, 1 thread", a.cpu_reps,
-                         sum(t["total"] for t in runs) + (one["total"] if one else 0.0))}
+            "sample": "1 of the same %d-point scenes through the CPU oracle (%s): 1 warm-up, one run per torch thread count %s, "
+                      "best of %d at the best count (%d threads), %.1f s of CPU work in total; build CPU oracle, not reference "
+                      "code (the reference has no CPU vote and MinkowskiEngine is absent)"
+                      % (a.points, "torch-CPU sparse MinkUNet34C + C vote/decode/NMS on 1 thread"
+                         if full else "C vote/decode/NMS, 1 thread", sweep, len(by_threads[best_n]), best_n,
+                         sum(t["total"] for t in runs))}
     return base, par
 
 
@@ -597,8 +681,10 @@ def main():
     global ADAPTIVE_SPLIT
     ADAPTIVE_SPLIT = bool(a.adaptive_split) and a.split_target < 0 and a.scene_call == "c"
     streams = [torch.cuda.Stream(dev) for _ in range(S)]
+    # (N < 0: the last -N steps on LOW-priority streams instead - oldest scene first at the drain)
+    hi_streams = [torch.cuda.Stream(dev, priority=-1 if a.tail_priority > 0 else 1) for _ in range(S)] if a.tail_priority != 0 else None
     hvs = [hv] + [HoughVoting(RES, NUM_ROTS) for _ in range(S - 1)]
-    hv_cuda.reserve_pinned(4 * S + 8)
+    hv_cuda.reserve_pinned((8 if hi_streams else 4) * S + 8)
 
     import itertools
     import threading
@@ -633,6 +719,12 @@ def main():
                     for j in range(len(scenes)):
                         run_step(model, hvs[i], scenes[(j + i) % len(scenes)], teacher=teacher)
                         warm_steps[i] += 1
+                if hi_streams is not None:                  # the priority stream of this thread: its scratch, pools and pinned buffers
+                    with torch.cuda.stream(hi_streams[i]):
+                        for j in range(len(scenes)):
+                            run_step(model, hvs[i], scenes[(j + i) % len(scenes)], teacher=teacher)
+                            warm_steps[i] += 1
+                    hi_streams[i].synchronize()
                 warm_gate.wait()
                 j = i
                 while time.perf_counter() - warm_t0 < a.min_warm_seconds:
@@ -651,10 +743,16 @@ def main():
                     if k >= a.steps:
                         break
                     ts = time.perf_counter()
-                    dets, _ = run_step(model, hvs[i], scenes[k % len(scenes)], events[k], teacher)
+                    if hi_streams is not None and k >= a.steps - abs(a.tail_priority):
+                        with torch.cuda.stream(hi_streams[i]):
+                            dets, _ = run_step(model, hvs[i], scenes[k % len(scenes)], events[k], teacher)
+                    else:
+                        dets, _ = run_step(model, hvs[i], scenes[k % len(scenes)], events[k], teacher)
                     step_log[k] = (i, ts, time.perf_counter())
                     counts[i] += len(dets)
                 streams[i].synchronize()
+                if hi_streams is not None:
+                    hi_streams[i].synchronize()
         except BaseException as e:      # a dead worker must not leave the others parked on a barrier
             errors.append(e)
             warm_gate.abort()
@@ -700,6 +798,7 @@ def main():
                   file=sys.stderr)
     dt = cvd.reduce_scalar(dt, "max", dev)
     torch.cuda.synchronize()
+    coll = collective_info()
 
     def stage_times(evs, stat=np.mean):
         return {"net": float(stat([e[0].elapsed_time(e[1]) for e in evs])),
@@ -751,7 +850,12 @@ def main():
     # HBM bytes of the vote kernel from the PMC counters are collected offline (rocprofv3 --pmc in its
     # own passes, profiles/r*/vote_hbm_traffic.json) for the default 80k workload; null otherwise
     traffic = traffic_source = None
-    for rnd in ("r4", "r3", "r2", "r1"):
+    default_workload = a.points == N_POINTS and not a.large and a.algo in (0, 2)
+    if rank == 0 and world == 1 and a.measure_traffic != 0 and default_workload:
+        m = measure_vote_traffic(a)
+        if m is not None:
+            traffic, traffic_source = m
+    for rnd in (() if traffic is not None else ("r5", "r4", "r3", "r2", "r1")):
         tj = os.path.join(ROOT, "profiles", rnd, "vote_hbm_traffic.json")
         if os.path.exists(tj) and a.points == N_POINTS and not a.large and a.algo in (0, 2):
             traffic = json.load(open(tj))["hbm_bytes_per_launch"]
@@ -785,7 +889,7 @@ def main():
                                   if teacher else "network output (random init: no cell reaches thresh_high)",
                    "points": a.points, "num_rots": NUM_ROTS, "res": RES, "grid": s0.dims,
                    "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}.get(a.algo, "ablation-%d" % a.algo),
-                   "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": S,
+                   "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": S, "tail_priority_steps": a.tail_priority,
                    "conv_split_target": "adaptive: 512 below four scenes in flight, 256 from four on" if ADAPTIVE_SPLIT else (split_target or 512),
                    **({"ablate": a.ablate, "INVALID": "timing ablation: results are wrong, not a reportable number"} if a.ablate else {})},
         "roofline": {"bound": "hbm",
@@ -831,6 +935,7 @@ def main():
                     "achieved counts only existing (input,output) pairs, sum 2*P*Cin*Cout over the 63 conv layers, "
                     "against the %s matrix peak" % ("bf16" if a.dtype == "bf16" else "fp32")},
         "detections_per_scene": n_det / a.steps,
+        "collective": coll,
         "stage_ms": stage_ms,
         "stage_ms_median": stage_times(events, np.median),
         "stage_ms_isolated": iso_stage,

@@ -1382,7 +1382,9 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
         CV_LAUNCH_CHECK();
         return CV_OK;
     }
-    CV_REQUIRE(d_ws && ws_bytes >= cv_hv_forward_workspace_bytes(n, num_rots, dims, 2), CV_ENOMEM,
+    // (sized by the SAME algo value that decides the launch shape below: ablation algo 23 takes the streaming launch on
+    // grids where algo 2 would take the work queue, and the two carve different workspaces)
+    CV_REQUIRE(d_ws && ws_bytes >= cv_hv_forward_workspace_bytes(n, num_rots, dims, algo == 23 ? 23 : 2), CV_ENOMEM,
                "workspace too small for the tiles algorithm");
     const int Y = dims[1];
     CvCarver cv(d_ws);

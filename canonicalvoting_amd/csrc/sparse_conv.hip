@@ -2955,6 +2955,10 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
     const bool vec = (d->cin % KC == 0) && (d->in_ld % 4 == 0) && (d->cout % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(d->in) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(d->weight) & 15) == 0);
+    // packed weights are only read by the vector path: without it the launch would fall back to `weight` - which a caller
+    // that packed W^T straight from the forward weights (cv_sp_pack_weights_t_f32) holds in the OTHER layout
+    CV_REQUIRE(!d->weight_x6 || vec || stem_h2, CV_EINVAL,
+               "weight_x6 needs the vector path: Cin %% 32 == 0, Cout %% 4 == 0, in_ld %% 4 == 0, 16-byte aligned in / weight");
     if (d->in2) {
         CV_REQUIRE(vec && d->weight_x6 && d->weight2_x6 && d->cin2 > 0 && d->cin2 % KC == 0 && d->in2_ld >= d->cin2 &&
                        d->in2_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->in2) & 15) == 0,

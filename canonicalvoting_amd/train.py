@@ -87,6 +87,13 @@ def train_step(model, optimizer, coords4, feats, xyz_labels, scale_labels, class
         loss.backward()
         return loss, parts
 
+    # the fp16-pair forward (opt-in) may have to be redone: keep the BatchNorm running statistics of before the step, so that
+    # the redo does not count the batch twice (one momentum update and one num_batches_tracked increment per iteration, as
+    # train_joint.py:250-283 gives)
+    bn_state = None
+    if ME.TRAIN_FWD_PIECES == 2:
+        bn_state = [(b, b.clone()) for m in model.modules() for b in (getattr(m, "running_mean", None), getattr(m, "running_var", None),
+                                                                       getattr(m, "num_batches_tracked", None)) if b is not None]
     with ME.pair_scale_hints(model):
         loss, parts = fwd_bwd()
     if ME.training_forward_left_fp16_range(feats.device):
@@ -94,6 +101,10 @@ def train_step(model, optimizer, coords4, feats, xyz_labels, scale_labels, class
         # redone on the bf16 triples before the optimizer sees a gradient
         prev, ME.TRAIN_FWD_PIECES = ME.TRAIN_FWD_PIECES, 3
         try:
+            if bn_state is not None:
+                with torch.no_grad():
+                    for b, saved in bn_state:
+                        b.copy_(saved)
             loss, parts = fwd_bwd()
         finally:
             ME.TRAIN_FWD_PIECES = prev
