@@ -32,7 +32,8 @@ static void scene_maps_layout(const long long* rows, long long n_orig, int stem_
     size_t off = 0;
     auto take = [&](size_t words) { const size_t at = off; off += cv_align_up(words, 64); return (long long)at; };
     const size_t K5 = (size_t)stem_k * stem_k * stem_k;
-    const size_t mp_w = mask_groups > 1 ? (size_t)mask_groups * (1 + (27 + mask_groups - 1) / mask_groups) : 0;
+    // orders [groups][rows] + map rows in processing order [groups][rows][W] + validity bytes [groups][rows] (1/4 word each)
+    const size_t mp_w = mask_groups > 1 ? (size_t)mask_groups * (1 + (27 + mask_groups - 1) / mask_groups) + (mask_groups + 3) / 4 : 0;
     // what depends on the caller's row count only comes first: cv_sp_scene_plan builds it before the coarse counts are known
     o->stem = take((size_t)rows[0] * K5);
     o->k3[0] = take((size_t)rows[0] * 27);
@@ -278,7 +279,10 @@ int cv_net_win_levels(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, i
                         (o.in2_buf < 0 || (o.cin2 % 32 == 0 && o.weight2_x6));
         (ok ? yes : no) |= 1 << o.perm;
     }
-    return yes & ~no;
+    long long lv = 31;
+    cv_sp_set_option("win_levels", 31, &lv);    // (read the mask: set it back)
+    cv_sp_set_option("win_levels", lv, nullptr);
+    return yes & ~no & (int)lv;
 }
 
 int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int n_bufs, const long long* level_rows,

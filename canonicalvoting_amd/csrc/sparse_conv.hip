@@ -955,6 +955,7 @@ __launch_bounds__(NW * 64, hl_blocks(NB, NS, NW)) void conv_hl(ConvArgs a) {
     }
     __syncthreads();
     const int n_units = __builtin_amdgcn_readfirstlane((int)units_s[HL_MAX_UNITS]);
+    if (n_units == 0 && a.gvalid) return;            // no row of the tile has a neighbour in this group: nothing to write (zskip)
 
     f32x16 acc[NB];
 #pragma unroll
@@ -1338,6 +1339,7 @@ __global__ __launch_bounds__(NW * 64, (hd_blocks(NB, NW, NSTG) * NW + 3) / 4) vo
     }
     __syncthreads();
     const int n_units = (CV_HD_ABL & 8) ? 0 : __builtin_amdgcn_readfirstlane((int)units_s[HL_MAX_UNITS]);      // (8: no unit loop)
+    if (n_units == 0 && a.gvalid && !(CV_HD_ABL & 8)) return;     // no row of the tile has a neighbour in this group (zskip)
 
     f32x16 acc[NB];
 #pragma unroll
@@ -2088,11 +2090,12 @@ __global__ __launch_bounds__(256) void conv_finish_small(ConvArgs a) {
     const int cq = a.cout >> 2;
     for (long long e4 = blockIdx.x * 256ll + threadIdx.x; e4 < total4; e4 += (long long)gridDim.x * 256) {
         const float4* p = reinterpret_cast<const float4*>(a.partial) + e4;
+        const long long row = e4 / cq;
         float4 pv[FINISH_SMALL_MAX];
 #pragma unroll
-        for (int k = 0; k < FINISH_SMALL_MAX; ++k)
-            pv[k] = k < a.splits ? partial_load4(p + (long long)k * total4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const long long row = e4 / cq;
+        for (int k = 0; k < FINISH_SMALL_MAX; ++k)          // (a.gvalid: partial tiles of rows without a neighbour in group k were never written)
+            pv[k] = (k < a.splits && (!a.gvalid || a.gvalid[(long long)k * a.n_out + row]))
+                        ? partial_load4(p + (long long)k * total4) : make_float4(0.f, 0.f, 0.f, 0.f);
         const int col = (int)(e4 - row * cq) * 4;
         float4 sq[4];
 #pragma unroll
@@ -2222,6 +2225,9 @@ __global__ __launch_bounds__(MP_BINS) void mp_scan(int* __restrict__ hist) {   /
 __global__ __launch_bounds__(MP_THREADS) void mp_scatter(const int* __restrict__ nbr, long long n, int K, int groups,
                                                          int* __restrict__ cursor, int* __restrict__ perm,
                                                          int* __restrict__ nbrp, int W) {
+    // with the map rows (nbrp): behind them, one byte per (group, row) - does the row have a neighbour in the group at all?
+    // (27 % of the rows of a scan have none below / above them: their partial sums are never written nor read, zskip)
+    unsigned char* gv = nbrp ? reinterpret_cast<unsigned char*>(nbrp + (long long)groups * n * W) : nullptr;
     __shared__ int lh[MP_BINS];
     const int g = blockIdx.y;
     const int jb = K * g / groups, je = K * (g + 1) / groups;
@@ -2240,8 +2246,10 @@ __global__ __launch_bounds__(MP_THREADS) void mp_scatter(const int* __restrict__
     if (row < n) {
         const long long pos = (long long)g * n + lh[key] + rank;
         perm[pos] = (int)row;
-        if (nbrp)
+        if (nbrp) {
             for (int j = jb; j < je; ++j) nbrp[pos * W + (j - jb)] = nbr[row * K + j];
+            gv[(long long)g * n + row] = key != 0;
+        }
     }
 }
 
@@ -2297,8 +2305,10 @@ __global__ __launch_bounds__(MP_THREADS) void mp_scatter_batch(const PermJobsDev
     if (row < jb.n) {
         const long long pos = (long long)g * jb.n + lh[key] + rank;
         jb.perm[pos] = (int)row;
-        if (nbrp)
+        if (nbrp) {
             for (int j = jlo; j < jhi; ++j) nbrp[pos * W + (j - jlo)] = jb.nbr[row * K + j];
+            reinterpret_cast<unsigned char*>(nbrp + (long long)jb.groups * jb.n * W)[(long long)g * jb.n + row] = key != 0;
+        }
     }
 }
 
@@ -2648,6 +2658,11 @@ __global__ __launch_bounds__(256) void head_separate(const float* __restrict__ f
 // defaults (profiles/r4/hd2_grid.txt, hd_shapes.txt): the 96-column fine-level launches (>= 16384 rows) on conv_hd, 8 waves x 2 ring
 // stages: 558 -> 573 scenes/s with eight scenes in flight (528 -> 575 under the one-call scene path); 32- and 64-column
 // launches and the coarse levels stay on conv_hl (conv_hd measured slower there)
+// zskip (round 5, OFF: measured slower, profiles/r5/zskip_ab.txt - 570 against 577 scenes/s seven in flight, 332 against 337 one
+// at a time): 27 % of a scan's rows have no neighbour in the first / last mask group; with the switch on their tiles write no
+// partial tile and the finish launch reads none for such (group, row) pairs - the three validity bytes a finish thread then
+// loads cost more than the zeros it no longer streams
+std::atomic<long long> g_opt_zskip{getenv("CV_ZSKIP") ? atoll(getenv("CV_ZSKIP")) : 0};
 std::atomic<long long> g_opt_hd_mask{getenv("CV_HD") ? atoll(getenv("CV_HD")) : 4};
 std::atomic<long long> g_opt_hd_min_rows{getenv("CV_HD_MIN_ROWS") ? atoll(getenv("CV_HD_MIN_ROWS")) : 16384};
 std::atomic<long long> g_opt_hd_shape{getenv("CV_HD_SHAPE") ? atoll(getenv("CV_HD_SHAPE")) : 2};      // 0: 8 waves x 3 stages, 1: 4 x 2, 2: 8 x 2
@@ -2835,8 +2850,8 @@ int cv_sp_set_option(const char* name, long long value, long long* previous) {
     CV_REQUIRE(name, CV_EINVAL, "null option name");
     if (cvsc::win_option(name, value, previous)) return CV_OK;
     std::atomic<long long>* o = !strcmp(name, "hd_mask") ? &g_opt_hd_mask : !strcmp(name, "hd_min_rows") ? &g_opt_hd_min_rows :
-                                !strcmp(name, "hd_shape") ? &g_opt_hd_shape : nullptr;
-    CV_REQUIRE(o, CV_EINVAL, "unknown option '%s' (hd_mask, hd_min_rows, hd_shape, win, win_xcd)", name);
+                                !strcmp(name, "hd_shape") ? &g_opt_hd_shape : !strcmp(name, "zskip") ? &g_opt_zskip : nullptr;
+    CV_REQUIRE(o, CV_EINVAL, "unknown option '%s' (hd_mask, hd_min_rows, hd_shape, zskip, win, win_xcd, win_levels)", name);
     const long long before = o->exchange(value, std::memory_order_relaxed);
     if (previous) *previous = before;
     return CV_OK;
@@ -3006,6 +3021,11 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         if (d->perm_has_map && jb == 0 && je == d->K && d->nbr) {
             a.nbr_perm = d->row_perm + (long long)d->perm_groups * d->n_out;
             a.nbr_perm_w = (d->K + d->perm_groups - 1) / d->perm_groups;
+            // zskip: tiles whose rows have no neighbour in their group write no partial tile and the finish launch does not read
+            // one (the validity bytes sit behind the map rows).  Not with a second source (its chunks are dealt to the groups:
+            // every row gets a sum from them) and only where conv_finish_small finishes.
+            if (g_opt_zskip.load(std::memory_order_relaxed) && !d->in2 && a.wide && d->perm_groups <= FINISH_SMALL_MAX && d->in_hl)
+                a.gvalid = reinterpret_cast<const unsigned char*>(a.nbr_perm + (long long)d->perm_groups * d->n_out * a.nbr_perm_w);
         }
         // Chain of group launches (CV_GROUP_CHAIN=1, round-3 experiment): group 0 writes its sums to the workspace, every
         // later group adds its own to what it reads back (acc_in, same thread, same element: in place), the last one runs
@@ -3021,6 +3041,7 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
                 ag.perm_per_split = 0;
                 ag.partial = nullptr;
                 ag.tickets = nullptr;
+                ag.gvalid = nullptr;                 // (every launch of the chain writes every row)
                 ag.j_begin = jb + (int)((long long)nj * g / G);
                 ag.j_end = jb + (int)((long long)nj * (g + 1) / G);
                 ag.row_perm = d->row_perm + (long long)g * d->n_out;

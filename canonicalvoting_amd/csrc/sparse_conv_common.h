@@ -49,6 +49,8 @@ struct ConvArgs {
     int xcd_tiles;               // conv_rows_wp / conv_hl: XCD-aware tile numbering (xcd_tile)
     int* tickets;                // conv_hl split-K: arrival counters per output tile (zero; the last arriver reduces, see there)
     const int* win;              // conv_win: the window block of the kernel map (cv_sp_build_windows), see sparse_win.hip
+    const unsigned char* gvalid; // mask groups: [splits][n_out] 1 = the row has a neighbour in the group; tiles without any write no
+                                 // partial tile and conv_finish_small reads none for such (group, row) pairs (NULL: off)
 };
 
 // ---- hl format: activations stored as the fp16 pairs the matrix cores multiply --------------------------------------
@@ -295,28 +297,6 @@ __device__ __forceinline__ void hd_read_frags(unsigned aa0, unsigned aa1, unsign
     }
 }
 
-// the weight fragments alone (A fragments already in registers)
-template <int NB>
-__device__ __forceinline__ void hd_read_b(unsigned ab, u32x4v (&B0)[NB], u32x4v (&B1)[NB]) {
-    constexpr int P1 = NB * 32 * 64;
-    if constexpr (NB == 1) {
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(B0[0]), "=&v"(B1[0]) : "v"(ab), "i"(P1) : "memory");
-    } else if constexpr (NB == 2) {
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\t"
-                     "ds_read_b128 %3, %4 offset:%7\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(B0[0]), "=&v"(B1[0]), "=&v"(B0[1]), "=&v"(B1[1])
-                     : "v"(ab), "i"(P1), "i"(2048), "i"(P1 + 2048) : "memory");
-    } else {
-        static_assert(NB == 3, "32, 64 or 96 columns per workgroup");
-        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:%7\n\tds_read_b128 %2, %6 offset:%8\n\t"
-                     "ds_read_b128 %3, %6 offset:%9\n\tds_read_b128 %4, %6 offset:%10\n\tds_read_b128 %5, %6 offset:%11\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(B0[0]), "=&v"(B1[0]), "=&v"(B0[1]), "=&v"(B1[1]), "=&v"(B0[2]), "=&v"(B1[2])
-                     : "v"(ab), "i"(P1), "i"(2048), "i"(P1 + 2048), "i"(4096), "i"(P1 + 4096) : "memory");
-    }
-}
-
 // ---- across the two translation units
 int launch_finish(const ConvArgs& a, hipStream_t st);                  // sparse_conv.hip: reduce the partial tiles + epilogue
 int nb_full(int cout);                                                 // sparse_conv.hip
@@ -324,4 +304,5 @@ bool win_eligible(const ConvArgs& a);                                  // sparse
 int launch_win(const ConvArgs& a, hipStream_t st);                     // sparse_win.hip
 bool win_option(const char* name, long long value, long long* previous);   // sparse_win.hip: "win", "win_xcd" of cv_sp_set_option
 bool win_enabled();
+int win_level_mask();                                                  // option "win_levels": levels that may take windows
 }  // namespace cvsc

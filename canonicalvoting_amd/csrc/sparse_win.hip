@@ -562,6 +562,7 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
 // 80 us against 63 us per 96 -> 96 layer at tensor stride 2, 161 us against 93 us at stride 1 (313 tiles on 256 CUs: two rounds)
 std::atomic<long long> g_win_on{getenv("CV_WIN") ? atoll(getenv("CV_WIN")) : 0};
 std::atomic<long long> g_win_xcd{getenv("CV_WIN_XCD") ? atoll(getenv("CV_WIN_XCD")) : 1};
+std::atomic<long long> g_win_levels{getenv("CV_WIN_LEVELS") ? atoll(getenv("CV_WIN_LEVELS")) : 31};      // levels that may take windows
 
 size_t win_lds_bytes(long long n) { return (size_t)((n + 31) / 32) * 6 + 64; }
 
@@ -570,13 +571,15 @@ size_t win_lds_bytes(long long n) { return (size_t)((n + 31) / 32) * 6 + 64; }
 namespace cvsc {
 
 bool win_option(const char* name, long long value, long long* previous) {
-    std::atomic<long long>* o = !strcmp(name, "win") ? &g_win_on : !strcmp(name, "win_xcd") ? &g_win_xcd : nullptr;
+    std::atomic<long long>* o = !strcmp(name, "win") ? &g_win_on : !strcmp(name, "win_xcd") ? &g_win_xcd :
+                                !strcmp(name, "win_levels") ? &g_win_levels : nullptr;
     if (!o) return false;
     const long long before = o->exchange(value, std::memory_order_relaxed);
     if (previous) *previous = before;
     return true;
 }
 bool win_enabled() { return g_win_on.load(std::memory_order_relaxed) != 0; }
+int win_level_mask() { return (int)g_win_levels.load(std::memory_order_relaxed); }
 
 bool win_eligible(const ConvArgs& a) {
     return a.win && a.in_hl && a.K == 27 && a.j_begin == 0 && a.j_end == 27 && a.nbr && a.n_in == a.n_out && a.wp6 &&

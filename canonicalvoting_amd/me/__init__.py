@@ -583,7 +583,8 @@ def _perms_with_map(nbr, groups):
     L = _lib.lib()
     n, K = nbr.shape
     W = (K + groups - 1) // groups
-    flat = torch.empty(groups * n * (1 + W), dtype=torch.int32, device=nbr.device)
+    # orders, the map rows in processing order, then one validity byte per (group, row) (cv_sp_mask_perms with_map = 1)
+    flat = torch.empty(groups * n * (1 + W) + (groups * n + 3) // 4, dtype=torch.int32, device=nbr.device)
     ws = torch.empty(groups * 4096, dtype=torch.uint8, device=nbr.device)
     with torch.cuda.device(nbr.device):
         _lib.check(L.cv_sp_mask_perms(_ptr(nbr), n, K, groups, _ptr(flat), _ptr(ws), ws.numel(), 1,

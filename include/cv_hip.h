@@ -401,7 +401,7 @@ int cv_sp_mask_keys(const int32_t* d_nbr, long long n, int K, int j_begin, int j
 
 /* d_perm[groups][n]: for each contiguous group of the K kernel offsets, the rows ordered by the bit
  * mask of their valid neighbours in that group (counting sort; at most 10 offsets per group).
- * d_ws: groups * 4096 bytes.  with_map = 1: d_perm holds groups*n*(1 + W) words, W = ceil(K/groups); after the
+ * d_ws: groups * 4096 bytes.  with_map = 1: d_perm holds groups*n*(1 + W) + ceil(groups*n/4) words, W = ceil(K/groups); after the
  * orders come the kernel map rows of every group in processing order, [groups][n][W]
  * (cv_conv_desc.perm_has_map).  Asynchronous. */
 int cv_sp_mask_perms(const int32_t* d_nbr, long long n, int K, int groups, int32_t* d_perm, void* d_ws,
