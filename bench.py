@@ -183,7 +183,9 @@ def measure_vote_traffic(a):
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3")
-    if exe is None or os.environ.get("CV_BENCH_CHILD"):
+    # not from inside a profiler run (this process is already a rocprofv3 child: the tool libraries are in its environment)
+    if exe is None or os.environ.get("CV_BENCH_CHILD") or any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB",
+                                                                                          "ROCPROF_OUTPUT_PATH")):
         return None
     vals = {}
     env = dict(os.environ, CV_BENCH_CHILD="1", TMPDIR="/tmp")

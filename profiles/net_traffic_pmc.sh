@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 # (--train-steps 0: round 3's number was wrong by 10x because the windows between the last stem launches held the
 # training steps of the `train_step_ms` side field, whose kernels also carry "conv_" in their names)
-CMD="python $R/bench.py --streams 1 --steps 6 --warmup 2 --cpu-scenes 0 --train-steps 0"
+CMD="python $R/bench.py --streams 1 --steps 6 --warmup 2 --cpu-scenes 0 --train-steps 0 --measure-traffic 0"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/nt_$c
   timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/nt_$c --output-format csv -- $CMD > /dev/null 2>&1

@@ -1,8 +1,8 @@
 # HBM traffic of the vote kernel from the PMC counters: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (with --kernel-trace
 # only), per launch of hv_fwd_tiles; gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE (KB) counts half of a wide
-# coalesced read stream -> doubled; WRITE_SIZE taken as is.  Writes gpurun_out/vote_pmc/vote_hbm_traffic.json (copied to profiles/r4/) (bench.py reads it).
+# coalesced read stream -> doubled; WRITE_SIZE taken as is.  Writes gpurun_out/vote_pmc/vote_hbm_traffic.json (copied to profiles/r5/) (bench.py reads it).
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-CMD="python $R/bench.py --streams 1 --stage vote_decode --steps 10 --warmup 2 --cpu-scenes 0"
+CMD="python $R/bench.py --streams 1 --stage vote_decode --steps 10 --warmup 2 --cpu-scenes 0 --measure-traffic 0"
 rm -rf /tmp/vp_f /tmp/vp_w
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/vp_f --output-format csv -- $CMD > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/vp_w --output-format csv -- $CMD > /dev/null 2>&1
@@ -20,7 +20,7 @@ out = {"kernel": "hv_fwd_tiles<0>", "workload": "80k-point scene, bench.py --str
        "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "launches": [nf, nw],
        "correction": "gfx950: FETCH_SIZE reads 1/2 of a wide coalesced stream (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE uncalibrated, taken as is",
        "hbm_bytes_per_launch": (2 * f + w) * 1024.0,
-       "source": ["profiles/r4/vote_pmc_fetch_size.csv", "profiles/r4/vote_pmc_write_size.csv"],
+       "source": ["profiles/r5/vote_pmc_fetch_size.csv", "profiles/r5/vote_pmc_write_size.csv"],
        "collected": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/vote_pmc.sh)"}
 json.dump(out, open("gpurun_out/vote_pmc/vote_hbm_traffic.json", "w"), indent=1)
 print(json.dumps(out))

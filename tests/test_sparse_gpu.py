@@ -801,3 +801,37 @@ def test_conv_hd_is_bit_identical_to_conv_hl(cuda, built_lib, cin, cout, n, mask
             assert torch.equal(a, b), "conv_hd (run %d) differs from conv_hl: %d of %d elements, max %g" % (
                 k, int((a != b).sum()), a.numel(), float((a - b).abs().max()))
     assert float(want[0].abs().max()) > 0.1
+
+
+def test_zskip_leaves_every_bit_in_place(cuda, built_lib):
+    """Option "zskip" (off by default: measured slower): tiles whose rows have no neighbour in their mask group write no partial
+    tile and conv_finish_small reads none for such (group, row) pairs - the sums are the same bits, with and without a
+    residual / ReLU / hl epilogue, on conv_hd and conv_hl."""
+    coords, _ = scene_coords(5, 40000, small=False)
+    N = len(coords)
+    rng = np.random.default_rng(11)
+    t = lambda a: torch.from_numpy(a).to(cuda)
+    cm = ME.CoordinateManager(torch.from_numpy(coords).to(cuda, torch.int32))
+    nbr, perms = cm.kernel_map(3, 1), cm.mask_perms(3, 1, 3)
+    assert float((nbr.view(N, 3, 9) >= 0).any(2).float().mean()) < 0.95           # some (row, group) pairs ARE empty
+    for cin, cout in ((96, 96), (32, 32)):
+        x = ME.to_hl(t(rng.normal(0, 1, (N, cin)).astype(np.float32)))
+        w = t((rng.normal(0, 1, (27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32))
+        res = ME.to_hl(t(rng.normal(0, 1, (N, cout)).astype(np.float32)))
+        shift = t(rng.normal(0, 0.2, cout).astype(np.float32))
+
+        def run():
+            plain = ME.conv_forward_masked(x, w, nbr, perms, N, pieces=2, in_hl=True)
+            out = torch.empty((N, cout), device=cuda)
+            ME.conv_forward_masked(x, w, nbr, perms, N, pieces=2, in_hl=True, shift=shift, residual=res, relu=True, out=out,
+                                   out_hl=True, res_hl=True)
+            return plain, out
+
+        prev = ME.set_option("zskip", 0)
+        try:
+            want = run()
+            ME.set_option("zskip", 1)
+            got = run()
+        finally:
+            ME.set_option("zskip", prev)
+        assert torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])
