@@ -191,3 +191,34 @@ def test_compiled_hv_cuda_extension_loads_and_checks_its_inputs(built_lib):
     assert inspect.ismodule(hv_cuda_ext.install()) and __import__("hv_cuda") is m
     import sys
     del sys.modules["hv_cuda"]
+
+
+def test_window_levels_of_a_program(built_lib):
+    """cv_net_win_levels (host only): a level takes neighbour windows when ALL its mask-grouped 3x3x3 ops are hl-format,
+    fp16-pair, Cout 32 / 64 / 96 - and only while the option "win" is on (off by default: DESIGN.md 4.3)."""
+    import ctypes
+    L = _lib.lib()
+    hl, fp32 = _lib.NetBuf(0, 96, 0, 1), _lib.NetBuf(0, 96, 0, 0)
+
+    def op(cin, cout, perm, in_buf=0, K=27, groups=3, pieces=2, in2=-1, cin2=0):
+        return _lib.NetOp(in_buf=in_buf, in_col=0, cin=cin, out_buf=0, out_col=0, cout=cout, res_buf=-1, res_col=0, map=5, K=K,
+                          perm=perm, perm_groups=groups, relu=1, weight=None, scale=None, shift=None, weight_x6=1,
+                          in2_buf=in2, in2_col=0, cin2=cin2, weight2_x6=1 if in2 >= 0 else None, weight_pieces=pieces, acc_scale=1.0)
+
+    bufs = (_lib.NetBuf * 2)(hl, fp32)
+    ops = [op(96, 96, 0), op(128, 96, 0, in2=0, cin2=128), op(32, 32, 1), op(64, 64, 2), op(128, 128, 2),     # level 2: one op too wide
+           op(96, 96, 3, in_buf=1), op(96, 96, 4, pieces=3), op(32, 32, 1, K=8, groups=1)]                      # fp32 input; bf16 triples; a k2s2 op does not count
+    c_ops = (_lib.NetOp * len(ops))(*ops)
+    prev = ctypes.c_longlong(0)
+    assert L.cv_sp_set_option(b"win", 0, ctypes.byref(prev)) == 0
+    try:
+        assert L.cv_net_win_levels(c_ops, len(ops), bufs, 2) == 0                  # the switch is off
+        L.cv_sp_set_option(b"win", 1, None)
+        assert L.cv_net_win_levels(c_ops, len(ops), bufs, 2) == 0b00011
+        lv = ctypes.c_longlong(0)
+        L.cv_sp_set_option(b"win_levels", 2, ctypes.byref(lv))
+        assert L.cv_net_win_levels(c_ops, len(ops), bufs, 2) == 0b00010
+        L.cv_sp_set_option(b"win_levels", lv.value, None)
+    finally:
+        L.cv_sp_set_option(b"win", prev.value, None)
+    assert L.cv_sp_set_option(b"no_such_knob", 1, None) != 0
