@@ -336,16 +336,6 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
     const unsigned b_src = (unsigned)((bt_pl * a.cout + bt_nb * 32 + (lane >> 1)) * 32 + (((lane & 1) ^ ((lane >> 5) & 1)) << 3));
     const unsigned slab_words = 2u * (unsigned)a.cout * 32u;
     const bool has_w = wave < B_INSTR;
-    // instruction i of this wave's share of the window of half chunk h.  ALWAYS one instruction (rows beyond the window - and a
-    // whole half chunk beyond the last, `dummy` - fetch the line of zeros): the counted waits know the queue at compile time
-    auto issue_win = [&](int h, int i, bool dummy) {
-        if (CV_WIN_ABL & 1) dummy = true;
-        const unsigned char* g = (!dummy && woff[i] != 0xFFFFFFFFu)
-                                     ? in_b + ((size_t)woff[i] + (size_t)((h >> 1) * 128 + (h & 1) * 32) + w_piece)
-                                     : g_zero_chunk + w_piece;
-        lds_dma16(g, lds + (h & 1) * WBUF + (wave + NW * i) * 1024);
-    };
-
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)lds;
     const unsigned b_rd = lds0 + (unsigned)(OFF_B + l31 * 32) + (unsigned)((half ^ ((l31 >> 4) & 1)) << 4);
     const long long my_row = row0 + my_t;
@@ -444,7 +434,6 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
         }
     };
     typedef std::integral_constant<int, 0> I0;
-    typedef std::integral_constant<int, 1> I1;
     // ---- prologue: the window of half chunk 0, the weight tiles of the first three steps
     {
         const bool dummy = CV_WIN_ABL & 1;
