@@ -23,7 +23,12 @@ def sorted_manager(cuda, coords4):
     return cm.fused_plan()[0]
 
 
-def scene(seed, n, dense=False):
+def scene(seed, n, dense=False, batch=1):
+    if batch > 1:   # several scans in one tensor (batch index in column 0, as the training collate does)
+        return np.concatenate([np.concatenate([np.full((n, 1), b, np.int64), scene(seed + b, n)[:, 1:]], 1) for b in range(batch)])
+    if n >= 200000:  # BASELINE config 5 shaped: a 9 x 3 x 9 m room
+        sc = make_scene(seed, n_points=n, room=(9.0, 3.0, 9.0), n_boxes=40)
+        return np.concatenate([np.zeros((n, 1), np.int64), sc.coords], 1)
     if dense:       # a solid block: every voxel has all 27 neighbours, windows overflow their capacity
         side = int(round(n ** (1 / 3)))
         g = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3)
@@ -42,10 +47,11 @@ def split_windows(win, n):
     return rows, lm.transpose(0, 2, 1)                                   # [tile][row][offset]
 
 
-@pytest.mark.parametrize("seed,n,ts,dense", [(0, 700, 1, False), (1, 40000, 1, False), (2, 40000, 2, False),
-                                              (3, 8000, 1, True), (4, 80000, 1, False)])
-def test_window_plan_resolves_every_map_entry(cuda, built_lib, seed, n, ts, dense):
-    cm = sorted_manager(cuda, scene(seed, n, dense))
+@pytest.mark.parametrize("seed,n,ts,dense,batch", [(0, 700, 1, False, 1), (1, 40000, 1, False, 1), (2, 40000, 2, False, 1),
+                                                    (3, 8000, 1, True, 1), (4, 80000, 1, False, 1), (5, 20000, 1, False, 3),
+                                                    (6, 300000, 1, False, 1), (6, 300000, 4, False, 1)])
+def test_window_plan_resolves_every_map_entry(cuda, built_lib, seed, n, ts, dense, batch):
+    cm = sorted_manager(cuda, scene(seed, n, dense, batch))
     nbr = cm.kernel_map(3, ts).cpu().numpy()
     N = nbr.shape[0]
     rows, lm = split_windows(cm.windows(ts), N)
@@ -81,14 +87,16 @@ def reference_f64(x, w, nbr, scale, shift, res, relu):
     return np.maximum(y, 0) if relu else y
 
 
-@pytest.mark.parametrize("cin,cout,n,ts,dense", [(96, 96, 40000, 1, False), (128, 96, 30000, 1, False), (32, 32, 40000, 2, False),
-                                                  (64, 64, 20000, 1, False), (96, 96, 300, 1, False), (32, 96, 17001, 1, False),
-                                                  (96, 96, 8000, 1, True), (32, 32, 4096, 1, True)])
-def test_conv_win_matches_conv_hl_and_float64(cuda, built_lib, cin, cout, n, ts, dense):
+@pytest.mark.parametrize("cin,cout,n,ts,dense,batch", [(96, 96, 40000, 1, False, 1), (128, 96, 30000, 1, False, 1),
+                                                        (32, 32, 40000, 2, False, 1), (64, 64, 20000, 1, False, 1),
+                                                        (96, 96, 300, 1, False, 1), (32, 96, 17001, 1, False, 1),
+                                                        (96, 96, 8000, 1, True, 1), (32, 32, 4096, 1, True, 1),
+                                                        (96, 96, 15000, 1, False, 3), (96, 96, 300000, 1, False, 1)])
+def test_conv_win_matches_conv_hl_and_float64(cuda, built_lib, cin, cout, n, ts, dense, batch):
     """conv_win against the mask-sorted kernels on the same hl operands (plain output; folded affine + hl residual + ReLU +
     hl output), ragged last tiles, a tile count below the XCD remap, and a solid block whose windows overflow (the pairs
     outside the window come through the extra units)."""
-    cm = sorted_manager(cuda, scene(cin + cout, n, dense))
+    cm = sorted_manager(cuda, scene(cin + cout, n, dense, batch))
     nbr = cm.kernel_map(3, ts)
     N = nbr.shape[0]
     rng = np.random.default_rng(cin + 3 * cout + n)
@@ -118,11 +126,13 @@ def test_conv_win_matches_conv_hl_and_float64(cuda, built_lib, cin, cout, n, ts,
     finally:
         ME.set_option("win", prev)
     nb = nbr.cpu().numpy()
-    ref = (reference_f64(x, w, nb, None, None, None, False), reference_f64(x, w, nb, scale, shift, res, True))
+    # (the float64 gather-matmul of the 300k-point case would take minutes of numpy: there the mask-sorted kernels are the check)
+    ref = (reference_f64(x, w, nb, None, None, None, False), reference_f64(x, w, nb, scale, shift, res, True)) if N <= 100000 \
+        else (None, None)
     for g, h, r in zip(got, want, ref):
-        tol = 1e-5 * max(1.0, float(np.abs(r).max()))
+        tol = 1e-5 * max(1.0, float(h.abs().max()))
         assert float((g - h).abs().max()) < tol
-        assert np.abs(g.cpu().numpy() - r).max() < tol
+        assert r is None or np.abs(g.cpu().numpy() - r).max() < tol
     assert float(got[0].abs().max()) > 0.1
     assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1])          # the same bits on every run
 
