@@ -137,6 +137,7 @@ SIGNATURES = {
     "cv_sp_set_split_target_thread": (ctypes.c_int, [ctypes.c_int]),
     "cv_sp_set_ablation": (ctypes.c_int, [ctypes.c_int]),
     "cv_sp_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
+    "cv_sp_get_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong)]),
     "cv_sp_pack_weights_x6_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     "cv_sp_pack_weights_h2_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
     "cv_sp_pack_weights_bf16_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),

@@ -49,6 +49,7 @@ struct ConvArgs {
     int xcd_tiles;               // conv_rows_wp / conv_hl: XCD-aware tile numbering (xcd_tile)
     int* tickets;                // conv_hl split-K: arrival counters per output tile (zero; the last arriver reduces, see there)
     const int* win;              // conv_win: the window block of the kernel map (cv_sp_build_windows), see sparse_win.hip
+    int gfuse;                   // conv_hd mask groups: 1 = the last group's workgroups sum the partial tiles (tickets[0..1]), no finish launch
     const unsigned char* gvalid; // mask groups: [splits][n_out] 1 = the row has a neighbour in the group; tiles without any write no
                                  // partial tile and conv_finish_small reads none for such (group, row) pairs (NULL: off)
 };
@@ -302,7 +303,8 @@ int launch_finish(const ConvArgs& a, hipStream_t st);                  // sparse
 int nb_full(int cout);                                                 // sparse_conv.hip
 bool win_eligible(const ConvArgs& a);                                  // sparse_win.hip: conv_win takes this launch
 int launch_win(const ConvArgs& a, hipStream_t st);                     // sparse_win.hip
-bool win_option(const char* name, long long value, long long* previous);   // sparse_win.hip: "win", "win_xcd" of cv_sp_set_option
+bool win_option(const char* name, long long value, long long* previous);
+bool win_option_get(const char* name, long long* value);                   // sparse_win.hip: the same knobs, read only   // sparse_win.hip: "win", "win_xcd" of cv_sp_set_option
 bool win_enabled();
 int win_level_mask();                                                  // option "win_levels": levels that may take windows
 }  // namespace cvsc

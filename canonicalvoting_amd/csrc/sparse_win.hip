@@ -567,6 +567,13 @@ bool win_option(const char* name, long long value, long long* previous) {
     if (previous) *previous = before;
     return true;
 }
+bool win_option_get(const char* name, long long* value) {
+    const std::atomic<long long>* o = !strcmp(name, "win") ? &g_win_on : !strcmp(name, "win_xcd") ? &g_win_xcd :
+                                      !strcmp(name, "win_levels") ? &g_win_levels : nullptr;
+    if (!o) return false;
+    *value = o->load(std::memory_order_relaxed);
+    return true;
+}
 bool win_enabled() { return g_win_on.load(std::memory_order_relaxed) != 0; }
 int win_level_mask() { return (int)g_win_levels.load(std::memory_order_relaxed); }
 

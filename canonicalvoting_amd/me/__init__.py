@@ -540,9 +540,9 @@ def set_option(name, value):
 
 def option(name):
     """current value of a cv_sp_set_option knob"""
-    v = set_option(name, 0)
-    set_option(name, v)
-    return v
+    v = ctypes.c_longlong(0)
+    _lib.check(_lib.lib().cv_sp_get_option(name.encode(), ctypes.byref(v)), "cv_sp_get_option")
+    return int(v.value)
 
 
 def to_hl(x):
