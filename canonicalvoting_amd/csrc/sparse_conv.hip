@@ -213,7 +213,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows(ConvArgs a) {
 // ------------------------------------------------------------------ fp32 products on the bf16 matrix cores
 // v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate, and wall-time ablations (profiles/conv_ablate.py) show the
 // fp32 MFMAs to be half of the conv time (ts1 96->96: 192 us, 95 us without them, gathers / weights / epilogue
-// each ~10 us) with the pipe only 60 % busy while they run.  conv_rows_x6 computes the SAME fp32 products on
+// each ~10 us) with the pipe only 60 % busy while they run.  The piece-product kernels compute the SAME fp32 products on
 // v_mfma_f32_32x32x16_bf16: every fp32 operand is split exactly into three bf16 pieces x = h + m + l (8 + 8 + 8
 // significant bits; the pieces of an operand sum to it to within half an fp32 ulp), and the six piece products whose
 // magnitude is >= 2^-16 of the full product (hh, hm, mh, mm, hl, lh) are accumulated in fp32 - bf16 x bf16 products
@@ -293,250 +293,6 @@ __global__ __launch_bounds__(256) void pack_weights_b1(const float* __restrict__
     }
 }
 
-// P = 3: bf16 triples, six piece products.  P = 2: fp16 pairs, three piece products (same tiles with two planes).
-// P = 1: operands rounded to bf16 (RNE), ONE bf16 x bf16 product with fp32 accumulation - the opt-in bf16 compute
-// mode of the training configuration (BASELINE configs 3-4); not an fp32-parity path.
-template <int NB, int P>
-__global__ __launch_bounds__(THREADS) void conv_rows_x6(ConvArgs a) {
-    // operand tiles and the epilogue tile share one buffer (the epilogue starts after the last MFMA)
-    constexpr int A_BYTES = P * TM * 64, B_BYTES = P * NB * 32 * 64, EP_BYTES = 4 * 32 * EP_LD * 4;
-    constexpr int SM_BYTES = A_BYTES + B_BYTES > EP_BYTES ? A_BYTES + B_BYTES : EP_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char sm[SM_BYTES];
-    __shared__ int nbr_s[TM];
-    __shared__ int rows_s[TM];
-    constexpr int NPRE = 8;
-    __shared__ int nbr_all[NPRE][TM];
-    unsigned char* const A_h = sm;                    // [plane][row][64 B]
-    unsigned char* const B_h = sm + A_BYTES;          // [plane][col][64 B]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.y * (NB * 32);
-
-    if (tid < TM) {
-        const long long tile_id = a.row_perm ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
-        const long long t = tile_id * TM + tid;
-        const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)blockIdx.z * a.n_out : 0) : nullptr;
-        rows_s[tid] = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
-    }
-    __syncthreads();
-
-    f32x16 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-
-    const int half = lane >> 5, l31 = lane & 31;
-    auto compute = [&]() {
-        const int arow = wave * 32 + l31;
-        const int aswz = (arow >> 2) & 3, bswz = (l31 >> 2) & 3;     // (nb*32 + l31) >> 2 & 3 == (l31 >> 2) & 3
-        bf16x8 av[P], bv[P];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = 2 * ks + half;
-            // ablation bits (CV_CONV_DBG): 128 = A fragments read once per unit, 64 = B fragments read once per unit
-            if (!(a.dbg & 128) || ks == 0)
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    av[p] = *reinterpret_cast<const bf16x8*>(A_h + (p * TM + arow) * 64 + ((chunk ^ aswz) << 4));
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                if (!(a.dbg & 64) || (ks == 0 && nb == 0))
-#pragma unroll
-                    for (int p = 0; p < P; ++p)
-                        bv[p] = *reinterpret_cast<const bf16x8*>(B_h + (p * NB * 32 + nb * 32 + l31) * 64 + ((chunk ^ bswz) << 4));
-                // smallest terms first
-                if constexpr (P == 1) {
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc[nb], 0, 0, 0);
-                } else if constexpr (P == 3) {
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[2], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[0], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[1], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[0], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc[nb], 0, 0, 0);
-                } else {
-                    const f16x8 a0 = __builtin_bit_cast(f16x8, av[0]), a1 = __builtin_bit_cast(f16x8, av[P - 1]);
-                    const f16x8 b0 = __builtin_bit_cast(f16x8, bv[0]), b1 = __builtin_bit_cast(f16x8, bv[P - 1]);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[nb], 0, 0, 0);
-                }
-            }
-        }
-    };
-
-    const int nj = a.j_end - a.j_begin;
-    // thread -> (row = tid/8 + 32*i, 4 channels at (tid%8)*4) : 8 lanes cover one 128 B row chunk
-    const int a_col = (tid & 7) * 4;
-    const int a_row = tid >> 3;                      // + 32*i, i = 0..3
-    constexpr int B_U4 = P * NB * 32 * 4;            // 16-byte pieces of the packed weight slab of one unit
-    constexpr int B_PER = (B_U4 + THREADS - 1) / THREADS;
-    const int nch = a.cin / KC;
-    int u_lo, u_hi;
-    if (a.perm_per_split) {
-        u_lo = (int)((long long)nj * blockIdx.z / a.splits) * nch;
-        u_hi = (int)((long long)nj * (blockIdx.z + 1) / a.splits) * nch;
-    } else {
-        u_lo = (int)((long long)nj * nch * blockIdx.z / a.splits);
-        u_hi = (int)((long long)nj * nch * (blockIdx.z + 1) / a.splits);
-    }
-    float4 ra[4];
-    uint4 rb[B_PER];
-    float in_max = 0.f;                              // fp16 pairs: largest staged input magnitude
-    auto load_b = [&](const unsigned short* slab) {
-#pragma unroll
-        for (int i = 0; i < B_PER; ++i) {
-            const int f = tid + i * THREADS;
-            if (f < B_U4) {
-                const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
-                const int col = rem >> 2, ch = rem & 3;
-                rb[i] = (n0 + col < a.cout && !(a.dbg & 4))
-                            ? *reinterpret_cast<const uint4*>(slab + ((long long)p * a.cout + n0 + col) * 32 + ch * 8)
-                            : make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
-    };
-    auto stage = [&]() {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = a_row + 32 * i;
-                unsigned h0 = 0, m0 = 0, l0 = 0, h1 = 0, m1 = 0, l1 = 0;
-                // channels a_col .. a_col+3 -> 8 bytes at offset (a_col & 7) * 2 of chunk a_col >> 3
-                unsigned char* dst = A_h + r * 64 + ((((a_col >> 3) ^ ((r >> 2) & 3))) << 4) + ((a_col & 7) << 1);
-                if constexpr (P == 1) {
-                    *reinterpret_cast<uint2*>(dst) = make_uint2(cvt_pk_bf16(ra[i].x, ra[i].y), cvt_pk_bf16(ra[i].z, ra[i].w));
-                } else if constexpr (P == 3) {
-                    if (!(a.dbg & 16)) {
-                        split3(ra[i].x, ra[i].y, h0, m0, l0);
-                        split3(ra[i].z, ra[i].w, h1, m1, l1);
-                    }
-                    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-                    *reinterpret_cast<uint2*>(dst + TM * 64) = make_uint2(m0, m1);
-                    *reinterpret_cast<uint2*>(dst + 2 * TM * 64) = make_uint2(l0, l1);
-                } else {
-                    in_max = fmaxf(fmaxf(in_max, fmaxf(fabsf(ra[i].x), fabsf(ra[i].y))), fmaxf(fabsf(ra[i].z), fabsf(ra[i].w)));
-                    if (!(a.dbg & 16)) {
-                        split2h(ra[i].x, ra[i].y, h0, l0);
-                        split2h(ra[i].z, ra[i].w, h1, l1);
-                    }
-                    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-                    *reinterpret_cast<uint2*>(dst + TM * 64) = make_uint2(l0, l1);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < B_PER; ++i) {
-                const int f = tid + i * THREADS;
-                if (f < B_U4) {
-                    const int p = f / (NB * 32 * 4), rem = f - p * (NB * 32 * 4);
-                    const int col = rem >> 2, ch = rem & 3;
-                    *reinterpret_cast<uint4*>(B_h + (p * NB * 32 + col) * 64 + ((ch ^ ((col >> 2) & 3)) << 4)) = rb[i];
-                }
-            }
-    };
-    const int j_first = a.j_begin + u_lo / nch, j_last = a.j_begin + (u_hi - 1) / nch;
-    // kernel-map entry of tile row t for offset j
-    auto map_entry = [&](int t, int j) {
-        const int row = rows_s[t];
-        if (row < 0) return -1;
-        if (a.nbr_perm) {
-            const long long tile_id = (long long)gridDim.x - 1 - blockIdx.x;
-            return a.nbr_perm[((long long)blockIdx.z * a.n_out + tile_id * TM + t) * a.nbr_perm_w +
-                              (j - (a.j_begin + (int)((long long)nj * blockIdx.z / a.splits)))];
-        }
-        return a.nbr ? a.nbr[(long long)row * a.K + j] : row;
-    };
-    // up to NPRE offsets per workgroup (mask groups, split-K ranges): all their map entries come in with ONE round of
-    // independent loads - a fetch per offset costs a global-memory latency per offset, dead offsets included
-    // (7 in a row for a mask group: about a third of the workgroup's lifetime once the MFMAs are cheap)
-    const int njl = u_hi > u_lo ? j_last - j_first + 1 : 0;
-    const bool pre = njl <= NPRE;
-    if (pre) {
-        for (int e = tid; e < njl * TM; e += THREADS) {
-            const int jj = e / TM, t = e - jj * TM;
-            nbr_all[jj][t] = map_entry(t, j_first + jj);
-        }
-        __syncthreads();
-    }
-    for (int j = j_first; j <= j_last && u_hi > u_lo; ++j) {
-        const int kc_begin = (j == j_first ? u_lo % nch : 0) * KC;
-        const int kc_end = (j == j_last ? (u_hi - 1) % nch + 1 : nch) * KC;
-        int my = -1;
-        if (tid < TM) {
-            my = pre ? nbr_all[j - j_first][tid] : map_entry(tid, j);
-            nbr_s[tid] = my;
-        }
-        if (!__syncthreads_or(my >= 0)) continue;    // nobody in the tile has this neighbour
-        const bool wave_live = __any(nbr_s[wave * 32 + l31] >= 0);
-        auto load = [&](int kc) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int src = nbr_s[a_row + 32 * i];
-                ra[i] = (src >= 0 && !(a.dbg & 2)) ? *reinterpret_cast<const float4*>(a.in + (long long)src * a.in_ld + kc + a_col)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            // packed slab of (j, chunk): [plane][cout][32 k] bf16; this workgroup's columns n0 .. n0 + NB*32
-            load_b(a.wp6 + (long long)(j * nch + kc / KC) * P * a.cout * 32);
-        };
-        load(kc_begin);
-        for (int kc = kc_begin; kc < kc_end; kc += KC) {
-            __syncthreads();                 // previous chunk's MFMAs are done with the LDS tiles
-            if (!(a.dbg & 32)) stage();
-            __syncthreads();
-            if (kc + KC < kc_end) load(kc + KC);  // in flight while the matrix cores run
-            if (wave_live && !(a.dbg & 1)) compute();
-        }
-        __syncthreads();
-    }
-    // second source (BasicBlock's 1x1 downsample branch folded into conv2: out += in2 @ W2 on the same rows): its
-    // 32-channel chunks are dealt round-robin to the offset splits / mask groups, whose partial sums add up anyway
-    if (a.in2) {
-        if (tid < TM) nbr_s[tid] = rows_s[tid];
-        __syncthreads();
-        const bool wave_live = __any(nbr_s[wave * 32 + l31] >= 0);
-        const int nch2 = a.cin2 / KC;
-        auto load2 = [&](int c2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int src = nbr_s[a_row + 32 * i];
-                ra[i] = src >= 0 ? *reinterpret_cast<const float4*>(a.in2 + (long long)src * a.in2_ld + c2 * KC + a_col)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            load_b(a.wp6_2 + (long long)c2 * P * a.cout * 32);
-        };
-        int c2 = blockIdx.z;
-        if (c2 < nch2) load2(c2);
-        for (; c2 < nch2; c2 += a.splits) {
-            __syncthreads();
-            stage();
-            __syncthreads();
-            if (c2 + a.splits < nch2) load2(c2 + a.splits);
-            if (wave_live) compute();
-        }
-        __syncthreads();
-    }
-    __syncthreads();                         // operand tiles are dead: the epilogue tile reuses their LDS
-    if constexpr (P == 2) {
-        // an input beyond the fp16 range makes h infinite: the caller is told and must redo the convolution on the
-        // bf16 triples (inputs that large do not occur behind BatchNorm; the flag makes that an observed fact)
-        if (in_max > 65000.f && a.range_flag) *a.range_flag = 1;
-        const float k = a.acc_scale;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] *= k;
-    }
-    float (*ep)[EP_LD] = reinterpret_cast<float (*)[EP_LD]>(sm + wave * 32 * EP_LD * 4);
-    if (a.dbg & 8) {
-        if (acc[0][0] == 123.456f) a.out[0] = 1.f;
-    } else if (a.wide) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) epilogue_store_wide(a, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep);
-    } else {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            epilogue_store(a, acc[nb], rows_s + wave * 32, n0 + nb * 32 + (lane & 31), lane);
-    }
-}
 
 // Tile of a workgroup.  a.xcd_tiles (CV_XCD_TILES=1, an experiment that is off by default; gridDim.x a multiple of 8): workgroups are dealt to the eight XCDs round-robin by
 // their linear id, so blockIdx.x % 8 is the XCD; XCD r takes the r-th eighth of the tiles.  Rows are in spatial order (or
@@ -548,17 +304,21 @@ __device__ __forceinline__ long long xcd_tile(const ConvArgs& a) {
     return a.row_perm ? (long long)gridDim.x - 1 - blockIdx.x : blockIdx.x;
 }
 
-// conv_rows_x6 with ONE workgroup barrier per (offset, 32-channel) unit instead of two plus two per offset.  The ablations
-// of conv_rows_x6 (profiles/r1/conv_ablate_h2.txt) left ~38 us of the 94 us ts1 96 -> 96 conv to the skeleton: ~56
-// workgroup barriers per workgroup at three workgroups per CU.  Two observations remove most of them:
+// Piece-product convolution on fp32 activations (the training path; the eval network reads the hl format: conv_hl / conv_hd).
+// P = 3: bf16 triples, six piece products.  P = 2: fp16 pairs, three piece products (same tiles with two planes).
+// P = 1: operands rounded to bf16 (RNE), ONE bf16 x bf16 product with fp32 accumulation - the opt-in bf16 compute
+// mode of the training configuration (BASELINE configs 3-4); not an fp32-parity path.
+// ONE workgroup barrier per (offset, 32-channel) unit (round 1's conv_rows_x6 - removed in round 5, git 2945191 holds it -
+// took two plus two per offset: ~56 barriers per workgroup, ~38 us of the 94 us ts1 96 -> 96 conv,
+// profiles/r1/conv_ablate_h2.txt).  Two observations remove most of them:
 //  * a wave's 32 rows are its own: it gathers, splits and stages exactly the A rows it multiplies, so the A tile needs
 //    wave-level ordering only (LDS operations of one wave execute in order);
 //  * the weight tile is shared, so it is double-buffered: the B planes of unit k+1 are written while slow waves may
 //    still multiply unit k out of the other buffer, and the single barrier of unit k+1 (B visible) is also the
 //    proof that everyone is done with unit k-1's buffer.
-// The map entries of all the workgroup's offsets (<= WP_NPRE = 10; the host falls back to conv_rows_x6 otherwise) come in
-// with one round of loads, a bit mask of the offsets that exist for the tile is reduced once, and dead offsets are
-// skipped without a barrier.  Same MFMA sequence per accumulator as conv_rows_x6: bit-identical results.
+// The map entries of all the workgroup's offsets (<= NPRE: 10 in the default instance - the host splits a launch further - and
+// 28 in the instance for unsplit 3x3x3 launches; beyond that the fp32 kernel conv_rows) come in with one round of loads, a bit mask of the offsets that exist for the
+// tile is reduced once, and dead offsets are skipped without a barrier.
 #ifndef CV_WP_ABL
 #define CV_WP_ABL 0       // timing ablations of conv_rows_wp (wrong results): 1 no fp16 split, 2 no MFMA, 4 no weight tile, 8 no gathers
 #endif
@@ -566,13 +326,14 @@ __device__ __forceinline__ long long xcd_tile(const ConvArgs& a) {
 #define CV_WP_NPRE 10
 #endif
 constexpr int WP_NPRE = CV_WP_NPRE;          // the traffic cap of pick_splits leaves 9 offsets per workgroup on the training ts8 level
-template <int NB, int P>
+constexpr int WP_NPRE_BIG = 28;              // the second instance: a whole 3x3x3 kernel in one workgroup (flavour 1, wide mask groups)
+template <int NB, int P, int NPRE = WP_NPRE>
 __global__ __launch_bounds__(THREADS, (NB >= 3 ? 3 : NB == 2 ? 4 : 5)) void conv_rows_wp(ConvArgs a) {
     constexpr int A_BYTES = P * TM * 64, B_BYTES = P * NB * 32 * 64, EP_BYTES = 4 * 32 * EP_LD * 4;
     constexpr int SM_BYTES = A_BYTES + 2 * B_BYTES > EP_BYTES ? A_BYTES + 2 * B_BYTES : EP_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char sm[SM_BYTES];
     __shared__ int rows_s[TM];
-    __shared__ int nbr_all[WP_NPRE + 1][TM];         // + the rows themselves: the "map" of the second source
+    __shared__ int nbr_all[NPRE + 1][TM];            // + the rows themselves: the "map" of the second source
     __shared__ unsigned live_mask;
     unsigned char* const A_h = sm;                    // [plane][row][64 B]
     unsigned char* const B_h = sm + A_BYTES;          // 2 x [plane][col][64 B]
@@ -2126,7 +1887,7 @@ struct WgradPlan {
 // X6: the 16 rows of a step group are ONE K = 16 bf16 MFMA group: the eight values a lane holds for the steps t = 0..7
 // (row 2t + half) are exactly its eight k slots (k = 8 * half + t, the same rows on the A and the B side), so the
 // fp32 operands are split into bf16 triples in registers and six piece products replace eight fp32 MFMAs per nb
-// (see conv_rows_x6; gradients keep the fp32 exponent range, which fp16 pairs would not).
+// (see conv_rows_wp; gradients keep the fp32 exponent range, which fp16 pairs would not).
 // NA x NB blocks of 32 x 32 per wave: a wave that owns NA input-channel blocks reads each dy row segment once for all
 // of them (and each x segment once for all NB output blocks).  With one input block per wave (the first version) a
 // 96 -> 96 convolution moved 1536 bytes per (input, output) pair from L2 for three tiles - the kernel ran at the L2
@@ -3031,9 +2792,6 @@ template <int NB>
 int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
     dim3 grid((unsigned)((a.n_out + TM - 1) / TM), (unsigned)((a.cout + NB * 32 - 1) / (NB * 32)),
               (unsigned)a.splits);
-    // one-barrier-per-unit kernel (CV_CONV_WP=0: conv_rows_x6 everywhere): no ablation switches, and every workgroup's
-    // offsets fit the map prefetch
-    static const bool wp_on = !(getenv("CV_CONV_WP") && atoi(getenv("CV_CONV_WP")) == 0);
     int per_wg = 0;                                  // most offsets one workgroup walks (the kernel's own formulas)
     if (vec) {
         const int nj_wp = a.j_end - a.j_begin, nch_wp = a.cin / KC;
@@ -3128,7 +2886,7 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         if (a.splits > 1) return launch_finish(a, st);
         return CV_OK;
     }
-    if (vec && a.wp6 && wp_on && !a.dbg && per_wg <= WP_NPRE) {
+    if (vec && a.wp6 && per_wg <= WP_NPRE) {
         if (a.pieces == 2) conv_rows_wp<NB, 2><<<gridx, THREADS, 0, st>>>(ax);
         else if (a.pieces == 1) conv_rows_wp<NB, 1><<<gridx, THREADS, 0, st>>>(ax);
         else conv_rows_wp<NB, 3><<<gridx, THREADS, 0, st>>>(ax);
@@ -3136,14 +2894,17 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         if (a.splits > 1) return launch_finish(a, st);
         return CV_OK;
     }
-    if (vec && a.wp6) {
-        if (a.pieces == 2) conv_rows_x6<NB, 2><<<grid, THREADS, 0, st>>>(a);
-        else if (a.pieces == 1) conv_rows_x6<NB, 1><<<grid, THREADS, 0, st>>>(a);
-        else conv_rows_x6<NB, 3><<<grid, THREADS, 0, st>>>(a);
+    // more offsets per workgroup than the default instance prefetches (flavour 1 with a whole 3x3x3 kernel, mask groups of > 10
+    // offsets): the instance that keeps 28 map rows per tile (more LDS, fewer workgroups per CU)
+    if (vec && a.wp6 && per_wg <= WP_NPRE_BIG) {
+        if (a.pieces == 2) conv_rows_wp<NB, 2, WP_NPRE_BIG><<<gridx, THREADS, 0, st>>>(ax);
+        else if (a.pieces == 1) conv_rows_wp<NB, 1, WP_NPRE_BIG><<<gridx, THREADS, 0, st>>>(ax);
+        else conv_rows_wp<NB, 3, WP_NPRE_BIG><<<gridx, THREADS, 0, st>>>(ax);
         CV_LAUNCH_CHECK();
         if (a.splits > 1) return launch_finish(a, st);
         return CV_OK;
     }
+    CV_REQUIRE(a.pieces != 1 || !(vec && a.wp6), CV_EINVAL, "the bf16 compute mode takes at most %d kernel offsets per workgroup", WP_NPRE_BIG);
     if (vec) conv_rows<NB, true><<<grid, THREADS, 0, st>>>(a);
     else conv_rows<NB, false><<<grid, THREADS, 0, st>>>(a);
     CV_LAUNCH_CHECK();
@@ -3334,10 +3095,6 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
                "weight_pieces = 2 needs weight_x6 from cv_sp_pack_weights_h2_f32 and Cin %% 32 == 0 (or the stem shape with "
                "cv_sp_pack_weights_stem_h2_f32)");
 
-    {
-        static const int dbg = getenv("CV_CONV_DBG") ? atoi(getenv("CV_CONV_DBG")) : 0;
-        a.dbg = dbg;
-    }
     if (!d->in_hl) a.tickets = nullptr;       // the in-launch split-K reduction exists in conv_hl only
     CV_REQUIRE(!d->plan_ent && !d->plan_cnt && !d->weight_packed && (d->flavour == 0 || d->flavour == 1), CV_EINVAL,
                "flavours 3 / 4 (the experimental wave / tile kernels of rounds 1-3) are gone: flavour is 0 or 1, plan_ent / plan_cnt / "
@@ -3445,10 +3202,10 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         }
     } else if (d->flavour == 0) {
         int sp = pick_splits(d->n_out, d->cout, je - jb, d->cin, vec);
-        if (d->in_hl) {
-            // conv_hl keeps the map entries of at most WP_NPRE offsets per workgroup (there is no second kernel for the hl
-            // format): launches that would not be split (>= 384 tiles below the mask-sorting threshold, e.g. 13k rows x
-            // 256 columns) are split over just enough workgroups
+        if (d->in_hl || (vec && a.wp6)) {
+            // conv_hl / conv_rows_wp keep the map entries of at most WP_NPRE offsets per workgroup: launches that would not
+            // be split (>= 384 tiles below the mask-sorting threshold, e.g. 13k rows x 256 columns) are split over just
+            // enough workgroups
             const int nj = je - jb;
             const int per_wg = sp <= 1 ? nj : (nj + sp - 1) / sp + 1;
             if (per_wg > WP_NPRE) sp = std::max(sp, (nj + WP_NPRE - 2) / (WP_NPRE - 1));
@@ -3504,7 +3261,7 @@ int cv_sp_mask_perms(const int32_t* d_nbr, long long n, int K, int groups, int32
 }
 
 // d_wp6[3*K*cin*cout] (16-bit words) = d_w[K][cin][cout] split into three bf16 pieces per value and laid out per
-// (offset, 32-channel chunk) as [piece][cout][32 channels] for conv_rows_x6 (cin % 32 == 0).  Redo when weights change.
+// (offset, 32-channel chunk) as [piece][cout][32 channels] for conv_rows_wp (cin % 32 == 0).  Redo when weights change.
 int cv_sp_pack_weights_x6_f32(const float* d_w, int K, int cin, int cout, const float* d_col_scale, void* d_wp6,
                               void* stream) {
     CV_REQUIRE(d_w && d_wp6 && K > 0 && cin > 0 && cout > 0, CV_EINVAL, "bad pack_weights_x6 arguments");

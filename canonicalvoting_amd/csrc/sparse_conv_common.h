@@ -37,9 +37,9 @@ struct ConvArgs {
     int wide;              // epilogue operands are 16-byte aligned with leading dimensions % 4 == 0: float4 row stores
     const int* nbr_perm;   // mask-sorted groups: [splits][n_out][nbr_perm_w] kernel map rows in processing order
     int nbr_perm_w;
-    int dbg;               // instrumented twin only (CV_CONV_DBG): 1 no MFMA, 2 no gathers, 4 no weight loads, 8 no epilogue
-    const unsigned short* wp6;   // weights split into bf16 pieces, see pack_weights_x6 (conv_rows_x6)
-    const float* in2;            // conv_rows_x6: second source on the output rows (out += in2 @ W2), or NULL
+    int reserved0;         // (was the switch of round 1's instrumented kernel)
+    const unsigned short* wp6;   // weights split into bf16 pieces, see pack_weights_x6
+    const float* in2;            // second source on the output rows (out += in2 @ W2), or NULL
     int in2_ld, cin2;
     const unsigned short* wp6_2;
     int pieces;                  // 3: wp6 holds bf16 triples (six piece products), 2: fp16 pairs (three piece products)

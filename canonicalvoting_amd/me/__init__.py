@@ -599,7 +599,7 @@ _packed = {}
 _packed_x6 = {}
 _packed_h2 = {}
 # 1 (default): vector-path convs run their fp32 products as six bf16 piece products on the bf16 matrix cores
-# (conv_rows_x6); 0: v_mfma_f32_32x32x2_f32
+# (conv_rows_wp); 0: v_mfma_f32_32x32x2_f32
 CONV_X6 = os.environ.get("CV_CONV_X6", "1") != "0"
 
 
@@ -619,7 +619,7 @@ def set_compute_dtype(dtype):
 
 
 def packed_weights_bf16(w3, col_scale=None):
-    """uncached: weights (times an optional per-output-column scale) rounded to bf16 in conv_rows_x6's layout"""
+    """uncached: weights (times an optional per-output-column scale) rounded to bf16 in conv_rows_wp's layout"""
     L = _lib.lib()
     K, cin, cout = w3.shape
     wp = torch.empty(w3.numel(), dtype=torch.int16, device=w3.device)
@@ -687,7 +687,7 @@ def packed_weights_stem_h2(w3, col_scale, scale_log2):
 
 
 def packed_weights_x6(weight, w3, cache=True):
-    """weights split into bf16 pieces for conv_rows_x6 (cv_sp_pack_weights_x6_f32), cached per parameter tensor and
+    """weights split into bf16 pieces for conv_rows_wp (cv_sp_pack_weights_x6_f32), cached per parameter tensor and
     re-packed when it is modified in place or re-allocated."""
     key = id(weight)
     ver = (weight.data_ptr(), weight._version, tuple(weight.shape))

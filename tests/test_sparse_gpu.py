@@ -624,7 +624,7 @@ def test_minkunet_edge_case_coordinate_sets(cuda, built_lib, case):
 
 
 def test_bf16x6_products_keep_fp32_accuracy(cuda, built_lib):
-    """conv_rows_x6 computes every fp32 product as six exact bf16 piece products: against a float64 reference its
+    """conv_rows_wp (bf16 triples) computes every fp32 product as six exact bf16 piece products: against a float64 reference its
     error must stay at fp32-rounding level, next to the fp32-MFMA kernel's own error on the same inputs (operands with
     a wide dynamic range, so the low pieces matter)."""
     coords, _ = scene_coords(41, 3000, small=False)
