@@ -2445,7 +2445,8 @@ __global__ __launch_bounds__(256) void affine_rows4(const float* __restrict__ x,
                                                     int x_ld, const float* __restrict__ scale,
                                                     const float* __restrict__ shift,
                                                     const float* __restrict__ residual, int res_ld, int relu,
-                                                    float* __restrict__ y, int y_ld) {
+                                                    float* __restrict__ y, int y_ld, float* __restrict__ y_hl = nullptr,
+                                                    int y_hl_ld = 0, int* __restrict__ range_flag = nullptr) {
     const int cq = c >> 2;
     for (long long t = blockIdx.x * 256ll + threadIdx.x; t < n * cq; t += (long long)gridDim.x * 256) {
         const long long r = t / cq;
@@ -2462,6 +2463,10 @@ __global__ __launch_bounds__(256) void affine_rows4(const float* __restrict__ x,
         }
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<float4*>(y + r * y_ld + k) = v;
+        if (y_hl) {                                  // the same values once more as the fp16 pairs the next convolution multiplies
+            if (range_flag && hl_out_of_range(v)) *range_flag = 1;
+            hl_store4(y_hl + r * y_hl_ld, k, v);
+        }
     }
 }
 
@@ -3506,6 +3511,22 @@ int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float
     else
         affine_rows<<<(unsigned)std::min<long long>((n * c + 255) / 256, 8192), 256, 0, st>>>(
             d_x, n, c, x_ld, d_scale, d_shift, d_residual, res_ld, relu, d_y, y_ld);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+int cv_sp_affine_hl_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale, const float* d_shift,
+                        const float* d_residual, int res_ld, int relu, float* d_y, int y_ld, float* d_y_hl, int y_hl_ld,
+                        int32_t* range_flag, void* stream) {
+    CV_REQUIRE(d_x && d_y && d_y_hl && n > 0 && c > 0 && x_ld >= c && y_ld >= c && y_hl_ld >= c, CV_EINVAL, "bad affine arguments");
+    CV_REQUIRE(!d_residual || res_ld >= c, CV_EINVAL, "bad residual stride");
+    CV_REQUIRE(c % 32 == 0 && y_hl_ld % 32 == 0 && (reinterpret_cast<uintptr_t>(d_y_hl) & 127) == 0, CV_EINVAL,
+               "hl-format output: channels and leading dimension %% 32 == 0, 128-byte aligned rows");
+    CV_REQUIRE(x_ld % 4 == 0 && y_ld % 4 == 0 && (!d_residual || res_ld % 4 == 0) && aligned16(d_x) && aligned16(d_y) &&
+                   aligned16(d_residual) && aligned16(d_scale) && aligned16(d_shift), CV_EINVAL,
+               "16-byte aligned operands with leading dimensions %% 4 == 0");
+    affine_rows4<<<(unsigned)std::min<long long>((n * (c / 4) + 255) / 256, 16384), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        d_x, n, c, x_ld, d_scale, d_shift, d_residual, res_ld, relu, d_y, y_ld, d_y_hl, y_hl_ld, range_flag);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

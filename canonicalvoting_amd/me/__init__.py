@@ -362,6 +362,7 @@ class SparseTensor:
             raise RuntimeError("canonicalvoting_amd SparseTensor runs on the GPU only (no CPU engine); "
                                "pass device='cuda'")
         self.F = features.to(device=device, dtype=torch.float32)
+        self.F_hl = None        # training forward: the same rows in the hl format (written by the producing BatchNorm pass)
         if coordinate_manager is None:
             if coordinates is None:
                 raise ValueError("coordinates or coordinate_manager required")
@@ -414,9 +415,11 @@ class SparseTensor:
             fs.append(Fm[m])
         return cs, fs
 
-    def _like(self, F, tensor_stride=None):
-        return SparseTensor(F, coordinate_manager=self.coordinate_manager,
-                            tensor_stride=self.tensor_stride if tensor_stride is None else tensor_stride)
+    def _like(self, F, tensor_stride=None, F_hl=None):
+        t = SparseTensor(F, coordinate_manager=self.coordinate_manager,
+                         tensor_stride=self.tensor_stride if tensor_stride is None else tensor_stride)
+        t.F_hl = F_hl
+        return t
 
 
 def _workspace(dev, nbytes):
@@ -822,14 +825,29 @@ def _gradient_untouched_until_end(kernel):
 
 
 TRAIN_FWD_PIECES = int(os.environ.get("CV_TRAIN_FWD_PIECES", "3"))      # 3 (default): bf16 triples; 2: fp16 pairs in the training forward (measured: no gain, profiles/r4/train_ab.txt)
+# 1 (default): the training forward's convolutions run on the eval path's hl-format kernels (conv_hl / conv_hd: fp16 pairs, operands
+# split once by the producing BatchNorm pass instead of once per gather) wherever the input has an hl twin; the range flag guards
+# it like TRAIN_FWD_PIECES = 2 (train.train_step redoes the step on the bf16 triples).  0: conv_rows_wp on the fp32 rows.
+TRAIN_FWD_HL = int(os.environ.get("CV_TRAIN_FWD_HL", "1"))
 _train_state = threading.local()
 
 
+def train_forward_hl():
+    return TRAIN_FWD_HL != 0 and COMPUTE_DTYPE != "bf16"
+
+
+def train_uses_pairs():
+    """the training forward multiplies fp16 pairs somewhere (range flag to check, weight scales to hand over)"""
+    return COMPUTE_DTYPE != "bf16" and (TRAIN_FWD_PIECES == 2 or TRAIN_FWD_HL != 0)
+
+
 class pair_scale_hints:
-    """power-of-two weight scales of the fp16-pair products for every convolution of `module`, from ONE multi-tensor
-    max-norm and ONE host read, valid inside the `with` block (a training step: the weights do not move between its forward
-    and its optimizer step).  Without it every fp16-pair convolution whose packed weights are not cached reads its own
-    maximum back (63 host waits per MinkUNet34C forward)."""
+    """power-of-two weight scales of the fp16-pair products for every convolution of `module`, valid inside the `with` block (a
+    training step: the weights do not move between its forward and its optimizer step).  Without it every fp16-pair convolution
+    whose packed weights are not cached reads its own maximum back (63 host waits per MinkUNet34C forward).
+    No host wait in the steady state: the max-norms (ONE multi-tensor launch) travel to pinned memory behind the step that
+    computed them and the NEXT step reads them - an optimizer step moves a weight maximum by a fraction of a percent and the scale
+    leaves a factor of 8 to the fp16 range.  The first step of a module (or a changed parameter list) waits once."""
 
     def __init__(self, module):
         self.module = module
@@ -838,17 +856,47 @@ class pair_scale_hints:
         self.outer = getattr(_train_state, "pair_scales", None)
         ks = [m.kernel for m in self.module.modules() if isinstance(m, MinkowskiConvolutionBase) and m.kernel.is_cuda]
         scales = {}
-        if ks and TRAIN_FWD_PIECES == 2 and COMPUTE_DTYPE != "bf16":
-            with torch.no_grad():
-                amax = torch.stack(torch._foreach_norm([k.detach() for k in ks], float("inf"))).tolist()
+        if ks and train_uses_pairs():
+            ptrs = tuple(k.data_ptr() for k in ks)
+            dev = ks[0].device
+            st = self.module.__dict__.get("_pair_scale_state")
+            if st is None or st["ptrs"] != ptrs:
+                st = self.module.__dict__["_pair_scale_state"] = {
+                    "ptrs": ptrs, "host": torch.empty(len(ks), dtype=torch.float32).pin_memory(), "event": None}
+                self._request(st, ks, dev)
+            st["event"].synchronize()                # (already passed in the steady state: it was recorded a step ago)
+            amax = st["host"].tolist()
+            self._request(st, ks, dev)               # for the next step
             for k, a in zip(ks, amax):
                 scales[k.data_ptr()] = (max(-60, min(60, 13 - math.ceil(math.log2(a)))) if (math.isfinite(a) and a > 0) else 0)
         _train_state.pair_scales = scales
         return self
 
+    @staticmethod
+    def _request(st, ks, dev):
+        with torch.no_grad():
+            amax = torch.stack(torch._foreach_norm([k.detach() for k in ks], float("inf")))
+            st["host"].copy_(amax, non_blocking=True)
+        st["event"] = torch.cuda.Event()
+        st["event"].record(torch.cuda.current_stream(dev))
+
     def __exit__(self, *exc):
         _train_state.pair_scales = self.outer
         return False
+
+
+def training_range_flag_device(dev):
+    """the range flag of this thread's stream as a float32 device scalar (1.0 = a training forward since the last reset left the
+    fp16 range), read in stream order behind the kernels that may raise it: hand it to a fused optimizer as `found_inf` and the
+    update is skipped on the device without a host wait (train.train_step).  None when no forward used the fp16 pairs."""
+    if not getattr(_train_state, "used_pairs", False):
+        return None
+    return range_flag(dev).to(dev, non_blocking=True).to(torch.float32).reshape(())
+
+
+def training_range_flag_peek(dev):
+    """the flag's current value without waiting for anything (kernels still in flight may raise it later)"""
+    return int(range_flag(dev)[0]) != 0
 
 
 def training_forward_left_fp16_range(dev):
@@ -871,7 +919,7 @@ class _ConvFn(torch.autograd.Function):
     transposed weights) and weight-gradient kernels."""
 
     @staticmethod
-    def forward(ctx, feats, kernel, bias, nbr, n_out):
+    def forward(ctx, feats, kernel, bias, nbr, n_out, feats_hl=None):
         feats = feats.contiguous()
         ctx.save_for_backward(feats, kernel, nbr if nbr is not None else torch.empty(0))
         ctx.has_nbr = nbr is not None
@@ -880,6 +928,10 @@ class _ConvFn(torch.autograd.Function):
         # fp32-level products of the training FORWARD: fp16 pairs (three piece products) while the activations are inside
         # the fp16 range - they sit behind BatchNorm - with the range flag as the guard (train.train_step reads it once per
         # step and redoes the step on the bf16 triples); the input gradient keeps the triples (gradients have no bound)
+        if feats_hl is not None and train_forward_hl() and feats.shape[1] % 32 == 0 and feats_hl.stride(0) % 32 == 0:
+            # the eval path's kernels on the hl twin (the fp32 rows stay saved for the weight gradient)
+            _train_state.used_pairs = True
+            return conv_forward(feats_hl, kernel, nbr, n_out, shift=shift, cache_weights=False, pieces=2, in_hl=True)
         pieces = None
         if TRAIN_FWD_PIECES == 2 and COMPUTE_DTYPE != "bf16" and feats.shape[1] % 32 == 0:
             pieces = 2
@@ -928,7 +980,7 @@ class _ConvFn(torch.autograd.Function):
             d_kernel = conv_wgrad(feats, grad, nbr, k3.shape[0]).reshape(kernel.shape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             d_bias = col_sum(grad).reshape(1, -1)
-        return d_feats, d_kernel, d_bias, None, None
+        return d_feats, d_kernel, d_bias, None, None, None
 
 
 class MinkowskiConvolutionBase(nn.Module):
@@ -974,7 +1026,7 @@ class MinkowskiConvolutionBase(nn.Module):
     def forward(self, x):
         nbr, ts_out = self._map(x)
         n_out = x.coordinate_manager.num_rows(ts_out)
-        F = _ConvFn.apply(x.F, self.kernel, self.bias, nbr, n_out)
+        F = _ConvFn.apply(x.F, self.kernel, self.bias, nbr, n_out, getattr(x, "F_hl", None))
         return x._like(F, ts_out)
 
     def extra_repr(self):
@@ -1003,11 +1055,19 @@ def bn_affine(bn):
     return out[0], out[1]
 
 
-def affine_forward(F, scale, shift, relu, out=None, residual=None):
+def affine_forward(F, scale, shift, relu, out=None, residual=None, out_hl=None):
+    """relu?(F * scale + shift + residual); out_hl: a second output in the hl format (cv_sp_affine_hl_f32)"""
     L = _lib.lib()
     dev = F.device
     if out is None:
         out = torch.empty_like(F)
+    if out_hl is not None:
+        with torch.cuda.device(dev):
+            _lib.check(L.cv_sp_affine_hl_f32(_ptr(F), F.shape[0], F.shape[1], F.stride(0), _ptr(scale), _ptr(shift),
+                                             _ptr(residual), residual.stride(0) if residual is not None else 0,
+                                             1 if relu else 0, _ptr(out), out.stride(0), _ptr(out_hl), out_hl.stride(0),
+                                             range_flag(dev).data_ptr(), _stream(dev)), "cv_sp_affine_hl_f32")
+        return out
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_affine_f32(_ptr(F), F.shape[0], F.shape[1], F.stride(0), _ptr(scale), _ptr(shift),
                                       _ptr(residual), residual.stride(0) if residual is not None else 0,
@@ -1021,7 +1081,7 @@ class _BNTrainFn(torch.autograd.Function):
     residual add and ReLU that follow it in BasicBlock folded into the same passes."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, want_hl=False):
         L = _lib.lib()
         x = x.contiguous()
         n, c = x.shape
@@ -1035,14 +1095,21 @@ class _BNTrainFn(torch.autograd.Function):
                                             _stream(dev)), "cv_sp_bn_stats_f32")
         if residual is not None and residual.stride(1) != 1:
             residual = residual.contiguous()
-        y = affine_forward(x, stats[2], stats[3], relu, residual=residual)
+        # want_hl: the output once more as fp16 pairs for the convolution that reads it (TRAIN_FWD_HL; c % 32 == 0)
+        y_hl = torch.empty_like(x) if want_hl else None
+        y = affine_forward(x, stats[2], stats[3], relu, residual=residual, out_hl=y_hl)
         ctx.save_for_backward(x, gamma, stats, y if relu else None)
         ctx.eps = float(eps)
         ctx.has_res = residual is not None
+        ctx.two = want_hl
+        if want_hl:
+            _train_state.used_pairs = True
+            ctx.mark_non_differentiable(y_hl)
+            return y, y_hl
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         L = _lib.lib()
         x, gamma, stats, y = ctx.saved_tensors
         dy = dy.contiguous()
@@ -1059,7 +1126,7 @@ class _BNTrainFn(torch.autograd.Function):
                                                _ptr(stats[1]), ctx.eps, _ptr(gamma), _ptr(dg[0]), _ptr(dg[1]),
                                                _ptr(dx), _ptr(dres) if y is not None else None, _ptr(ws), ws.numel(),
                                                _stream(dev)), "cv_sp_bn_backward_f32")
-        return dx, dg[0], dg[1], None, None, None, None, dres, None
+        return dx, dg[0], dg[1], None, None, None, None, dres, None, None
 
 
 # `num_batches_tracked += 1` of every BatchNorm of a training forward (62 one-element launches per MinkUNet34C step) as ONE
@@ -1104,6 +1171,12 @@ class MinkowskiBatchNorm(nn.Module):
             else:
                 with torch.no_grad():
                     bn.num_batches_tracked += 1
+            if relu and train_forward_hl() and x.F.shape[1] % 32 == 0:
+                # every convolution input of the network is the output of such a pass (or a concat of two): it leaves with
+                # its hl twin
+                y, y_hl = _BNTrainFn.apply(x.F, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                           residual, True, True)
+                return x._like(y, F_hl=y_hl)
             return x._like(_BNTrainFn.apply(x.F, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                             bn.momentum, bn.eps, residual, bool(relu)))
         if self.training or torch.is_grad_enabled() and (x.F.requires_grad or residual is not None and
@@ -1207,7 +1280,10 @@ def cat(*tensors):
     t0 = tensors[0]
     for t in tensors[1:]:
         assert t.coordinate_manager is t0.coordinate_manager and t.tensor_stride == t0.tensor_stride
-    return t0._like(torch.cat([t.F for t in tensors], dim=1))
+    hl = None
+    if all(getattr(t, "F_hl", None) is not None and t.F.shape[1] % 32 == 0 for t in tensors):
+        hl = torch.cat([t.F_hl for t in tensors], dim=1)       # 32-channel chunks keep their bytes: the concat of hl rows is hl
+    return t0._like(torch.cat([t.F for t in tensors], dim=1), F_hl=hl)
 
 
 from . import modules  # noqa: E402,F401

@@ -77,37 +77,77 @@ def separate_loss(out_feats, xyz_labels, scale_labels, obj_labels, coords4=None,
     return sum(losses.values()), losses
 
 
+def _skips_on_device(optimizer):
+    """a fused torch Adam / AdamW takes `found_inf` (what torch.cuda.amp.GradScaler hands it): the update is skipped on the device"""
+    return isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)) and all(g.get("fused") for g in optimizer.param_groups)
+
+
 def train_step(model, optimizer, coords4, feats, xyz_labels, scale_labels, class_labels, **loss_kw):
-    """one iteration of train_joint.py:246-288; feats already recentred (:248-249)."""
+    """one iteration of train_joint.py:246-288; feats already recentred (:248-249).
+
+    The forward multiplies fp16 pairs on the eval path's kernels (ME.TRAIN_FWD_HL); an activation beyond the fp16 range - never
+    behind a healthy BatchNorm - raises the range flag.  With a fused Adam the flag rides to the optimizer as `found_inf`: the
+    update of such a step is skipped ON THE DEVICE (no host wait in the step), the host notices at one of the next calls, counts
+    it (model.train_range_fallbacks) and runs the following steps on the bf16 triples.  Other optimizers: the host waits for the
+    flag and redoes the step on the triples before the optimizer sees a gradient."""
+    dev = feats.device
+
     def fwd_bwd():
         optimizer.zero_grad(set_to_none=True)
-        x = ME.SparseTensor(feats, coords4, device=feats.device)
+        x = ME.SparseTensor(feats, coords4, device=dev)
         out = model(x)
         loss, parts = joint_loss(out.F, xyz_labels, scale_labels, class_labels, **loss_kw)
         loss.backward()
         return loss, parts
 
-    # the fp16-pair forward (opt-in) may have to be redone: keep the BatchNorm running statistics of before the step, so that
-    # the redo does not count the batch twice (one momentum update and one num_batches_tracked increment per iteration, as
-    # train_joint.py:250-283 gives)
-    bn_state = None
-    if ME.TRAIN_FWD_PIECES == 2:
-        bn_state = [(b, b.clone()) for m in model.modules() for b in (getattr(m, "running_mean", None), getattr(m, "running_var", None),
-                                                                       getattr(m, "num_batches_tracked", None)) if b is not None]
-    with ME.pair_scale_hints(model):
-        loss, parts = fwd_bwd()
-    if ME.training_forward_left_fp16_range(feats.device):
-        # the forward's fp16-pair products met an activation beyond 65000 (never behind a healthy BatchNorm): the step is
-        # redone on the bf16 triples before the optimizer sees a gradient
+    def on_triples(fn):
         prev, ME.TRAIN_FWD_PIECES = ME.TRAIN_FWD_PIECES, 3
+        prev_hl, ME.TRAIN_FWD_HL = ME.TRAIN_FWD_HL, 0
         try:
-            if bn_state is not None:
-                with torch.no_grad():
-                    for b, saved in bn_state:
-                        b.copy_(saved)
-            loss, parts = fwd_bwd()
+            return fn()
         finally:
             ME.TRAIN_FWD_PIECES = prev
+            ME.TRAIN_FWD_HL = prev_hl
+
+    if not ME.train_uses_pairs() or model.__dict__.get("_pairs_off", False):
+        loss, parts = on_triples(fwd_bwd) if ME.train_uses_pairs() else fwd_bwd()
+        optimizer.step()
+        return loss.detach(), {k: v.detach() for k, v in parts.items()}
+
+    if _skips_on_device(optimizer):
+        if ME.training_range_flag_peek(dev):
+            # an earlier step left the fp16 range: its update (and that of every step queued since) was skipped on the device
+            torch.cuda.current_stream(dev).synchronize()
+            ME.range_flag(dev).zero_()
+            model.train_range_fallbacks = getattr(model, "train_range_fallbacks", 0) + 1
+            model.__dict__["_pairs_off"] = True
+            return train_step(model, optimizer, coords4, feats, xyz_labels, scale_labels, class_labels, **loss_kw)
+        with ME.pair_scale_hints(model):
+            loss, parts = fwd_bwd()
+        optimizer.found_inf = ME.training_range_flag_device(dev)
+        try:
+            optimizer.step()
+        finally:
+            optimizer.found_inf = None
+        return loss.detach(), {k: v.detach() for k, v in parts.items()}
+
+    # the step may have to be redone: keep the BatchNorm running statistics of before the step, so that the redo does not count
+    # the batch twice (one momentum update and one num_batches_tracked increment per iteration, as train_joint.py:250-283 gives)
+    # (one multi-tensor copy into buffers that live with the model: 186 one-element clones per step were 186 launches)
+    bufs = [b for m in model.modules() for b in (getattr(m, "running_mean", None), getattr(m, "running_var", None),
+                                                 getattr(m, "num_batches_tracked", None)) if b is not None]
+    saved = model.__dict__.get("_bn_snapshot")
+    if saved is None or len(saved) != len(bufs) or any(a.shape != b.shape or a.device != b.device or a.dtype != b.dtype
+                                                       for a, b in zip(saved, bufs)):
+        saved = model.__dict__["_bn_snapshot"] = [torch.empty_like(b) for b in bufs]
+    with torch.no_grad():
+        torch._foreach_copy_(saved, bufs)
+    with ME.pair_scale_hints(model):
+        loss, parts = fwd_bwd()
+    if ME.training_forward_left_fp16_range(dev):
+        with torch.no_grad():
+            torch._foreach_copy_(bufs, saved)
+        loss, parts = on_triples(fwd_bwd)
         model.train_range_fallbacks = getattr(model, "train_range_fallbacks", 0) + 1
     optimizer.step()
     return loss.detach(), {k: v.detach() for k, v in parts.items()}

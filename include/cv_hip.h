@@ -453,6 +453,13 @@ int cv_sp_bn_backward_f32(const float* d_x, const float* d_dy, const float* d_y,
 int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale,
                      const float* d_shift, const float* d_residual, int res_ld, int relu, float* d_y, int y_ld,
                      void* stream);
+/* The same pass with a second output: d_y_hl receives the values of d_y in the hl format (the fp16 pairs the hl-format
+ * convolutions multiply, cv_conv_desc.in_hl; c % 32 == 0, 128-byte aligned rows) and *range_flag is raised when one exceeds
+ * 65000.  The training forward feeds the next convolution from d_y_hl and keeps d_y for autograd (BatchNorm backward, the
+ * weight gradient, residual adds). */
+int cv_sp_affine_hl_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale, const float* d_shift,
+                        const float* d_residual, int res_ld, int relu, float* d_y, int y_ld, float* d_y_hl, int y_hl_ld,
+                        int32_t* range_flag, void* stream);
 
 /* scale = gamma / sqrt(var + eps), shift = beta - mean * scale (+ bias * scale). */
 int cv_sp_bn_fold_f32(const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_var,

@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r5s26
 mkdir -p $O
-(cd /tmp && rm -rf /tmp/pt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python $GRAFT_REPO_ROOT/bench.py --mode train --steps 8 --warmup 2 --cpu-scenes 0 > /tmp/pt.log 2>&1; f=$(find /tmp/pt -name "*kernel_stats.csv" | head -1); cp "$f" $O/train_kernel_stats.csv; tail -1 /tmp/pt.log > $O/bench_train_rocprof.json)
+(cd /tmp && rm -rf /tmp/pt && CV_TRAIN_FWD_HL=${HL:-1} rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python $GRAFT_REPO_ROOT/bench.py --mode train --steps 8 --warmup 2 --cpu-scenes 0 > /tmp/pt.log 2>&1; f=$(find /tmp/pt -name "*kernel_stats.csv" | head -1); cp "$f" $O/train_kernel_stats.csv; tail -1 /tmp/pt.log > $O/bench_train_rocprof.json)
 python - <<'P'
 import csv
 rows=list(csv.DictReader(open('gpurun_out/r5s26/train_kernel_stats.csv')))

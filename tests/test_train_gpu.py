@@ -62,9 +62,17 @@ def test_conv_backward_matches_oracle_autograd(cuda, built_lib, cin, cout, kind)
     run_pair(cuda, coords, cin, cout, kind, seed=cin + cout)
 
 
-def test_minkunet_training_step_gradients_match_oracle(cuda, built_lib):
+@pytest.mark.parametrize("fwd_hl,bar", [(0, 2e-3), (1, 5e-2)])
+def test_minkunet_training_step_gradients_match_oracle(cuda, built_lib, monkeypatch, fwd_hl, bar):
     """train-mode forward (batch-statistics BN) + backward of a masked MSE/CE loss shaped like
-    train_joint.py:253-283; every parameter gradient vs autograd through the CPU oracle."""
+    train_joint.py:253-283; every parameter gradient vs autograd through the CPU oracle.  Nothing here shares ReLU masks
+    with the oracle, so the bar is set by which side of zero a few pre-activations land on: with the forward on the bf16
+    triples (24 significant bits, ME.TRAIN_FWD_HL = 0) every gradient is within 2e-3 of its maximum; on the hl-format
+    kernels (fp16 pairs, 22 bits - the default) a few of the 1400 rows flip a ReLU: the typical parameter stays where it was
+    (median error below 2e-3), the ones downstream of a flip move by up to 1e-2 of their maximum (block1.0.norm1's gain,
+    the stem kernel 4.3e-3).  That the products themselves are exact enough is what the shared-mask comparison pins: all 249
+    gradients within 7e-6 at 3 x 20k rows in the default mode (tests/test_production_size_gpu.py)."""
+    monkeypatch.setattr(ME, "TRAIN_FWD_HL", fwd_hl)
     coords, feats = scene_coords(13, 700, batch=2)
     n = len(coords)
     sd = so.make_state_dict(3, 64, seed=5)
@@ -86,13 +94,14 @@ def test_minkunet_training_step_gradients_match_oracle(cuda, built_lib):
         yo[:, 54:], torch.from_numpy(labels))
     lo.backward()
     assert abs(float(loss) - float(lo)) < 1e-4 * max(1.0, abs(float(lo)))
-    worst = 0.0
+    worst, errs = 0.0, []
     for name, p in model.named_parameters():
         g, go = p.grad.cpu().numpy(), sdo[name].grad.numpy()
         err = np.abs(g - go).max() / max(1e-6, np.abs(go).max())
         worst = max(worst, err)
-        assert err < 2e-3, (name, err)
-    assert worst > 0
+        errs.append(err)
+        assert err < bar, (name, err)
+    assert worst > 0 and np.median(errs) < 2e-3
 
 
 def test_backward_overlap_changes_no_gradient_bit(cuda, built_lib, monkeypatch):
@@ -210,6 +219,102 @@ def test_train_step_reduces_loss_and_matches_reference_loss(cuda, built_lib):
     hist = [float(train.train_step(model, opt, coords, feats, xyz, scale, cls)[0]) for _ in range(6)]
     assert all(np.isfinite(hist)) and hist[-1] < hist[0]
     assert train.adjust_learning_rate(opt, 85) == pytest.approx(1e-4) and opt.param_groups[0]["lr"] == pytest.approx(1e-4)
+
+
+def _small_batch(cuda, seed0=30, n=900):
+    from canonicalvoting_amd.synth import make_scene
+    scenes = [make_scene(seed0 + b, n_points=n, res=0.06, room=(1.5, 0.9, 1.5), n_boxes=2, margin=0.5, box_scale=0.4) for b in range(3)]
+    coords = torch.cat([torch.cat([torch.full((n, 1), b, dtype=torch.int32), torch.from_numpy(s.coords)], 1)
+                        for b, s in enumerate(scenes)]).to(cuda)
+    feats = torch.cat([torch.from_numpy(s.feats) for s in scenes]).to(cuda) * 2 - 1
+    xyz = torch.cat([torch.from_numpy(s.xyz_labels) for s in scenes]).to(cuda)
+    scale = torch.cat([torch.from_numpy(s.scale_labels) for s in scenes]).to(cuda)
+    cls = torch.cat([torch.from_numpy(s.class_labels) for s in scenes]).to(cuda)
+    return coords, feats, xyz, scale, cls
+
+
+def test_training_forward_on_the_hl_kernels(cuda, built_lib, monkeypatch):
+    """ME.TRAIN_FWD_HL (default): every BatchNorm + ReLU pass of the training forward writes its output a second time as fp16
+    pairs (cv_sp_affine_hl_f32) and the convolution that reads it runs on the eval path's hl-format kernels.  The twin holds
+    exactly the bits ME.to_hl gives, the network output agrees with the forward on the bf16 triples within 1e-5 of its largest
+    value (a ReLU is continuous: a flipped pre-activation moves the OUTPUT by its own tiny value), the loss follows, and the
+    saved tensors of autograd are the fp32 rows (the weight gradients of the two modes agree to the same level on a layer
+    that no ReLU precedes... the stem's output feeds BatchNorm directly)."""
+    coords, feats, xyz, scale, cls = _small_batch(cuda)
+    from canonicalvoting_amd import train
+    # the twin of one pass
+    torch.manual_seed(1)
+    bn = ME.MinkowskiBatchNorm(64).cuda().train()
+    x = ME.SparseTensor(torch.randn(len(coords), 64, device=cuda) * 3, coords, device=cuda)
+    res = torch.randn(len(coords), 64, device=cuda)
+    monkeypatch.setattr(ME, "TRAIN_FWD_HL", 1)
+    y = bn.forward_fused(x, residual=res, relu=True)
+    assert y.F_hl is not None and torch.equal(y.F_hl.view(torch.int32), ME.to_hl(y.F.detach()).view(torch.int32))
+    assert bn.forward_fused(x, relu=False).F_hl is None              # only what a convolution reads gets a twin
+    z = ME.cat(y, y)
+    assert torch.equal(ME.from_hl(z.F_hl), ME.from_hl(ME.to_hl(z.F.detach())))
+    monkeypatch.setattr(ME, "TRAIN_FWD_HL", 0)
+    y0 = bn.forward_fused(x, residual=res, relu=True)
+    assert y0.F_hl is None and torch.equal(y0.F, y.F)
+    # the network
+    outs, grads = [], []
+    for hl in (1, 0):
+        monkeypatch.setattr(ME, "TRAIN_FWD_HL", hl)
+        torch.manual_seed(0)
+        model = MinkUNet34C(3, 64).cuda().train()
+        out = model(ME.SparseTensor(feats, coords, device=cuda)).F
+        loss, _ = train.joint_loss(out, xyz, scale, cls)
+        loss.backward()
+        outs.append((out.detach(), float(loss)))
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    (o1, l1), (o0, l0) = outs
+    assert float((o1 - o0).abs().max()) < 1e-5 * max(1.0, float(o0.abs().max()))
+    assert abs(l1 - l0) < 1e-5 * abs(l0)
+    assert float(o0.abs().max()) > 1e-3
+    # the last layer's gradients do not pass a ReLU on their way back: the two modes agree to product precision there
+    for k in ("final.kernel", "final.bias"):
+        assert float((grads[0][k] - grads[1][k]).abs().max()) < 2e-5 * float(grads[1][k].abs().max()), k
+
+
+def test_a_forward_beyond_the_fp16_range_skips_its_update_on_the_device(cuda, built_lib, monkeypatch):
+    """train.train_step with the fused Adam: no host wait in the step.  A BatchNorm gain of 1e7 puts activations beyond 65000:
+    the hl twin raises the range flag, the optimizer gets it as found_inf and leaves every parameter (and its step count)
+    alone; the NEXT call notices, counts the fallback, runs on the bf16 triples from then on and updates.  With an optimizer
+    that cannot skip on the device (SGD) the step is redone on the triples before the optimizer sees a gradient, and the
+    BatchNorm running statistics count the batch once."""
+    from canonicalvoting_amd import train
+    batch = _small_batch(cuda, seed0=40)
+    monkeypatch.setattr(ME, "TRAIN_FWD_HL", 1)
+    torch.manual_seed(0)
+    model = MinkUNet34C(3, 64).cuda().train()
+    opt = train.make_optimizer(model, lr=1e-3)
+    train.train_step(model, opt, *batch)                               # healthy
+    assert getattr(model, "train_range_fallbacks", 0) == 0
+    with torch.no_grad():
+        model.bn0.bn.weight.fill_(1e7)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    nbt = int(model.bn0.bn.num_batches_tracked)
+    loss, _ = train.train_step(model, opt, *batch)
+    torch.cuda.synchronize()
+    assert all(torch.equal(before[k], p.detach()) for k, p in model.named_parameters())       # skipped on the device
+    assert getattr(model, "train_range_fallbacks", 0) == 0                                   # ... and nobody has looked yet
+    loss, _ = train.train_step(model, opt, *batch)
+    torch.cuda.synchronize()
+    assert model.train_range_fallbacks == 1 and np.isfinite(float(loss))
+    assert any(not torch.equal(before[k], p.detach()) for k, p in model.named_parameters())   # the triples step went through
+    assert int(model.bn0.bn.num_batches_tracked) == nbt + 2
+    assert int(ME.range_flag(torch.device(cuda))[0]) == 0
+    # an optimizer without found_inf: redone inside the step
+    torch.manual_seed(0)
+    model = MinkUNet34C(3, 64).cuda().train()
+    with torch.no_grad():
+        model.bn0.bn.weight.fill_(1e7)
+    sgd = torch.optim.SGD(model.parameters(), lr=1e-6)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    loss, _ = train.train_step(model, sgd, *batch)
+    assert model.train_range_fallbacks == 1 and np.isfinite(float(loss))
+    assert int(model.bn0.bn.num_batches_tracked) == 1
+    assert any(not torch.equal(before[k], p.detach()) for k, p in model.named_parameters())
 
 
 def test_batchnorm_training_kernels_match_torch(cuda, built_lib):
