@@ -42,7 +42,7 @@ class ConvDesc(ctypes.Structure):
                 ("weight_packed", vp), ("weight_x6", vp), ("in2", vp), ("in2_ld", ctypes.c_int), ("cin2", ctypes.c_int),
                 ("weight2_x6", vp), ("perm_has_map", ctypes.c_int), ("weight_pieces", ctypes.c_int),
                 ("acc_scale", ctypes.c_float), ("range_flag", vp), ("in_hl", ctypes.c_int), ("out_hl", ctypes.c_int),
-                ("res_hl", ctypes.c_int), ("split_tickets", vp), ("win", vp)]
+                ("res_hl", ctypes.c_int), ("split_tickets", vp), ("win", vp), ("acc_scale_dev", vp)]
 
 
 class SceneMaps(ctypes.Structure):
@@ -179,6 +179,8 @@ SIGNATURES = {
                                           ctypes.c_float, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]),
     "cv_sp_bn_backward_f32": (ctypes.c_int, [vp, vp, vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp,
                                              ctypes.c_float, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]),
+    "cv_sp_bn_backward_hl_f32": (ctypes.c_int, [vp, vp, vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp,
+                                                ctypes.c_float, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp]),
     "cv_sp_affine_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int,
                                         ctypes.c_int, vp, ctypes.c_int, vp]),
     "cv_sp_affine_hl_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int,

@@ -890,7 +890,7 @@ __launch_bounds__(NW * 64, hl_blocks(NB, NS, NW)) void conv_hl(ConvArgs a) {
     }
     __syncthreads();                                 // weight tiles are dead: the epilogue tile reuses their LDS
     {
-        const float sc = a.acc_scale;
+        const float sc = a.acc_scale_dev ? a.acc_scale * *a.acc_scale_dev : a.acc_scale;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -1414,7 +1414,7 @@ __global__ __launch_bounds__(NW * 64, (hd_blocks(NB, NW, NSTG) * NW + 3) / 4) vo
     wait_vmcnt_le<0>();
     __syncthreads();                                 // the ring is dead: the epilogue tile reuses its LDS
     {
-        const float sc = a.acc_scale;
+        const float sc = a.acc_scale_dev ? a.acc_scale * *a.acc_scale_dev : a.acc_scale;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -1639,7 +1639,7 @@ __global__ __launch_bounds__(NW * 64, 4) void conv_hh(ConvArgs a) {
     wait_vmcnt_le<0>();
     __syncthreads();                                 // the ring is dead: the epilogue tile reuses its LDS
     {
-        const float sc = a.acc_scale;
+        const float sc = a.acc_scale_dev ? a.acc_scale * *a.acc_scale_dev : a.acc_scale;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -1832,7 +1832,7 @@ __global__ __launch_bounds__(THREADS, (CIN <= 3 ? 3 : 1)) void conv_stem_mfma(Co
     }
     if (in_max > 65000.f && a.range_flag) *a.range_flag = 1;
     {
-        const float sc = a.acc_scale;
+        const float sc = a.acc_scale_dev ? a.acc_scale * *a.acc_scale_dev : a.acc_scale;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] *= sc;
     }
@@ -2665,6 +2665,7 @@ __global__ __launch_bounds__(256) void bn_col_finish(const double* __restrict__ 
     }
 }
 
+constexpr int BN_SLOT_BLOCKS = 2048;          // = the grid cap of the launch with the hl twin (cv_sp_bn_backward_hl_f32: CV_BN_SLOT_WORDS)
 // dx = gamma*istd * (dy' - sum_dy/n - xhat * sum_dy_xhat/n)
 __global__ __launch_bounds__(256) void bn_backward_apply(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const float* __restrict__ y, long long n, int c, int ld,
@@ -2693,9 +2694,31 @@ __global__ __launch_bounds__(256) void bn_backward_apply4(const float* __restric
                                                           float eps, const float* __restrict__ gamma,
                                                           const float* __restrict__ sum_dy,
                                                           const float* __restrict__ sum_dy_xhat, float* __restrict__ dx,
-                                                          float* __restrict__ dres) {
+                                                          float* __restrict__ dres, float* __restrict__ dx_hl = nullptr,
+                                                          unsigned* __restrict__ slot = nullptr,
+                                                          int* __restrict__ range_flag = nullptr) {
     const float inv_n = 1.0f / (float)n;
     const int cq = c >> 2;
+    // dx_hl: dx once more as fp16 pairs for the input-gradient convolution of the layer below, times the power of two that put
+    // the PREVIOUS step's largest |dx| of this layer into [2^9, 2^10) (a factor of 64 to the fp16 range - beyond it the range
+    // flag stops the optimizer step).  slot: BN_SLOT_BLOCKS words, one per workgroup, that receive this step's maxima (bits of
+    // non-negative floats; plain stores - atomics on shared words cost ~1 us each across the XCDs: a fixed 28-50 us per launch),
+    // BN_SLOT_BLOCKS words with the previous step's, one float that receives the inverse factor for that convolution's epilogue.
+    __shared__ unsigned wred[4];
+    float hs = 1.f, dmax = 0.f;
+    if (dx_hl) {
+        unsigned mb = 0u;
+        for (int i = threadIdx.x; i < BN_SLOT_BLOCKS; i += 256) mb = max(mb, slot[BN_SLOT_BLOCKS + i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, off));
+        if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = mb;
+        __syncthreads();
+        mb = max(max(wred[0], wred[1]), max(wred[2], wred[3]));
+        __syncthreads();
+        const unsigned E = (mb >> 23) & 255u;        // m in [2^(E - 127), 2^(E - 126))
+        hs = (E >= 10u && E <= 250u) ? __uint_as_float((263u - E) << 23) : 1.f;          // 2^(136 - E)
+        if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<float*>(slot)[2 * BN_SLOT_BLOCKS] = 1.f / hs;
+    }
     for (long long t = blockIdx.x * 256ll + threadIdx.x; t < n * cq; t += (long long)gridDim.x * 256) {
         const long long r = t / cq;
         const int k = (int)(t - r * cq) * 4;
@@ -2719,6 +2742,19 @@ __global__ __launch_bounds__(256) void bn_backward_apply4(const float* __restric
         }
         *reinterpret_cast<float4*>(dx + o) = make_float4(d[0], d[1], d[2], d[3]);
         if (dres) *reinterpret_cast<float4*>(dres + o) = g;
+        if (dx_hl) {
+            dmax = fmaxf(fmaxf(dmax, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
+            const float4 v = make_float4(d[0] * hs, d[1] * hs, d[2] * hs, d[3] * hs);
+            if (range_flag && hl_out_of_range(v)) *range_flag = 1;
+            hl_store4(dx_hl + r * ld, k, v);
+        }
+    }
+    if (dx_hl) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+        if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = __float_as_uint(dmax);
+        __syncthreads();
+        if (threadIdx.x == 0) slot[blockIdx.x] = max(max(wred[0], wred[1]), max(wred[2], wred[3]));
     }
 }
 
@@ -3150,6 +3186,7 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
         return CV_OK;
     }
     a.win = d->win;
+    a.acc_scale_dev = d->acc_scale_dev;
     if (a.win && cvsc::win_enabled() && cvsc::win_eligible(a)) return cvsc::launch_win(a, st);
     if (d->perm_groups > 1) {
         // offsets split into perm_groups contiguous groups, each processed in its own row order, all in
@@ -3601,9 +3638,10 @@ int cv_sp_bn_stats_f32(const float* d_x, long long n, int c, int ld, const float
 // Backward of training-mode BatchNorm (optionally with the ReLU that follows it: pass its output d_y, else NULL):
 // d_dgamma, d_dbeta, d_dx, and optionally d_dres = the ReLU-masked incoming gradient (gradient of a residual
 // that was added between the normalisation and the ReLU).
-int cv_sp_bn_backward_f32(const float* d_x, const float* d_dy, const float* d_y, long long n, int c, int ld,
-                          const float* d_mean, const float* d_var, float eps, const float* d_gamma, float* d_dgamma,
-                          float* d_dbeta, float* d_dx, float* d_dres, void* d_ws, size_t ws_bytes, void* stream) {
+static int bn_backward_impl(const float* d_x, const float* d_dy, const float* d_y, long long n, int c, int ld,
+                            const float* d_mean, const float* d_var, float eps, const float* d_gamma, float* d_dgamma,
+                            float* d_dbeta, float* d_dx, float* d_dres, void* d_ws, size_t ws_bytes, float* d_dx_hl,
+                            unsigned* d_slot, int32_t* range_flag, void* stream) {
     CV_REQUIRE(d_x && d_dy && d_mean && d_var && d_gamma && d_dgamma && d_dbeta && d_dx && d_ws, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(n > 0 && c > 0 && ld >= c, CV_EINVAL, "bad bn sizes");
     CV_REQUIRE(ws_bytes >= cv_sp_bn_workspace_bytes(c), CV_ENOMEM, "workspace too small");
@@ -3621,14 +3659,32 @@ int cv_sp_bn_backward_f32(const float* d_x, const float* d_dy, const float* d_y,
     bn_col_finish<1><<<(c + 15) / 16, 256, 0, st>>>(partial, chunks, n, c, d_dbeta, d_dgamma, nullptr, nullptr, 0.f,
                                                      nullptr, nullptr, eps, nullptr, nullptr);
     CV_LAUNCH_CHECK();
+    CV_REQUIRE(!d_dx_hl || (v4 && d_slot && c % 32 == 0 && ld % 32 == 0 && (reinterpret_cast<uintptr_t>(d_dx_hl) & 127) == 0), CV_EINVAL,
+               "hl-format gradient: channels and leading dimension %% 32 == 0, 128-byte aligned rows, a scale slot");
     if (v4)
-        bn_backward_apply4<<<(unsigned)std::min<long long>((n * (c / 4) + 255) / 256, 16384), 256, 0, st>>>(
-            d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dbeta, d_dgamma, d_dx, d_dres);
+        bn_backward_apply4<<<(unsigned)std::min<long long>((n * (c / 4) + 255) / 256, d_dx_hl ? BN_SLOT_BLOCKS : 16384), 256, 0, st>>>(
+            d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dbeta, d_dgamma, d_dx, d_dres, d_dx_hl, d_slot, range_flag);
     else
         bn_backward_apply<<<(unsigned)std::min<long long>((n * c + 255) / 256, 8192), 256, 0, st>>>(
             d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dbeta, d_dgamma, d_dx, d_dres);
     CV_LAUNCH_CHECK();
     return CV_OK;
+}
+
+int cv_sp_bn_backward_f32(const float* d_x, const float* d_dy, const float* d_y, long long n, int c, int ld,
+                          const float* d_mean, const float* d_var, float eps, const float* d_gamma, float* d_dgamma,
+                          float* d_dbeta, float* d_dx, float* d_dres, void* d_ws, size_t ws_bytes, void* stream) {
+    return bn_backward_impl(d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dgamma, d_dbeta, d_dx, d_dres, d_ws, ws_bytes,
+                            nullptr, nullptr, nullptr, stream);
+}
+
+int cv_sp_bn_backward_hl_f32(const float* d_x, const float* d_dy, const float* d_y, long long n, int c, int ld,
+                             const float* d_mean, const float* d_var, float eps, const float* d_gamma, float* d_dgamma,
+                             float* d_dbeta, float* d_dx, float* d_dres, void* d_ws, size_t ws_bytes, float* d_dx_hl,
+                             uint32_t* d_slot, int32_t* range_flag, void* stream) {
+    CV_REQUIRE(d_dx_hl && d_slot, CV_EINVAL, "null pointer argument");
+    return bn_backward_impl(d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dgamma, d_dbeta, d_dx, d_dres, d_ws, ws_bytes,
+                            d_dx_hl, d_slot, range_flag, stream);
 }
 
 int cv_head_joint_f32(const float* d_feats, long long n, int ld, int nclasses, int log_scale, float* d_xyz,

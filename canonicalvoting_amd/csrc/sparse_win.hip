@@ -533,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void conv_win(ConvArgs a, int xcd_per) {
     wait_vmcnt_le<0>();
     __syncthreads();                                                // the window buffers are dead: the epilogue tile reuses them
     {
-        const float sc = a.acc_scale;
+        const float sc = a.acc_scale_dev ? a.acc_scale * *a.acc_scale_dev : a.acc_scale;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll

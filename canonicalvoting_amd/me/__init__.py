@@ -446,7 +446,7 @@ def range_flag(dev):
 def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=None, relu=False,
                  out=None, flavour=0, row_perm=None, j_begin=0, j_end=0, acc_in=None, perm_groups=0,
                  cache_weights=True, pieces=None, in_hl=False, out_hl=False, res_hl=False, stem_mfma=False,
-                 split_tickets=None, weight_t=False, win=None):
+                 split_tickets=None, weight_t=False, win=None, acc_scale_dev=None):
     """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout].
     in_hl / out_hl / res_hl: the operand is in the hl format (to_hl / from_hl; cv_conv_desc.in_hl), pieces=2 only.
     pieces=2: fp16-pair products (weights packed per call; the caller reads range_flag(dev) after synchronising);
@@ -460,7 +460,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
         # the TRANSPOSED convolution of `weight` ([K, Cout', Cin'] = a layer's forward kernel; the input gradient):
         # packed straight from the forward layout where the 16-bit piece path runs, transposed by a copy otherwise
         K, cout, cin = w.shape
-        x6_ok = CONV_X6 and flavour in (0, 1) and cin % 32 == 0 and cout % 4 == 0 and pieces in (1, 3)
+        x6_ok = CONV_X6 and flavour in (0, 1) and cin % 32 == 0 and cout % 4 == 0 and pieces in (1, 2, 3)
         if not x6_ok:
             w = w.permute(0, 2, 1)
             weight_t = False
@@ -479,7 +479,18 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
     wp6 = None
     acc_scale, flag = 0.0, None
     if CONV_X6 and flavour in (0, 1) and cin % 32 == 0 and cout % 4 == 0:
-        if pieces == 2:
+        if pieces == 2 and weight_t:
+            # the input gradient on fp16 pairs: W^T packed straight from the forward layout with the layer's scale of this step
+            hints = _bwd_ctx.get("pair_scales")         # (the backward nodes run on the autograd engine's thread)
+            k = hints.get(weight.data_ptr()) if hints is not None else None
+            if k is None:
+                k = h2_scale_log2((w, None))
+            wp6 = torch.empty(2 * w.numel(), dtype=torch.int16, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.cv_sp_pack_weights_t_f32(_ptr(w), K, cout, cin, 2, int(k), _ptr(wp6), _stream(dev)),
+                           "cv_sp_pack_weights_t_f32")
+            acc_scale, flag = 2.0 ** -k, range_flag(dev)
+        elif pieces == 2:
             key = id(weight)
             ver = (weight.data_ptr(), weight._version, tuple(weight.shape))
             hit = _packed_h2.get(key) if cache_weights else None
@@ -521,7 +532,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
                       None, None, None, p(wp6), None, 0, 0, None,
                       1 if (perm_groups > 1 and getattr(row_perm, "_cv_has_map", False)) else 0,
                       2 if flag is not None else (1 if (pieces == 1 and wp6 is not None) else 0), acc_scale, p(flag),
-                      1 if in_hl else 0, 1 if out_hl else 0, 1 if res_hl else 0, p(split_tickets), p(win))
+                      1 if in_hl else 0, 1 if out_hl else 0, 1 if res_hl else 0, p(split_tickets), p(win), p(acc_scale_dev))
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
     return out
@@ -836,6 +847,45 @@ def train_forward_hl():
     return TRAIN_FWD_HL != 0 and COMPUTE_DTYPE != "bf16"
 
 
+# 1 (default): the input gradients run on the hl-format kernels too.  The BatchNorm backward writes dx a second time as fp16 pairs
+# times a per-layer power of two taken from the PREVIOUS step's largest |dx| of that layer (three words per layer that live on
+# the device: cv_sp_bn_backward_hl_f32) - inside train.train_step only (ME.pair_scale_hints rotates the maxima between steps);
+# a layer's first step, and every backward outside a step, takes the bf16 triples.
+TRAIN_BWD_HL = int(os.environ.get("CV_TRAIN_BWD_HL", "1"))
+
+
+TRAIN_COUNTERS = {"hl_dgrad": 0}           # (tests: how many input gradients took the hl path)
+# what the backward nodes of the step in progress share.  Process-wide, not thread-local: the autograd engine runs the nodes on
+# its own thread.  One training step at a time per process (the one-process-per-GPU layout of train_joint.py).
+_bwd_ctx = {"slots": None, "twins": {}, "pair_scales": None}
+
+
+class _GradSlots:
+    """per-layer words of the hl-format gradient twins (keyed by the BatchNorm gain's storage), one device buffer per module tree"""
+
+    def __init__(self, dev):
+        self.buf = torch.zeros((128, 4104), dtype=torch.int32, device=dev)  # [layer][2048 x this step's maxima | 2048 x last step's | 1 / s] (CV_BN_SLOT_WORDS)
+        self.index = {}
+        self.seen = set()                    # layers whose slot[1] holds a maximum (they ran a backward in the step before)
+        self.running = set()
+
+    def rotate(self):
+        with torch.no_grad():
+            self.buf[:, 2048:4096].copy_(self.buf[:, 0:2048])
+            self.buf[:, 0:2048].zero_()
+        self.seen, self.running = self.running, set()
+
+    def take(self, key):
+        """(slot tensor, usable) for the layer; usable = last step left a maximum"""
+        i = self.index.get(key)
+        if i is None:
+            if len(self.index) >= self.buf.shape[0]:
+                return None, False
+            i = self.index[key] = len(self.index)
+        self.running.add(key)
+        return self.buf[i], key in self.seen
+
+
 def train_uses_pairs():
     """the training forward multiplies fp16 pairs somewhere (range flag to check, weight scales to hand over)"""
     return COMPUTE_DTYPE != "bf16" and (TRAIN_FWD_PIECES == 2 or TRAIN_FWD_HL != 0)
@@ -870,6 +920,15 @@ class pair_scale_hints:
             for k, a in zip(ks, amax):
                 scales[k.data_ptr()] = (max(-60, min(60, 13 - math.ceil(math.log2(a)))) if (math.isfinite(a) and a > 0) else 0)
         _train_state.pair_scales = scales
+        self.outer_slots = _bwd_ctx["slots"]
+        _bwd_ctx["slots"], _bwd_ctx["twins"] = None, {}
+        if ks and train_forward_hl() and TRAIN_BWD_HL:
+            slots = self.module.__dict__.get("_grad_slots")
+            if slots is None or slots.buf.device != ks[0].device:
+                slots = self.module.__dict__["_grad_slots"] = _GradSlots(ks[0].device)
+            slots.rotate()
+            _bwd_ctx["slots"] = slots
+            _bwd_ctx["pair_scales"] = scales
         return self
 
     @staticmethod
@@ -882,6 +941,7 @@ class pair_scale_hints:
 
     def __exit__(self, *exc):
         _train_state.pair_scales = self.outer
+        _bwd_ctx["slots"], _bwd_ctx["twins"], _bwd_ctx["pair_scales"] = self.outer_slots, {}, None
         return False
 
 
@@ -972,7 +1032,16 @@ class _ConvFn(torch.autograd.Function):
                     LATE_GRAD_LOG.append((kernel, d_kernel.data_ptr()))
         if ctx.needs_input_grad[0]:
             nbr_t = transposed_map(nbr, feats.shape[0]) if nbr is not None else None
-            d_feats = conv_forward(grad, k3.detach(), nbr_t, feats.shape[0], cache_weights=False, weight_t=True)
+            twins = _bwd_ctx["twins"]
+            twin = twins.pop(grad.data_ptr(), None) if twins else None
+            if (twin is not None and twin[2] == grad.shape and COMPUTE_DTYPE != "bf16" and k3.shape[2] % 32 == 0
+                    and k3.shape[1] % 4 == 0):
+                # the eval path's kernels on the gradient's hl twin (written by the BatchNorm backward above this layer)
+                d_feats = conv_forward(twin[0], k3.detach(), nbr_t, feats.shape[0], cache_weights=False, weight_t=True,
+                                       pieces=2, in_hl=True, acc_scale_dev=twin[1])
+                TRAIN_COUNTERS["hl_dgrad"] += 1
+            else:
+                d_feats = conv_forward(grad, k3.detach(), nbr_t, feats.shape[0], cache_weights=False, weight_t=True)
         if side is not None:
             if not late:
                 cur.wait_stream(side)
@@ -1121,6 +1190,22 @@ class _BNTrainFn(torch.autograd.Function):
         if ctx.has_res and ctx.needs_input_grad[7]:
             dres = torch.empty_like(x) if y is not None else dy
         ws = torch.empty(int(L.cv_sp_bn_workspace_bytes(c)), dtype=torch.uint8, device=dev)
+        slots = _bwd_ctx["slots"]
+        if slots is not None and c % 32 == 0 and x.stride(0) % 32 == 0 and x.stride(0) == dx.stride(0):
+            slot, usable = slots.take(gamma.data_ptr())
+            if slot is not None:
+                # dx leaves with its hl twin for the input gradient of the convolution that produced x (usable from the layer's
+                # second step on: the factor comes from the maximum the step before left in the slot)
+                dx_hl = torch.empty_like(dx)
+                with torch.cuda.device(dev):
+                    _lib.check(L.cv_sp_bn_backward_hl_f32(_ptr(x), _ptr(dy), _ptr(y), n, c, x.stride(0), _ptr(stats[0]),
+                                                          _ptr(stats[1]), ctx.eps, _ptr(gamma), _ptr(dg[0]), _ptr(dg[1]),
+                                                          _ptr(dx), _ptr(dres) if y is not None else None, _ptr(ws), ws.numel(),
+                                                          _ptr(dx_hl), _ptr(slot), range_flag(dev).data_ptr(), _stream(dev)),
+                               "cv_sp_bn_backward_hl_f32")
+                if usable:
+                    _bwd_ctx["twins"][dx.data_ptr()] = (dx_hl, slot[4096:4097].view(torch.float32), dx.shape)
+                return dx, dg[0], dg[1], None, None, None, None, dres, None, None
         with torch.cuda.device(dev):
             _lib.check(L.cv_sp_bn_backward_f32(_ptr(x), _ptr(dy), _ptr(y), n, c, x.stride(0), _ptr(stats[0]),
                                                _ptr(stats[1]), ctx.eps, _ptr(gamma), _ptr(dg[0]), _ptr(dg[1]),

@@ -247,6 +247,9 @@ typedef struct cv_conv_desc {
                                conv_win: every 256-row tile lands its window of input rows in LDS once and multiplies all 27
                                offsets out of it - no mask groups, no partial tiles, no finish launch (row_perm / perm_groups
                                are ignored).  Other shapes ignore it. */
+    const float* acc_scale_dev; /* optional, hl-format input only: a device scalar multiplied into acc_scale when the kernel
+                               runs (the training backward scales a layer's gradient rows by a power of two chosen on the
+                               device, cv_sp_bn_backward_hl_f32, and hands the inverse over here: no host wait). */
 } cv_conv_desc;
 #define CV_SPLIT_TICKETS 4096
 
@@ -447,6 +450,19 @@ int cv_sp_bn_stats_f32(const float* d_x, long long n, int c, int ld, const float
 int cv_sp_bn_backward_f32(const float* d_x, const float* d_dy, const float* d_y, long long n, int c, int ld,
                           const float* d_mean, const float* d_var, float eps, const float* d_gamma, float* d_dgamma,
                           float* d_dbeta, float* d_dx, float* d_dres, void* d_ws, size_t ws_bytes, void* stream);
+
+/* cv_sp_bn_backward_f32 with a second output for the input-gradient convolution of the layer below (the eval path's hl-format
+ * kernels on the transposed map): d_dx_hl = d_dx * s as fp16 pairs, s the power of two that put the PREVIOUS call's largest
+ * |dx| of this layer into [2^9, 2^10) - a factor of 64 below the fp16 range; *range_flag is raised beyond it.  d_slot =
+ * CV_BN_SLOT_WORDS 32-bit words of the layer that live across steps: [0, 2048) receive this call's largest |dx| per workgroup
+ * (bits of non-negative floats, plain stores), [2048, 4096) hold the previous step's (the caller copies the first half there
+ * and zeroes it between steps; all zero = unknown: s = 1), [4096] receives 1 / s as a float for cv_conv_desc.acc_scale_dev.
+ * c % 32 == 0, ld % 32 == 0, 128-byte aligned rows. */
+#define CV_BN_SLOT_WORDS 4104
+int cv_sp_bn_backward_hl_f32(const float* d_x, const float* d_dy, const float* d_y, long long n, int c, int ld,
+                             const float* d_mean, const float* d_var, float eps, const float* d_gamma, float* d_dgamma,
+                             float* d_dbeta, float* d_dx, float* d_dres, void* d_ws, size_t ws_bytes, float* d_dx_hl,
+                             uint32_t* d_slot, int32_t* range_flag, void* stream);
 
 /* y = relu?(x * scale + shift + residual): MinkowskiBatchNorm (eval) / MinkowskiReLU / the residual add of
  * BasicBlock on feature rows; scale, shift and residual may each be NULL. */
