@@ -180,11 +180,11 @@ SIGNATURES = {
     "cv_sp_bn_backward_f32": (ctypes.c_int, [vp, vp, vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp,
                                              ctypes.c_float, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]),
     "cv_sp_bn_backward_hl_f32": (ctypes.c_int, [vp, vp, vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp,
-                                                ctypes.c_float, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp]),
+                                                ctypes.c_float, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp, vp, vp, vp, vp]),
     "cv_sp_affine_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int,
                                         ctypes.c_int, vp, ctypes.c_int, vp]),
     "cv_sp_affine_hl_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int,
-                                           ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
+                                           ctypes.c_int, vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp]),
     "cv_sp_bn_fold_f32": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_int, vp, vp, vp]),
     "cv_head_joint_f32": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          vp, vp, vp, vp, vp]),

@@ -2446,7 +2446,8 @@ __global__ __launch_bounds__(256) void affine_rows4(const float* __restrict__ x,
                                                     const float* __restrict__ shift,
                                                     const float* __restrict__ residual, int res_ld, int relu,
                                                     float* __restrict__ y, int y_ld, float* __restrict__ y_hl = nullptr,
-                                                    int y_hl_ld = 0, int* __restrict__ range_flag = nullptr) {
+                                                    int y_hl_ld = 0, int* __restrict__ range_flag = nullptr,
+                                                    unsigned* __restrict__ ybits = nullptr) {
     const int cq = c >> 2;
     for (long long t = blockIdx.x * 256ll + threadIdx.x; t < n * cq; t += (long long)gridDim.x * 256) {
         const long long r = t / cq;
@@ -2466,6 +2467,15 @@ __global__ __launch_bounds__(256) void affine_rows4(const float* __restrict__ x,
         if (y_hl) {                                  // the same values once more as the fp16 pairs the next convolution multiplies
             if (range_flag && hl_out_of_range(v)) *range_flag = 1;
             hl_store4(y_hl + r * y_hl_ld, k, v);
+        }
+        if (ybits) {
+            // where the ReLU is open, one bit per element: the 8 lanes of a row's 32-channel chunk (c % 32 == 0: they are
+            // consecutive lanes of one wave, all active together) OR their nibbles into one word
+            unsigned w = ((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u)) << (k & 31);
+            w |= (unsigned)__shfl_xor((int)w, 1);
+            w |= (unsigned)__shfl_xor((int)w, 2);
+            w |= (unsigned)__shfl_xor((int)w, 4);
+            if ((k & 31) == 0) ybits[r * (c >> 5) + (k >> 5)] = w;
         }
     }
 }
@@ -2551,11 +2561,23 @@ __global__ __launch_bounds__(256) void bn_col_reduce(const float* __restrict__ x
 // float4 flavour of bn_col_reduce (c % 4 == 0, c <= 1024, ld % 4 == 0, 16-byte aligned): a thread owns a quad of
 // channels, 256 / (c/4) row lanes per block, four rows of loads in flight per thread; the scalar kernel above kept
 // one 4-byte load per thread in flight (1.8 TB/s on the ts1 levels).  Same partial layout, fixed summation order.
+// The ReLU mask of a BatchNorm + ReLU output for its backward: either the output rows themselves (y > 0) or one bit per
+// element, [row][c / 32] words written by the forward pass (cv_sp_affine_hl_f32) - a 32nd of the bytes of y in the two
+// backward passes that only want to know where the ReLU was open.
+__device__ __forceinline__ float4 relu_open4(const float* __restrict__ y, const unsigned* __restrict__ ybits, long long r, int k,
+                                             int ld, int c) {
+    if (ybits) {
+        const unsigned w = ybits[r * (c >> 5) + (k >> 5)] >> (k & 31);
+        return make_float4((float)(w & 1u), (float)((w >> 1) & 1u), (float)((w >> 2) & 1u), (float)((w >> 3) & 1u));
+    }
+    return *reinterpret_cast<const float4*>(y + r * ld + k);
+}
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_col_reduce4(const float* __restrict__ x, const float* __restrict__ dy,
                                                       const float* __restrict__ y, long long n, int c, int ld,
                                                       const float* __restrict__ mean, const float* __restrict__ var,
-                                                      float eps, double* __restrict__ partial) {
+                                                      float eps, double* __restrict__ partial,
+                                                      const unsigned* __restrict__ ybits = nullptr) {
     __shared__ double red[256][9];                     // [thread][2 x 4 sums], padded
     const int cq = c >> 2, rl = 256 / cq;              // row lanes
     const int quad = threadIdx.x % cq, lane_r = threadIdx.x / cq;
@@ -2595,15 +2617,15 @@ __global__ __launch_bounds__(256) void bn_col_reduce4(const float* __restrict__ 
                 const long long o = (r + (long long)u * rl) * ld + k;
                 xv[u] = *reinterpret_cast<const float4*>(x + o);
                 gv[u] = MODE == 1 ? *reinterpret_cast<const float4*>(dy + o) : z4;
-                yv[u] = (MODE == 1 && y) ? *reinterpret_cast<const float4*>(y + o) : z4;
+                yv[u] = (MODE == 1 && (y || ybits)) ? relu_open4(y, ybits, r + (long long)u * rl, k, ld, c) : z4;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) take(xv[u], gv[u], yv[u], y != nullptr);
+            for (int u = 0; u < 4; ++u) take(xv[u], gv[u], yv[u], y != nullptr || ybits != nullptr);
         }
         for (; r < r_hi; r += rl) {
             const long long o = r * ld + k;
             take(*reinterpret_cast<const float4*>(x + o), MODE == 1 ? *reinterpret_cast<const float4*>(dy + o) : z4,
-                 (MODE == 1 && y) ? *reinterpret_cast<const float4*>(y + o) : z4, y != nullptr);
+                 (MODE == 1 && (y || ybits)) ? relu_open4(y, ybits, r, k, ld, c) : z4, y != nullptr || ybits != nullptr);
         }
     }
 #pragma unroll
@@ -2665,7 +2687,7 @@ __global__ __launch_bounds__(256) void bn_col_finish(const double* __restrict__ 
     }
 }
 
-constexpr int BN_SLOT_BLOCKS = 2048;          // = the grid cap of the launch with the hl twin (cv_sp_bn_backward_hl_f32: CV_BN_SLOT_WORDS)
+constexpr int BN_SLOT_BLOCKS = 4096;          // = the grid cap of the launch with the hl twin (cv_sp_bn_backward_hl_f32: CV_BN_SLOT_WORDS)
 // dx = gamma*istd * (dy' - sum_dy/n - xhat * sum_dy_xhat/n)
 __global__ __launch_bounds__(256) void bn_backward_apply(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const float* __restrict__ y, long long n, int c, int ld,
@@ -2696,7 +2718,8 @@ __global__ __launch_bounds__(256) void bn_backward_apply4(const float* __restric
                                                           const float* __restrict__ sum_dy_xhat, float* __restrict__ dx,
                                                           float* __restrict__ dres, float* __restrict__ dx_hl = nullptr,
                                                           unsigned* __restrict__ slot = nullptr,
-                                                          int* __restrict__ range_flag = nullptr) {
+                                                          int* __restrict__ range_flag = nullptr,
+                                                          const unsigned* __restrict__ ybits = nullptr) {
     const float inv_n = 1.0f / (float)n;
     const int cq = c >> 2;
     // dx_hl: dx once more as fp16 pairs for the input-gradient convolution of the layer below, times the power of two that put
@@ -2725,8 +2748,8 @@ __global__ __launch_bounds__(256) void bn_backward_apply4(const float* __restric
         const long long o = r * ld + k;
         const float4 xv = *reinterpret_cast<const float4*>(x + o);
         float4 g = *reinterpret_cast<const float4*>(dy + o);
-        if (y) {
-            const float4 yv = *reinterpret_cast<const float4*>(y + o);
+        if (y || ybits) {
+            const float4 yv = relu_open4(y, ybits, r, k, ld, c);
             if (!(yv.x > 0.f)) g.x = 0.f;
             if (!(yv.y > 0.f)) g.y = 0.f;
             if (!(yv.z > 0.f)) g.z = 0.f;
@@ -3554,7 +3577,7 @@ int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float
 
 int cv_sp_affine_hl_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale, const float* d_shift,
                         const float* d_residual, int res_ld, int relu, float* d_y, int y_ld, float* d_y_hl, int y_hl_ld,
-                        int32_t* range_flag, void* stream) {
+                        uint32_t* d_relu_bits, int32_t* range_flag, void* stream) {
     CV_REQUIRE(d_x && d_y && d_y_hl && n > 0 && c > 0 && x_ld >= c && y_ld >= c && y_hl_ld >= c, CV_EINVAL, "bad affine arguments");
     CV_REQUIRE(!d_residual || res_ld >= c, CV_EINVAL, "bad residual stride");
     CV_REQUIRE(c % 32 == 0 && y_hl_ld % 32 == 0 && (reinterpret_cast<uintptr_t>(d_y_hl) & 127) == 0, CV_EINVAL,
@@ -3563,7 +3586,7 @@ int cv_sp_affine_hl_f32(const float* d_x, long long n, int c, int x_ld, const fl
                    aligned16(d_residual) && aligned16(d_scale) && aligned16(d_shift), CV_EINVAL,
                "16-byte aligned operands with leading dimensions %% 4 == 0");
     affine_rows4<<<(unsigned)std::min<long long>((n * (c / 4) + 255) / 256, 16384), 256, 0, static_cast<hipStream_t>(stream)>>>(
-        d_x, n, c, x_ld, d_scale, d_shift, d_residual, res_ld, relu, d_y, y_ld, d_y_hl, y_hl_ld, range_flag);
+        d_x, n, c, x_ld, d_scale, d_shift, d_residual, res_ld, relu, d_y, y_ld, d_y_hl, y_hl_ld, range_flag, d_relu_bits);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }
@@ -3641,7 +3664,7 @@ int cv_sp_bn_stats_f32(const float* d_x, long long n, int c, int ld, const float
 static int bn_backward_impl(const float* d_x, const float* d_dy, const float* d_y, long long n, int c, int ld,
                             const float* d_mean, const float* d_var, float eps, const float* d_gamma, float* d_dgamma,
                             float* d_dbeta, float* d_dx, float* d_dres, void* d_ws, size_t ws_bytes, float* d_dx_hl,
-                            unsigned* d_slot, int32_t* range_flag, void* stream) {
+                            unsigned* d_slot, int32_t* range_flag, const unsigned* d_relu_bits, void* stream) {
     CV_REQUIRE(d_x && d_dy && d_mean && d_var && d_gamma && d_dgamma && d_dbeta && d_dx && d_ws, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(n > 0 && c > 0 && ld >= c, CV_EINVAL, "bad bn sizes");
     CV_REQUIRE(ws_bytes >= cv_sp_bn_workspace_bytes(c), CV_ENOMEM, "workspace too small");
@@ -3651,8 +3674,9 @@ static int bn_backward_impl(const float* d_x, const float* d_dy, const float* d_
     dim3 grid((unsigned)((c + 31) / 32), (unsigned)chunks);
     const bool v4 = c % 4 == 0 && c <= 1024 && ld % 4 == 0 && aligned16(d_x) && aligned16(d_dy) && aligned16(d_y) &&
                     aligned16(d_dx) && aligned16(d_dres) && aligned16(d_mean) && aligned16(d_var);
+    CV_REQUIRE(!d_relu_bits || (v4 && c % 32 == 0), CV_EINVAL, "ReLU bits: c %% 32 == 0 and 16-byte aligned operands");
     if (v4)
-        bn_col_reduce4<1><<<chunks, 256, 0, st>>>(d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, partial);
+        bn_col_reduce4<1><<<chunks, 256, 0, st>>>(d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, partial, d_relu_bits);
     else
         bn_col_reduce<1><<<grid, 256, 0, st>>>(d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, partial);
     CV_LAUNCH_CHECK();
@@ -3663,7 +3687,7 @@ static int bn_backward_impl(const float* d_x, const float* d_dy, const float* d_
                "hl-format gradient: channels and leading dimension %% 32 == 0, 128-byte aligned rows, a scale slot");
     if (v4)
         bn_backward_apply4<<<(unsigned)std::min<long long>((n * (c / 4) + 255) / 256, d_dx_hl ? BN_SLOT_BLOCKS : 16384), 256, 0, st>>>(
-            d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dbeta, d_dgamma, d_dx, d_dres, d_dx_hl, d_slot, range_flag);
+            d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dbeta, d_dgamma, d_dx, d_dres, d_dx_hl, d_slot, range_flag, d_relu_bits);
     else
         bn_backward_apply<<<(unsigned)std::min<long long>((n * c + 255) / 256, 8192), 256, 0, st>>>(
             d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dbeta, d_dgamma, d_dx, d_dres);
@@ -3675,16 +3699,16 @@ int cv_sp_bn_backward_f32(const float* d_x, const float* d_dy, const float* d_y,
                           const float* d_mean, const float* d_var, float eps, const float* d_gamma, float* d_dgamma,
                           float* d_dbeta, float* d_dx, float* d_dres, void* d_ws, size_t ws_bytes, void* stream) {
     return bn_backward_impl(d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dgamma, d_dbeta, d_dx, d_dres, d_ws, ws_bytes,
-                            nullptr, nullptr, nullptr, stream);
+                            nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 int cv_sp_bn_backward_hl_f32(const float* d_x, const float* d_dy, const float* d_y, long long n, int c, int ld,
                              const float* d_mean, const float* d_var, float eps, const float* d_gamma, float* d_dgamma,
                              float* d_dbeta, float* d_dx, float* d_dres, void* d_ws, size_t ws_bytes, float* d_dx_hl,
-                             uint32_t* d_slot, int32_t* range_flag, void* stream) {
-    CV_REQUIRE(d_dx_hl && d_slot, CV_EINVAL, "null pointer argument");
+                             uint32_t* d_slot, int32_t* range_flag, const uint32_t* d_relu_bits, void* stream) {
+    CV_REQUIRE((d_dx_hl != nullptr) == (d_slot != nullptr), CV_EINVAL, "the hl twin of dx and its scale slot come together");
     return bn_backward_impl(d_x, d_dy, d_y, n, c, ld, d_mean, d_var, eps, d_gamma, d_dgamma, d_dbeta, d_dx, d_dres, d_ws, ws_bytes,
-                            d_dx_hl, d_slot, range_flag, stream);
+                            d_dx_hl, d_slot, range_flag, d_relu_bits, stream);
 }
 
 int cv_head_joint_f32(const float* d_feats, long long n, int ld, int nclasses, int log_scale, float* d_xyz,

@@ -864,15 +864,15 @@ class _GradSlots:
     """per-layer words of the hl-format gradient twins (keyed by the BatchNorm gain's storage), one device buffer per module tree"""
 
     def __init__(self, dev):
-        self.buf = torch.zeros((128, 4104), dtype=torch.int32, device=dev)  # [layer][2048 x this step's maxima | 2048 x last step's | 1 / s] (CV_BN_SLOT_WORDS)
+        self.buf = torch.zeros((128, 8200), dtype=torch.int32, device=dev)  # [layer][4096 x this step's maxima | 4096 x last step's | 1 / s] (CV_BN_SLOT_WORDS)
         self.index = {}
         self.seen = set()                    # layers whose slot[1] holds a maximum (they ran a backward in the step before)
         self.running = set()
 
     def rotate(self):
         with torch.no_grad():
-            self.buf[:, 2048:4096].copy_(self.buf[:, 0:2048])
-            self.buf[:, 0:2048].zero_()
+            self.buf[:, 4096:8192].copy_(self.buf[:, 0:4096])
+            self.buf[:, 0:4096].zero_()
         self.seen, self.running = self.running, set()
 
     def take(self, key):
@@ -1124,7 +1124,7 @@ def bn_affine(bn):
     return out[0], out[1]
 
 
-def affine_forward(F, scale, shift, relu, out=None, residual=None, out_hl=None):
+def affine_forward(F, scale, shift, relu, out=None, residual=None, out_hl=None, relu_bits=None):
     """relu?(F * scale + shift + residual); out_hl: a second output in the hl format (cv_sp_affine_hl_f32)"""
     L = _lib.lib()
     dev = F.device
@@ -1135,7 +1135,7 @@ def affine_forward(F, scale, shift, relu, out=None, residual=None, out_hl=None):
             _lib.check(L.cv_sp_affine_hl_f32(_ptr(F), F.shape[0], F.shape[1], F.stride(0), _ptr(scale), _ptr(shift),
                                              _ptr(residual), residual.stride(0) if residual is not None else 0,
                                              1 if relu else 0, _ptr(out), out.stride(0), _ptr(out_hl), out_hl.stride(0),
-                                             range_flag(dev).data_ptr(), _stream(dev)), "cv_sp_affine_hl_f32")
+                                             _ptr(relu_bits), range_flag(dev).data_ptr(), _stream(dev)), "cv_sp_affine_hl_f32")
         return out
     with torch.cuda.device(dev):
         _lib.check(L.cv_sp_affine_f32(_ptr(F), F.shape[0], F.shape[1], F.stride(0), _ptr(scale), _ptr(shift),
@@ -1166,8 +1166,11 @@ class _BNTrainFn(torch.autograd.Function):
             residual = residual.contiguous()
         # want_hl: the output once more as fp16 pairs for the convolution that reads it (TRAIN_FWD_HL; c % 32 == 0)
         y_hl = torch.empty_like(x) if want_hl else None
-        y = affine_forward(x, stats[2], stats[3], relu, residual=residual, out_hl=y_hl)
-        ctx.save_for_backward(x, gamma, stats, y if relu else None)
+        # ... and where its ReLU is open as one bit per element: what the backward reads instead of y (a 32nd of the bytes)
+        bits = torch.empty((n, c // 32), dtype=torch.int32, device=dev) if (want_hl and relu) else None
+        y = affine_forward(x, stats[2], stats[3], relu, residual=residual, out_hl=y_hl, relu_bits=bits)
+        ctx.save_for_backward(x, gamma, stats, bits if bits is not None else (y if relu else None))
+        ctx.bits = bits is not None
         ctx.eps = float(eps)
         ctx.has_res = residual is not None
         ctx.two = want_hl
@@ -1190,27 +1193,31 @@ class _BNTrainFn(torch.autograd.Function):
         if ctx.has_res and ctx.needs_input_grad[7]:
             dres = torch.empty_like(x) if y is not None else dy
         ws = torch.empty(int(L.cv_sp_bn_workspace_bytes(c)), dtype=torch.uint8, device=dev)
+        bits = y if ctx.bits else None
+        y_rows = None if ctx.bits else y
         slots = _bwd_ctx["slots"]
+        slot, usable, dx_hl = None, False, None
         if slots is not None and c % 32 == 0 and x.stride(0) % 32 == 0 and x.stride(0) == dx.stride(0):
             slot, usable = slots.take(gamma.data_ptr())
             if slot is not None:
                 # dx leaves with its hl twin for the input gradient of the convolution that produced x (usable from the layer's
                 # second step on: the factor comes from the maximum the step before left in the slot)
                 dx_hl = torch.empty_like(dx)
-                with torch.cuda.device(dev):
-                    _lib.check(L.cv_sp_bn_backward_hl_f32(_ptr(x), _ptr(dy), _ptr(y), n, c, x.stride(0), _ptr(stats[0]),
-                                                          _ptr(stats[1]), ctx.eps, _ptr(gamma), _ptr(dg[0]), _ptr(dg[1]),
-                                                          _ptr(dx), _ptr(dres) if y is not None else None, _ptr(ws), ws.numel(),
-                                                          _ptr(dx_hl), _ptr(slot), range_flag(dev).data_ptr(), _stream(dev)),
-                               "cv_sp_bn_backward_hl_f32")
-                if usable:
-                    _bwd_ctx["twins"][dx.data_ptr()] = (dx_hl, slot[4096:4097].view(torch.float32), dx.shape)
-                return dx, dg[0], dg[1], None, None, None, None, dres, None, None
         with torch.cuda.device(dev):
-            _lib.check(L.cv_sp_bn_backward_f32(_ptr(x), _ptr(dy), _ptr(y), n, c, x.stride(0), _ptr(stats[0]),
-                                               _ptr(stats[1]), ctx.eps, _ptr(gamma), _ptr(dg[0]), _ptr(dg[1]),
-                                               _ptr(dx), _ptr(dres) if y is not None else None, _ptr(ws), ws.numel(),
-                                               _stream(dev)), "cv_sp_bn_backward_f32")
+            if dx_hl is not None or bits is not None:
+                _lib.check(L.cv_sp_bn_backward_hl_f32(_ptr(x), _ptr(dy), _ptr(y_rows), n, c, x.stride(0), _ptr(stats[0]),
+                                                      _ptr(stats[1]), ctx.eps, _ptr(gamma), _ptr(dg[0]), _ptr(dg[1]),
+                                                      _ptr(dx), _ptr(dres) if y is not None else None, _ptr(ws), ws.numel(),
+                                                      _ptr(dx_hl), _ptr(slot) if dx_hl is not None else None,
+                                                      range_flag(dev).data_ptr(), _ptr(bits), _stream(dev)),
+                           "cv_sp_bn_backward_hl_f32")
+            else:
+                _lib.check(L.cv_sp_bn_backward_f32(_ptr(x), _ptr(dy), _ptr(y), n, c, x.stride(0), _ptr(stats[0]),
+                                                   _ptr(stats[1]), ctx.eps, _ptr(gamma), _ptr(dg[0]), _ptr(dg[1]),
+                                                   _ptr(dx), _ptr(dres) if y is not None else None, _ptr(ws), ws.numel(),
+                                                   _stream(dev)), "cv_sp_bn_backward_f32")
+        if dx_hl is not None and usable:
+            _bwd_ctx["twins"][dx.data_ptr()] = (dx_hl, slot[8192:8193].view(torch.float32), dx.shape)
         return dx, dg[0], dg[1], None, None, None, None, dres, None, None
 
 

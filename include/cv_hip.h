@@ -454,15 +454,16 @@ int cv_sp_bn_backward_f32(const float* d_x, const float* d_dy, const float* d_y,
 /* cv_sp_bn_backward_f32 with a second output for the input-gradient convolution of the layer below (the eval path's hl-format
  * kernels on the transposed map): d_dx_hl = d_dx * s as fp16 pairs, s the power of two that put the PREVIOUS call's largest
  * |dx| of this layer into [2^9, 2^10) - a factor of 64 below the fp16 range; *range_flag is raised beyond it.  d_slot =
- * CV_BN_SLOT_WORDS 32-bit words of the layer that live across steps: [0, 2048) receive this call's largest |dx| per workgroup
- * (bits of non-negative floats, plain stores), [2048, 4096) hold the previous step's (the caller copies the first half there
- * and zeroes it between steps; all zero = unknown: s = 1), [4096] receives 1 / s as a float for cv_conv_desc.acc_scale_dev.
- * c % 32 == 0, ld % 32 == 0, 128-byte aligned rows. */
-#define CV_BN_SLOT_WORDS 4104
+ * CV_BN_SLOT_WORDS 32-bit words of the layer that live across steps: [0, 4096) receive this call's largest |dx| per workgroup
+ * (bits of non-negative floats, plain stores), [4096, 8192) hold the previous step's (the caller copies the first half there
+ * and zeroes it between steps; all zero = unknown: s = 1), [8192] receives 1 / s as a float for cv_conv_desc.acc_scale_dev.
+ * c % 32 == 0, ld % 32 == 0, 128-byte aligned rows.  d_dx_hl and d_slot may both be NULL (no twin).  d_relu_bits (optional): the
+ * ReLU mask as cv_sp_affine_hl_f32 wrote it, read instead of d_y (which may then be NULL). */
+#define CV_BN_SLOT_WORDS 8200
 int cv_sp_bn_backward_hl_f32(const float* d_x, const float* d_dy, const float* d_y, long long n, int c, int ld,
                              const float* d_mean, const float* d_var, float eps, const float* d_gamma, float* d_dgamma,
                              float* d_dbeta, float* d_dx, float* d_dres, void* d_ws, size_t ws_bytes, float* d_dx_hl,
-                             uint32_t* d_slot, int32_t* range_flag, void* stream);
+                             uint32_t* d_slot, int32_t* range_flag, const uint32_t* d_relu_bits, void* stream);
 
 /* y = relu?(x * scale + shift + residual): MinkowskiBatchNorm (eval) / MinkowskiReLU / the residual add of
  * BasicBlock on feature rows; scale, shift and residual may each be NULL. */
@@ -472,10 +473,11 @@ int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float
 /* The same pass with a second output: d_y_hl receives the values of d_y in the hl format (the fp16 pairs the hl-format
  * convolutions multiply, cv_conv_desc.in_hl; c % 32 == 0, 128-byte aligned rows) and *range_flag is raised when one exceeds
  * 65000.  The training forward feeds the next convolution from d_y_hl and keeps d_y for autograd (BatchNorm backward, the
- * weight gradient, residual adds). */
+ * weight gradient, residual adds).  d_relu_bits (optional, with relu): [n][c / 32] words, bit i of word (r, q) = (y[r][32 q + i] > 0)
+ * - what the BatchNorm backward reads instead of the rows of y (cv_sp_bn_backward_hl_f32). */
 int cv_sp_affine_hl_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale, const float* d_shift,
                         const float* d_residual, int res_ld, int relu, float* d_y, int y_ld, float* d_y_hl, int y_hl_ld,
-                        int32_t* range_flag, void* stream);
+                        uint32_t* d_relu_bits, int32_t* range_flag, void* stream);
 
 /* scale = gamma / sqrt(var + eps), shift = beta - mean * scale (+ bias * scale). */
 int cv_sp_bn_fold_f32(const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_var,

@@ -13,12 +13,12 @@ x = torch.randn(n, c, device=dev); dy = torch.randn(n, c, device=dev) * 1e-4; y 
 mean, var, gamma = x.mean(0), x.var(0, unbiased=False), torch.ones(c, device=dev)
 dg = torch.empty(2, c, device=dev); dx = torch.empty_like(x); dres = torch.empty_like(x); dx_hl = torch.empty_like(x)
 ws = torch.empty(int(L.cv_sp_bn_workspace_bytes(c)), dtype=torch.uint8, device=dev)
-slot = torch.zeros(4104, dtype=torch.int32, device=dev)
+slot = torch.zeros(8200, dtype=torch.int32, device=dev)
 flag = ME.range_flag(dev); st = torch.cuda.current_stream().cuda_stream
 def plain():
     _lib.check(L.cv_sp_bn_backward_f32(p(x), p(dy), p(y), n, c, c, p(mean), p(var), 1e-5, p(gamma), p(dg[0]), p(dg[1]), p(dx), p(dres), p(ws), ws.numel(), st), "bn")
 def twin():
-    _lib.check(L.cv_sp_bn_backward_hl_f32(p(x), p(dy), p(y), n, c, c, p(mean), p(var), 1e-5, p(gamma), p(dg[0]), p(dg[1]), p(dx), p(dres), p(ws), ws.numel(), p(dx_hl), p(slot), flag.data_ptr(), st), "bn hl")
+    _lib.check(L.cv_sp_bn_backward_hl_f32(p(x), p(dy), p(y), n, c, c, p(mean), p(var), 1e-5, p(gamma), p(dg[0]), p(dg[1]), p(dx), p(dres), p(ws), ws.numel(), p(dx_hl), p(slot), flag.data_ptr(), None, st), "bn hl")
 def timed(f, reps=20):
     for _ in range(3): f()
     torch.cuda.synchronize()
@@ -29,8 +29,8 @@ def timed(f, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 print("plain %.1f us" % timed(plain))
 print("twin, no maximum yet (s = 1) %.1f us, flag %d" % (timed(twin), int(flag[0])))
-slot[2048:4096] = slot[0:2048]; slot[0:2048] = 0
-print("twin, scaled %.1f us, flag %d, 1/s %g, max |dx| %g" % (timed(twin), int(flag[0]), float(slot[4096:4097].view(torch.float32)), float(dx.abs().max())))
-inv = float(slot[4096:4097].view(torch.float32))
+slot[4096:8192] = slot[0:4096]; slot[0:4096] = 0
+print("twin, scaled %.1f us, flag %d, 1/s %g, max |dx| %g" % (timed(twin), int(flag[0]), float(slot[8192:8193].view(torch.float32)), float(dx.abs().max())))
+inv = float(slot[8192:8193].view(torch.float32))
 back = ME.from_hl(dx_hl) * inv
 print("twin * 1/s against dx: max |d| / max |dx| = %.2e" % (float((back - dx).abs().max()) / float(dx.abs().max())))

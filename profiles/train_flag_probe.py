@@ -14,6 +14,6 @@ for i in range(5):
     loss, _ = train.train_step(model, opt, *batch)
     torch.cuda.synchronize()
     sl = model.__dict__.get("_grad_slots")
-    cur = sl.buf[:len(sl.index), 0:2048].view(torch.float32).max(1).values if sl is not None else None
+    cur = sl.buf[:len(sl.index), 0:4096].view(torch.float32).max(1).values if sl is not None else None
     print("step %d loss %.4f flag %d fallbacks %d hl dgrads %d" % (i, float(loss), int(ME.range_flag(dev)[0]), getattr(model, "train_range_fallbacks", 0), ME.TRAIN_COUNTERS["hl_dgrad"]),
           "max|dx| per layer: min %.2e max %.2e" % (float(cur.min()), float(cur.max())) if cur is not None else "")
