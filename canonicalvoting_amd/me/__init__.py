@@ -1174,6 +1174,7 @@ class _BNTrainFn(torch.autograd.Function):
         ctx.eps = float(eps)
         ctx.has_res = residual is not None
         ctx.two = want_hl
+        ctx.set_materialize_grads(False)         # (no zero tensor for the twin's "gradient": it was a fill of N x C per layer)
         if want_hl:
             _train_state.used_pairs = True
             ctx.mark_non_differentiable(y_hl)
