@@ -115,9 +115,10 @@ class MinkUNetBase(ResNetBase):
     # reads the caller's rows through its map and writes Z-order rows, `final` writes back through the inverse order (the
     # row-order invariant of train_joint.py:256-272 holds), and every level, kernel map and mask order comes from ONE
     # cv_sp_scene_plan call instead of ~25 lazy ones.  Measured (profiles/r4/train_sorted_ab.txt, random row order in): 31.9-32.0 ->
-    # 31.2-31.4 ms per step - the step is bound by its host side (enqueue time = step time), not by the gathers - so it is
-    # opt-in (CV_TRAIN_SORTED=1); the gradient tests that hand ReLU masks to the oracle read the caller-order forward.
-    SORTED_TRAINING = os.environ.get("CV_TRAIN_SORTED", "0") != "0"
+    # 31.2-31.4 ms per step on conv_rows_wp; with the hl-format kernels underneath (round 5) 27.4-27.9 -> 26.5-27.2 ms
+    # (profiles/r5/train_sorted.txt): the default since then (CV_TRAIN_SORTED=0 switches it off; the gradient tests that hand ReLU
+    # masks to the oracle set SORTED_TRAINING = False on their model: they read the masks in the caller's row order).
+    SORTED_TRAINING = os.environ.get("CV_TRAIN_SORTED", "1") != "0"
 
     def modular_forward(self, x):
         if self.SORTED_TRAINING and x.tensor_stride == 1 and type(self.conv0p1s1) is ME.MinkowskiConvolution:

@@ -241,6 +241,7 @@ def _training_gradients_on_shared_relu_masks(cuda, n_points, seed0, separate=Fal
             return train.joint_loss(out, to(xyz), to(scale), torch.from_numpy(cls).to(out.device))[0]
     torch.manual_seed(1)
     model = MinkUNet34C(3, 8 if separate else 6 * 9 + 9 + 1).cuda().train()
+    model.SORTED_TRAINING = False            # (the masks are compared row by row with the oracle's: the caller's order)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     masks = []
     fused = ME.MinkowskiBatchNorm.forward_fused
