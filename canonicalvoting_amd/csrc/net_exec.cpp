@@ -318,11 +318,7 @@ int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int 
     // splits), eight in flight 555 -> 545 scenes/s (2-8 splits) - profiles/r4/throughput_ablations.txt.  A finish launch
     // spreads the same reads over the chip.
     static const bool fuse_on = getenv("CV_HL_FUSE_FINISH") && atoi(getenv("CV_HL_FUSE_FINISH")) != 0;
-    // Option "gfuse": the mask groups of the conv_hd launches are summed inside the launch by the last group's workgroups
-    // (sparse_conv.hip group_fused_tail) - those ops get the counters, the split-K ops keep their finish launches.
-    long long gfuse_on = 0;
-    cv_sp_get_option("gfuse", &gfuse_on);
-    if ((fuse_on || gfuse_on) && d_ws && ws_bytes > ((size_t)1 << 20) + ticket_bytes) {
+    if (fuse_on && d_ws && ws_bytes > ((size_t)1 << 20) + ticket_bytes) {
         conv_ws_bytes = (ws_bytes - ticket_bytes) & ~(size_t)255;
         tickets = reinterpret_cast<int32_t*>(static_cast<char*>(d_ws) + conv_ws_bytes);
         CV_HIP_CHECK(hipMemsetAsync(tickets, 0, ticket_bytes, static_cast<hipStream_t>(stream)));
@@ -371,7 +367,7 @@ int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int 
         d.ws_bytes = conv_ws_bytes;
         if (wins && o.K == 27 && o.perm >= 0 && o.perm < n_wins && o.perm_groups > 1) d.win = wins[o.perm];
         const int32_t* perm = o.perm >= 0 ? perms[o.perm] : nullptr;
-        d.split_tickets = d.in_hl && (fuse_on || (gfuse_on && perm && o.perm_groups > 1)) ? tickets : nullptr;
+        d.split_tickets = d.in_hl ? tickets : nullptr;
         if (perm) {
             d.row_perm = perm;
             d.perm_groups = o.perm_groups;

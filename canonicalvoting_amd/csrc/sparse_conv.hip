@@ -949,131 +949,6 @@ __launch_bounds__(NW * 64, hl_blocks(NB, NS, NW)) void conv_hl(ConvArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ mask groups finished inside the launch (round 5)
-// A mask-sorted launch runs the G offset groups as blockIdx.z = 0 .. G - 1, each in its own row order, and a finish launch
-// adds the G partial tile sets (conv_finish_small: 2 x G x rows x Cout x 4 bytes of traffic and a launch per layer).  With
-// ConvArgs.gfuse the workgroups of the LAST group keep their sums in registers instead: the groups before publish their
-// partial tiles (write-through stores, per-wave vmcnt(0), barrier, one relaxed agent-scope count - the hand-off of the
-// split-K tickets above), a last-group workgroup waits until all of them have counted (its rows sit anywhere in the other
-// groups' orders), reads its rows' G - 1 partial sums and runs the epilogue.  Workgroups are dispatched in blockIdx order,
-// z slowest: when a last-group workgroup runs, every workgroup it waits for is already on a CU and waits for nothing
-// itself.  Summation order and arithmetic = conv_finish_small's: bit-identical outputs.  tickets[0] counts the published
-// workgroups, tickets[1] the finished readers; the last reader leaves both at zero for the next launch.
-#ifndef GF_SLEEP
-#define GF_SLEEP 8          // x 64 clocks between two polls of the producers' counter
-#endif
-#ifndef GF_ABL
-#define GF_ABL 0            // timing ablations (WRONG results): 1 no wait, 2 no partial reads
-#endif
-template <int NB>
-__device__ __forceinline__ void group_fused_tail(const ConvArgs& a, f32x16 (&acc)[NB], const int* rows, int n0, int lane, int tid,
-                                                 float (*T)[EP_LD]) {
-    const int G = a.splits;
-    if ((int)blockIdx.z < G - 1) {
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) epilogue_store_wide(a, acc[nb], rows, n0 + nb * 32, lane, T);    // (a.tickets: sc1 stores)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(a.tickets, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    // a last-group workgroup: everything that does not depend on the other groups is requested before the wait (the rows'
-    // residuals), all partial sums of the wave's 32 rows x NB x 32 columns right behind it - one round trip each (the
-    // workgroup is alone on its CU: nobody else hides its latencies)
-    const int h = lane >> 5, c = lane & 31;
-    const int cl = (lane & 7) * 4;
-    int row[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) row[it] = rows[(lane >> 3) + 8 * it];
-    float4 rv[NB][4];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int col = n0 + nb * 32 + cl;
-            rv[nb][it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.res && row[it] >= 0 && col < a.cout)
-                rv[nb][it] = a.res_hl ? hl_load4(a.res + (long long)row[it] * a.res_ld, col)
-                                      : *reinterpret_cast<const float4*>(a.res + (long long)row[it] * a.res_ld + col);
-        }
-    if (tid == 0) {
-        const int target = (G - 1) * (int)(gridDim.x * gridDim.y);
-        // (bounded: ~1 s of polling means the counters were not zero / not this launch's - abort the launch, never hang the queue)
-        int spins = 0;
-        while (!(GF_ABL & 1) && __hip_atomic_load(a.tickets, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(GF_SLEEP);
-            if (++spins > (1 << 22)) __builtin_trap();
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    const long long plane4 = a.n_out * (long long)a.cout / 4;
-    float4 pv[NB][4][2];                             // G <= 3 (host)
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int col = n0 + nb * 32 + cl;
-            const float4* p = reinterpret_cast<const float4*>(a.partial) + ((long long)max(row[it], 0) * a.cout + min(col, a.cout - 4)) / 4;
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-                pv[nb][it][k] = (k < G - 1 && row[it] >= 0 && col < a.cout && !(GF_ABL & 2)) ? partial_load4(p + k * plane4)
-                                                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) T[(r & 3) + 8 * (r >> 2) + 4 * h][c] = acc[nb][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int col = n0 + nb * 32 + cl;
-        if (col < a.cout) {
-            const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
-            const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                if (row[it] < 0) continue;
-                const float4 v = *reinterpret_cast<const float4*>(&T[(lane >> 3) + 8 * it][cl]);
-                // conv_finish_small's order: running sums sq[k & 3] (from zero) over the groups, then ((s0 + s1) + s2) + s3
-                float4 sq[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) sq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    if (k > G - 1) continue;
-                    const float4 t = k == G - 1 ? v : pv[nb][it][k < 2 ? k : 1];
-                    sq[k].x += t.x; sq[k].y += t.y; sq[k].z += t.z; sq[k].w += t.w;
-                }
-                float4 x = make_float4(sq[0].x + sq[1].x + sq[2].x + sq[3].x, sq[0].y + sq[1].y + sq[2].y + sq[3].y,
-                                       sq[0].z + sq[1].z + sq[2].z + sq[3].z, sq[0].w + sq[1].w + sq[2].w + sq[3].w);
-                if (a.acc_in) {
-                    const float4 q = *reinterpret_cast<const float4*>(a.acc_in + (long long)row[it] * a.acc_ld + col);
-                    x.x += q.x; x.y += q.y; x.z += q.z; x.w += q.w;
-                }
-                x.x = x.x * sc.x + sh.x; x.y = x.y * sc.y + sh.y; x.z = x.z * sc.z + sh.z; x.w = x.w * sc.w + sh.w;
-                if (a.res) { x.x += rv[nb][it].x; x.y += rv[nb][it].y; x.z += rv[nb][it].z; x.w += rv[nb][it].w; }
-                if (a.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
-                if (a.out_hl) {
-                    if (a.range_flag && hl_out_of_range(x)) *a.range_flag = 1;
-                    hl_store4(a.out + (long long)row[it] * a.out_ld, col, x);
-                } else {
-                    *reinterpret_cast<float4*>(a.out + (long long)row[it] * a.out_ld + col) = x;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();                                 // every wave has its partial sums
-    if (tid == 0) {
-        const int readers = (int)(gridDim.x * gridDim.y);
-        if (__hip_atomic_fetch_add(a.tickets + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == readers - 1) {
-            __hip_atomic_store(a.tickets, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.tickets + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 // ------------------------------------------------------------------ hl convolution fed by LDS-DMA rings (round 4)
 // What the timing ablations of round 4 say binds the throughput with eight scenes in flight (profiles/r4/
 // throughput_ablations.txt): conv_hl's row gathers (21 % of the scene rate: the vector cache's address pipe takes one
@@ -1133,7 +1008,7 @@ __device__ __forceinline__ void hd_reads3_wait(u32x4v& a0, u32x4v& a1, u32x4v (&
                  : "+v"(a0), "+v"(a1), "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2])
                  : "n"(N) : "memory");
 }
-template <int NB, int NW, int NSTG, bool GF = false>      // GF: mask groups summed inside the launch (group_fused_tail; its prefetches take 246 VGPRs)
+template <int NB, int NW, int NSTG>
 __global__ __launch_bounds__(NW * 64, (hd_blocks(NB, NW, NSTG) * NW + 3) / 4) void conv_hd(ConvArgs a) {
     static_assert(NSTG == 2 || NSTG == 3, "two or three ring stages");
     constexpr int TMv = NW * 32, THv = NW * 64;
@@ -1422,235 +1297,17 @@ __global__ __launch_bounds__(NW * 64, (hd_blocks(NB, NW, NSTG) * NW + 3) / 4) vo
     }
     float (*ep)[EP_LD] = reinterpret_cast<float (*)[EP_LD]>(sm + wave * 32 * EP_LD * 4);
     if ((CV_HD_ABL & 16) && a.acc_scale != 12345.f) return;      // (16: no epilogue)
-    if constexpr (GF) { group_fused_tail<NB>(a, acc, rows_s + wave * 32, n0, lane, tid, ep); return; }
     ConvArgs ae = a;
     ae.tickets = nullptr;                            // (the in-launch split-K reduction is conv_hl's)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) epilogue_store_wide(ae, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep);
 }
 
-// ------------------------------------------------------------------ conv_hd with half-chunk ring stages (round 5)
-// conv_hd keeps ONE workgroup per CU (two ring stages of 44 KB at 96 columns): its tile set-up (two dependent global round
-// trips, two barriers) and its 96 KB partial-tile epilogue run with nothing beside them - half of the time of a workgroup
-// that has ~10 live units (profiles/r4/hd_skeleton.txt).  conv_hh keeps conv_hd's units, MFMA sequence per accumulator
-// and epilogue (bit-identical results) and moves the operands in HALF chunks: a ring stage holds the 16 channels of one
-// k-step - 32 B of high and 32 B of low pieces per gathered row (a 64-byte row image, 2 KB per wave) and the weight tile
-// [plane][col][32 B] (2 KB per 32 columns) - 22 KB per stage at 96 columns instead of 44.  Three stages + the tile's tables
-// are 79 KB: TWO 8-wave workgroups per CU, each still fetching a weight tile once per 256 rows; one workgroup's set-up and
-// epilogue run beside the other's unit loop.  A row's two half chunks are requested back to back (the second hits the
-// line the first brought in).  Every wave issues its two row requests for every half unit (dead rows fetch the line of
-// zeros): the counted waits are immediates.
-template <int NB>
-__device__ __forceinline__ void hh_read_frags(unsigned aa_h, unsigned aa_l, unsigned ab, u32x4v& Ah, u32x4v& Al,
-                                              u32x4v (&Bh)[NB], u32x4v (&Bl)[NB]) {
-    if constexpr (NB == 1) {
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %6 offset:1024\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(Ah), "=&v"(Al), "=&v"(Bh[0]), "=&v"(Bl[0]) : "v"(aa_h), "v"(aa_l), "v"(ab) : "memory");
-    } else if constexpr (NB == 2) {
-        asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %8 offset:1024\n\t"
-                     "ds_read_b128 %4, %8 offset:2048\n\tds_read_b128 %5, %8 offset:3072\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(Ah), "=&v"(Al), "=&v"(Bh[0]), "=&v"(Bh[1]), "=&v"(Bl[0]), "=&v"(Bl[1])
-                     : "v"(aa_h), "v"(aa_l), "v"(ab) : "memory");
-    } else {
-        static_assert(NB == 3, "conv_hh: 32, 64 or 96 columns per workgroup");
-        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %10 offset:1024\n\t"
-                     "ds_read_b128 %4, %10 offset:2048\n\tds_read_b128 %5, %10 offset:3072\n\tds_read_b128 %6, %10 offset:4096\n\t"
-                     "ds_read_b128 %7, %10 offset:5120\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(Ah), "=&v"(Al), "=&v"(Bh[0]), "=&v"(Bh[1]), "=&v"(Bh[2]), "=&v"(Bl[0]), "=&v"(Bl[1]), "=&v"(Bl[2])
-                     : "v"(aa_h), "v"(aa_l), "v"(ab) : "memory");
-    }
-}
-constexpr int hh_lds_bytes(int NB, int NW, int NSTG) {
-    return NSTG * (NW * 2048 + NB * 2048) + NW * 32 * 4 + (WP_NPRE + 1) * NW * 32 * 4 + NW * 4 + (HL_MAX_UNITS + 4) * 2;
-}
-template <int NB, int NW, int NSTG>
-__global__ __launch_bounds__(NW * 64, 4) void conv_hh(ConvArgs a) {
-    static_assert(NW == 8 && NSTG == 3, "eight waves, three half-chunk ring stages");
-    constexpr int TMv = NW * 32, THv = NW * 64;
-    constexpr int A_BYTES = NW * 2048, B_BYTES = NB * 2048, STAGE = A_BYTES + B_BYTES;
-    constexpr int B_INSTR = B_BYTES / 1024;                         // 2 NB <= 6: wave t requests KB t = (plane, nb) of the weight tile
-    constexpr int EP_BYTES = NW * 32 * EP_LD * 4;
-    static_assert(EP_BYTES <= NSTG * STAGE && B_INSTR <= NW, "the epilogue tile aliases the ring");
-    constexpr int OFF_ROWS = NSTG * STAGE, OFF_NBR = OFF_ROWS + TMv * 4, OFF_MASK = OFF_NBR + (WP_NPRE + 1) * TMv * 4,
-                  OFF_UNITS = OFF_MASK + NW * 4, LDS_TOTAL = OFF_UNITS + (HL_MAX_UNITS + 4) * 2;
-    static_assert(LDS_TOTAL == hh_lds_bytes(NB, NW, NSTG) && 2 * LDS_TOTAL <= 160 * 1024, "two workgroups per CU");
-    // ONE __shared__ object (a second one makes hipcc drain vmcnt in front of the LDS reads of an LDS-DMA pipeline)
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_TOTAL];
-    unsigned char* const sm = lds;
-    int* const rows_s = reinterpret_cast<int*>(lds + OFF_ROWS);
-    int (*const nbr_all)[TMv] = reinterpret_cast<int (*)[TMv]>(lds + OFF_NBR);
-    unsigned* const wave_mask = reinterpret_cast<unsigned*>(lds + OFF_MASK);
-    unsigned short* const units_s = reinterpret_cast<unsigned short*>(lds + OFF_UNITS);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = blockIdx.y * (NB * 32);
-    const long long tile_id = xcd_tile(a);
-    const int half = lane >> 5, l31 = lane & 31;
-    const int nj = a.j_end - a.j_begin;
-    const int nch = a.cin / KC;
-    int u_lo, u_hi;
-    if (a.perm_per_split) {
-        u_lo = (int)((long long)nj * blockIdx.z / a.splits) * nch;
-        u_hi = (int)((long long)nj * (blockIdx.z + 1) / a.splits) * nch;
-    } else {
-        u_lo = (int)((long long)nj * nch * blockIdx.z / a.splits);
-        u_hi = (int)((long long)nj * nch * (blockIdx.z + 1) / a.splits);
-    }
-    const int j_first = a.j_begin + u_lo / nch, j_last = a.j_begin + (u_hi - 1) / nch;
-    const int njl = u_hi > u_lo ? j_last - j_first + 1 : 0;       // <= WP_NPRE (host)
-    const int nch2 = a.in2 ? a.cin2 / KC : 0;
-
-    // ---- tile set-up as conv_hl / conv_hd: processing order, map entries of the workgroup's offsets, live-unit list
-    const int* perm = a.row_perm ? a.row_perm + (a.perm_per_split ? (long long)blockIdx.z * a.n_out : 0) : nullptr;
-    if (tid < TMv) {
-        const long long t = tile_id * TMv + tid;
-        const int row = t < a.n_out ? (perm ? perm[t] : (int)t) : -1;
-        rows_s[tid] = row;
-        if (a.in2) nbr_all[njl][tid] = row;
-    }
-    {
-        unsigned m = 0u;
-        const int jg0 = a.j_begin + (int)((long long)nj * blockIdx.z / a.splits);      // first offset of this mask group
-        for (int e = tid; e < njl * TMv; e += THv) {
-            const int jj = e / TMv, t = e - jj * TMv;
-            const long long pos = tile_id * TMv + t;
-            int v = -1;
-            if (pos < a.n_out) {
-                if (a.nbr_perm) {
-                    v = a.nbr_perm[((long long)blockIdx.z * a.n_out + pos) * a.nbr_perm_w + (j_first + jj - jg0)];
-                } else {
-                    const int row = perm ? perm[pos] : (int)pos;
-                    v = a.nbr ? a.nbr[(long long)row * a.K + j_first + jj] : row;
-                }
-            }
-            nbr_all[jj][t] = v;
-            if (v >= 0) m |= 1u << jj;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m |= __shfl_xor(m, off);
-        if (lane == 0) wave_mask[wave] = m;
-    }
-    __syncthreads();
-    unsigned lm = 0u;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) lm |= wave_mask[w];
-    if (wave == 0) {
-        const int n_first = u_hi - u_lo, n_second = nch2 > (int)blockIdx.z ? (nch2 - (int)blockIdx.z + a.splits - 1) / a.splits : 0;
-        int cnt = 0;
-        for (int base = 0; base < n_first + n_second; base += 64) {
-            const int e = base + lane;
-            int code = -1;
-            if (e < n_first) {
-                const int u = u_lo + e, q = u / nch;
-                const int jj = a.j_begin + q - j_first;
-                if ((lm >> jj) & 1u) code = (jj << 8) | (u - q * nch);
-            } else if (e < n_first + n_second) {
-                code = (njl << 8) | ((int)blockIdx.z + (e - n_first) * a.splits);
-            }
-            const unsigned long long bal = __ballot(code >= 0);
-            if (code >= 0) units_s[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)code;
-            cnt += __popcll(bal);
-        }
-        if (lane == 0) units_s[HL_MAX_UNITS] = (unsigned short)cnt;
-    }
-    __syncthreads();
-    const int n_units = __builtin_amdgcn_readfirstlane((int)units_s[HL_MAX_UNITS]);
-    if (n_units == 0 && a.gvalid) return;            // no row of the tile has a neighbour in this group (zskip)
-    const int H = 2 * n_units;                        // half units: (unit h >> 1, k-step h & 1)
-
-    f32x16 acc[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-
-    // ---- per-thread invariants of the requests
-    // weight tile of a half unit: [plane][NB x 32 columns][32 B]; wave t < 2 NB requests KB t = (plane t / NB, column block
-    // t % NB): lane f -> column f >> 1, LDS slot f & 1 of the column's 32 bytes, which receives the 16-byte piece
-    // (f & 1) ^ ((col >> 4) & 1) (conflict-free b128 reads, see conv_win)
-    const bool has_b = wave < B_INSTR;
-    const int b_gc = min(n0 + (wave % NB) * 32 + (lane >> 1), a.cout - 1);          // columns beyond Cout are never stored
-    const unsigned b_src = (unsigned)(((wave / NB) * a.cout + b_gc) * 32 + (((lane & 1) ^ ((lane >> 5) & 1)) << 3));
-    const unsigned slab_words = 2u * (unsigned)a.cout * 32u;
-    const unsigned in_row_bytes = (unsigned)a.in_ld * 4u, in2_row_bytes = (unsigned)a.in2_ld * 4u;
-    const unsigned char* const in_b = reinterpret_cast<const unsigned char*>(a.in);
-    const unsigned char* const in2_b = reinterpret_cast<const unsigned char*>(a.in2);
-    // gathered rows: instruction q covers rows 16 q + (lane >> 2) of the wave; LDS slot lane & 3 of row r receives the row's
-    // piece (lane & 3) ^ ((r >> 2) & 3) of the half chunk's four [h lo-half, h hi-half, l lo-half, l hi-half] - and
-    // (r >> 2) & 3 = (lane >> 4) & 3 for both instructions
-    const unsigned a_sp = (unsigned)((lane & 3) ^ ((lane >> 4) & 3));
-    const unsigned a_piece = (a_sp >> 1) * 64u + (a_sp & 1u) * 16u;                 // byte offset inside the 128-byte chunk, k-step 0
-
-    auto issue = [&](int st, int h) {                 // requests of half unit h into ring stage st (wave-uniform)
-        const int code = __builtin_amdgcn_readfirstlane((int)units_s[h >> 1]);
-        const int jj = code >> 8, c = code & 255, ks = h & 1;
-        const bool second = jj == njl;
-        const unsigned rb_ = second ? in2_row_bytes : in_row_bytes;
-        const unsigned char* const base = (second ? in2_b : in_b) + (unsigned)(c * 128 + ks * 32) + a_piece;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int src = nbr_all[jj][wave * 32 + 16 * q + (lane >> 2)];
-            const unsigned char* g = src >= 0 ? base + (size_t)((unsigned)src * rb_) : g_zero_chunk + a_piece;
-            lds_dma16(g, sm + st * STAGE + wave * 2048 + q * 1024);
-        }
-        if (has_b) {
-            const unsigned short* slab = second ? a.wp6_2 + (size_t)c * slab_words
-                                                : a.wp6 + (size_t)((j_first + jj) * nch + c) * slab_words;
-            lds_dma16(slab + b_src + ks * 16, sm + st * STAGE + A_BYTES + wave * 1024);
-        }
-    };
-    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)lds;
-    const unsigned a_sw = (unsigned)((l31 >> 2) & 3);
-    const unsigned aa_h0 = lds0 + (unsigned)(wave * 2048 + l31 * 64) + (((unsigned)half ^ a_sw) << 4);
-    const unsigned aa_l0 = lds0 + (unsigned)(wave * 2048 + l31 * 64) + (((2u + (unsigned)half) ^ a_sw) << 4);
-    const unsigned ab0 = lds0 + (unsigned)(A_BYTES + l31 * 32) + (unsigned)((half ^ ((l31 >> 4) & 1)) << 4);
-    auto compute = [&](int st, int h) {
-        // a wave whose 32 rows have no neighbour at this offset multiplies zeros: skip (the list holds the units of the workgroup)
-        const int code = __builtin_amdgcn_readfirstlane((int)units_s[h >> 1]);
-        const int jj = code >> 8;
-        if (!__any(nbr_all[jj][wave * 32 + l31] >= 0)) return;
-        u32x4v Ah, Al, Bh[NB], Bl[NB];
-        hh_read_frags<NB>(aa_h0 + (unsigned)(st * STAGE), aa_l0 + (unsigned)(st * STAGE), ab0 + (unsigned)(st * STAGE), Ah, Al, Bh, Bl);
-        const f16x8 a0 = __builtin_bit_cast(f16x8, Ah), a1 = __builtin_bit_cast(f16x8, Al);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const f16x8 b0 = __builtin_bit_cast(f16x8, Bh[nb]), b1 = __builtin_bit_cast(f16x8, Bl[nb]);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[nb], 0, 0, 0);
-        }
-    };
-    // step h (stage h % 3): this wave's requests of half unit h have landed (those of h + 1 - two row instructions and, for
-    // the waves that have one, a weight instruction - may stay in flight); barrier = everybody's have, and everybody is
-    // past the MFMAs of half unit h - 1, whose stage takes the requests of h + 2; then the MFMAs of h
-    if (H > 0) issue(0, 0);
-    if (H > 1) issue(1, 1);
-    int st = 0;
-#pragma unroll 1
-    for (int h = 0; h < H; ++h) {
-        if (h + 1 < H) { if (has_b) wait_vmcnt_le<3>(); else wait_vmcnt_le<2>(); }
-        else wait_vmcnt_le<0>();
-        __builtin_amdgcn_s_barrier();
-        const int st2 = st == 0 ? 2 : st - 1;         // (h + 2) % 3
-        if (h + 2 < H) issue(st2, h + 2);
-        compute(st, h);
-        st = st == 2 ? 0 : st + 1;
-    }
-    wait_vmcnt_le<0>();
-    __syncthreads();                                 // the ring is dead: the epilogue tile reuses its LDS
-    {
-        const float sc = a.acc_scale_dev ? a.acc_scale * *a.acc_scale_dev : a.acc_scale;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] *= sc;
-    }
-    float (*ep)[EP_LD] = reinterpret_cast<float (*)[EP_LD]>(sm + wave * 32 * EP_LD * 4);
-    ConvArgs ae = a;
-    ae.tickets = nullptr;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) epilogue_store_wide(ae, acc[nb], rows_s + wave * 32, n0 + nb * 32, lane, ep);
-}
+// (Round 5, measured and removed - git 2945191 holds the code: `conv_hh`, conv_hd with 16-channel half-chunk ring stages so that two
+// 8-wave workgroups share a CU (bit-identical; ts1 96->96 98.5 -> 96.0 us, ts2 61.5 -> 73.9 us per layer, 575 -> 549-559 scenes/s),
+// and `group_fused_tail`, the mask groups summed inside the conv_hd launch by the last group's workgroups instead of a finish
+// launch (bit-identical; one scene in flight +0.5-1 %, 576 -> 544-566 scenes/s with seven: its prefetches take 246 VGPRs and the
+// polling workgroups hold their CU).  LABNOTES "Round 5".)
 
 // ------------------------------------------------------------------ stem (tiny Cin, 32 outputs)
 // conv0p1s1 (utils/minkunet.py:53: 5x5x5, 3 or 6 -> 32 channels) is a kernel-map walk, not a GEMM: 13 % of its
@@ -2839,18 +2496,7 @@ __global__ __launch_bounds__(256) void head_separate(const float* __restrict__ f
 std::atomic<long long> g_opt_zskip{getenv("CV_ZSKIP") ? atoll(getenv("CV_ZSKIP")) : 0};
 std::atomic<long long> g_opt_hd_mask{getenv("CV_HD") ? atoll(getenv("CV_HD")) : 4};
 std::atomic<long long> g_opt_hd_min_rows{getenv("CV_HD_MIN_ROWS") ? atoll(getenv("CV_HD_MIN_ROWS")) : 16384};
-// 1: the mask groups of a conv_hd launch are summed by the last group's workgroups (group_fused_tail) - no finish launch
-std::atomic<long long> g_opt_gfuse{getenv("CV_GFUSE") ? atoll(getenv("CV_GFUSE")) : 0};
-bool overlaps_inputs(const ConvArgs& a) {
-    auto hit = [&](const float* p, long long rows, int ld) {
-        if (!p) return false;
-        const char* b0 = reinterpret_cast<const char*>(p), *b1 = b0 + (size_t)rows * ld * 4;
-        const char* o0 = reinterpret_cast<const char*>(a.out), *o1 = o0 + (size_t)a.n_out * a.out_ld * 4;
-        return b0 < o1 && o0 < b1;
-    };
-    return hit(a.in, a.n_in, a.in_ld) || hit(a.in2, a.n_out, a.in2_ld);
-}
-std::atomic<long long> g_opt_hd_shape{getenv("CV_HD_SHAPE") ? atoll(getenv("CV_HD_SHAPE")) : 2};      // 0: 8 waves x 3 stages, 1: 4 x 2, 2: 8 x 2, 3: conv_hh (half-chunk stages, two workgroups per CU)
+std::atomic<long long> g_opt_hd_shape{getenv("CV_HD_SHAPE") ? atoll(getenv("CV_HD_SHAPE")) : 2};      // 0: 8 waves x 3 stages, 1: 4 x 2, 2: 8 x 2
 
 template <int NB>
 int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
@@ -2898,22 +2544,14 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
         if constexpr (NB <= 3) {
             if (((hd_mask >> (NB - 1)) & 1) && a.n_out >= hd_min_rows && !ax.xcd_tiles) {
                 ConvArgs ah = a;
-                // mask groups finished inside the launch (group_fused_tail): the caller handed two zeroed counters over, the
-                // operands are 16-byte aligned, and no output row is an input row of a workgroup that may still be gathering
-                const bool gfuse = g_opt_gfuse.load(std::memory_order_relaxed) && (hd_shape == 0 || hd_shape == 2) && a.tickets && a.perm_per_split && a.splits >= 2 &&
-                                   a.splits <= 3 && a.wide && !a.gvalid && !overlaps_inputs(a);
-                ah.gfuse = gfuse ? 1 : 0;
-                if (!gfuse) ah.tickets = nullptr;
+                ah.tickets = nullptr;
                 const int nw = hd_shape == 1 ? 4 : 8;
                 dim3 g((unsigned)((a.n_out + nw * 32 - 1) / (nw * 32)), grid.y, grid.z);
                 if (hd_shape == 1) conv_hd<NB, 4, 2><<<g, 256, 0, st>>>(ah);
-                else if (hd_shape == 3) conv_hh<NB, 8, 3><<<g, 512, 0, st>>>(ah);
-                else if (hd_shape == 2 && gfuse) conv_hd<NB, 8, 2, true><<<g, 512, 0, st>>>(ah);
                 else if (hd_shape == 2) conv_hd<NB, 8, 2><<<g, 512, 0, st>>>(ah);
-                else if (gfuse) conv_hd<NB, 8, 3, true><<<g, 512, 0, st>>>(ah);
                 else conv_hd<NB, 8, 3><<<g, 512, 0, st>>>(ah);
                 CV_LAUNCH_CHECK();
-                if (a.splits > 1 && !gfuse) return launch_finish(a, st);
+                if (a.splits > 1) return launch_finish(a, st);
                 return CV_OK;
             }
         }
@@ -3043,9 +2681,8 @@ int cv_sp_set_option(const char* name, long long value, long long* previous) {
     CV_REQUIRE(name, CV_EINVAL, "null option name");
     if (cvsc::win_option(name, value, previous)) return CV_OK;
     std::atomic<long long>* o = !strcmp(name, "hd_mask") ? &g_opt_hd_mask : !strcmp(name, "hd_min_rows") ? &g_opt_hd_min_rows :
-                                !strcmp(name, "hd_shape") ? &g_opt_hd_shape : !strcmp(name, "zskip") ? &g_opt_zskip :
-                                !strcmp(name, "gfuse") ? &g_opt_gfuse : nullptr;
-    CV_REQUIRE(o, CV_EINVAL, "unknown option '%s' (hd_mask, hd_min_rows, hd_shape, zskip, gfuse, win, win_xcd, win_levels)", name);
+                                !strcmp(name, "hd_shape") ? &g_opt_hd_shape : !strcmp(name, "zskip") ? &g_opt_zskip : nullptr;
+    CV_REQUIRE(o, CV_EINVAL, "unknown option '%s' (hd_mask, hd_min_rows, hd_shape, zskip, win, win_xcd, win_levels)", name);
     const long long before = o->exchange(value, std::memory_order_relaxed);
     if (previous) *previous = before;
     return CV_OK;
@@ -3055,8 +2692,7 @@ int cv_sp_get_option(const char* name, long long* value) {
     CV_REQUIRE(name && value, CV_EINVAL, "null option name / value");
     if (cvsc::win_option_get(name, value)) return CV_OK;
     const std::atomic<long long>* o = !strcmp(name, "hd_mask") ? &g_opt_hd_mask : !strcmp(name, "hd_min_rows") ? &g_opt_hd_min_rows :
-                                      !strcmp(name, "hd_shape") ? &g_opt_hd_shape : !strcmp(name, "zskip") ? &g_opt_zskip :
-                                      !strcmp(name, "gfuse") ? &g_opt_gfuse : nullptr;
+                                      !strcmp(name, "hd_shape") ? &g_opt_hd_shape : !strcmp(name, "zskip") ? &g_opt_zskip : nullptr;
     CV_REQUIRE(o, CV_EINVAL, "unknown option '%s'", name);
     *value = o->load(std::memory_order_relaxed);
     return CV_OK;

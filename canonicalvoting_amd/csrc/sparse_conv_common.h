@@ -51,7 +51,6 @@ struct ConvArgs {
     const int* win;              // conv_win: the window block of the kernel map (cv_sp_build_windows), see sparse_win.hip
     const float* acc_scale_dev;  // optional device scalar multiplied into acc_scale (the input gradient's hl operand carries a
                                  // per-layer power of two chosen on the device)
-    int gfuse;                   // conv_hd mask groups: 1 = the last group's workgroups sum the partial tiles (tickets[0..1]), no finish launch
     const unsigned char* gvalid; // mask groups: [splits][n_out] 1 = the row has a neighbour in the group; tiles without any write no
                                  // partial tile and conv_finish_small reads none for such (group, row) pairs (NULL: off)
 };

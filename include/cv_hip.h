@@ -239,9 +239,7 @@ typedef struct cv_conv_desc {
     int32_t* split_tickets; /* optional, hl-format input only: CV_SPLIT_TICKETS zero-initialised ints owned by the caller's
                                stream.  A split launch then reduces its partial tiles in the last-arriving workgroup of every
                                output tile (same summation order as the finish launch: bit-identical) instead of a second
-                               launch; the library leaves the counters at zero.  NULL: two launches.  With option "gfuse" a
-                               mask-sorted launch (perm_groups > 1) on conv_hd uses the first two counters: the workgroups of the
-                               last offset group wait for the others' partial tiles and run the epilogue themselves. */
+                               launch; the library leaves the counters at zero.  NULL: two launches. */
     const int32_t* win;     /* optional: neighbour windows of `nbr` (cv_sp_build_windows; K == 27, n_in == n_out rows in spatial
                                order).  With hl-format input, fp16-pair weights and Cout 32 / 64 / 96 the convolution then runs as
                                conv_win: every 256-row tile lands its window of input rows in LDS once and multiplies all 27
@@ -316,8 +314,7 @@ int cv_sp_set_ablation(int bits);
  * bit-identical under every setting).  "hd_mask": bit NB - 1 sends the hl-format convolutions whose workgroups are
  * NB x 32 columns wide to conv_hd (LDS-DMA operand rings, 256-row workgroups) instead of conv_hl when the launch has at
  * least "hd_min_rows" output rows; "hd_shape": 0 = 8 waves x 3 ring stages (one workgroup per CU), 1 = 4 waves x 2 stages
- * (two per CU), 2 = 8 waves x 2 stages, 3 = conv_hh (half-chunk stages, two 8-wave workgroups per CU); "gfuse": 1 = mask groups
- * summed inside the conv_hd launch (cv_conv_desc.split_tickets), no finish launch.  *previous (may be NULL) receives the old value.  Environment defaults: CV_HD,
+ * (two per CU), 2 = 8 waves x 2 stages.  *previous (may be NULL) receives the old value.  Environment defaults: CV_HD,
  * CV_HD_MIN_ROWS, CV_HD_SHAPE. */
 int cv_sp_set_option(const char* name, long long value, long long* previous);
 /* Reads a knob of cv_sp_set_option without touching it (other threads may be launching). */

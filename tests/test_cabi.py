@@ -223,7 +223,7 @@ def test_window_levels_of_a_program(built_lib):
         L.cv_sp_set_option(b"win", prev.value, None)
     assert L.cv_sp_set_option(b"no_such_knob", 1, None) != 0
     # cv_sp_get_option reads a knob without touching it (what the executor uses while other threads launch)
-    for name in (b"hd_mask", b"hd_min_rows", b"hd_shape", b"zskip", b"gfuse", b"win", b"win_xcd", b"win_levels"):
+    for name in (b"hd_mask", b"hd_min_rows", b"hd_shape", b"zskip", b"win", b"win_xcd", b"win_levels"):
         v, old = ctypes.c_longlong(-7), ctypes.c_longlong(-9)
         assert L.cv_sp_get_option(name, ctypes.byref(v)) == 0
         assert L.cv_sp_set_option(name, v.value, ctypes.byref(old)) == 0 and old.value == v.value

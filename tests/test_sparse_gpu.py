@@ -789,7 +789,7 @@ def test_conv_hd_is_bit_identical_to_conv_hl(cuda, built_lib, cin, cout, n, mask
         want = run()
         ME.set_option("hd_mask", 7)
         got = []
-        for shape in (0, 1, 2, 3, 0):   # 8 waves x 3 ring stages, 4 x 2, 8 x 2, conv_hh (half-chunk stages)
+        for shape in (0, 1, 2, 0):      # 8 waves x 3 ring stages, 4 x 2, 8 x 2
             prev_shape = ME.set_option("hd_shape", shape)
             got.append(run())
             ME.set_option("hd_shape", prev_shape)
@@ -800,51 +800,6 @@ def test_conv_hd_is_bit_identical_to_conv_hl(cuda, built_lib, cin, cout, n, mask
         for a, b in zip(want, g):
             assert torch.equal(a, b), "conv_hd (run %d) differs from conv_hl: %d of %d elements, max %g" % (
                 k, int((a != b).sum()), a.numel(), float((a - b).abs().max()))
-    assert float(want[0].abs().max()) > 0.1
-
-
-@pytest.mark.parametrize("cin,cout,n,groups,shape", [(96, 96, 40000, 3, 2), (128, 96, 40000, 3, 2), (32, 32, 20000, 3, 2),
-                                                      (64, 64, 30000, 3, 2), (32, 64, 33000, 3, 2), (96, 96, 40000, 3, 0),
-                                                      (96, 96, 700, 3, 2)])
-def test_mask_groups_summed_inside_the_launch_are_the_same_bits(cuda, built_lib, cin, cout, n, groups, shape):
-    """Option "gfuse": the workgroups of a conv_hd launch's LAST offset group wait for the other groups' partial tiles
-    (published write-through, counted on split_tickets[0]) and run the epilogue themselves - no finish launch.  Same
-    summation order as conv_finish_small: the same bits, plain and with the folded affine + hl residual + ReLU + hl output,
-    on every repetition, with a ragged last tile; the counters are back at zero after every launch; without counters the
-    launch keeps its finish launch."""
-    coords, _ = scene_coords(7, n, small=n < 10000)
-    N = len(coords)
-    rng = np.random.default_rng(cin + 5 * cout + groups)
-    t = lambda a: torch.from_numpy(a).to(cuda)
-    xh = ME.to_hl(t(rng.normal(0, 1, (N, cin)).astype(np.float32)))
-    w = t((rng.normal(0, 1, (27, cin, cout)) / np.sqrt(cin * 27)).astype(np.float32))
-    scale = t(rng.uniform(0.5, 1.5, cout).astype(np.float32))
-    shift = t(rng.normal(0, 0.2, cout).astype(np.float32))
-    rh = ME.to_hl(t(rng.normal(0, 1, (N, cout)).astype(np.float32)))
-    cm = ME.CoordinateManager(torch.from_numpy(coords).to(cuda, torch.int32))
-    nbr, perms = cm.kernel_map(3, 1), cm.mask_perms(3, 1, groups)
-    tickets = torch.zeros(4096, dtype=torch.int32, device=cuda)
-
-    def run(tk):
-        plain = ME.conv_forward_masked(xh, w, nbr, perms, N, pieces=2, in_hl=True, split_tickets=tk)
-        out = torch.empty((N, cout), device=cuda)
-        ME.conv_forward_masked(xh, w, nbr, perms, N, pieces=2, in_hl=True, scale=scale, shift=shift, residual=rh, relu=True,
-                               out=out, out_hl=True, res_hl=True, split_tickets=tk)
-        return plain, out
-
-    prev = [ME.set_option("hd_mask", 7), ME.set_option("hd_min_rows", 1), ME.set_option("hd_shape", shape), ME.set_option("gfuse", 0)]
-    try:
-        want = run(None)
-        ME.set_option("gfuse", 1)
-        got = [run(tickets) for _ in range(3)]
-        assert int(tickets.abs().sum()) == 0
-        no_counters = run(None)
-    finally:
-        for k, v in zip(("hd_mask", "hd_min_rows", "hd_shape", "gfuse"), prev):
-            ME.set_option(k, v)
-    for g in got + [no_counters]:
-        for a, b in zip(want, g):
-            assert torch.equal(a, b), "%d of %d elements differ, max %g" % (int((a != b).sum()), a.numel(), float((a - b).abs().max()))
     assert float(want[0].abs().max()) > 0.1
 
 
