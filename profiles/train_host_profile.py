@@ -1,29 +1,51 @@
-"""cProfile of the host side of train_joint.py steps (3 x 80k rows): where the Python time of a step goes."""
-import cProfile, pstats, sys, os
+"""host side of the training step: cProfile of train.train_step at 3 x 2000 points (the kernels are short: the step is its host
+side), top functions by own time - main thread only; the autograd engine's thread is sampled through total step time"""
+import os, sys, cProfile, pstats, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from canonicalvoting_amd import train
+import torch
+import bench
+from canonicalvoting_amd import me as ME, train
 from canonicalvoting_amd.minkunet import MinkUNet34C
-from canonicalvoting_amd.synth import make_scene
-dev = torch.device("cuda")
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 80000
-scenes = [make_scene(40 + b, n_points=n) for b in range(3)]
-t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-coords = t(np.concatenate([np.concatenate([np.full((n, 1), b, np.int64), s.coords], 1) for b, s in enumerate(scenes)])).int()
-feats = t(np.concatenate([s.feats for s in scenes]).astype(np.float32)) * 2 - 1
-xyz, scale, cls = [t(np.concatenate([getattr(s, k) for s in scenes])) for k in ("xyz_labels", "scale_labels", "class_labels")]
+dev = torch.device('cuda')
+batch = bench.train_batch(0, 3, int(sys.argv[1]) if len(sys.argv) > 1 else 2000, dev)
 torch.manual_seed(0)
 model = MinkUNet34C(3, 64).cuda().train()
 opt = train.make_optimizer(model)
-for _ in range(3):
-    train.train_step(model, opt, coords, feats, xyz, scale, cls)
+for _ in range(4):
+    train.train_step(model, opt, *batch)
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    train.train_step(model, opt, *batch)
+torch.cuda.synchronize()
+print("step %.2f ms" % ((time.perf_counter() - t0) * 100))
+# forward only / backward only host time
+x = None
+def fwd():
+    ME._train_state.used_pairs = False
+    with ME.pair_scale_hints(model):
+        out = model(ME.SparseTensor(batch[1], batch[0], device=dev))
+        return train.joint_loss(out.F, batch[2], batch[3], batch[4])[0]
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10):
+    loss = fwd()
+t1 = time.perf_counter(); torch.cuda.synchronize()
+print("forward + loss, host enqueue %.2f ms" % ((t1 - t0) * 100))
+with ME.pair_scale_hints(model):
+    losses = []
+    t_b = 0.0
+    for _ in range(10):
+        out = model(ME.SparseTensor(batch[1], batch[0], device=dev))
+        loss = train.joint_loss(out.F, batch[2], batch[3], batch[4])[0]
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        loss.backward()
+        t_b += time.perf_counter() - t0
+        torch.cuda.synchronize()
+print("backward, host enqueue %.2f ms" % (t_b * 100))
 pr = cProfile.Profile()
 pr.enable()
-for _ in range(5):
-    train.train_step(model, opt, coords, feats, xyz, scale, cls)
-torch.cuda.synchronize()
+for _ in range(10):
+    loss = fwd()
 pr.disable()
-st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(35)
-st.sort_stats("cumulative").print_stats(30)
+torch.cuda.synchronize()
+st = pstats.Stats(pr); st.sort_stats('tottime'); st.print_stats(22)
