@@ -35,7 +35,26 @@ def _ptr(t):
 
 
 def _stream(dev):
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    # (the raw handle: torch.cuda.current_stream builds a Stream object per call - 4 us x ~10 per layer of a training step)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device()))
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(dev):
+    """`with torch.cuda.device(dev)` that costs nothing when dev is the current device already (one process per GPU: always)"""
+    if dev.index is None or torch.cuda.current_device() == dev.index:
+        return _NO_SWITCH
+    return torch.cuda.device(dev)
 
 
 class _FusedPlan:
@@ -105,7 +124,7 @@ class CoordinateManager:
         ws = torch.empty(int(L.cv_sp_levels_workspace_bytes(n)), dtype=torch.uint8, device=dev)
         arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
         sync = check or num_levels > 1
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(L.cv_sp_build_levels(arr(self._coords_buf), arr(self._keys), arr(self._vals), n,
                                             self.cap, num_levels, _ptr(self._counts_d),
                                             counts_h if sync else None, _ptr(ws), ws.numel(), _stream(dev)),
@@ -249,7 +268,7 @@ class CoordinateManager:
         c_vals = (vp * NL)(*[ib + 4 * o for o in o_vals])
         counts_h = (ctypes.c_int32 * 8)()
         off = _lib.SceneMaps()
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(L.cv_sp_scene_plan(_ptr(self._input), n, vp(ib + 4 * o_perm), vp(ib + 4 * o_inv), c_coords, c_keys,
                                           c_vals, cap, vp(ib + 4 * o_counts), counts_h, stem_k, G, self.MASKED_MIN_ROWS,
                                           win_levels, vp(ib + 4 * o_arena), words, ctypes.byref(off), vp(wb), sws_b, vp(wb + up64(sws_b)),
@@ -486,7 +505,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
             if k is None:
                 k = h2_scale_log2((w, None))
             wp6 = torch.empty(2 * w.numel(), dtype=torch.int16, device=dev)
-            with torch.cuda.device(dev):
+            with _on(dev):
                 _lib.check(L.cv_sp_pack_weights_t_f32(_ptr(w), K, cout, cin, 2, int(k), _ptr(wp6), _stream(dev)),
                            "cv_sp_pack_weights_t_f32")
             acc_scale, flag = 2.0 ** -k, range_flag(dev)
@@ -507,7 +526,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
             wp6, acc_scale, flag = hit[1], 2.0 ** -hit[2], range_flag(dev)
         elif weight_t:
             wp6 = torch.empty((3 if pieces == 3 else 1) * w.numel(), dtype=torch.int16, device=dev)
-            with torch.cuda.device(dev):
+            with _on(dev):
                 _lib.check(L.cv_sp_pack_weights_t_f32(_ptr(w), K, cout, cin, pieces, 0, _ptr(wp6), _stream(dev)),
                            "cv_sp_pack_weights_t_f32")
         elif pieces == 1:
@@ -533,7 +552,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
                       1 if (perm_groups > 1 and getattr(row_perm, "_cv_has_map", False)) else 0,
                       2 if flag is not None else (1 if (pieces == 1 and wp6 is not None) else 0), acc_scale, p(flag),
                       1 if in_hl else 0, 1 if out_hl else 0, 1 if res_hl else 0, p(split_tickets), p(win), p(acc_scale_dev))
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
     return out
 
@@ -562,7 +581,7 @@ def option(name):
 def to_hl(x):
     """fp32 rows [n, C] (C % 32 == 0) -> the hl format (same shape and dtype, the bytes hold the fp16 pairs)"""
     y = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.lib().cv_sp_to_hl_f32(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), y.data_ptr(), y.stride(0),
                                               range_flag(x.device).data_ptr(), _stream(x.device)), "cv_sp_to_hl_f32")
     return y
@@ -570,7 +589,7 @@ def to_hl(x):
 
 def from_hl(x):
     y = torch.empty((x.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(_lib.lib().cv_sp_from_hl_f32(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), y.data_ptr(),
                                                 y.stride(0), _stream(x.device)), "cv_sp_from_hl_f32")
     return y
@@ -600,7 +619,7 @@ def _perms_with_map(nbr, groups):
     # orders, the map rows in processing order, then one validity byte per (group, row) (cv_sp_mask_perms with_map = 1)
     flat = torch.empty(groups * n * (1 + W) + (groups * n + 3) // 4, dtype=torch.int32, device=nbr.device)
     ws = torch.empty(groups * 4096, dtype=torch.uint8, device=nbr.device)
-    with torch.cuda.device(nbr.device):
+    with _on(nbr.device):
         _lib.check(L.cv_sp_mask_perms(_ptr(nbr), n, K, groups, _ptr(flat), _ptr(ws), ws.numel(), 1,
                                       _stream(nbr.device)), "cv_sp_mask_perms")
     m = flat[:groups * n].view(groups, n)
@@ -637,7 +656,7 @@ def packed_weights_bf16(w3, col_scale=None):
     L = _lib.lib()
     K, cin, cout = w3.shape
     wp = torch.empty(w3.numel(), dtype=torch.int16, device=w3.device)
-    with torch.cuda.device(w3.device):
+    with _on(w3.device):
         _lib.check(L.cv_sp_pack_weights_bf16_f32(_ptr(w3), K, cin, cout, _ptr(col_scale), _ptr(wp),
                                                  _stream(w3.device)), "cv_sp_pack_weights_bf16_f32")
     return wp
@@ -657,7 +676,7 @@ def packed_weights_x6_scaled(w3, col_scale):
     L = _lib.lib()
     K, cin, cout = w3.shape
     wp = torch.empty(3 * w3.numel(), dtype=torch.int16, device=w3.device)
-    with torch.cuda.device(w3.device):
+    with _on(w3.device):
         _lib.check(L.cv_sp_pack_weights_x6_f32(_ptr(w3), K, cin, cout, _ptr(col_scale), _ptr(wp), _stream(w3.device)),
                    "cv_sp_pack_weights_x6_f32")
     return wp
@@ -681,7 +700,7 @@ def packed_weights_h2(w3, col_scale, scale_log2):
     L = _lib.lib()
     K, cin, cout = w3.shape
     wp = torch.empty(2 * w3.numel(), dtype=torch.int16, device=w3.device)
-    with torch.cuda.device(w3.device):
+    with _on(w3.device):
         _lib.check(L.cv_sp_pack_weights_h2_f32(_ptr(w3), K, cin, cout, _ptr(col_scale), int(scale_log2), _ptr(wp),
                                                _stream(w3.device)), "cv_sp_pack_weights_h2_f32")
     return wp
@@ -694,7 +713,7 @@ def packed_weights_stem_h2(w3, col_scale, scale_log2):
     K, cin, cout = w3.shape
     assert cout == 32
     wp = torch.empty(8 * cin * 1024, dtype=torch.int16, device=w3.device)
-    with torch.cuda.device(w3.device):
+    with _on(w3.device):
         _lib.check(L.cv_sp_pack_weights_stem_h2_f32(_ptr(w3), K, cin, _ptr(col_scale), int(scale_log2), _ptr(wp),
                                                     _stream(w3.device)), "cv_sp_pack_weights_stem_h2_f32")
     return wp
@@ -713,7 +732,7 @@ def packed_weights_x6(weight, w3, cache=True):
         L = _lib.lib()
         K, cin, cout = w3.shape
         wp = torch.empty(3 * w3.numel(), dtype=torch.int16, device=w3.device)
-        with torch.cuda.device(w3.device):
+        with _on(w3.device):
             _lib.check(L.cv_sp_pack_weights_x6_f32(_ptr(w3), K, cin, cout, None, _ptr(wp), _stream(w3.device)),
                        "cv_sp_pack_weights_x6_f32")
         try:
@@ -739,7 +758,7 @@ def transposed_map(nbr, n_in):
     if hit is None or hit.shape[0] != n_in:
         L = _lib.lib()
         hit = torch.empty((n_in, nbr.shape[1]), dtype=torch.int32, device=nbr.device)
-        with torch.cuda.device(nbr.device):
+        with _on(nbr.device):
             _lib.check(L.cv_sp_transpose_map(_ptr(nbr), nbr.shape[0], nbr.shape[1], n_in, _ptr(hit),
                                              _stream(nbr.device)), "cv_sp_transpose_map")
         nbr._cv_transposed = hit
@@ -753,7 +772,7 @@ def conv_wgrad(x_feats, grad_out, nbr, K):
     cin, cout, n_out = x_feats.shape[1], grad_out.shape[1], grad_out.shape[0]
     dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
     ws = _workspace(dev, int(L.cv_sp_wgrad_workspace_bytes(n_out, cin, cout, K)))
-    with torch.cuda.device(dev):
+    with _on(dev):
         if COMPUTE_DTYPE == "bf16":
             _lib.check(L.cv_sp_conv_wgrad_px_f32(_ptr(x_feats), x_feats.stride(0), cin, _ptr(grad_out),
                                                  grad_out.stride(0), cout, _ptr(nbr), K, n_out, _ptr(dw), _ptr(ws),
@@ -770,7 +789,7 @@ def col_sum(x):
     L = _lib.lib()
     out = torch.empty((x.shape[1],), dtype=torch.float32, device=x.device)
     ws = _lib.scratch(x.device, "col_sum", int(L.cv_sp_col_sum_workspace_bytes(x.shape[0], x.shape[1])))
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _lib.check(L.cv_sp_col_sum_det_f32(_ptr(x), x.shape[0], x.shape[1], x.stride(0), _ptr(out), _ptr(ws), ws.numel(),
                                            _stream(x.device)), "cv_sp_col_sum_det_f32")
     return out
@@ -1117,7 +1136,7 @@ def bn_affine(bn):
     c = bn.num_features
     dev = bn.weight.device
     out = torch.empty((2, c), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.cv_sp_bn_fold_f32(_ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean),
                                        _ptr(bn.running_var), _ptr(None), float(bn.eps), c, _ptr(out[0]),
                                        _ptr(out[1]), _stream(dev)), "cv_sp_bn_fold_f32")
@@ -1131,13 +1150,13 @@ def affine_forward(F, scale, shift, relu, out=None, residual=None, out_hl=None, 
     if out is None:
         out = torch.empty_like(F)
     if out_hl is not None:
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(L.cv_sp_affine_hl_f32(_ptr(F), F.shape[0], F.shape[1], F.stride(0), _ptr(scale), _ptr(shift),
                                              _ptr(residual), residual.stride(0) if residual is not None else 0,
                                              1 if relu else 0, _ptr(out), out.stride(0), _ptr(out_hl), out_hl.stride(0),
                                              _ptr(relu_bits), range_flag(dev).data_ptr(), _stream(dev)), "cv_sp_affine_hl_f32")
         return out
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.cv_sp_affine_f32(_ptr(F), F.shape[0], F.shape[1], F.stride(0), _ptr(scale), _ptr(shift),
                                       _ptr(residual), residual.stride(0) if residual is not None else 0,
                                       1 if relu else 0, _ptr(out), out.stride(0), _stream(dev)),
@@ -1157,7 +1176,7 @@ class _BNTrainFn(torch.autograd.Function):
         dev = x.device
         stats = torch.empty((4, c), dtype=torch.float32, device=dev)          # mean, var, scale, shift
         ws = torch.empty(int(L.cv_sp_bn_workspace_bytes(c)), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(L.cv_sp_bn_stats_f32(_ptr(x), n, c, x.stride(0), _ptr(gamma), _ptr(beta), float(eps),
                                             float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(stats[0]),
                                             _ptr(stats[1]), _ptr(stats[2]), _ptr(stats[3]), _ptr(ws), ws.numel(),
@@ -1204,7 +1223,7 @@ class _BNTrainFn(torch.autograd.Function):
                 # dx leaves with its hl twin for the input gradient of the convolution that produced x (usable from the layer's
                 # second step on: the factor comes from the maximum the step before left in the slot)
                 dx_hl = torch.empty_like(dx)
-        with torch.cuda.device(dev):
+        with _on(dev):
             if dx_hl is not None or bits is not None:
                 _lib.check(L.cv_sp_bn_backward_hl_f32(_ptr(x), _ptr(dy), _ptr(y_rows), n, c, x.stride(0), _ptr(stats[0]),
                                                       _ptr(stats[1]), ctx.eps, _ptr(gamma), _ptr(dg[0]), _ptr(dg[1]),
