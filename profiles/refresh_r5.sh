@@ -18,6 +18,8 @@ python bench.py --points 8000 --steps 240 --cpu-scenes 0 --train-steps 0 --measu
 # kernel stats + per-dispatch trace, one scene in flight and the default streams
 (cd /tmp && rm -rf /tmp/p1 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python $GRAFT_REPO_ROOT/bench.py --streams 1 --steps 10 --warmup 3 --cpu-scenes 0 --train-steps 0 --measure-traffic 0 > /tmp/p1.log 2>&1; f=$(find /tmp/p1 -name "*kernel_stats.csv" | head -1); cp "$f" $O/full_path_kernel_stats.csv; t=$(find /tmp/p1 -name "*kernel_trace.csv" | head -1); python $GRAFT_REPO_ROOT/profiles/layer_trace.py "$t" > $O/layer_times.txt)
 (cd /tmp && rm -rf /tmp/p3 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p3 -- python $GRAFT_REPO_ROOT/bench.py --steps 24 --warmup 6 --cpu-scenes 0 --train-steps 0 --measure-traffic 0 > /tmp/p3.log 2>&1; f=$(find /tmp/p3 -name "*kernel_stats.csv" | head -1); cp "$f" $O/full_path_kernel_stats_default_streams.csv)
+# the training step per kernel (weight gradients on their side stream) and where its main stream idles
+(cd /tmp && rm -rf /tmp/pt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pt -- python $GRAFT_REPO_ROOT/bench.py --mode train --steps 8 --warmup 3 --cpu-scenes 0 > /tmp/pt.log 2>&1; f=$(find /tmp/pt -name "*kernel_stats.csv" | head -1); cp "$f" $O/train_kernel_stats.csv; t=$(find /tmp/pt -name "*kernel_trace.csv" | head -1); python $GRAFT_REPO_ROOT/profiles/train_gaps.py "$t" > $O/train_gaps.txt)
 bash profiles/vote_pmc_sq.sh r5final > /dev/null 2>&1
 bash profiles/vote_pmc.sh > $O/vote_pmc.log 2>&1; cp gpurun_out/vote_pmc/* $O/ 2>/dev/null
 bash profiles/net_traffic_pmc.sh > $O/net_traffic_pmc.txt 2>&1
