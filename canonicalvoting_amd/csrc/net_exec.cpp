@@ -39,7 +39,9 @@ static void scene_maps_layout(const long long* rows, long long n_orig, int stem_
     o->k3[0] = take((size_t)rows[0] * 27);
     o->win[0] = level_has_windows(win_levels, 0, rows[0], masked_min_rows) ? take(cv_sp_windows_words(rows[0])) : -1;
     o->mask_perm[0] = (o->win[0] < 0 && mask_groups > 1 && rows[0] >= masked_min_rows) ? take(mp_w * rows[0]) : -1;
-    o->scratch = take((size_t)(5 * std::max(mask_groups, 1) + 4) * 1024);
+    // bin counts + running counts of the mask orders (cv_sp_mask_perms_batch: 2 x 1024 words per group): level 0, then <= 4
+    // coarse levels and the 4 up-map orders
+    o->scratch = take((size_t)(5 * std::max(mask_groups, 1) + 4) * 2048);
     o->bitmap = take((size_t)CV_BITMAP_WORDS);          // occupancy bits of the level-0 set (cv_sp_scene_plan only)
     o->out = -1;                       // (the sort's inverse permutation is the final map)
     (void)n_orig;
@@ -89,7 +91,7 @@ static int scene_maps_level0(int32_t* const* d_coords, const unsigned long long*
     }
     if (o.mask_perm[0] >= 0) {
         CvPermJob pj = {d_arena + o.k3[0], n, 27, mask_groups, d_arena + o.mask_perm[0], 1};
-        rc = cv_sp_mask_perms_batch(&pj, 1, d_arena + o.scratch, sizeof(int) * (size_t)mask_groups * 1024, stream, pre_cleared);
+        rc = cv_sp_mask_perms_batch(&pj, 1, d_arena + o.scratch, sizeof(int) * (size_t)mask_groups * 2048, stream, pre_cleared);
         if (rc != CV_OK) return rc;
     }
     return CV_OK;
@@ -134,8 +136,8 @@ static int scene_maps_coarse(int32_t* const* d_coords, const unsigned long long*
         pj[np++] = {d_arena + o.up[i], level_rows[3 - i], 8, 1, d_arena + o.up_perm[i], 0};
         groups += 1;
     }
-    return cv_sp_mask_perms_batch(pj, np, d_arena + o.scratch + (size_t)std::max(mask_groups, 1) * 1024,
-                                  sizeof(int) * (size_t)groups * 1024, stream, pre_zeroed);
+    return cv_sp_mask_perms_batch(pj, np, d_arena + o.scratch + (size_t)std::max(mask_groups, 1) * 2048,
+                                  sizeof(int) * (size_t)groups * 2048, stream, pre_zeroed);
 }
 
 int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,

@@ -2049,8 +2049,14 @@ __global__ __launch_bounds__(MP_THREADS) void mp_hist_batch(const PermJobsDev jo
         if (lh[i]) atomicAdd(&hist[blockIdx.y * MP_BINS + i], lh[i]);
 }
 
-__global__ __launch_bounds__(MP_THREADS) void mp_scatter_batch(const PermJobsDev jobs, int* __restrict__ cursor) {
+// (round 5: no scan launch between the histogram and the scatter of the batched orders - a scatter workgroup scans its group's
+// 1024 bin counts itself (one per thread) and claims its rows' places from a SECOND zeroed array of running counts per bin)
+__global__ __launch_bounds__(MP_THREADS) void mp_scatter_batch(const PermJobsDev jobs, const int* __restrict__ hist,
+                                                               int* __restrict__ cursor) {
+    static_assert(MP_THREADS == MP_BINS, "one bin per thread in the scan");
     __shared__ int lh[MP_BINS];
+    __shared__ int pre[MP_BINS];
+    __shared__ int wtot[MP_THREADS / 64];
     const int ji = perm_job_of(jobs, blockIdx.y);
     const CvPermJob& jb = jobs.j[ji];
     if (blockIdx.x * (long long)MP_THREADS >= jb.n) return;
@@ -2058,6 +2064,22 @@ __global__ __launch_bounds__(MP_THREADS) void mp_scatter_batch(const PermJobsDev
     const int K = jb.K, jlo = K * g / jb.groups, jhi = K * (g + 1) / jb.groups, W = (K + jb.groups - 1) / jb.groups;
     int* nbrp = jb.with_map ? jb.perm + (long long)jb.groups * jb.n : nullptr;
     for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS) lh[i] = 0;
+    {   // exclusive scan of the group's bin counts: first slot of every bin
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int v = hist[blockIdx.y * MP_BINS + threadIdx.x];
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int w = 0; w < MP_THREADS / 64; ++w) base += w < wave ? wtot[w] : 0;
+        pre[threadIdx.x] = base + incl - v;
+    }
     __syncthreads();
     const long long row = blockIdx.x * (long long)MP_THREADS + threadIdx.x;
     int key = 0, rank = 0;
@@ -2067,7 +2089,7 @@ __global__ __launch_bounds__(MP_THREADS) void mp_scatter_batch(const PermJobsDev
     }
     __syncthreads();
     for (int i = threadIdx.x; i < MP_BINS; i += MP_THREADS)
-        if (lh[i]) lh[i] = atomicAdd(&cursor[blockIdx.y * MP_BINS + i], lh[i]);
+        if (lh[i]) lh[i] = pre[i] + atomicAdd(&cursor[blockIdx.y * MP_BINS + i], lh[i]);
     __syncthreads();
     if (row < jb.n) {
         const long long pos = (long long)g * jb.n + lh[key] + rank;
@@ -2729,16 +2751,16 @@ int cv_sp_mask_perms_batch(const CvPermJob* jobs, int n_jobs, void* d_ws, size_t
         max_n = std::max(max_n, j.n);
     }
     d.group_begin[n_jobs] = groups;
-    CV_REQUIRE(ws_bytes >= sizeof(int) * (size_t)groups * MP_BINS, CV_ENOMEM, "workspace too small");
+    // workspace: [groups][1024] bin counts, then [groups][1024] running counts of the scatter (both zero at the start)
+    CV_REQUIRE(ws_bytes >= sizeof(int) * (size_t)groups * MP_BINS * 2, CV_ENOMEM, "workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     int* hist = static_cast<int*>(d_ws);
-    if (!pre_zeroed) CV_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * (size_t)groups * MP_BINS, st));
+    int* cursor = hist + (size_t)groups * MP_BINS;
+    if (!pre_zeroed) CV_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * (size_t)groups * MP_BINS * 2, st));
     dim3 grid((unsigned)((max_n + MP_THREADS - 1) / MP_THREADS), (unsigned)groups);
     mp_hist_batch<<<grid, MP_THREADS, 0, st>>>(d, hist);
     CV_LAUNCH_CHECK();
-    mp_scan<<<groups, MP_BINS, 0, st>>>(hist);
-    CV_LAUNCH_CHECK();
-    mp_scatter_batch<<<grid, MP_THREADS, 0, st>>>(d, hist);
+    mp_scatter_batch<<<grid, MP_THREADS, 0, st>>>(d, hist, cursor);
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

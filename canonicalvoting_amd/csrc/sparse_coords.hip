@@ -75,7 +75,6 @@ __global__ __launch_bounds__(256) void table_clear(unsigned long long* keys, int
 //                    of the fused network arrive spatially sorted, so most lanes do)
 //   flag_levels      row i is the first descendant of its level-L voxel iff vals_L[slot] == i (+ the duplicate check
 //                    of level 0 as one more job of the same launch)
-//   scan_levels      block offsets of the flags, the level sizes
 //   emit_levels      rank of a flagged row = its coarse row: coordinates out, table value := coarse row
 struct LevelsDev { unsigned long long* keys[5]; int* vals[5]; int* coords[5]; int n_levels; };
 
@@ -158,27 +157,30 @@ __global__ __launch_bounds__(1024) void flag_levels(const int* __restrict__ coor
     if (threadIdx.x == 0) bsum[blockIdx.y * 1024 + blockIdx.x] = s[0];
 }
 
-// one block per coarse level: exclusive scan of its block sums, total -> counts[level]
-__global__ __launch_bounds__(1024) void scan_levels(int* __restrict__ bsum, int nblocks, int* counts) {
-    __shared__ int s[1024];
-    int* bs = bsum + blockIdx.x * 1024;
-    const int v = (int)threadIdx.x < nblocks ? bs[threadIdx.x] : 0;
-    const int ex = block_exclusive_scan(v, s);
-    if ((int)threadIdx.x < nblocks) bs[threadIdx.x] = ex;
-    if (threadIdx.x == 1023) counts[blockIdx.x + 1] = ex + v;
-}
-
+// (round 5: the one-block-per-level scan launch between flag_levels and emit_levels is gone - a block adds up the sums of the
+// blocks before it itself (at most 1024 words, one per thread), the last block of a level also writes the level's row count)
 template <int SCAN_PER>
 __global__ __launch_bounds__(1024) void emit_levels(const int* __restrict__ coords, int n, const LevelsDev t,
-                                                    const int* __restrict__ slots, const int* __restrict__ boff) {
+                                                    const int* __restrict__ slots, const int* __restrict__ bsum,
+                                                    int* __restrict__ counts) {
     __shared__ int s[1024];
+    __shared__ int wsum[16];
     const int L = blockIdx.y + 1;
     const int* sl = slots + (long long)blockIdx.y * n;
     const int b0 = (blockIdx.x * 1024 + threadIdx.x) * SCAN_PER;
     int v[SCAN_PER], sum = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_PER; ++j) { v[j] = (b0 + j < n) ? sl[b0 + j] : -1; sum += v[j] >= 0; }
-    int run = block_exclusive_scan(sum, s) + boff[blockIdx.y * 1024 + blockIdx.x];
+    int before = (int)threadIdx.x < (int)blockIdx.x ? bsum[blockIdx.y * 1024 + threadIdx.x] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = before;
+    __syncthreads();
+    int boff = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) boff += wsum[w];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) counts[L] = boff + bsum[blockIdx.y * 1024 + blockIdx.x];
+    int run = block_exclusive_scan(sum, s) + boff;
     const int m = ~((1 << L) - 1);
 #pragma unroll
     for (int j = 0; j < SCAN_PER; ++j) {
@@ -696,10 +698,8 @@ int cv_sp_build_levels_zero(int32_t* const* d_coords, unsigned long long* const*
     else flag_levels<8><<<dim3(nsb, num_levels), 1024, 0, st>>>(d_coords[0], (int)n, lv, cap - 1, slots, bsum, d_counts + 5);
     CV_LAUNCH_CHECK();
     if (num_levels > 1) {
-        scan_levels<<<num_levels - 1, 1024, 0, st>>>(bsum, nsb, d_counts);
-        CV_LAUNCH_CHECK();
-        if (scan_per == 1) emit_levels<1><<<dim3(nsb, num_levels - 1), 1024, 0, st>>>(d_coords[0], (int)n, lv, slots, bsum);
-        else emit_levels<8><<<dim3(nsb, num_levels - 1), 1024, 0, st>>>(d_coords[0], (int)n, lv, slots, bsum);
+        if (scan_per == 1) emit_levels<1><<<dim3(nsb, num_levels - 1), 1024, 0, st>>>(d_coords[0], (int)n, lv, slots, bsum, d_counts);
+        else emit_levels<8><<<dim3(nsb, num_levels - 1), 1024, 0, st>>>(d_coords[0], (int)n, lv, slots, bsum, d_counts);
         CV_LAUNCH_CHECK();
     }
     if (h_counts) {

@@ -117,7 +117,7 @@ def test_host_side_layout_functions(built_lib):
         assert off.out == -1          # the caller's rows <- sorted rows map is cv_sp_sort_rows' inverse permutation
         spans = [(off.stem, 80000 * 125)] + [(off.down[i], rows[i + 1] * 8) for i in range(4)] + \
                 [(off.k3[i], rows[i] * 27) for i in range(5)] + [(off.up[i], rows[3 - i] * 8) for i in range(4)] + \
-                [(off.up_perm[i], rows[3 - i]) for i in range(4)] + [(off.scratch, (5 * 4 + 4) * 1024), (off.bitmap, 1 << 20)]
+                [(off.up_perm[i], rows[3 - i]) for i in range(4)] + [(off.scratch, (5 * 4 + 4) * 2048), (off.bitmap, 1 << 20)]
         for i in range(5):
             windows = rows[i] >= 16384 and (win_levels >> i) & 1          # a level has windows OR mask orders
             if windows:
