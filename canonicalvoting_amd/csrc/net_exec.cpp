@@ -212,12 +212,25 @@ int cv_sp_scene_plan(const int32_t* d_input, long long n, int32_t* d_perm, int32
                      int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int win_levels, int32_t* d_arena,
                      size_t arena_words, cv_scene_maps* offsets, void* d_sort_ws, size_t sort_ws_bytes, void* d_levels_ws,
                      size_t levels_ws_bytes, void* stream) {
+    return cv_sp_scene_plan_ex(d_input, n, d_perm, d_inv, d_coords, d_keys, d_vals, cap, d_counts, h_counts, stem_k, mask_groups,
+                               masked_min_rows, win_levels, d_arena, arena_words, offsets, d_sort_ws, sort_ws_bytes, d_levels_ws,
+                               levels_ws_bytes, false, stream);
+}
+
+}  // extern "C"
+
+// (C++ linkage, cv_common.h) single_batch: the rows are one scene (cv_detect_scene_f32): the sort skips its batch digit
+int cv_sp_scene_plan_ex(const int32_t* d_input, long long n, int32_t* d_perm, int32_t* d_inv, int32_t* const* d_coords,
+                        unsigned long long* const* d_keys, int32_t* const* d_vals, long long cap, int32_t* d_counts,
+                        int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int win_levels,
+                        int32_t* d_arena, size_t arena_words, cv_scene_maps* offsets, void* d_sort_ws, size_t sort_ws_bytes,
+                        void* d_levels_ws, size_t levels_ws_bytes, bool single_batch, void* stream) {
     CV_REQUIRE(d_input && d_perm && d_inv && d_coords && d_keys && d_vals && d_counts && h_counts && d_arena && offsets &&
                    d_sort_ws && d_levels_ws, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(arena_words >= cv_sp_scene_plan_words(n, stem_k, mask_groups, masked_min_rows, win_levels), CV_ENOMEM,
                "scene map arena too small (cv_sp_scene_plan_words)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = cv_sp_sort_rows(d_input, n, d_coords[0], d_perm, d_inv, d_sort_ws, sort_ws_bytes, stream);
+    int rc = cv_sp_sort_rows_ex(d_input, n, d_coords[0], d_perm, d_inv, d_sort_ws, sort_ws_bytes, single_batch, stream);
     if (rc != CV_OK) return rc;
     // level-0 layout of the arena (depends on n only): the histogram scratch of the mask orders and the occupancy bitmap
     // are neighbours there and are zeroed by the first launch of the level build (no fill launches of their own)
@@ -253,6 +266,8 @@ int cv_sp_scene_plan(const int32_t* d_input, long long n, int32_t* d_perm, int32
     *offsets = o;
     return scene_maps_coarse(d_coords, d_keys, d_vals, cap, rows, mask_groups, o, d_arena, stream, true);
 }
+
+extern "C" {
 
 size_t cv_net_arena_bytes(const cv_net_buf* bufs, int n_bufs, const long long* level_rows, int n_levels) {
     if (!bufs || !level_rows || n_bufs <= 0) return 0;

@@ -123,8 +123,8 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
     }
     int32_t counts_h[8] = {0};
     cv_scene_maps off;
-    rc = cv_sp_scene_plan(d->d_coords4, n, ibuf + o_perm, ibuf + o_inv, c_coords, c_keys, c_vals, cap, ibuf + o_counts, counts_h,
-                          d->stem_k, d->mask_groups, d->masked_min_rows, win_levels, ibuf + o_arena, words, &off, sort_ws, sws_b, lev_ws, lws_b,
+    rc = cv_sp_scene_plan_ex(d->d_coords4, n, ibuf + o_perm, ibuf + o_inv, c_coords, c_keys, c_vals, cap, ibuf + o_counts, counts_h,
+                          d->stem_k, d->mask_groups, d->masked_min_rows, win_levels, ibuf + o_arena, words, &off, sort_ws, sws_b, lev_ws, lws_b, /* one scene: the sort skips its batch digit */ true,
                           stream);
     if (rc != CV_OK) return rc;
     r->duplicates = counts_h[5];

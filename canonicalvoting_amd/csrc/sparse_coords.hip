@@ -491,13 +491,15 @@ __global__ __launch_bounds__(SORT_T) void sort_scatter(const unsigned* __restric
                                                        unsigned* __restrict__ keys_out, int* __restrict__ vals_out,
                                                        const int* __restrict__ coords_in, int* __restrict__ perm,
                                                        int* __restrict__ inv, int* __restrict__ sorted,
-                                                       const int* __restrict__ mm) {
+                                                       const int* __restrict__ mm, int force_single = 0) {
     constexpr int NWAVE = SORT_T / 64, ROUNDS = SORT_ROWS / SORT_T, PER_T = SORT_BINS / SORT_T;
     __shared__ int wcnt[NWAVE][SORT_BINS];          // rows of (wave, bin); then the first output slot of (wave, bin)
     __shared__ int wave_tot[NWAVE];
     // a single scene (largest batch index 0) is sorted after two digits: pass 1 then writes the final outputs and
     // pass 2 has nothing to do (two launches that exit at once instead of 30 us of histogram + scatter)
-    const bool single = mm[6] == 0;
+    // (force_single: the caller says so - cv_detect_scene_f32's input is one scene - and does not even queue pass 2; rows with
+    // another batch index would only lose their batch-major grouping, every table key carries the batch index)
+    const bool single = force_single || mm[6] == 0;
     if (pass == 2 && single) return;
     const int* coords = (pass == 2 || (pass == 1 && single)) ? coords_in : nullptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -739,6 +741,15 @@ size_t cv_sp_sort_workspace_bytes(long long n) {
 //   original row.  Asynchronous, 8 launches, no host synchronisation.
 int cv_sp_sort_rows(const int32_t* d_coords, long long n, int32_t* d_sorted, int32_t* d_perm, int32_t* d_inv,
                     void* d_ws, size_t ws_bytes, void* stream) {
+    return cv_sp_sort_rows_ex(d_coords, n, d_sorted, d_perm, d_inv, d_ws, ws_bytes, false, stream);
+}
+
+}  // extern "C"
+
+// (C++ linkage, cv_common.h) single_batch: every row is of one scene - the third digit (the batch index) is not sorted:
+// five launches instead of seven
+int cv_sp_sort_rows_ex(const int32_t* d_coords, long long n, int32_t* d_sorted, int32_t* d_perm, int32_t* d_inv,
+                       void* d_ws, size_t ws_bytes, bool single_batch, void* stream) {
     CV_REQUIRE(d_coords && d_sorted && d_perm && d_inv && d_ws, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(n > 0 && n < (1ll << 30), CV_EINVAL, "bad row count %lld", n);
     CV_REQUIRE(ws_bytes >= cv_sp_sort_workspace_bytes(n), CV_ENOMEM, "workspace too small");
@@ -762,8 +773,9 @@ int cv_sp_sort_rows(const int32_t* d_coords, long long n, int32_t* d_sorted, int
     sort_hist<<<nblk, SORT_T, 0, st>>>(nullptr, mm, keys_b, n, 1, hist);
     CV_LAUNCH_CHECK();
     sort_scatter<<<nblk, SORT_T, 0, st>>>(keys_b, vals_b, n, 1, hist, nblk, keys_a, vals_a, d_coords, d_perm, d_inv,
-                                          d_sorted, mm);
+                                          d_sorted, mm, single_batch ? 1 : 0);
     CV_LAUNCH_CHECK();
+    if (single_batch) return CV_OK;
     sort_hist<<<nblk, SORT_T, 0, st>>>(nullptr, mm, keys_a, n, 2, hist);
     CV_LAUNCH_CHECK();
     sort_scatter<<<nblk, SORT_T, 0, st>>>(keys_a, vals_a, n, 2, hist, nblk, nullptr, nullptr, d_coords, d_perm, d_inv,
@@ -771,6 +783,8 @@ int cv_sp_sort_rows(const int32_t* d_coords, long long n, int32_t* d_sorted, int
     CV_LAUNCH_CHECK();
     return CV_OK;
 }
+
+extern "C" {
 
 // Kernel map of a k^3 kernel: out set (rows n_out) looked up in the input set's table.
 // d_nbr: int32 [n_out][k^3].  ts = tensor stride of the INPUT set (offset unit).

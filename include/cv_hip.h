@@ -497,7 +497,9 @@ int cv_head_separate_f32(const float* d_feats, long long n, int ld, int log_scal
  * ------------------------------------------------------------------------ */
 typedef struct cv_scene_desc {
     /* the scene */
-    const int32_t* d_coords4;     /* [n][4] (batch, x, y, z), unique rows (eval_joint.py:169) */
+    const int32_t* d_coords4;     /* [n][4] (batch, x, y, z), unique rows (eval_joint.py:169).  ONE scene: the spatial row sort does not
+                                     sort by the batch column (two launches fewer); rows with different batch indices stay distinct
+                                     voxels (every table key carries the index), they only lose their batch-major grouping */
     long long n;
     const float* d_feats;         /* [n][feats_ld] network input features (eval_joint.py:167-168) */
     int feats_ld;
