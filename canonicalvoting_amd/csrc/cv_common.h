@@ -74,7 +74,8 @@ int cv_sp_occupancy_bitmap(const int32_t* d_coords, long long n, const int32_t* 
 // cv_sp_build_levels with an extra range of words zeroed by its first launch (saves the caller's fill launches)
 int cv_sp_build_levels_zero(int32_t* const* d_coords, unsigned long long* const* d_keys, int32_t* const* d_vals,
                             long long n, long long cap, int num_levels, int32_t* d_counts, int32_t* h_counts, void* d_ws,
-                            size_t ws_bytes, int32_t* d_zero, long long n_zero, int32_t* d_set_one, void* stream);
+                            size_t ws_bytes, int32_t* d_zero, long long n_zero, int32_t* d_set_one, void* stream,
+                            uint32_t* d_bits = nullptr);       // d_bits: the occupancy bitmap (inside the zeroed range) is filled too
 
 struct CvUpJob { const int32_t* nbr_down; long long n_coarse; int32_t* up; };
 int cv_sp_up_maps_batch(const CvUpJob* jobs, int n_jobs, void* stream);      // the up arrays must be pre-filled with -1

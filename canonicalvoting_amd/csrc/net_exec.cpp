@@ -69,13 +69,15 @@ size_t cv_sp_scene_maps_words(const long long* level_rows, long long n_orig, int
 static int scene_maps_level0(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
                              long long cap, long long n, const int32_t* d_perm, int stem_k, int mask_groups,
                              const cv_scene_maps& o, int32_t* d_arena, const int32_t* d_bbox, void* stream,
-                             bool pre_cleared = false) {
+                             bool pre_cleared = false, bool bitmap_filled = false) {
     const unsigned* bits = nullptr;
     if (d_bbox) {       // occupancy bitmap in front of the hash probes (bounds from the sort; cv_sp_scene_plan)
         bits = reinterpret_cast<const unsigned*>(d_arena + o.bitmap);
-        const int rc0 = cv_sp_occupancy_bitmap(d_coords[0], n, d_bbox, reinterpret_cast<unsigned*>(d_arena + o.bitmap), stream,
-                                               pre_cleared);
-        if (rc0 != CV_OK) return rc0;
+        if (!bitmap_filled) {          // (cv_sp_scene_plan: the level build's insert pass set the bits already)
+            const int rc0 = cv_sp_occupancy_bitmap(d_coords[0], n, d_bbox, reinterpret_cast<unsigned*>(d_arena + o.bitmap), stream,
+                                                   pre_cleared);
+            if (rc0 != CV_OK) return rc0;
+        }
     }
     CvMapJob mj[2];
     // stem: sorted rows <- rows of the ORIGINAL order = the sorted set's own map with the permutation folded in
@@ -243,7 +245,8 @@ int cv_sp_scene_plan_ex(const int32_t* d_input, long long n, int32_t* d_perm, in
     // (the sort leaves its bounds - min, -max per axis, -max batch - in the first 8 ints of its workspace; [7] = 1 marks
     // the bitmap as trusted until bitmap_set finds a row outside them)
     rc = cv_sp_build_levels_zero(d_coords, d_keys, d_vals, n, cap, 5, d_counts, nullptr, d_levels_ws, levels_ws_bytes,
-                                 d_arena + o.scratch, n_zero, bitmap_on ? static_cast<int32_t*>(d_sort_ws) + 7 : nullptr, stream);
+                                 d_arena + o.scratch, n_zero, bitmap_on ? static_cast<int32_t*>(d_sort_ws) + 7 : nullptr, stream,
+                                 bitmap_on ? reinterpret_cast<uint32_t*>(d_arena + o.bitmap) : nullptr);
     if (rc != CV_OK) return rc;
     PlanSideLease lease;
     rc = plan_side_acquire(&lease.ps);
@@ -254,7 +257,7 @@ int cv_sp_scene_plan_ex(const int32_t* d_input, long long n, int32_t* d_perm, in
     CV_HIP_CHECK(hipEventRecord(ps.ev, st));
     // level-0 maps: their arena offsets depend on n only
     rc = scene_maps_level0(d_coords, d_keys, d_vals, cap, n, d_perm, stem_k, mask_groups, o, d_arena,
-                           bitmap_on ? static_cast<const int32_t*>(d_sort_ws) : nullptr, stream, true);
+                           bitmap_on ? static_cast<const int32_t*>(d_sort_ws) : nullptr, stream, true, bitmap_on);
     if (rc != CV_OK) return rc;
     CV_HIP_CHECK(hipEventSynchronize(ps.ev));          // the counts have landed; the level-0 maps are still being built
     for (int i = 0; i < 8; ++i) h_counts[i] = ps.h_pinned[i];

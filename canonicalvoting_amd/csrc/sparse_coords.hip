@@ -90,10 +90,46 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* s /*[1024]*/) {
     return s[threadIdx.x] - v;
 }
 
+// ---- occupancy bitmap over the bounding box (cv_sp_occupancy_bitmap) ----
+struct BitBox { int mn[3], d[3], nb; bool ok; };
+__device__ __forceinline__ BitBox bitbox(const int* __restrict__ mm) {
+    BitBox b;
+    long long cells = 1;
+    bool sane = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        // extents in 64 bits: coordinates far outside the key window must not wrap the product into the accepted range
+        const long long d = -(long long)mm[3 + k] - (long long)mm[k] + 1;
+        sane = sane && d > 0 && d <= 65536;
+        b.mn[k] = mm[k];
+        b.d[k] = sane ? (int)d : 0;
+        cells *= sane ? d : 0;
+    }
+    const long long nb = -(long long)mm[6] + 1;
+    sane = sane && nb > 0 && nb <= 65536;
+    b.nb = sane ? (int)nb : 0;
+    cells = sane ? cells * nb : 0;
+    b.ok = sane && cells > 0 && cells <= CV_BITMAP_WORDS * 32 && mm[7] == 1;      // mm[7] == 1: no negative batch index seen
+    return b;
+}
+// bit of (batch, x, y, z), or -1 outside the box
+__device__ __forceinline__ long long bitbox_index(const BitBox& b, int bi, int x, int y, int z) {
+    const int ux = x - b.mn[0], uy = y - b.mn[1], uz = z - b.mn[2];
+    if ((unsigned)ux >= (unsigned)b.d[0] || (unsigned)uy >= (unsigned)b.d[1] || (unsigned)uz >= (unsigned)b.d[2] ||
+        (unsigned)bi >= (unsigned)b.nb) return -1;
+    return (((long long)bi * b.d[0] + ux) * b.d[1] + uy) * b.d[2] + uz;
+}
+
 __global__ __launch_bounds__(256) void insert_all(const int* __restrict__ coords, int n, const LevelsDev t, long long mask,
-                                                  int* __restrict__ slots /*[n_levels - 1][n]*/, int* dup_count) {
+                                                  int* __restrict__ slots /*[n_levels - 1][n]*/, int* dup_count,
+                                                  int* __restrict__ mm = nullptr, unsigned* __restrict__ bits = nullptr) {
     const int lane = threadIdx.x & 63;
     const int n_pad = (n + 255) / 256 * 256;           // whole waves stay in the loop (the shuffles need them)
+    // bits (cv_sp_scene_plan): this pass also sets the occupancy bits of the level-0 rows over the sort's bounding box (what
+    // bitmap_set did in a launch of its own; the launch in front cleared the words and set mm[7] = 1 = "may be trusted")
+    BitBox bb;
+    bb.ok = false;
+    if (bits) bb = bitbox(mm);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n_pad; i += gridDim.x * 256) {
         const bool have = i < n;
         int4 c = make_int4(0, 0, 0, 0);
@@ -105,6 +141,11 @@ __global__ __launch_bounds__(256) void insert_all(const int* __restrict__ coords
             if ((unsigned)c.x > 0xffffu || c.y < lo || c.y > hi || c.z < lo || c.z > hi || c.w < lo || c.w > hi)
                 atomicAdd(dup_count + 1, 1);
             table_insert_min(t.keys[0], t.vals[0], mask, pack_key(c.x, c.y, c.z, c.w), i);
+            if (bb.ok) {
+                const long long bit = bitbox_index(bb, c.x, c.y, c.z, c.w);
+                if (bit >= 0) atomicOr(&bits[bit >> 5], 1u << (bit & 31));
+                else mm[7] = 0;                // a row outside its own bounds (negative batch index): do not trust the bitmap
+            }
         }
         for (int L = 1; L < t.n_levels; ++L) {
             const int m = ~((1 << L) - 1);             // floor(c / 2^L) * 2^L in two's complement
@@ -240,35 +281,7 @@ __global__ __launch_bounds__(256) void build_up_map(const int* __restrict__ nbr_
     }
 }
 
-// ---- occupancy bitmap over the bounding box (cv_sp_occupancy_bitmap) ----
-struct BitBox { int mn[3], d[3], nb; bool ok; };
-__device__ __forceinline__ BitBox bitbox(const int* __restrict__ mm) {
-    BitBox b;
-    long long cells = 1;
-    bool sane = true;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        // extents in 64 bits: coordinates far outside the key window must not wrap the product into the accepted range
-        const long long d = -(long long)mm[3 + k] - (long long)mm[k] + 1;
-        sane = sane && d > 0 && d <= 65536;
-        b.mn[k] = mm[k];
-        b.d[k] = sane ? (int)d : 0;
-        cells *= sane ? d : 0;
-    }
-    const long long nb = -(long long)mm[6] + 1;
-    sane = sane && nb > 0 && nb <= 65536;
-    b.nb = sane ? (int)nb : 0;
-    cells = sane ? cells * nb : 0;
-    b.ok = sane && cells > 0 && cells <= CV_BITMAP_WORDS * 32 && mm[7] == 1;      // mm[7] == 1: no negative batch index seen
-    return b;
-}
-// bit of (batch, x, y, z), or -1 outside the box
-__device__ __forceinline__ long long bitbox_index(const BitBox& b, int bi, int x, int y, int z) {
-    const int ux = x - b.mn[0], uy = y - b.mn[1], uz = z - b.mn[2];
-    if ((unsigned)ux >= (unsigned)b.d[0] || (unsigned)uy >= (unsigned)b.d[1] || (unsigned)uz >= (unsigned)b.d[2] ||
-        (unsigned)bi >= (unsigned)b.nb) return -1;
-    return (((long long)bi * b.d[0] + ux) * b.d[1] + uy) * b.d[2] + uz;
-}
+// ---- occupancy bitmap over the bounding box (cv_sp_occupancy_bitmap; BitBox is defined in front of insert_all) ----
 __global__ __launch_bounds__(256) void bitmap_clear(const int* __restrict__ coords, long long n, int* __restrict__ mm,
                                                     unsigned* __restrict__ bits) {
     // mm[7] = "the bitmap may be trusted": set here, taken back by bitmap_set when a row falls outside the bounds (a negative
@@ -670,7 +683,8 @@ size_t cv_sp_levels_workspace_bytes(long long n) {
 // (C++ linkage, cv_common.h) d_zero / n_zero: an optional range of words the first launch also clears
 int cv_sp_build_levels_zero(int32_t* const* d_coords, unsigned long long* const* d_keys, int32_t* const* d_vals,
                             long long n, long long cap, int num_levels, int32_t* d_counts, int32_t* h_counts, void* d_ws,
-                            size_t ws_bytes, int32_t* d_zero, long long n_zero, int32_t* d_set_one, void* stream) {
+                            size_t ws_bytes, int32_t* d_zero, long long n_zero, int32_t* d_set_one, void* stream,
+                            uint32_t* d_bits) {
     CV_REQUIRE(d_coords && d_keys && d_vals && d_counts && d_ws, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(n > 0 && n < (1ll << 30), CV_EINVAL, "bad row count %lld", n);
     CV_REQUIRE(num_levels >= 1 && num_levels <= 5, CV_EINVAL, "num_levels must be 1..5");
@@ -694,7 +708,9 @@ int cv_sp_build_levels_zero(int32_t* const* d_coords, unsigned long long* const*
     }
     table_clear_all<<<grid_for(cap * num_levels), 256, 0, st>>>(tabs, cap, d_counts, (int)n, d_zero, d_zero ? n_zero : 0, d_set_one);
     CV_LAUNCH_CHECK();
-    insert_all<<<g, 256, 0, st>>>(d_coords[0], (int)n, lv, cap - 1, slots, d_counts + 5);
+    // d_bits (with d_set_one = the eighth word of the sort's bounds): the occupancy bitmap is filled by the same pass
+    insert_all<<<g, 256, 0, st>>>(d_coords[0], (int)n, lv, cap - 1, slots, d_counts + 5,
+                                  (d_bits && d_set_one) ? d_set_one - 7 : nullptr, (d_bits && d_set_one) ? d_bits : nullptr);
     CV_LAUNCH_CHECK();
     if (scan_per == 1) flag_levels<1><<<dim3(nsb, num_levels), 1024, 0, st>>>(d_coords[0], (int)n, lv, cap - 1, slots, bsum, d_counts + 5);
     else flag_levels<8><<<dim3(nsb, num_levels), 1024, 0, st>>>(d_coords[0], (int)n, lv, cap - 1, slots, bsum, d_counts + 5);
