@@ -83,13 +83,16 @@ int cv_sp_up_maps_batch(const CvUpJob* jobs, int n_jobs, void* stream);      // 
 struct CvPermJob { const int32_t* nbr; long long n; int K, groups; int32_t* perm; int with_map; };
 constexpr int CV_MAX_PERM_JOBS = 8;
 // d_ws: (sum of groups) * 1024 ints, zero-filled by the call (unless pre_zeroed)
+int cv_hv_minmax_async_ex(const float* d_points, int64_t n, float* h_minmax6, void* d_ws, size_t ws_bytes, int32_t* d_zero_word,
+                          int32_t* d_fill7f, void* stream);                                // hv_vote.hip
 int cv_sp_sort_rows_ex(const int32_t* d_coords, long long n, int32_t* d_sorted, int32_t* d_perm, int32_t* d_inv, void* d_ws,
-                       size_t ws_bytes, bool single_batch, void* stream);                 // sparse_coords.hip
+                       size_t ws_bytes, bool single_batch, void* stream, bool bounds_prefilled = false);   // sparse_coords.hip
 int cv_sp_scene_plan_ex(const int32_t* d_input, long long n, int32_t* d_perm, int32_t* d_inv, int32_t* const* d_coords,
                         unsigned long long* const* d_keys, int32_t* const* d_vals, long long cap, int32_t* d_counts,
                         int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int win_levels,
                         int32_t* d_arena, size_t arena_words, cv_scene_maps* offsets, void* d_sort_ws, size_t sort_ws_bytes,
-                        void* d_levels_ws, size_t levels_ws_bytes, bool single_batch, void* stream);     // net_exec.cpp
+                        void* d_levels_ws, size_t levels_ws_bytes, bool single_batch, void* stream,
+                        bool bounds_prefilled = false);                                       // net_exec.cpp
 int cv_sp_mask_perms_batch(const CvPermJob* jobs, int n_jobs, void* d_ws, size_t ws_bytes, void* stream,
                            bool pre_zeroed = false);
 

@@ -107,8 +107,13 @@ __global__ __launch_bounds__(256) void minmax_partial(const float* __restrict__ 
     if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
 }
 
+// zero_word / fill7f: words of the scene call's next stages initialised by this one-workgroup launch (the range flag := 0, the
+// eight bound words of the row sort := 0x7f7f7f7f) instead of two fill launches of their own
 __global__ __launch_bounds__(256) void minmax_final(const float* __restrict__ part, int nblocks,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ out, int* __restrict__ zero_word = nullptr,
+                                                    int* __restrict__ fill7f = nullptr) {
+    if (zero_word && threadIdx.x == 32) *zero_word = 0;
+    if (fill7f && threadIdx.x >= 64 && threadIdx.x < 72) fill7f[threadIdx.x - 64] = 0x7f7f7f7f;
     __shared__ float s[6][256];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int b = threadIdx.x; b < nblocks; b += 256)
@@ -1288,6 +1293,14 @@ int cv_hv_minmax_f32(const float* d_points, int64_t n, float* h_min3, float* h_m
 // the bounds reduction of a scene before its network forward instead of stalling in front of the vote.
 int cv_hv_minmax_async_f32(const float* d_points, int64_t n, float* h_minmax6, void* d_ws, size_t ws_bytes,
                            void* stream) {
+    return cv_hv_minmax_async_ex(d_points, n, h_minmax6, d_ws, ws_bytes, nullptr, nullptr, stream);
+}
+
+}  // extern "C"
+
+// (C++ linkage, cv_common.h) d_zero_word / d_fill7f: one word set to 0 and eight words set to 0x7f7f7f7f by the final launch
+int cv_hv_minmax_async_ex(const float* d_points, int64_t n, float* h_minmax6, void* d_ws, size_t ws_bytes, int32_t* d_zero_word,
+                          int32_t* d_fill7f, void* stream) {
     CV_REQUIRE(d_points && h_minmax6 && d_ws, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(n > 0, CV_EINVAL, "n must be positive (got %lld)", (long long)n);
     CV_REQUIRE(ws_bytes >= cv_hv_minmax_workspace_bytes(), CV_ENOMEM, "workspace too small");
@@ -1298,11 +1311,13 @@ int cv_hv_minmax_async_f32(const float* d_points, int64_t n, float* h_minmax6, v
     const int blocks = (int)std::min<int64_t>(MM_BLOCKS, (n + 255) / 256);
     minmax_partial<<<blocks, 256, 0, st>>>(d_points, n, part);
     CV_LAUNCH_CHECK();
-    minmax_final<<<1, 256, 0, st>>>(part, blocks, out);
+    minmax_final<<<1, 256, 0, st>>>(part, blocks, out, d_zero_word, d_fill7f);
     CV_LAUNCH_CHECK();
     CV_HIP_CHECK(hipMemcpyAsync(h_minmax6, out, 6 * sizeof(float), hipMemcpyDeviceToHost, st));
     return CV_OK;
 }
+
+extern "C" {
 
 int cv_hv_grid_dims_f32(const float h_min3[3], const float h_max3[3], float res, int dims_out[3]) {
     CV_REQUIRE(h_min3 && h_max3 && dims_out, CV_EINVAL, "null pointer argument");

@@ -226,13 +226,13 @@ int cv_sp_scene_plan_ex(const int32_t* d_input, long long n, int32_t* d_perm, in
                         unsigned long long* const* d_keys, int32_t* const* d_vals, long long cap, int32_t* d_counts,
                         int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int win_levels,
                         int32_t* d_arena, size_t arena_words, cv_scene_maps* offsets, void* d_sort_ws, size_t sort_ws_bytes,
-                        void* d_levels_ws, size_t levels_ws_bytes, bool single_batch, void* stream) {
+                        void* d_levels_ws, size_t levels_ws_bytes, bool single_batch, void* stream, bool bounds_prefilled) {
     CV_REQUIRE(d_input && d_perm && d_inv && d_coords && d_keys && d_vals && d_counts && h_counts && d_arena && offsets &&
                    d_sort_ws && d_levels_ws, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(arena_words >= cv_sp_scene_plan_words(n, stem_k, mask_groups, masked_min_rows, win_levels), CV_ENOMEM,
                "scene map arena too small (cv_sp_scene_plan_words)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = cv_sp_sort_rows_ex(d_input, n, d_coords[0], d_perm, d_inv, d_sort_ws, sort_ws_bytes, single_batch, stream);
+    int rc = cv_sp_sort_rows_ex(d_input, n, d_coords[0], d_perm, d_inv, d_sort_ws, sort_ws_bytes, single_batch, stream, bounds_prefilled);
     if (rc != CV_OK) return rc;
     // level-0 layout of the arena (depends on n only): the histogram scratch of the mask orders and the occupancy bitmap
     // are neighbours there and are zeroed by the first launch of the level build (no fill launches of their own)

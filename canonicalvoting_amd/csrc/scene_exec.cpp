@@ -109,9 +109,11 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
         r->needed_ws_bytes = fixed_end * 2 + ((size_t)256 << 20);
         CV_REQUIRE(false, CV_ENOMEM, "scene workspace too small (needs at least %zu bytes)", r->needed_ws_bytes);
     }
-    int rc = cv_hv_minmax_async_f32(d->d_points, n, h_minmax, mm_ws, cv_hv_minmax_workspace_bytes(), stream);
+    // (the one-workgroup final launch of the bounds also zeroes the range flag and fills the eight bound words at the head of the
+    // sort's workspace: two fill launches fewer)
+    int rc = cv_hv_minmax_async_ex(d->d_points, n, h_minmax, mm_ws, cv_hv_minmax_workspace_bytes(), d_flag,
+                                   reinterpret_cast<int32_t*>(sort_ws), stream);
     if (rc != CV_OK) return rc;
-    CV_HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int32_t), st));
 
     int32_t* c_coords[NL];
     unsigned long long* c_keys[NL];
@@ -125,7 +127,7 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
     cv_scene_maps off;
     rc = cv_sp_scene_plan_ex(d->d_coords4, n, ibuf + o_perm, ibuf + o_inv, c_coords, c_keys, c_vals, cap, ibuf + o_counts, counts_h,
                           d->stem_k, d->mask_groups, d->masked_min_rows, win_levels, ibuf + o_arena, words, &off, sort_ws, sws_b, lev_ws, lws_b, /* one scene: the sort skips its batch digit */ true,
-                          stream);
+                          stream, /* bound words filled above */ true);
     if (rc != CV_OK) return rc;
     r->duplicates = counts_h[5];
     r->out_of_window = counts_h[6];

@@ -765,7 +765,7 @@ int cv_sp_sort_rows(const int32_t* d_coords, long long n, int32_t* d_sorted, int
 // (C++ linkage, cv_common.h) single_batch: every row is of one scene - the third digit (the batch index) is not sorted:
 // five launches instead of seven
 int cv_sp_sort_rows_ex(const int32_t* d_coords, long long n, int32_t* d_sorted, int32_t* d_perm, int32_t* d_inv,
-                       void* d_ws, size_t ws_bytes, bool single_batch, void* stream) {
+                       void* d_ws, size_t ws_bytes, bool single_batch, void* stream, bool bounds_prefilled) {
     CV_REQUIRE(d_coords && d_sorted && d_perm && d_inv && d_ws, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(n > 0 && n < (1ll << 30), CV_EINVAL, "bad row count %lld", n);
     CV_REQUIRE(ws_bytes >= cv_sp_sort_workspace_bytes(n), CV_ENOMEM, "workspace too small");
@@ -778,7 +778,7 @@ int cv_sp_sort_rows_ex(const int32_t* d_coords, long long n, int32_t* d_sorted, 
     int* vals_b = cv.take<int>(n);
     const int nblk = (int)((n + SORT_ROWS - 1) / SORT_ROWS);
     int* hist = cv.take<int>((size_t)nblk * SORT_BINS);
-    CV_HIP_CHECK(hipMemsetAsync(mm, 0x7f, sizeof(int) * 8, st));
+    if (!bounds_prefilled) CV_HIP_CHECK(hipMemsetAsync(mm, 0x7f, sizeof(int) * 8, st));      // (the scene call's first stage fills them)
     sort_minmax<<<(unsigned)std::min<long long>((n + 255) / 256, 256), 256, 0, st>>>(d_coords, n, mm);
     CV_LAUNCH_CHECK();
     sort_hist<<<nblk, SORT_T, 0, st>>>(d_coords, mm, keys_a, n, 0, hist);
