@@ -969,8 +969,12 @@ __launch_bounds__(NW * 64, hl_blocks(NB, NS, NW)) void conv_hl(ConvArgs a) {
 #define CV_HD_ABL 0
 #endif
 // LDS of one workgroup: NSTG ring stages (gathered rows of NW waves + the weight tile), the tile's row / map tables, unit list
+#ifndef HD_LDS_PAD
+#define HD_LDS_PAD 0        // experiment: LDS the workgroup does not use, to control what else fits on its CU (profiles/r5/hd_lds_pad.txt)
+#endif
 constexpr int hd_lds_bytes(int NB, int NW, int NSTG) {
-    return NSTG * (NW * 4096 + 2 * NB * 32 * 64) + NW * 32 * 4 + (WP_NPRE + 1) * NW * 32 * 4 + NW * 4 + (HL_MAX_UNITS + 4) * 2;
+    return NSTG * (NW * 4096 + 2 * NB * 32 * 64) + NW * 32 * 4 + (WP_NPRE + 1) * NW * 32 * 4 + NW * 4 + (HL_MAX_UNITS + 4) * 2 +
+           ((NB == 3 && NW == 8 && NSTG == 2) ? HD_LDS_PAD : 0);
 }
 constexpr int hd_blocks(int NB, int NW, int NSTG) {          // workgroups per CU (LDS-bound), at most 8 waves per SIMD
     const int b = (160 * 1024) / hd_lds_bytes(NB, NW, NSTG);
@@ -1018,7 +1022,8 @@ __global__ __launch_bounds__(NW * 64, (hd_blocks(NB, NW, NSTG) * NW + 3) / 4) vo
     constexpr int EP_BYTES = NW * 32 * EP_LD * 4;
     static_assert(EP_BYTES <= NSTG * STAGE, "the epilogue tile aliases the ring");
     constexpr int OFF_ROWS = NSTG * STAGE, OFF_NBR = OFF_ROWS + TMv * 4, OFF_MASK = OFF_NBR + (WP_NPRE + 1) * TMv * 4,
-                  OFF_UNITS = OFF_MASK + NW * 4, LDS_TOTAL = OFF_UNITS + (HL_MAX_UNITS + 4) * 2;
+                  OFF_UNITS = OFF_MASK + NW * 4,
+                  LDS_TOTAL = OFF_UNITS + (HL_MAX_UNITS + 4) * 2 + ((NB == 3 && NW == 8 && NSTG == 2) ? HD_LDS_PAD : 0);
     static_assert(LDS_TOTAL == hd_lds_bytes(NB, NW, NSTG) && LDS_TOTAL <= 160 * 1024, "LDS budget");
     // ONE __shared__ object (a second one makes hipcc drain vmcnt in front of the LDS reads of an LDS-DMA pipeline)
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_TOTAL];
