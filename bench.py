@@ -91,6 +91,11 @@ def parse():
                          "-1 (default): 256 from four scenes in flight (the other scenes fill the chip, the partial "
                          "tiles only cost traffic), else the library's 512; the one-scene-in-flight side pass always "
                          "runs on the library default")
+    ap.add_argument("--vote-part-records", type=int, default=-1,
+                    help="cv_hv_set_part_records for the timed region: records of a plane's two y-bins one vote workgroup takes. "
+                         "-1 (default): 12288 from four scenes in flight (fewer, longer workgroups and less merge traffic while "
+                         "the other scenes fill the chip), else the library's 4096; the one-scene-in-flight side pass always "
+                         "runs on the library default.  The grids are the same bits under every setting")
     ap.add_argument("--stagger-us", type=float, default=400.0,
                     help="scene thread i takes its first timed step i x this many microseconds after the clock started: scenes that "
                          "start together stay in the same stage (all in the convolutions, then all in the vote) and share the chip "
@@ -678,6 +683,8 @@ def main():
     S = scene_threads(a.streams)
     split_target = a.split_target if a.split_target >= 0 else (256 if S >= 4 else 0)
     ME.set_split_target(split_target)
+    part_records = a.vote_part_records if a.vote_part_records >= 0 else (12288 if S >= 4 else 0)
+    _lib.lib().cv_hv_set_part_records(int(part_records))
     # one-call scenes size their coarse-level launches by the scenes in flight when they start (512 workgroups below four, 256
     # from four on): the tail of a short run, where the scene threads run dry one by one, gets the one-scene sizing
     global ADAPTIVE_SPLIT
@@ -835,6 +842,7 @@ def main():
         # resident scenes first, then the MEDIAN over the measured steps (one cold step used to double the mean)
         iso_steps = max(min(a.steps, 48), 24)
         ME.set_split_target(0)                    # one scene in flight: the library's default launch sizing
+        _lib.lib().cv_hv_set_part_records(0)
         for k in range(2 * len(scenes)):
             run_step(model, hv, scenes[k % len(scenes)], teacher=teacher)
         ev2 = [step_events() for _ in range(iso_steps)]
@@ -893,6 +901,7 @@ def main():
                    "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}.get(a.algo, "ablation-%d" % a.algo),
                    "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": S, "tail_priority_steps": a.tail_priority,
                    "conv_split_target": "adaptive: 512 below four scenes in flight, 256 from four on" if ADAPTIVE_SPLIT else (split_target or 512),
+                   "vote_part_records": part_records or 4096,
                    **({"ablate": a.ablate, "INVALID": "timing ablation: results are wrong, not a reportable number"} if a.ablate else {})},
         "roofline": {"bound": "hbm",
                      "kernel": "hv_fwd_tiles (the accumulation kernel of cv_hv_forward_f32)" if kernel_timed

@@ -133,6 +133,7 @@ SIGNATURES = {
     "cv_sp_conv_workspace_bytes": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int]),
     "cv_sp_conv_f32": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp]),
     "cv_sp_set_split_target": (ctypes.c_int, [ctypes.c_int]),
+    "cv_hv_set_part_records": (ctypes.c_int, [ctypes.c_int]),
     "cv_sp_pack_weights_t_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_set_split_target_thread": (ctypes.c_int, [ctypes.c_int]),
     "cv_sp_set_ablation": (ctypes.c_int, [ctypes.c_int]),

@@ -25,6 +25,8 @@
 //            second pass over the 63 MB grid.
 #include "cv_common.h"
 
+#include <atomic>
+#include <algorithm>
 #include <cmath>
 #include <cstddef>
 #include <mutex>
@@ -298,7 +300,8 @@ __global__ __launch_bounds__(256) void hv_prep_scan(const int* __restrict__ ycou
                                                     int* __restrict__ ystart,
                                                     int* __restrict__ cursor,
                                                     int* __restrict__ part_start, int4* __restrict__ q_info, int max_q,
-                                                    int* __restrict__ chunk_start, int* __restrict__ bin_of_chunk) {
+                                                    int* __restrict__ chunk_start, int* __restrict__ bin_of_chunk,
+                                                    int part_records) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) {
         const int total = wave_excl_scan(Y, [&](int i) { return ycount[i]; },
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void hv_prep_scan(const int* __restrict__ ycou
         const int total = wave_excl_scan(Y,
             [&](int i) {
                 const int n2 = (i >= 1 ? ycount[i - 1] : 0) + (i <= Y - 2 ? ycount[i] : 0);
-                return min(max((n2 + PART_RECORDS - 1) / PART_RECORDS, 1), MAX_PARTS);
+                return min(max((n2 + part_records - 1) / part_records, 1), MAX_PARTS);
             },
             [&](int i, int excl, int v) {
                 part_start[i] = excl;
@@ -1360,6 +1363,17 @@ size_t cv_hv_forward_workspace_bytes(int64_t n, int num_rots, const int dims[3],
 // after the accumulation kernel (hv_fwd_tiles), on the stream of the call
 static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
 
+// records of a plane's two y-bins one workgroup of a hot (tile, plane) takes in the streaming launch: PART_RECORDS (the workspace
+// bound assumes at least that many) or more - with several scenes in flight fewer, longer parts pay (less merge traffic, the other
+// scenes fill the chip): profiles/r5/vote_parts.txt
+static std::atomic<long long> g_part_records{getenv("CV_HV_PART_RECORDS") ? std::max<long long>(PART_RECORDS, atoll(getenv("CV_HV_PART_RECORDS")))
+                                                                          : (long long)PART_RECORDS};
+
+int cv_hv_set_part_records(int records) {
+    const long long v = records <= 0 ? (long long)PART_RECORDS : std::max<long long>(PART_RECORDS, records);
+    return (int)g_part_records.exchange(v, std::memory_order_relaxed);
+}
+
 int cv_hv_set_kernel_events(void* ev_start, void* ev_stop) {
     t_ev_start = static_cast<hipEvent_t>(ev_start);
     t_ev_stop = static_cast<hipEvent_t>(ev_stop);
@@ -1438,7 +1452,8 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
     hv_prep_count<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, n, res, corner.y, Y, fy, ycount);
     CV_LAUNCH_CHECK();
-    hv_prep_scan<<<1, 256, 0, st>>>(ycount, Y, ystart, cursor, part_start, q_info, (int)max_q, chunk_start, bin_of_chunk);
+    hv_prep_scan<<<1, 256, 0, st>>>(ycount, Y, ystart, cursor, part_start, q_info, (int)max_q, chunk_start, bin_of_chunk,
+                                    (int)g_part_records.load(std::memory_order_relaxed));
     CV_LAUNCH_CHECK();
     hv_prep_scatter<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, d_obj, fy, n, Y, res, corner, cursor, rec, n);

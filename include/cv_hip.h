@@ -76,6 +76,14 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
                       float* d_grid_rot, float* d_grid_scale, void* d_ws, size_t ws_bytes,
                       int algo, void* stream);
 
+/* Launch sizing of the vote's streaming launch: records of a plane's two y-bins that one workgroup of a (tile, plane) takes; a
+ * plane with more is split over up to 8 workgroups per tile whose partial tiles the last arriver adds (integer sums: the grids
+ * are the same bits under every setting).  Default 4096 (or CV_HV_PART_RECORDS) - the fastest kernel for ONE scene in flight;
+ * a host that keeps several scenes in flight sets a larger value (bench.py: 12288 from four scenes in flight: fewer, longer
+ * workgroups and less merge traffic while the other scenes fill the chip; 574 -> 585 scenes/s with seven).  Values below 4096 are raised to it (the workspace
+ * bound assumes it); records <= 0 restores the default.  Returns the previous value.  Process-wide, like
+ * cv_sp_set_split_target. */
+int cv_hv_set_part_records(int records);
 /* Measurement hook (no reference counterpart): the CALLING THREAD's following cv_hv_forward_f32 calls record the two
  * hipEvent_t handles directly before and after the accumulation kernel of the tile algorithm (hv_fwd_tiles), on the
  * stream of the call - bench.py times exactly the kernel its `roofline` prices, with other scenes in flight, instead
