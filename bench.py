@@ -96,6 +96,11 @@ def parse():
                          "-1 (default): 12288 from four scenes in flight (fewer, longer workgroups and less merge traffic while "
                          "the other scenes fill the chip), else the library's 4096; the one-scene-in-flight side pass always "
                          "runs on the library default.  The grids are the same bits under every setting")
+    ap.add_argument("--masked-min-rows", type=int, default=-1,
+                    help="rows from which a level's 3x3x3 convolutions run mask-sorted (cv_scene_desc.masked_min_rows) in the timed "
+                         "region.  -1 (default): 8192 from four scenes in flight (the ts4 level too: fewer live units per workgroup, "
+                         "one more set of partial tiles - pays when other scenes fill the chip), else the library's 16384 (best for "
+                         "one scene at a time); the one-scene-in-flight side pass always runs on the library default")
     ap.add_argument("--stagger-us", type=float, default=400.0,
                     help="scene thread i takes its first timed step i x this many microseconds after the clock started: scenes that "
                          "start together stay in the same stage (all in the convolutions, then all in the vote) and share the chip "
@@ -685,6 +690,14 @@ def main():
     ME.set_split_target(split_target)
     part_records = a.vote_part_records if a.vote_part_records >= 0 else (12288 if S >= 4 else 0)
     _lib.lib().cv_hv_set_part_records(int(part_records))
+    lib_masked_min_rows = ME.CoordinateManager.MASKED_MIN_ROWS
+    masked_min_rows = a.masked_min_rows if a.masked_min_rows >= 0 else (min(8192, lib_masked_min_rows) if S >= 4 else lib_masked_min_rows)
+
+    def set_masked_min_rows(v):
+        ME.CoordinateManager.MASKED_MIN_ROWS = int(v)       # (what the scene call and the plans read)
+        if model is not None:
+            model.MASKED_MIN_ROWS = int(v)                  # (the module paths' copy)
+    set_masked_min_rows(masked_min_rows)
     # one-call scenes size their coarse-level launches by the scenes in flight when they start (512 workgroups below four, 256
     # from four on): the tail of a short run, where the scene threads run dry one by one, gets the one-scene sizing
     global ADAPTIVE_SPLIT
@@ -843,6 +856,7 @@ def main():
         iso_steps = max(min(a.steps, 48), 24)
         ME.set_split_target(0)                    # one scene in flight: the library's default launch sizing
         _lib.lib().cv_hv_set_part_records(0)
+        set_masked_min_rows(lib_masked_min_rows)
         for k in range(2 * len(scenes)):
             run_step(model, hv, scenes[k % len(scenes)], teacher=teacher)
         ev2 = [step_events() for _ in range(iso_steps)]
@@ -901,7 +915,7 @@ def main():
                    "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}.get(a.algo, "ablation-%d" % a.algo),
                    "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": S, "tail_priority_steps": a.tail_priority,
                    "conv_split_target": "adaptive: 512 below four scenes in flight, 256 from four on" if ADAPTIVE_SPLIT else (split_target or 512),
-                   "vote_part_records": part_records or 4096,
+                   "vote_part_records": part_records or 4096, "masked_min_rows": masked_min_rows,
                    **({"ablate": a.ablate, "INVALID": "timing ablation: results are wrong, not a reportable number"} if a.ablate else {})},
         "roofline": {"bound": "hbm",
                      "kernel": "hv_fwd_tiles (the accumulation kernel of cv_hv_forward_f32)" if kernel_timed
