@@ -2641,8 +2641,7 @@ int launch_rows(const ConvArgs& a, bool vec, hipStream_t st) {
     return CV_OK;
 }
 
-// 32-column blocks per workgroup.  Wider than 96 columns is split over blockIdx.y in 64-column workgroups (32 on
-// the tiny coarsest levels): measured 118 -> 97 us (2349 rows, 256 -> 256), 143 -> 117 us (9929 rows, 128 -> 128),
+// 32-column blocks per workgroup.  Wider than 96 columns is split over blockIdx.y in 64-column workgroups: measured 118 -> 97 us (2349 rows, 256 -> 256), 143 -> 117 us (9929 rows, 128 -> 128),
 // 40 -> 33 us (494 rows) against 128-column workgroups - more, lighter workgroups hide the gather latency better
 // than the saved operand re-reads are worth; 96 columns stay one workgroup (64 + 32 is uneven: 144 -> 180 us).
 }  // namespace
@@ -2662,7 +2661,10 @@ int nb_for(int cout, long long n_out) {
     static const int nb_coarse = getenv("CV_NB_COARSE") ? atoi(getenv("CV_NB_COARSE")) : 0;
     static const long long coarse_rows = getenv("CV_NB_COARSE_ROWS") ? atoll(getenv("CV_NB_COARSE_ROWS")) : 16384;
     if (nb_coarse > 0 && n_out < coarse_rows) return std::max(1, std::min(nb_coarse, 4));
-    return n_out < 1024 ? 1 : std::max(1, std::min(nb_wide, 2));
+    // (until round 5 the levels below 1024 rows took 32-column workgroups - measured with the fp32-row kernels of round 1; on the hl
+    // kernels 64 columns are better alone and with scenes in flight: net 2.32 -> 2.29-2.30 ms, 592 -> 599-600 scenes/s,
+    // profiles/r5/nb_coarse.txt; 96 / 128 columns: 591 / 583)
+    return std::max(1, std::min(nb_wide, 2));
 }
 
 // workgroups a split launch aims at: CV_SPLIT_TARGET or 512 until cv_sp_set_split_target changes it
