@@ -597,7 +597,7 @@ def from_hl(x):
 
 # conv_forward applies mask-sorted offset groups to big 3x3x3 maps on its own (0 = off)
 AUTO_MASK_GROUPS = int(os.environ.get("CV_MASK_GROUPS", "4"))
-AUTO_MASK_MIN_ROWS = 16384
+AUTO_MASK_MIN_ROWS = int(os.environ.get("CV_AUTO_MASK_MIN_ROWS", "16384"))
 
 
 def map_mask_perms(nbr, groups):
