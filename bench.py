@@ -686,12 +686,14 @@ def main():
                     s.v_in = hv_cuda.count_votes(s.points, xyz, scale, RES, NUM_ROTS, s.corner, s.dims)
                     s.vote_bytes = 40 * a.points + 192 * s.v_in + 68 * s.cells
     S = scene_threads(a.streams)
-    split_target = a.split_target if a.split_target >= 0 else (256 if S >= 4 else 0)
+    # launch sizing by the scenes the host keeps in flight (pipeline.configure_for_scenes_in_flight: what a serving host would
+    # call), then the explicit overrides of the command line
+    cfg = pipeline.configure_for_scenes_in_flight(S, model)
+    split_target = a.split_target if a.split_target >= 0 else cfg["conv_split_target"]
     ME.set_split_target(split_target)
-    part_records = a.vote_part_records if a.vote_part_records >= 0 else (12288 if S >= 4 else 0)
+    part_records = a.vote_part_records if a.vote_part_records >= 0 else cfg["vote_part_records"]
     _lib.lib().cv_hv_set_part_records(int(part_records))
-    lib_masked_min_rows = ME.CoordinateManager.MASKED_MIN_ROWS
-    masked_min_rows = a.masked_min_rows if a.masked_min_rows >= 0 else (min(8192, lib_masked_min_rows) if S >= 4 else lib_masked_min_rows)
+    masked_min_rows = a.masked_min_rows if a.masked_min_rows >= 0 else cfg["masked_min_rows"]
 
     def set_masked_min_rows(v):
         ME.CoordinateManager.MASKED_MIN_ROWS = int(v)       # (what the scene call and the plans read)
@@ -854,9 +856,7 @@ def main():
         # This pass runs on the main thread's stream, which has its own allocator pool and scratch: two passes over the
         # resident scenes first, then the MEDIAN over the measured steps (one cold step used to double the mean)
         iso_steps = max(min(a.steps, 48), 24)
-        ME.set_split_target(0)                    # one scene in flight: the library's default launch sizing
-        _lib.lib().cv_hv_set_part_records(0)
-        set_masked_min_rows(lib_masked_min_rows)
+        pipeline.configure_for_scenes_in_flight(1, model)          # one scene in flight: the library's default launch sizing
         for k in range(2 * len(scenes)):
             run_step(model, hv, scenes[k % len(scenes)], teacher=teacher)
         ev2 = [step_events() for _ in range(iso_steps)]

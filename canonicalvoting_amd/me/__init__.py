@@ -215,6 +215,7 @@ class CoordinateManager:
     # were better with the round-1 kernels: 2.99 vs 3.20 ms)
     MASK_GROUPS = int(os.environ.get("CV_NET_MASK_GROUPS", "3"))
     MASKED_MIN_ROWS = int(os.environ.get("CV_MASKED_MIN_ROWS", "16384"))
+    LIB_MASKED_MIN_ROWS = MASKED_MIN_ROWS          # the one-scene-at-a-time default (pipeline.configure_for_scenes_in_flight)
 
     def windows(self, ts=1):
         """neighbour windows of the 3x3x3 map at tensor stride ts (cv_sp_build_windows; int32 block, cached): hand it to

@@ -10,6 +10,25 @@ from . import _lib, decode, hv_cuda
 from . import me as ME
 
 
+def configure_for_scenes_in_flight(n, model=None):
+    """Launch sizing for a host that keeps `n` scenes in flight on separate streams (one thread + stream per scene, as bench.py
+    does).  The library's defaults are the best for ONE scene at a time; from four scenes in flight the other scenes fill the
+    chip and three choices turn (measured on MI355X, LABNOTES rounds 3 and 5): the split convolutions aim at 256 workgroups
+    instead of 512, a hot (tile, plane) of the vote takes 12288 records per workgroup instead of 4096, and the 3x3x3
+    convolutions run mask-sorted from 8192 rows instead of 16384.  Every integer output stays the same; the network output
+    moves in fp32 summation order only.  Process-wide: call it before the scene threads start.  Returns the settings."""
+    from . import _lib
+    many = int(n) >= 4
+    cfg = {"conv_split_target": 256 if many else 0, "vote_part_records": 12288 if many else 0,
+           "masked_min_rows": min(8192, ME.CoordinateManager.LIB_MASKED_MIN_ROWS) if many else ME.CoordinateManager.LIB_MASKED_MIN_ROWS}
+    ME.set_split_target(cfg["conv_split_target"])
+    _lib.lib().cv_hv_set_part_records(cfg["vote_part_records"])
+    ME.CoordinateManager.MASKED_MIN_ROWS = cfg["masked_min_rows"]          # (what the scene call and the plans read)
+    if model is not None:
+        model.MASKED_MIN_ROWS = cfg["masked_min_rows"]                     # (the module paths' copy)
+    return cfg
+
+
 def head_joint(out_feats, nclasses=9, log_scale=True):
     """eval_joint.py:173-190 in one kernel: -> xyz[N,3], scale[N,3], prob[N], class[N] (int32)."""
     L = _lib.lib()

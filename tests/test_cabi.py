@@ -228,3 +228,22 @@ def test_window_levels_of_a_program(built_lib):
         assert L.cv_sp_get_option(name, ctypes.byref(v)) == 0
         assert L.cv_sp_set_option(name, v.value, ctypes.byref(old)) == 0 and old.value == v.value
     assert L.cv_sp_get_option(b"no_such_knob", ctypes.byref(v)) != 0 and L.cv_sp_get_option(b"win", None) != 0
+
+
+def test_in_flight_launch_sizing_policy(built_lib):
+    """pipeline.configure_for_scenes_in_flight: the library defaults below four scenes in flight, the in-flight sizes from four on
+    (host-side settings only: no GPU needed); cv_hv_set_part_records never goes below the 4096 the workspace bound assumes"""
+    from canonicalvoting_amd import me as ME, pipeline
+    L = _lib.lib()
+    try:
+        cfg = pipeline.configure_for_scenes_in_flight(7)
+        assert cfg == {"conv_split_target": 256, "vote_part_records": 12288, "masked_min_rows": min(8192, ME.CoordinateManager.LIB_MASKED_MIN_ROWS)}
+        assert ME.CoordinateManager.MASKED_MIN_ROWS == cfg["masked_min_rows"]
+        assert L.cv_hv_set_part_records(100) == 12288 and L.cv_hv_set_part_records(0) == 4096      # (clamped up, then the default)
+        assert L.cv_hv_set_part_records(20000) == 4096 and L.cv_hv_set_part_records(0) == 20000
+        cfg = pipeline.configure_for_scenes_in_flight(1)
+        assert cfg["conv_split_target"] == 0 and cfg["vote_part_records"] == 0
+        assert ME.CoordinateManager.MASKED_MIN_ROWS == ME.CoordinateManager.LIB_MASKED_MIN_ROWS
+        assert L.cv_hv_set_part_records(0) == 4096
+    finally:
+        pipeline.configure_for_scenes_in_flight(1)
