@@ -700,7 +700,7 @@ def main():
         if model is not None:
             model.MASKED_MIN_ROWS = int(v)                  # (the module paths' copy)
     set_masked_min_rows(masked_min_rows)
-    # one-call scenes size their coarse-level launches by the scenes in flight when they start (512 workgroups below four, 256
+    # one-call scenes size their coarse-level launches by the scenes in flight when they start (768 workgroups below four, 256
     # from four on): the tail of a short run, where the scene threads run dry one by one, gets the one-scene sizing
     global ADAPTIVE_SPLIT
     ADAPTIVE_SPLIT = bool(a.adaptive_split) and a.split_target < 0 and a.scene_call == "c"
@@ -914,7 +914,7 @@ def main():
                    "points": a.points, "num_rots": NUM_ROTS, "res": RES, "grid": s0.dims,
                    "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}.get(a.algo, "ablation-%d" % a.algo),
                    "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": S, "tail_priority_steps": a.tail_priority,
-                   "conv_split_target": "adaptive: 512 below four scenes in flight, 256 from four on" if ADAPTIVE_SPLIT else (split_target or 512),
+                   "conv_split_target": "adaptive: 768 below four scenes in flight, 256 from four on" if ADAPTIVE_SPLIT else (split_target or 768),
                    "vote_part_records": part_records or 4096, "masked_min_rows": masked_min_rows,
                    **({"ablate": a.ablate, "INVALID": "timing ablation: results are wrong, not a reportable number"} if a.ablate else {})},
         "roofline": {"bound": "hbm",

@@ -45,7 +45,7 @@ struct SceneCount {
     explicit SceneCount(bool adaptive_) : before(g_scenes_inside.fetch_add(1, std::memory_order_relaxed)), adaptive(adaptive_) {
         // scenes in flight (this one included) when the scene starts: the other scenes fill the chip from about four on, below
         // that the deeper splits of the one-scene optimum pay (profiles/r3/split_target_8streams.txt)
-        if (adaptive) prev_target = cv_sp_set_split_target_thread(before + 1 >= 4 ? 256 : 512);
+        if (adaptive) prev_target = cv_sp_set_split_target_thread(before + 1 >= 4 ? 256 : 768);
     }
     ~SceneCount() {
         if (adaptive) cv_sp_set_split_target_thread(prev_target);

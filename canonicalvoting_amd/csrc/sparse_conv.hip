@@ -2667,14 +2667,14 @@ int nb_for(int cout, long long n_out) {
     return std::max(1, std::min(nb_wide, 2));
 }
 
-// workgroups a split launch aims at: CV_SPLIT_TARGET or 512 until cv_sp_set_split_target changes it
+// workgroups a split launch aims at: CV_SPLIT_TARGET or 768 until cv_sp_set_split_target changes it
 std::atomic<long long> g_split_target{-1};
 thread_local long long t_split_target = 0;       // cv_sp_set_split_target_thread: this thread's launches (0 = the process-wide value)
 long long split_target() {
     if (t_split_target > 0) return t_split_target;
     long long v = g_split_target.load(std::memory_order_relaxed);
     if (v <= 0) {
-        v = getenv("CV_SPLIT_TARGET") ? std::max(1ll, atoll(getenv("CV_SPLIT_TARGET"))) : 512;
+        v = getenv("CV_SPLIT_TARGET") ? std::max(1ll, atoll(getenv("CV_SPLIT_TARGET"))) : 768;
         g_split_target.store(v, std::memory_order_relaxed);
     }
     return v;
@@ -2687,7 +2687,9 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
     const long long tiles = ((n_out + TM - 1) / TM) * ((cout + nb * 32 - 1) / (nb * 32));
     const long long units = vec ? (long long)K * (cin / KC) : ((long long)K * cin + KC - 1) / KC;
     if (tiles >= 384 || units <= 1) return 1;
-    // workgroups a split launch aims at.  512 since round 2: 384 / 512 / 768 / 1024 = 513 / 508 / 496 / 491 scenes/s six in
+    // workgroups a split launch aims at.  768 since round 5 (the one-scene-at-a-time optimum on the hl kernels: 384 / 512 / 768 /
+    // 1024 = 339 / 341-344 / 347.0 / 347.2 scenes/s one in flight, profiles/r5/one_in_flight_defaults.txt; hosts with scenes in flight
+    // set their own value).  512 from round 2 on: 384 / 512 / 768 / 1024 = 513 / 508 / 496 / 491 scenes/s six in
     // flight, net 2.58 / 2.51 / 2.47 / 2.47 ms one in flight - the partial tiles of the coarse levels are 0.8 GB of the
     // 1.7 GB a forward writes, and with several scenes in flight the other scenes fill the chip, not the splits
     // (cv_sp_set_split_target: with EIGHT scenes in flight 256 gives 562-566 scenes/s against 550 for 512 and 549-555

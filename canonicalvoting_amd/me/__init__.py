@@ -559,7 +559,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
 
 
 def set_split_target(workgroups):
-    """cv_sp_set_split_target: workgroups a split convolution launch aims at (0: the library default, 512 - best for one
+    """cv_sp_set_split_target: workgroups a split convolution launch aims at (0: the library default, 768 - best for one
     scene in flight; 256 pays from about four scenes in flight).  Returns the previous value."""
     return int(_lib.lib().cv_sp_set_split_target(int(workgroups)))
 

@@ -14,7 +14,7 @@ def configure_for_scenes_in_flight(n, model=None):
     """Launch sizing for a host that keeps `n` scenes in flight on separate streams (one thread + stream per scene, as bench.py
     does).  The library's defaults are the best for ONE scene at a time; from four scenes in flight the other scenes fill the
     chip and three choices turn (measured on MI355X, LABNOTES rounds 3 and 5): the split convolutions aim at 256 workgroups
-    instead of 512, a hot (tile, plane) of the vote takes 12288 records per workgroup instead of 4096, and the 3x3x3
+    instead of 768, a hot (tile, plane) of the vote takes 12288 records per workgroup instead of 4096, and the 3x3x3
     convolutions run mask-sorted from 8192 rows instead of 16384.  Every integer output stays the same; the network output
     moves in fp32 summation order only.  Process-wide: call it before the scene threads start.  Returns the settings."""
     from . import _lib

@@ -304,7 +304,7 @@ int cv_sp_windows_supported(long long n);
 size_t cv_sp_windows_words(long long n);
 int cv_sp_build_windows(const int32_t* d_nbr, long long n, int32_t* d_win, void* stream);
 /* Launch sizing of the convolutions whose output tiles alone do not fill the chip (the coarse levels): the number of
- * workgroups a launch is split up to (over the kernel offsets; partial tiles, then a finish pass).  Default 512
+ * workgroups a launch is split up to (over the kernel offsets; partial tiles, then a finish pass).  Default 768
  * (or CV_SPLIT_TARGET) - best for ONE scene in flight; a host that keeps several scenes in flight on separate streams
  * lets the other scenes fill the chip and sets a smaller value (bench.py: 256 from four scenes in flight).  Results
  * change in the summation order only (fp32 rounding).  workgroups <= 0 restores the default.  Returns the previous
@@ -540,7 +540,7 @@ typedef struct cv_scene_desc {
     float* h_boxes; float* h_scores; int32_t* h_classes;      /* accepted boxes in acceptance order: [k][8][3], [k], [k] */
     int32_t* h_pick;                                          /* detections after per-class NMS: indices into the box list, class by class */
     int adaptive_split;           /* 1: launch sizing of the coarse-level convolutions by the scenes inside cv_detect_scene_f32 when this
-                                     one starts - the one-scene optimum (512 workgroups) below four, 256 from four on (what
+                                     one starts - the one-scene optimum (768 workgroups) below four, 256 from four on (what
                                      bench.py sets by hand for the call-by-call path); 0: the process-wide cv_sp_set_split_target */
     /* optional measurement hook: hipEvent_t handles recorded on `stream` at the scene's start, behind the network, the head
      * split, the vote and the decode (NULL entries are skipped) */
