@@ -27,23 +27,45 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.
           "-I" + HERE, "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"] + NO_PACKED_FP32
 # strict fp32 (no FMA contraction) where results must match the oracle bit for bit
 STRICT = ["-ffp-contract=off"]
-SOURCES = {
-    "cv_host.cpp": STRICT,
-    "hv_vote.hip": STRICT + os.environ.get("CV_HV_DEFS", "").split(),     # tile-shape experiments (-DHV_TX=16 -DHV_TW=8)
-    "hv_decode.hip": STRICT + os.environ.get("CV_DEC_DEFS", "").split(),  # greedy-walk experiments (-DDEC_BLOCKED=0)
-    "sparse_coords.hip": [],
-    "sparse_conv.hip": os.environ.get("CV_SC_DEFS", "").split(),          # kernel experiments (-DCV_WP_CLAMPED_GATHER=1)
-    "sparse_win.hip": os.environ.get("CV_WIN_DEFS", "").split(),          # conv_win ablations (-DCV_WIN_ABL=2)
-    "net_exec.cpp": [],
-    "scene_exec.cpp": [],
-}
 
 
-def _stale(target, deps):
+def _sources():
+    """source -> extra flags, with the experiment switches of the environment as they are NOW (read per call, and part of
+    the recorded command line: an object built with other -D flags is stale)"""
+    env = lambda k: os.environ.get(k, "").split()
+    return {
+        "cv_host.cpp": STRICT,
+        "hv_vote.hip": STRICT + env("CV_HV_DEFS"),       # tile-shape experiments (-DHV_TX=16 -DHV_TW=8)
+        "hv_decode.hip": STRICT + env("CV_DEC_DEFS"),    # greedy-walk experiments (-DDEC_BLOCKED=0)
+        "sparse_coords.hip": [],
+        "sparse_conv.hip": env("CV_SC_DEFS"),            # kernel experiments (-DCV_WP_CLAMPED_GATHER=1)
+        "sparse_win.hip": env("CV_WIN_DEFS"),            # conv_win ablations (-DCV_WIN_ABL=2)
+        "net_exec.cpp": [],
+        "scene_exec.cpp": [],
+    }
+
+
+
+def _stale(target, deps, cmd=None):
+    """target is older than a dependency, or was built by another command line (a changed -D through CV_*_DEFS, another
+    HIPCC): the command that made an object is kept beside it as <object>.cmd and compared word for word."""
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    if cmd is not None:
+        try:
+            with open(target + ".cmd") as f:
+                return f.read() != _cmd_text(cmd)
+        except OSError:
+            return True
+    return False
+
+
+def _cmd_text(cmd):
+    # (the checkout's own path is written as $ROOT: the tree is built here and runs from another path on the GPU box)
+    return "\n".join(c.replace(ROOT, "$ROOT") for c in cmd) + "\n"
 
 
 def build(force=False, verbose=False):
@@ -53,30 +75,49 @@ def build(force=False, verbose=False):
     headers.append(os.path.abspath(__file__))
     jobs = []
     objs = []
-    for src, extra in SOURCES.items():
+    for src, extra in _sources().items():
         s = os.path.join(HERE, src)
         o = os.path.join(OBJ_DIR, src + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            cmd = [HIPCC] + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+        cmd = [HIPCC] + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+        if force or _stale(o, [s] + headers, cmd):
             jobs.append(cmd)
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
+        out = cmd[cmd.index("-o") + 1]
+        if os.path.exists(out + ".cmd"):
+            os.remove(out + ".cmd")             # (a failed or interrupted build leaves no record behind)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n%s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
         if verbose and r.stderr.strip():
             print(r.stderr)
+        with open(out + ".cmd", "w") as f:
+            f.write(_cmd_text(cmd))
         return True
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if jobs or force or _stale(LIB, objs, link):
+        run(link)
     return LIB
+
+
+def plan(force=False):
+    """the sources build() would compile now (tests: a changed CV_*_DEFS must show up here)"""
+    headers = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
+    headers += [os.path.join(ROOT, "include", "cv_hip.h"), os.path.abspath(__file__)]
+    todo = []
+    for src, extra in _sources().items():
+        s, o = os.path.join(HERE, src), os.path.join(OBJ_DIR, src + ".o")
+        cmd = [HIPCC] + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+        if force or _stale(o, [s] + headers, cmd):
+            todo.append(src)
+    return todo
 
 
 def ext_path():

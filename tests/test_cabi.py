@@ -247,3 +247,22 @@ def test_in_flight_launch_sizing_policy(built_lib):
         assert L.cv_hv_set_part_records(0) == 4096
     finally:
         pipeline.configure_for_scenes_in_flight(1)
+
+
+def test_a_changed_define_makes_the_object_stale(built_lib, monkeypatch):
+    """csrc/build.py keeps the command line of every object beside it: another -D through CV_*_DEFS (or another HIPCC)
+    is a rebuild of exactly that source, not a silent re-use (round 5 lost a table of ablations to that)."""
+    from canonicalvoting_amd.csrc import build as b
+    for k in ("CV_HV_DEFS", "CV_DEC_DEFS", "CV_SC_DEFS", "CV_WIN_DEFS"):
+        monkeypatch.delenv(k, raising=False)
+    assert b.plan() == []
+    monkeypatch.setenv("CV_SC_DEFS", "-DX=1")
+    assert b.plan() == ["sparse_conv.hip"]
+    monkeypatch.setenv("CV_HV_DEFS", "-DHV_TX=16 -DHV_TW=8")
+    assert b.plan() == ["hv_vote.hip", "sparse_conv.hip"]
+    monkeypatch.delenv("CV_SC_DEFS")
+    monkeypatch.delenv("CV_HV_DEFS")
+    assert b.plan() == []
+    obj = os.path.join(b.OBJ_DIR, "cv_host.cpp.o")
+    assert open(obj + ".cmd").read().split("\n")[0] == b.HIPCC and not b._stale(obj, [])
+    assert b._stale(obj, [], ["another", "command"])
