@@ -278,6 +278,8 @@ def step_events():
 ABLATE = ()
 ADAPTIVE_SPLIT = False
 SCENE_CALL = "c"
+TIMED_POLICY = None     # the policy of the timed region (the parity object is computed under it)
+POLICY = None           # pipeline.ScenePolicy of every run_step call (launch sizing per call: cv_scene_desc / the thread's values)
 
 
 def run_step(model, hv, s, ev=None, teacher=False, keep=None):
@@ -293,11 +295,17 @@ def run_step(model, hv, s, ev=None, teacher=False, keep=None):
             dets, raw, y = pipeline.detect_scene_c(model, hv, s.coords4, s.feats_in, RES, scan_points=s.points,
                                                    predictions=(s.xyz, s.scale, s.prob, s.cls) if teacher else None,
                                                    events=ev[:5] if ev is not None else None, keep=keep,
-                                                   adaptive_split=ADAPTIVE_SPLIT)
+                                                   adaptive_split=ADAPTIVE_SPLIT, policy=POLICY)
         finally:
             if ev is not None and len(ev) > 6:
                 _lib.lib().cv_hv_set_kernel_events(None, None)
         return dets, raw
+    with pipeline.scene_policy(POLICY):
+        return _run_step_calls(model, hv, s, ev, rec, teacher, keep)
+
+
+def _run_step_calls(model, hv, s, ev, rec, teacher, keep):
+    """run_step, call by call (the Python pipeline: --scene-call py, the timing ablations, vote-only stages)"""
     with torch.no_grad():
         rec(0)
         hv_cuda.prefetch_geometry(s.points)       # bounds reduction of the vote grid starts before the network
@@ -438,20 +446,45 @@ def cpu_baseline(a, scenes, model, hv, full, teacher):
     best = min(by_threads[best_n], key=lambda t: t["total"])
     if full and 1 in by_threads:
         one = by_threads[1][0]
-    keep = {}
-    run_step(model, hv, s, teacher=teacher, keep=keep)
-    torch.cuda.synchronize()
-    if full:
-        xyz, scale = (s.xyz, s.scale) if teacher else keep["net_pred"][:2]
-    else:
-        xyz, scale = s.xyz, s.scale
-    s.v_in_run = hv_cuda.count_votes(s.points, xyz, scale, RES, NUM_ROTS, s.corner, s.dims)
-    sc, hx, hs, hp, hc = s.host
-    if full and not teacher:
-        hx, hs, hp, hc = [t.cpu().numpy() for t in keep["net_pred"]]
-    corner, _, _ = oracle.grid_geometry(sc.points, RES)
-    dec_ref = oracle.decode(*[t.cpu().numpy() for t in keep["grids"]], corner, RES, sc.points, hx, hp, hc)
-    par = parity_flags(keep, ref, s, dec_ref)
+
+    def gpu_parity(policy):
+        """scene 0 through the HIP path under `policy`, against the oracle's results of the same scene"""
+        global POLICY
+        before, POLICY = POLICY, policy
+        try:
+            keep = {}
+            run_step(model, hv, s, teacher=teacher, keep=keep)
+            torch.cuda.synchronize()
+        finally:
+            POLICY = before
+        if full:
+            xyz, scale = (s.xyz, s.scale) if teacher else keep["net_pred"][:2]
+        else:
+            xyz, scale = s.xyz, s.scale
+        s.v_in_run = hv_cuda.count_votes(s.points, xyz, scale, RES, NUM_ROTS, s.corner, s.dims)
+        sc, hx, hs, hp, hc = s.host
+        if full and not teacher:
+            hx, hs, hp, hc = [t.cpu().numpy() for t in keep["net_pred"]]
+        corner, _, _ = oracle.grid_geometry(sc.points, RES)
+        dec_ref = oracle.decode(*[t.cpu().numpy() for t in keep["grids"]], corner, RES, sc.points, hx, hp, hc)
+        out = parity_flags(keep, ref, s, dec_ref)
+        out["config"] = dict((policy or pipeline.policy_for_scenes_in_flight(1)).as_config(),
+                             note="the launch sizing this scene ran under" + (" = the timed region's" if policy is TIMED_POLICY else ""))
+        return out, keep
+
+    # `parity`: under the launch sizing the timed region ran with; `parity_one_in_flight`: under the library's one-scene sizing,
+    # plus whether the two runs agree bit for bit on every integer output and on the three vote grids
+    par, keep_t = gpu_parity(TIMED_POLICY)
+    lib_policy = pipeline.policy_for_scenes_in_flight(1)
+    par_one = None
+    if TIMED_POLICY is not None and TIMED_POLICY != lib_policy:
+        par_one, keep_1 = gpu_parity(lib_policy)
+        par_one["same_bits_as_timed_config"] = {
+            "vote_grids": bool(all(torch.equal(x, y) for x, y in zip(keep_t["grids"], keep_1["grids"]))),
+            "candidates_verdicts_boxes": bool(np.array_equal(keep_t["raw"]["cand_idx"], keep_1["raw"]["cand_idx"]) and
+                                              np.array_equal(keep_t["raw"]["verdict"], keep_1["raw"]["verdict"]) and
+                                              np.array_equal(keep_t["raw"]["boxes"], keep_1["raw"]["boxes"])),
+            "net_max_abs_diff": float((keep_t["y"] - keep_1["y"]).abs().max()) if keep_t.get("y") is not None else None}
     base = {"value": 1.0 / best["total"], "unit": "scenes/s", "cores": best_n if full else 1, "kind": "port",
             "host_threads_available": nthreads,
             "thread_sweep_s": {str(n_): round(min(t["total"] for t in v), 4) for n_, v in sorted(by_threads.items())},
@@ -464,7 +497,7 @@ def cpu_baseline(a, scenes, model, hv, full, teacher):
                       % (a.points, "torch-CPU sparse MinkUNet34C + C vote/decode/NMS on 1 thread"
                          if full else "C vote/decode/NMS, 1 thread", sweep, len(by_threads[best_n]), best_n,
                          sum(t["total"] for t in runs))}
-    return base, par
+    return base, par, par_one
 
 
 def train_batch(rank, B, n, dev, scenes=None):
@@ -688,18 +721,14 @@ def main():
     S = scene_threads(a.streams)
     # launch sizing by the scenes the host keeps in flight (pipeline.configure_for_scenes_in_flight: what a serving host would
     # call), then the explicit overrides of the command line
-    cfg = pipeline.configure_for_scenes_in_flight(S, model)
-    split_target = a.split_target if a.split_target >= 0 else cfg["conv_split_target"]
-    ME.set_split_target(split_target)
-    part_records = a.vote_part_records if a.vote_part_records >= 0 else cfg["vote_part_records"]
-    _lib.lib().cv_hv_set_part_records(int(part_records))
-    masked_min_rows = a.masked_min_rows if a.masked_min_rows >= 0 else cfg["masked_min_rows"]
-
-    def set_masked_min_rows(v):
-        ME.CoordinateManager.MASKED_MIN_ROWS = int(v)       # (what the scene call and the plans read)
-        if model is not None:
-            model.MASKED_MIN_ROWS = int(v)                  # (the module paths' copy)
-    set_masked_min_rows(masked_min_rows)
+    cfg = pipeline.policy_for_scenes_in_flight(S)
+    split_target = a.split_target if a.split_target >= 0 else cfg.conv_split_target
+    part_records = a.vote_part_records if a.vote_part_records >= 0 else cfg.vote_part_records
+    masked_min_rows = a.masked_min_rows if a.masked_min_rows >= 0 else cfg.masked_min_rows
+    # the policy travels with every call (cv_scene_desc.conv_split_target / vote_part_records / masked_min_rows; the thread's
+    # values for the call-by-call path): nothing process-wide is touched
+    global POLICY, TIMED_POLICY
+    POLICY = TIMED_POLICY = pipeline.ScenePolicy(int(split_target), int(part_records), int(masked_min_rows))
     # one-call scenes size their coarse-level launches by the scenes in flight when they start (768 workgroups below four, 256
     # from four on): the tail of a short run, where the scene threads run dry one by one, gets the one-scene sizing
     global ADAPTIVE_SPLIT
@@ -856,7 +885,7 @@ def main():
         # This pass runs on the main thread's stream, which has its own allocator pool and scratch: two passes over the
         # resident scenes first, then the MEDIAN over the measured steps (one cold step used to double the mean)
         iso_steps = max(min(a.steps, 48), 24)
-        pipeline.configure_for_scenes_in_flight(1, model)          # one scene in flight: the library's default launch sizing
+        POLICY = pipeline.policy_for_scenes_in_flight(1)           # one scene in flight: the library's default launch sizing
         for k in range(2 * len(scenes)):
             run_step(model, hv, scenes[k % len(scenes)], teacher=teacher)
         ev2 = [step_events() for _ in range(iso_steps)]
@@ -870,6 +899,7 @@ def main():
         iso_op = float(np.median(op2))
         vb2 = np.array([scenes[k % len(scenes)].vote_bytes for k in range(iso_steps)], dtype=np.float64)
         iso_achieved = float(np.median(vb2 / (v2 * 1e-3)) / 1e9)
+        POLICY = TIMED_POLICY
     s0 = scenes[0]
     # HBM bytes of the vote kernel from the PMC counters are collected offline (rocprofv3 --pmc in its
     # own passes, profiles/r*/vote_hbm_traffic.json) for the default 80k workload; null otherwise
@@ -970,11 +1000,11 @@ def main():
         "step_host_ms": {"median": float(np.median([(e - b) * 1e3 for _, b, e in step_log])),
                          "max": float(max((e - b) * 1e3 for _, b, e in step_log))},
     }
-    out["cpu_baseline"] = out["parity"] = out["train_step_ms"] = None
+    out["cpu_baseline"] = out["parity"] = out["parity_one_in_flight"] = out["train_step_ms"] = None
     if rank == 0 and full and a.train_steps > 0 and not a.large:
         out["train_step_ms"] = train_side_field(a, scenes, dev)
     if rank == 0 and a.cpu_scenes > 0:
-        out["cpu_baseline"], out["parity"] = cpu_baseline(a, scenes, model, hv, full, teacher)
+        out["cpu_baseline"], out["parity"], out["parity_one_in_flight"] = cpu_baseline(a, scenes, model, hv, full, teacher)
     if rank == 0:
         print(json.dumps(out), flush=True)
     cvd.finalize()

@@ -15,7 +15,7 @@ c_int_p = ctypes.POINTER(ctypes.c_int)
 c_i32_p = ctypes.POINTER(ctypes.c_int32)
 c_i64_p = ctypes.POINTER(ctypes.c_int64)
 vp = ctypes.c_void_p
-ABI_VERSION = 2          # CV_ABI_VERSION of include/cv_hip.h that these ctypes signatures were written against
+ABI_VERSION = 3          # CV_ABI_VERSION of include/cv_hip.h that these ctypes signatures were written against
 
 
 class CvError(RuntimeError):
@@ -81,7 +81,8 @@ class SceneDesc(ctypes.Structure):
                 ("nms_threshold", ctypes.c_double), ("d_ws", vp), ("ws_bytes", ctypes.c_size_t), ("d_grids", vp),
                 ("grid_capacity_floats", ctypes.c_size_t), ("h_pinned", vp), ("pinned_bytes", ctypes.c_size_t),
                 ("h_cand_idx", vp), ("h_verdict", vp), ("h_boxes", vp), ("h_scores", vp), ("h_classes", vp), ("h_pick", vp),
-                ("adaptive_split", ctypes.c_int), ("events", vp * 5)]
+                ("adaptive_split", ctypes.c_int), ("events", vp * 5),
+                ("conv_split_target", ctypes.c_int), ("vote_part_records", ctypes.c_int)]
 
 
 class SceneResult(ctypes.Structure):
@@ -134,6 +135,8 @@ SIGNATURES = {
     "cv_sp_conv_f32": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp]),
     "cv_sp_set_split_target": (ctypes.c_int, [ctypes.c_int]),
     "cv_hv_set_part_records": (ctypes.c_int, [ctypes.c_int]),
+    "cv_hv_set_part_records_thread": (ctypes.c_int, [ctypes.c_int]),
+    "cv_sp_copy_unless_flag": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_longlong), ctypes.c_int, vp, vp]),
     "cv_sp_pack_weights_t_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_set_split_target_thread": (ctypes.c_int, [ctypes.c_int]),
     "cv_sp_set_ablation": (ctypes.c_int, [ctypes.c_int]),

@@ -85,6 +85,13 @@ constexpr int CV_MAX_PERM_JOBS = 8;
 // d_ws: (sum of groups) * 1024 ints, zero-filled by the call (unless pre_zeroed)
 int cv_hv_minmax_async_ex(const float* d_points, int64_t n, float* h_minmax6, void* d_ws, size_t ws_bytes, int32_t* d_zero_word,
                           int32_t* d_fill7f, void* stream);                                // hv_vote.hip
+// cv_decode_f32 with an event (hipEvent_t, may be NULL) recorded behind its LAST launch, in front of the host's wait for the
+// results: the scene call's "decode done" mark is then a device time (hv_decode.hip)
+int cv_decode_f32_ev(float* d_grid_obj, const float* d_grid_rot, const float* d_grid_scale, const int dims[3],
+                     const float h_corner3[3], float res, const float* d_points, const float* d_xyz, const float* d_prob,
+                     const int32_t* d_class, int64_t n, const cv_decode_params* params, int mutate_grid, void* d_ws, size_t ws_bytes,
+                     int* h_n_cand, int64_t* h_cand_idx, int32_t* h_verdict, int* h_n_boxes, float* h_boxes, float* h_scores,
+                     int32_t* h_classes, int* h_truncated, void* stream, void* ev_done);
 int cv_sp_sort_rows_ex(const int32_t* d_coords, long long n, int32_t* d_sorted, int32_t* d_perm, int32_t* d_inv, void* d_ws,
                        size_t ws_bytes, bool single_batch, void* stream, bool bounds_prefilled = false);   // sparse_coords.hip
 int cv_sp_scene_plan_ex(const int32_t* d_input, long long n, int32_t* d_perm, int32_t* d_inv, int32_t* const* d_coords,

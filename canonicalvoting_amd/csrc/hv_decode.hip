@@ -886,6 +886,13 @@ PinnedPool g_pinned;
 
 }  // namespace
 
+int cv_decode_f32_ev(float* d_grid_obj, const float* d_grid_rot, const float* d_grid_scale,
+                     const int dims[3], const float h_corner3[3], float res, const float* d_points,
+                     const float* d_xyz, const float* d_prob, const int32_t* d_class, int64_t n,
+                     const cv_decode_params* params, int mutate_grid, void* d_ws, size_t ws_bytes,
+                     int* h_n_cand, int64_t* h_cand_idx, int32_t* h_verdict, int* h_n_boxes,
+                     float* h_boxes, float* h_scores, int32_t* h_classes, int* h_truncated, void* stream, void* ev_done);
+
 extern "C" {
 
 size_t cv_decode_workspace_bytes(const int dims[3], int64_t n, int max_iters) {
@@ -900,6 +907,19 @@ int cv_decode_f32(float* d_grid_obj, const float* d_grid_rot, const float* d_gri
                   const cv_decode_params* params, int mutate_grid, void* d_ws, size_t ws_bytes,
                   int* h_n_cand, int64_t* h_cand_idx, int32_t* h_verdict, int* h_n_boxes,
                   float* h_boxes, float* h_scores, int32_t* h_classes, int* h_truncated, void* stream) {
+    return cv_decode_f32_ev(d_grid_obj, d_grid_rot, d_grid_scale, dims, h_corner3, res, d_points, d_xyz, d_prob, d_class, n, params,
+                            mutate_grid, d_ws, ws_bytes, h_n_cand, h_cand_idx, h_verdict, h_n_boxes, h_boxes, h_scores, h_classes,
+                            h_truncated, stream, nullptr);
+}
+
+}  // extern "C"
+
+int cv_decode_f32_ev(float* d_grid_obj, const float* d_grid_rot, const float* d_grid_scale,
+                     const int dims[3], const float h_corner3[3], float res, const float* d_points,
+                     const float* d_xyz, const float* d_prob, const int32_t* d_class, int64_t n,
+                     const cv_decode_params* params, int mutate_grid, void* d_ws, size_t ws_bytes,
+                     int* h_n_cand, int64_t* h_cand_idx, int32_t* h_verdict, int* h_n_boxes,
+                     float* h_boxes, float* h_scores, int32_t* h_classes, int* h_truncated, void* stream, void* ev_done) {
     CV_REQUIRE(d_grid_obj && d_grid_rot && d_grid_scale && dims && h_corner3 && d_points && d_xyz &&
                    d_prob && d_class && params && d_ws && h_n_cand && h_cand_idx && h_verdict &&
                    h_n_boxes && h_boxes && h_scores && h_classes,
@@ -950,6 +970,11 @@ int cv_decode_f32(float* d_grid_obj, const float* d_grid_rot, const float* d_gri
     // the same code over the global arrays - both are launched, the one that does not apply returns at once
     // (grids beyond 4 M cells - 300k-point scenes - list more cells than the 256-thread walker keeps in registers)
     static const long long big_cells = getenv("CV_DEC_BIG_CELLS") ? atoll(getenv("CV_DEC_BIG_CELLS")) : (4ll << 20);
+    // (round 6, profiles/r6/decode_in_flight.txt: a walk with the whole list in registers and no 115 KB LDS copy - placeable next
+    // to any workgroup - and s_setprio 3 on the walk's waves were built and measured with seven scenes in flight: 0.213 against
+    // 0.198 ms in the timed region, 0.163 against 0.147 alone, no change of the scene rate; what round 5 read as "decode takes
+    // 4-14 x longer under load" was the host's wake-up behind the stream wait, inside the stage's event pair - the event now sits
+    // in front of the wait)
     if (G > big_cells) dec_greedy_dispatch_big<<<1, GREEDY_T_BIG, 0, st>>>(geo, *params, L, list_n, cands, stats, n_cand);
     else dec_greedy_dispatch<<<1, GREEDY_T, 0, st>>>(geo, *params, L, list_n, cands, stats, n_cand);
     CV_LAUNCH_CHECK();
@@ -964,6 +989,7 @@ int cv_decode_f32(float* d_grid_obj, const float* d_grid_rot, const float* d_gri
         dec_apply<<<M, 256, 0, st>>>(d_grid_obj, geo, *params, cands, n_cand);
         CV_LAUNCH_CHECK();
     }
+    if (ev_done) CV_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(ev_done), st));
     CV_HIP_CHECK(hipStreamSynchronize(st));
     const int* hdr = reinterpret_cast<const int*>(host);
     const int nc = hdr[0], nb = hdr[1];
@@ -979,4 +1005,4 @@ int cv_decode_f32(float* d_grid_obj, const float* d_grid_rot, const float* d_gri
     return CV_OK;
 }
 
-}  // extern "C"
+

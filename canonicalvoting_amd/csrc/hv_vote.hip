@@ -725,6 +725,32 @@ __device__ __forceinline__ void drain64(TileShared& sh, int wave, int slot, bool
     float rx = 0.f, rz = 0.f, wy = 0.f, ob = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
     float2 cs = make_float2(0.f, 0.f);
     int lx = 0, lz = 0;
+#ifdef HV_BANK_BUCKET
+    // Experiment (-DHV_BANK_BUCKET=1 through CV_HV_DEFS): the 64 votes of a drain are independent, and all
+    // 24 ds_add_u64 of a vote hit bank pair (lx * 8 + lz + const) mod 32 (ACC_PITCH 40).  A 64-lane LDS instruction runs as two
+    // halves of 32 lanes: the votes are dealt to the halves so that the lanes of one bank pair alternate between them (rank among
+    // the lanes of the same bank pair, parity = half) - a half's largest bank load drops from ~3.6 to ~ceil(max / 2).  Five
+    // ballots build the same-bank mask, two more the positions, one ds_permute moves the queue slot.
+    {
+        const uint32_t rec0 = active ? sh.vq_rec[wave][slot] : 0u;
+        const int bank = (int)((((rec0 >> 14) & 63u) * 8u + ((rec0 >> 20) & 63u)) & 31u);
+        uint64_t same = __ballot(active);
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            const uint64_t m = __ballot(active && ((bank >> b) & 1));
+            same &= ((bank >> b) & 1) ? m : ~m;
+        }
+        const int rank = lanes_below(same);
+        const bool odd = active && (rank & 1), even = active && !(rank & 1);
+        const uint64_t me = __ballot(even), mo = __ballot(odd);
+        const int n_even = __popcll(me), n_act = n_even + __popcll(mo);
+        const int lane_id = (int)(threadIdx.x & 63);
+        // inactive lanes keep the tail
+        const int pos = even ? lanes_below(me) : odd ? n_even + lanes_below(mo) : n_act + lanes_below(~(me | mo));
+        slot = __builtin_amdgcn_ds_permute(pos << 2, slot);
+        active = lane_id < n_act;
+    }
+#endif
     if (active) {
         const uint32_t rec = sh.vq_rec[wave][slot];
         rx = sh.vq_rx[wave][slot]; rz = sh.vq_rz[wave][slot];
@@ -1369,9 +1395,17 @@ static thread_local hipEvent_t t_ev_start = nullptr, t_ev_stop = nullptr;
 static std::atomic<long long> g_part_records{getenv("CV_HV_PART_RECORDS") ? std::max<long long>(PART_RECORDS, atoll(getenv("CV_HV_PART_RECORDS")))
                                                                           : (long long)PART_RECORDS};
 
+static thread_local long long t_part_records = 0;     // cv_hv_set_part_records_thread: this thread's launches (0 = process-wide)
+
 int cv_hv_set_part_records(int records) {
     const long long v = records <= 0 ? (long long)PART_RECORDS : std::max<long long>(PART_RECORDS, records);
     return (int)g_part_records.exchange(v, std::memory_order_relaxed);
+}
+
+int cv_hv_set_part_records_thread(int records) {
+    const int before = (int)t_part_records;
+    t_part_records = records <= 0 ? 0 : std::max<long long>(PART_RECORDS, records);
+    return before;
 }
 
 int cv_hv_set_kernel_events(void* ev_start, void* ev_stop) {
@@ -1453,7 +1487,7 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
         d_points, d_xyz, d_scale, n, res, corner.y, Y, fy, ycount);
     CV_LAUNCH_CHECK();
     hv_prep_scan<<<1, 256, 0, st>>>(ycount, Y, ystart, cursor, part_start, q_info, (int)max_q, chunk_start, bin_of_chunk,
-                                    (int)g_part_records.load(std::memory_order_relaxed));
+                                    (int)(t_part_records > 0 ? t_part_records : g_part_records.load(std::memory_order_relaxed)));
     CV_LAUNCH_CHECK();
     hv_prep_scatter<<<(unsigned)((n + PREP_THREADS - 1) / PREP_THREADS), PREP_THREADS, 0, st>>>(
         d_points, d_xyz, d_scale, d_obj, fy, n, Y, res, corner, cursor, rec, n);

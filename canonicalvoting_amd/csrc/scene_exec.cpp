@@ -40,15 +40,21 @@ struct Carver {
 std::atomic<int> g_scenes_inside{0};
 struct SceneCount {
     int before;
-    bool adaptive;
-    int prev_target = 0;
-    explicit SceneCount(bool adaptive_) : before(g_scenes_inside.fetch_add(1, std::memory_order_relaxed)), adaptive(adaptive_) {
-        // scenes in flight (this one included) when the scene starts: the other scenes fill the chip from about four on, below
-        // that the deeper splits of the one-scene optimum pay (profiles/r3/split_target_8streams.txt)
-        if (adaptive) prev_target = cv_sp_set_split_target_thread(before + 1 >= 4 ? 256 : 768);
+    bool set_target, set_records;
+    int prev_target = 0, prev_records = 0;
+    // the launch sizing of THIS call (cv_scene_desc.conv_split_target / vote_part_records / adaptive_split) lives in the calling
+    // thread's values for the duration of the call: two hosts with different policies in one process do not see each other
+    SceneCount(bool adaptive, int split_target, int part_records)
+        : before(g_scenes_inside.fetch_add(1, std::memory_order_relaxed)), set_target(adaptive || split_target > 0),
+          set_records(part_records > 0) {
+        // adaptive: scenes in flight (this one included) when the scene starts: the other scenes fill the chip from about four on,
+        // below that the deeper splits of the one-scene optimum pay (profiles/r3/split_target_8streams.txt)
+        if (set_target) prev_target = cv_sp_set_split_target_thread(split_target > 0 ? split_target : before + 1 >= 4 ? 256 : 768);
+        if (set_records) prev_records = cv_hv_set_part_records_thread(part_records);
     }
     ~SceneCount() {
-        if (adaptive) cv_sp_set_split_target_thread(prev_target);
+        if (set_target) cv_sp_set_split_target_thread(prev_target);
+        if (set_records) cv_hv_set_part_records_thread(prev_records);
         g_scenes_inside.fetch_sub(1, std::memory_order_relaxed);
     }
 };
@@ -74,7 +80,8 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
     const long long n = d->n;
     const int NL = 5;
     std::memset(r, 0, sizeof(*r));
-    SceneCount in_flight(d->adaptive_split != 0);
+    CV_REQUIRE(d->conv_split_target >= 0 && d->vote_part_records >= 0, CV_EINVAL, "negative launch sizing");
+    SceneCount in_flight(d->adaptive_split != 0, d->conv_split_target, d->vote_part_records);
     r->scenes_in_flight = in_flight.before + 1;
     Carver cv(d->d_ws, d->ws_bytes);
     auto mark = [&](int i) { return d->events[i] ? hipEventRecord(static_cast<hipEvent_t>(d->events[i]), st) : hipSuccess; };
@@ -209,10 +216,10 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
     cv_decode_params prm = d->decode;
     prm.max_iters = d->max_candidates;
     int n_cand = 0, n_boxes = 0, truncated = 0;
-    rc = cv_decode_f32(g_obj, g_rot, g_scale, dims, mn, d->res, d->d_points, v_xyz, v_prob, v_cls, n, &prm, 0, dec_ws, dec_ws_b, &n_cand,
-                       d->h_cand_idx, d->h_verdict, &n_boxes, d->h_boxes, d->h_scores, d->h_classes, &truncated, stream);
+    // (events[4] is recorded behind the decode's last launch, in front of its host wait: a device time)
+    rc = cv_decode_f32_ev(g_obj, g_rot, g_scale, dims, mn, d->res, d->d_points, v_xyz, v_prob, v_cls, n, &prm, 0, dec_ws, dec_ws_b, &n_cand,
+                          d->h_cand_idx, d->h_verdict, &n_boxes, d->h_boxes, d->h_scores, d->h_classes, &truncated, stream, d->events[4]);
     if (rc != CV_OK) return rc;
-    CV_HIP_CHECK(mark(4));
     r->n_cand = n_cand;
     r->n_boxes = n_boxes;
     r->truncated = truncated;

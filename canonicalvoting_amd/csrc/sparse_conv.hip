@@ -2670,8 +2670,7 @@ int nb_for(int cout, long long n_out) {
 // workgroups a split launch aims at: CV_SPLIT_TARGET or 768 until cv_sp_set_split_target changes it
 std::atomic<long long> g_split_target{-1};
 thread_local long long t_split_target = 0;       // cv_sp_set_split_target_thread: this thread's launches (0 = the process-wide value)
-long long split_target() {
-    if (t_split_target > 0) return t_split_target;
+long long process_split_target() {
     long long v = g_split_target.load(std::memory_order_relaxed);
     if (v <= 0) {
         v = getenv("CV_SPLIT_TARGET") ? std::max(1ll, atoll(getenv("CV_SPLIT_TARGET"))) : 768;
@@ -2679,6 +2678,7 @@ long long split_target() {
     }
     return v;
 }
+long long split_target() { return t_split_target > 0 ? t_split_target : process_split_target(); }
 
 // Enough workgroups to fill 256 CUs a few times with short dependent chains: split the (offset,
 // chunk) units over blockIdx.z; the partial tiles cost 8 bytes of traffic per output element per split.
@@ -2738,7 +2738,7 @@ int cv_sp_set_split_target_thread(int workgroups) {
 }
 
 int cv_sp_set_split_target(int workgroups) {
-    const int before = (int)split_target();
+    const int before = (int)process_split_target();          // (the process-wide value, whatever the calling thread's own is)
     g_split_target.store(workgroups > 0 ? workgroups : -1, std::memory_order_relaxed);
     return before;
 }
@@ -3295,6 +3295,40 @@ int cv_sp_bn_fold_f32(const float* d_gamma, const float* d_beta, const float* d_
     hipStream_t st = static_cast<hipStream_t>(stream);
     bn_fold<<<(c + 127) / 128, 128, 0, st>>>(d_gamma, d_beta, d_mean, d_var, d_bias, eps, c, d_scale, d_shift);
     CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+// dst_i = src_i for up to COPY_BATCH small tensors in ONE launch, unless *flag != 0 (cv_sp_copy_unless_flag)
+constexpr int COPY_BATCH = 96;
+struct CopyJobs {
+    const uint32_t* src[COPY_BATCH];
+    uint32_t* dst[COPY_BATCH];
+    int words[COPY_BATCH];
+};
+static __global__ __launch_bounds__(256) void copy_unless_flag(CopyJobs jobs, const int32_t* __restrict__ flag) {
+    if (flag && __builtin_nontemporal_load(flag) != 0) return;
+    const uint32_t* s = jobs.src[blockIdx.x];
+    uint32_t* d = jobs.dst[blockIdx.x];
+    for (int i = threadIdx.x; i < jobs.words[blockIdx.x]; i += 256) d[i] = s[i];
+}
+
+int cv_sp_copy_unless_flag(const void* const* h_src, void* const* h_dst, const long long* h_bytes, int n, const int32_t* flag,
+                           void* stream) {
+    CV_REQUIRE(n >= 0 && (n == 0 || (h_src && h_dst && h_bytes)), CV_EINVAL, "bad copy batch");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int base = 0; base < n; base += COPY_BATCH) {
+        CopyJobs jobs;
+        const int m = std::min(COPY_BATCH, n - base);
+        for (int i = 0; i < m; ++i) {
+            CV_REQUIRE(h_src[base + i] && h_dst[base + i] && h_bytes[base + i] >= 0 && h_bytes[base + i] % 4 == 0 &&
+                           h_bytes[base + i] < (1ll << 33), CV_EINVAL, "copy %d: null pointer or a size that is not a multiple of 4 bytes", base + i);
+            jobs.src[i] = static_cast<const uint32_t*>(h_src[base + i]);
+            jobs.dst[i] = static_cast<uint32_t*>(h_dst[base + i]);
+            jobs.words[i] = (int)(h_bytes[base + i] / 4);
+        }
+        copy_unless_flag<<<m, 256, 0, st>>>(jobs, flag);
+        CV_LAUNCH_CHECK();
+    }
     return CV_OK;
 }
 

@@ -214,8 +214,8 @@ class CoordinateManager:
     # scenes/s six in flight - a quarter less partial-sum traffic is worth more than the 4 % more MFMA blocks (four groups
     # were better with the round-1 kernels: 2.99 vs 3.20 ms)
     MASK_GROUPS = int(os.environ.get("CV_NET_MASK_GROUPS", "3"))
-    MASKED_MIN_ROWS = int(os.environ.get("CV_MASKED_MIN_ROWS", "16384"))
-    LIB_MASKED_MIN_ROWS = MASKED_MIN_ROWS          # the one-scene-at-a-time default (pipeline.configure_for_scenes_in_flight)
+    MASKED_MIN_ROWS = int(os.environ.get("CV_MASKED_MIN_ROWS", "16384"))      # process-wide; a thread's own: masked_min_rows()
+    LIB_MASKED_MIN_ROWS = MASKED_MIN_ROWS          # the one-scene-at-a-time default (pipeline.policy_for_scenes_in_flight)
 
     def windows(self, ts=1):
         """neighbour windows of the 3x3x3 map at tensor stride ts (cv_sp_build_windows; int32 block, cached): hand it to
@@ -241,15 +241,16 @@ class CoordinateManager:
         ONE C call (cv_sp_scene_plan: spatial row sort, the five levels of the sorted set, every map and order) into
         three allocations; the tensor views of the plan (fused_plan) are only made when somebody asks for them."""
         cache = self.__dict__.setdefault("_fused_cache", {})
-        if (stem_k, win_levels) in cache:
-            return cache[(stem_k, win_levels)]
+        mmr = masked_min_rows()                # (part of the key: a plan built under another launch policy has other orders)
+        if (stem_k, win_levels, mmr) in cache:
+            return cache[(stem_k, win_levels, mmr)]
         L = _lib.lib()
         dev = self.device
         n = self._input.shape[0]
         NL = CoordinateManager.NUM_LEVELS
         G = self.MASK_GROUPS if (27 + self.MASK_GROUPS - 1) // self.MASK_GROUPS <= 10 else 0   # wide groups: lazily
         cap = int(L.cv_sp_table_capacity(n))
-        words = int(L.cv_sp_scene_plan_words(n, stem_k, G, self.MASKED_MIN_ROWS, win_levels))
+        words = int(L.cv_sp_scene_plan_words(n, stem_k, G, mmr, win_levels))
         up64 = lambda v: (v + 63) // 64 * 64
         # int32 buffer: perm | inv | coords of the 5 levels | table values of the 5 levels | counts | arena (sized for
         # the worst case, every coarse level bounded by n: the call does not come back between the levels and the maps)
@@ -271,7 +272,7 @@ class CoordinateManager:
         off = _lib.SceneMaps()
         with _on(dev):
             _lib.check(L.cv_sp_scene_plan(_ptr(self._input), n, vp(ib + 4 * o_perm), vp(ib + 4 * o_inv), c_coords, c_keys,
-                                          c_vals, cap, vp(ib + 4 * o_counts), counts_h, stem_k, G, self.MASKED_MIN_ROWS,
+                                          c_vals, cap, vp(ib + 4 * o_counts), counts_h, stem_k, G, mmr,
                                           win_levels, vp(ib + 4 * o_arena), words, ctypes.byref(off), vp(wb), sws_b, vp(wb + up64(sws_b)),
                                           lws_b, _stream(dev)), "cv_sp_scene_plan")
         self._raise_on_dups(counts_h[5], counts_h[6])
@@ -287,7 +288,7 @@ class CoordinateManager:
                          [ap(off.up_perm[i]) for i in range(4)]
         plan.win_ptrs = [ap(off.win[i]) if off.win[i] >= 0 else None for i in range(5)]
         plan.views = None
-        cache[(stem_k, win_levels)] = plan
+        cache[(stem_k, win_levels, mmr)] = plan
         self._fused = plan
         self._fused_k = stem_k
         return plan
@@ -556,6 +557,24 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
     with _on(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
     return out
+
+
+_policy_tls = threading.local()
+
+
+def masked_min_rows():
+    """Rows from which a level's 3x3x3 convolutions run mask-sorted: the CALLING THREAD's value while it is inside
+    pipeline.scene_policy(...) (launch sizing per call: two hosts with different policies in one process do not see each
+    other), else the process-wide CoordinateManager.MASKED_MIN_ROWS."""
+    v = getattr(_policy_tls, "masked_min_rows", None)
+    return CoordinateManager.MASKED_MIN_ROWS if v is None else v
+
+
+def set_masked_min_rows_thread(rows):
+    """the calling thread's masked_min_rows() (None: follow the process-wide value); returns the previous thread value"""
+    before = getattr(_policy_tls, "masked_min_rows", None)
+    _policy_tls.masked_min_rows = None if rows is None else int(rows)
+    return before
 
 
 def set_split_target(workgroups):
@@ -979,19 +998,42 @@ def training_range_flag_peek(dev):
     return int(range_flag(dev)[0]) != 0
 
 
-def training_forward_left_fp16_range(dev):
+def training_forward_left_fp16_range(dev, group=None):
     """True when a convolution of this thread's training forwards since the last call staged an input beyond the fp16
     range on the current stream (synchronises the stream; the flag is reset).  False without a wait when no forward used
-    the fp16 pairs."""
-    if not getattr(_train_state, "used_pairs", False):
+    the fp16 pairs.  group: a process group whose ranks step together (DDP) - the answer is then the MAXIMUM over the ranks
+    (what GradScaler does with found_inf): every rank redoes the step, or none does."""
+    used = getattr(_train_state, "used_pairs", False)
+    if not used and group is None:
         return False
     _train_state.used_pairs = False
     torch.cuda.current_stream(dev).synchronize()
     flag = range_flag(dev)
-    if int(flag[0]) == 0:
+    raised = int(flag[0]) != 0
+    if group is not None:
+        import torch.distributed as dist
+        t = torch.tensor([1.0 if raised else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        raised = float(t[0]) != 0.0
+    if not raised:
         return False
     flag.zero_()
     return True
+
+
+def copy_unless_flag(srcs, dsts, dev, flag=None):
+    """dsts[i].copy_(srcs[i]) for lists of same-shaped device tensors in ceil(n / 96) launches, skipped ON THE DEVICE while
+    `flag` (a device-visible int32 tensor, e.g. range_flag(dev); None: always copy) is non-zero: cv_sp_copy_unless_flag."""
+    n = len(srcs)
+    if n == 0:
+        return
+    vp = ctypes.c_void_p
+    a_src = (vp * n)(*[t.data_ptr() for t in srcs])
+    a_dst = (vp * n)(*[t.data_ptr() for t in dsts])
+    a_len = (ctypes.c_longlong * n)(*[t.numel() * t.element_size() for t in srcs])
+    with _on(dev):
+        _lib.check(_lib.lib().cv_sp_copy_unless_flag(a_src, a_dst, a_len, n, vp(flag.data_ptr()) if flag is not None else None,
+                                                     _stream(dev)), "cv_sp_copy_unless_flag")
 
 
 class _ConvFn(torch.autograd.Function):
@@ -1050,10 +1092,10 @@ class _ConvFn(torch.autograd.Function):
                 _join_at_end_of_backward(cur, side)
                 if LATE_GRAD_LOG is not None:
                     LATE_GRAD_LOG.append((kernel, d_kernel.data_ptr()))
+        twins = _bwd_ctx["twins"]
+        twin = twins.pop(grad.data_ptr(), None) if twins else None          # (taken out whether or not it is used)
         if ctx.needs_input_grad[0]:
             nbr_t = transposed_map(nbr, feats.shape[0]) if nbr is not None else None
-            twins = _bwd_ctx["twins"]
-            twin = twins.pop(grad.data_ptr(), None) if twins else None
             if (twin is not None and twin[2] == grad.shape and COMPUTE_DTYPE != "bf16" and k3.shape[2] % 32 == 0
                     and k3.shape[1] % 4 == 0):
                 # the eval path's kernels on the gradient's hl twin (written by the BatchNorm backward above this layer)
@@ -1238,7 +1280,10 @@ class _BNTrainFn(torch.autograd.Function):
                                                    _ptr(dx), _ptr(dres) if y is not None else None, _ptr(ws), ws.numel(),
                                                    _stream(dev)), "cv_sp_bn_backward_f32")
         if dx_hl is not None and usable:
-            _bwd_ctx["twins"][dx.data_ptr()] = (dx_hl, slot[8192:8193].view(torch.float32), dx.shape)
+            # (the entry holds dx itself: while it is in the table the allocator cannot hand dx's address to another gradient
+            # tensor, so a twin whose consumer is not a _ConvFn - it then stays until the step's table is dropped - can never be
+            # taken for a later tensor at the same address: ADVICE r5)
+            _bwd_ctx["twins"][dx.data_ptr()] = (dx_hl, slot[8192:8193].view(torch.float32), dx.shape, dx)
         return dx, dg[0], dg[1], None, None, None, None, dres, None, None
 
 

@@ -159,7 +159,15 @@ class MinkUNetBase(ResNetBase):
         return hit[1]
 
     # levels with at least this many rows run the mask-sorted grouped conv (the coordinate manager builds the orders)
-    MASKED_MIN_ROWS = ME.CoordinateManager.MASKED_MIN_ROWS
+    # None: follow ME.masked_min_rows() (the calling thread's launch policy, else the process-wide value); a number pins it for
+    # this model outside a policy (profiles/sweep_mask_groups.py)
+    MASKED_MIN_ROWS = None
+
+    def masked_min_rows(self):
+        v = getattr(ME._policy_tls, "masked_min_rows", None)
+        if v is not None:
+            return v
+        return self.MASKED_MIN_ROWS if self.MASKED_MIN_ROWS is not None else ME.CoordinateManager.MASKED_MIN_ROWS
     MASK_GROUPS = ME.CoordinateManager.MASK_GROUPS
     # eval forward through the C executor (cv_net_run_f32, one call per scene: host time 1.46 -> 0.72 ms).  Off by
     # default: the GPU, not the host, bounds the scene rate today, and the executor's per-scene arena (257 MB at
@@ -209,7 +217,7 @@ class MinkUNetBase(ResNetBase):
         dev = x.F.device
         exp = self.BLOCK.expansion
         n = [cm.num_rows(1 << i) for i in range(5)]
-        perms = lambda ts, rows: cm.mask_perms(3, ts, self.MASK_GROUPS) if rows >= self.MASKED_MIN_ROWS else None
+        perms = lambda ts, rows: cm.mask_perms(3, ts, self.MASK_GROUPS) if rows >= self.masked_min_rows() else None
         # concat buffers of the decoder: [convtr output | encoder skip]
         up_c = [self.PLANES[4 + i] for i in range(4)]
         skip_c = (self.PLANES[2] * exp, self.PLANES[1] * exp, self.PLANES[0] * exp, self.INIT_DIM)
@@ -417,7 +425,7 @@ class MinkUNetBase(ResNetBase):
         plan = x.coordinate_manager.fused_fast(self.conv0p1s1.kernel_size, win_levels)
         flag = ME.range_flag(dev) if pieces == 2 else None
         n = plan.counts
-        masked = [n[i] >= self.MASKED_MIN_ROWS and plan.win_ptrs[i] is None for i in range(5)]
+        masked = [n[i] >= self.masked_min_rows() and plan.win_ptrs[i] is None for i in range(5)]
         if any(m and plan.perm_ptrs[i] is None for i, m in enumerate(masked)):
             # mask groups too wide for the plan's counting sort: orders from the generic path
             cm = x.coordinate_manager.fused_plan(self.conv0p1s1.kernel_size)[0]

@@ -1,6 +1,8 @@
 """The eval_joint.py per-scene path as functions: network -> head split -> vote -> decode -> NMS
 (eval_joint.py:163-280), everything on the device, three host syncs per scene (coordinate-set
 sizes, vote-grid shape, decode results)."""
+import collections
+import contextlib
 import ctypes
 import os
 
@@ -10,23 +12,63 @@ from . import _lib, decode, hv_cuda
 from . import me as ME
 
 
+class ScenePolicy(collections.namedtuple("ScenePolicy", "conv_split_target vote_part_records masked_min_rows")):
+    """Launch sizing of ONE scene call - the three choices that depend on how many scenes the host keeps in flight:
+    conv_split_target  workgroups a split coarse-level convolution aims at (0: the library's value, 768)
+    vote_part_records  records one workgroup of a hot (tile, plane) of the vote takes (0: the library's value, 4096)
+    masked_min_rows    rows from which a level's 3x3x3 convolutions run mask-sorted (library: 16384)
+    Every integer output is the same under every policy; the network output moves in fp32 summation order only
+    (tests/test_production_size_gpu.py runs the parity cases under both policies).  A policy travels WITH the call -
+    cv_scene_desc.conv_split_target / vote_part_records / masked_min_rows for detect_scene_c, the calling thread's values inside
+    scene_policy(...) for the call-by-call path - so two hosts with different policies in one process do not see each other."""
+    __slots__ = ()
+
+    def as_config(self):
+        return {"conv_split_target": self.conv_split_target, "vote_part_records": self.vote_part_records,
+                "masked_min_rows": self.masked_min_rows}
+
+
+def policy_for_scenes_in_flight(n):
+    """The launch sizing for a host that keeps `n` scenes in flight on separate streams (one thread + stream per scene, as
+    bench.py does).  The library's defaults are the best for ONE scene at a time; from four scenes in flight the other scenes
+    fill the chip and three choices turn (measured on MI355X, LABNOTES rounds 3 and 5): the split convolutions aim at 256
+    workgroups instead of 768, a hot (tile, plane) of the vote takes 12288 records per workgroup instead of 4096, and the
+    3x3x3 convolutions run mask-sorted from 8192 rows instead of 16384."""
+    lib_rows = ME.CoordinateManager.LIB_MASKED_MIN_ROWS
+    if int(n) >= 4:
+        return ScenePolicy(256, 12288, min(8192, lib_rows))
+    return ScenePolicy(0, 0, lib_rows)
+
+
+@contextlib.contextmanager
+def scene_policy(policy):
+    """The calling thread's launches inside the block run under `policy` (None: no change): what detect_scene and the module
+    paths read (cv_sp_set_split_target_thread, cv_hv_set_part_records_thread, ME.masked_min_rows()); restored on exit."""
+    if policy is None:
+        yield
+        return
+    L = _lib.lib()
+    prev_t = L.cv_sp_set_split_target_thread(int(policy.conv_split_target))
+    prev_r = L.cv_hv_set_part_records_thread(int(policy.vote_part_records))
+    prev_m = ME.set_masked_min_rows_thread(policy.masked_min_rows)
+    try:
+        yield
+    finally:
+        L.cv_sp_set_split_target_thread(prev_t)
+        L.cv_hv_set_part_records_thread(prev_r)
+        ME.set_masked_min_rows_thread(prev_m)
+
+
 def configure_for_scenes_in_flight(n, model=None):
-    """Launch sizing for a host that keeps `n` scenes in flight on separate streams (one thread + stream per scene, as bench.py
-    does).  The library's defaults are the best for ONE scene at a time; from four scenes in flight the other scenes fill the
-    chip and three choices turn (measured on MI355X, LABNOTES rounds 3 and 5): the split convolutions aim at 256 workgroups
-    instead of 768, a hot (tile, plane) of the vote takes 12288 records per workgroup instead of 4096, and the 3x3x3
-    convolutions run mask-sorted from 8192 rows instead of 16384.  Every integer output stays the same; the network output
-    moves in fp32 summation order only.  Process-wide: call it before the scene threads start.  Returns the settings."""
-    from . import _lib
-    many = int(n) >= 4
-    cfg = {"conv_split_target": 256 if many else 0, "vote_part_records": 12288 if many else 0,
-           "masked_min_rows": min(8192, ME.CoordinateManager.LIB_MASKED_MIN_ROWS) if many else ME.CoordinateManager.LIB_MASKED_MIN_ROWS}
-    ME.set_split_target(cfg["conv_split_target"])
-    _lib.lib().cv_hv_set_part_records(cfg["vote_part_records"])
-    ME.CoordinateManager.MASKED_MIN_ROWS = cfg["masked_min_rows"]          # (what the scene call and the plans read)
-    if model is not None:
-        model.MASKED_MIN_ROWS = cfg["masked_min_rows"]                     # (the module paths' copy)
-    return cfg
+    """policy_for_scenes_in_flight(n) installed PROCESS-WIDE (the default of every thread that runs without a policy of its
+    own): for a process with one host loop.  Call it before the scene threads start; hosts that share a process pass
+    `policy=` per call instead.  `model` is not needed any more (the models follow ME.masked_min_rows()).  Returns the
+    settings as a dict."""
+    pol = policy_for_scenes_in_flight(n)
+    ME.set_split_target(pol.conv_split_target)
+    _lib.lib().cv_hv_set_part_records(pol.vote_part_records)
+    ME.CoordinateManager.MASKED_MIN_ROWS = pol.masked_min_rows
+    return pol.as_config()
 
 
 def head_joint(out_feats, nclasses=9, log_scale=True):
@@ -46,10 +88,10 @@ def head_joint(out_feats, nclasses=9, log_scale=True):
     return xyz, scale, prob, cls
 
 
-def detect_scene(model, hv, coords4, feats, res, nclasses=9, log_scale=True, **decode_kw):
-    """coords4 [N,4] int (batch 0), feats [N,C] already recentred (eval_joint.py:167-168).
+def detect_scene(model, hv, coords4, feats, res, nclasses=9, log_scale=True, policy=None, **decode_kw):
+    """coords4 [N,4] int (batch 0), feats [N,C] already recentred (eval_joint.py:167-168).  policy: ScenePolicy of this call.
     Returns (detections [(class, box[8,3], score)], raw decode dict, network output)."""
-    with torch.no_grad():
+    with torch.no_grad(), scene_policy(policy):
         # eval_joint.py:193 scan points; their bounds reduction (the vote grid shape) runs under the network
         scan_points = (coords4[:, 1:].to(feats.device) * res).float().contiguous()
         hv_cuda.prefetch_geometry(scan_points)
@@ -130,13 +172,14 @@ _scene_lock = __import__("threading").Lock()
 
 
 def detect_scene_c(model, hv, coords4, feats, res, nclasses=9, log_scale=True, scan_points=None, predictions=None,
-                   max_candidates=512, keep=None, events=None, adaptive_split=False, **decode_kw):
+                   max_candidates=512, keep=None, events=None, adaptive_split=False, policy=None, **decode_kw):
     """detect_scene through ONE C call (cv_detect_scene_f32: coordinate plan -> network program -> head -> vote -> decode
     -> per-class NMS; two host waits inside it, the GIL released for its whole duration).  Same kernels in the same order
     as detect_scene: bit-identical results (tests/test_scene_call_gpu.py).  ``predictions`` = (xyz, scale, prob, class)
     fed to vote + decode instead of the network's (bench.py --predictions teacher).  A scene that needs what the call
     does not do - a range fallback onto the bf16 triples, a decode walk beyond ``max_candidates`` - is redone by the
     call-by-call path.  ``events``: five recorded torch.cuda.Event that the call re-records at the stage boundaries.
+    ``policy``: ScenePolicy of THIS call (None: the thread's / process-wide values).
     Returns (detections, raw decode dict, network output [N, C])."""
     import numpy as np
     L = _lib.lib()
@@ -161,7 +204,10 @@ def detect_scene_c(model, hv, coords4, feats, res, nclasses=9, log_scale=True, s
     d.d_coords4, d.n, d.d_feats, d.feats_ld = vp(coords4.data_ptr()), n, vp(feats.data_ptr()), feats.stride(0)
     d.d_points, d.res, d.num_rots = vp(scan_points.data_ptr()), float(res), hv_cuda._scalar(hv.num_rots, "i")
     d.ops, d.n_ops, d.bufs, d.n_bufs = ctypes.cast(c_ops, vp), len(c_ops), ctypes.cast(c_bufs, vp), len(c_bufs)
-    d.stem_k, d.mask_groups, d.masked_min_rows = model.conv0p1s1.kernel_size, G, cm_cls.MASKED_MIN_ROWS
+    d.stem_k, d.mask_groups = model.conv0p1s1.kernel_size, G
+    d.masked_min_rows = policy.masked_min_rows if policy is not None else model.masked_min_rows()
+    if policy is not None:
+        d.conv_split_target, d.vote_part_records = int(policy.conv_split_target), int(policy.vote_part_records)
     d.win_levels = int(L.cv_net_win_levels(c_ops, len(c_ops), c_bufs, len(c_bufs))) if ME.option("win") else 0
     d.max_channels, d.use_range_flag = max(model.PLANES), 1 if pieces == 2 else 0
     d.d_out_feats, d.out_ld, d.out_channels = vp(y.data_ptr()), y.stride(0), y.shape[1]
@@ -214,7 +260,7 @@ def detect_scene_c(model, hv, coords4, feats, res, nclasses=9, log_scale=True, s
         # rare: a convolution input beyond the fp16 range, or more candidate cells than the result arrays hold
         if r.range_flag:
             model.range_fallbacks = getattr(model, "range_fallbacks", 0) + 1
-        with torch.no_grad():
+        with torch.no_grad(), scene_policy(policy):
             x = ME.SparseTensor(feats, coords4, device=dev)
             yy = model.program_forward(x, pieces=3) if r.range_flag else x._like(y, 1)
             pred = head_joint(yy.F, nclasses, log_scale) if predictions is None else predictions

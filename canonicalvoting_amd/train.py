@@ -38,14 +38,20 @@ def joint_loss(out_feats, xyz_labels, scale_labels, class_labels, nclasses=9, lo
     # line makes the host wait for the forward, and the backward is only queued once the chip has run dry (3-4 ms of a 27 ms
     # step, profiles/r5/train_gaps.txt).  The same means as sums over all rows times the mask, divided by the object rows on
     # the device: equal up to summation order; no object row: both terms are zero, as the reference's `if` leaves them.
-    m = mask[:, None].to(out_feats.dtype)
+    # Background rows are SELECTED away in front of the arithmetic (prediction and target both become 0 there), not multiplied by
+    # zero behind it: a non-finite prediction in a row the reference never touches (:262-272 index with the mask) reaches
+    # neither the loss nor - through 0 * inf in a backward formula - a gradient.
+    m = mask[:, None]
     cnt = mask.sum()
     denom = (cnt * 3).clamp(min=1).to(out_feats.dtype)
-    safe_scale = torch.where(mask[:, None], scale_labels, torch.ones_like(scale_labels))
-    tgt_scale = torch.log(safe_scale) if log_scale else safe_scale              # :266-269
-    safe_xyz = torch.where(mask[:, None], xyz_labels, torch.zeros_like(xyz_labels))
-    losses = {"loss_scale": torch.sum((out_scale - tgt_scale) ** 2 * w * m) / denom * scale_factor,
-              "loss_xyz": torch.sum((out_xyz - safe_xyz) ** 2 * w * m) / denom * xyz_factor}
+    zero = torch.zeros((), dtype=out_feats.dtype, device=out_feats.device)
+    safe_scale = torch.where(m, scale_labels, torch.ones_like(scale_labels))
+    tgt_scale = torch.where(m, torch.log(safe_scale) if log_scale else safe_scale, zero)       # :266-269
+    tgt_xyz = torch.where(m, xyz_labels, zero)
+    out_scale = torch.where(m, out_scale, zero)
+    out_xyz = torch.where(m, out_xyz, zero)
+    losses = {"loss_scale": torch.sum((out_scale - tgt_scale) ** 2 * w) / denom * scale_factor,
+              "loss_xyz": torch.sum((out_xyz - tgt_xyz) ** 2 * w) / denom * xyz_factor}
     # :273; the reference's labels are 0..9 (9 = background, utils/dataloader.py:172) - a negative label would make its
     # CrossEntropyLoss raise, here it counts as background
     losses["loss_class"] = F.cross_entropy(out_class, torch.where(labels < 0, torch.full_like(labels, nclasses), labels))
@@ -88,15 +94,86 @@ def _skips_on_device(optimizer):
     return isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)) and all(g.get("fused") for g in optimizer.param_groups)
 
 
+FLAG_LAG = 2        # train_step reads the range flag of the step this many calls ago (all ranks the same one)
+
+
+def _step_group(model):
+    """the process group whose ranks step together with this model (DDP), or None"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = getattr(model, "process_group", None)
+    if group is None and not isinstance(model, torch.nn.parallel.DistributedDataParallel):
+        return None
+    return group if dist.get_world_size(group) > 1 else None
+
+
+class _FlagRing:
+    """The range flag of the step FLAG_LAG calls ago - the SAME step on every rank, after an all-reduce (MAX) over the group:
+    ranks that step together act on one value at one step (skip / restore / redo / switch to the triples together; a rank
+    acting on its own flag, or on a live peek that lands at another step, leaves the others with diverged parameters or in a
+    collective nobody joins: ADVICE r5).  push() stores this step's flag behind the step's work (pinned memory + event, no
+    host wait); noticed() reads the oldest stored one, whose event passed long ago."""
+
+    def __init__(self, dev, lag=FLAG_LAG):
+        self.dev, self.lag, self.k, self.slots = dev, lag, 0, [None] * lag
+
+    def noticed(self):
+        slot = self.slots[self.k % self.lag]
+        if slot is None or not slot["valid"]:
+            return False
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+        return float(slot["host"][0]) != 0.0
+
+    def push(self, found, group=None):
+        """found: float scalar tensor on the step's device (None: the step used no fp16 pairs); returns the group's value"""
+        i = self.k % self.lag
+        self.k += 1
+        slot = self.slots[i]
+        if slot is None:
+            cuda = self.dev.type == "cuda"
+            host = torch.zeros(1, dtype=torch.float32)
+            slot = self.slots[i] = {"host": host.pin_memory() if cuda else host, "event": torch.cuda.Event() if cuda else None,
+                                    "valid": False}
+        slot["valid"] = found is not None
+        if found is None:
+            return None
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(found, op=dist.ReduceOp.MAX, group=group)
+        slot["host"].copy_(found.reshape(1), non_blocking=True)
+        if slot["event"] is not None:
+            slot["event"].record(torch.cuda.current_stream(self.dev))
+        return found
+
+
+def _bn_state(model):
+    """(the BatchNorm running statistics and counters of `model`, a snapshot buffer for each that lives with the model)"""
+    bufs = [b for m in model.modules() for b in (getattr(m, "running_mean", None), getattr(m, "running_var", None),
+                                                 getattr(m, "num_batches_tracked", None)) if b is not None]
+    saved = model.__dict__.get("_bn_snapshot")
+    if saved is None or len(saved) != len(bufs) or any(a.shape != b.shape or a.device != b.device or a.dtype != b.dtype
+                                                       for a, b in zip(saved, bufs)):
+        saved = model.__dict__["_bn_snapshot"] = [torch.empty_like(b) for b in bufs]
+    return bufs, saved
+
+
 def train_step(model, optimizer, coords4, feats, xyz_labels, scale_labels, class_labels, **loss_kw):
     """one iteration of train_joint.py:246-288; feats already recentred (:248-249).
 
     The forward multiplies fp16 pairs on the eval path's kernels (ME.TRAIN_FWD_HL); an activation beyond the fp16 range - never
     behind a healthy BatchNorm - raises the range flag.  With a fused Adam the flag rides to the optimizer as `found_inf`: the
-    update of such a step is skipped ON THE DEVICE (no host wait in the step), the host notices at one of the next calls, counts
-    it (model.train_range_fallbacks) and runs the following steps on the bf16 triples.  Other optimizers: the host waits for the
-    flag and redoes the step on the triples before the optimizer sees a gradient."""
+    update of such a step is skipped ON THE DEVICE (no host wait in the step).  The host reads the flag of the step FLAG_LAG
+    calls ago (pinned memory + an event that has long passed): it then restores the BatchNorm running statistics and counters
+    from a snapshot that a device-side guard has kept at the state before the FIRST flagged step (cv_sp_copy_unless_flag: the
+    flagged batches are dropped as a whole - no update, no statistics, exactly as if they had not been drawn), counts the
+    fallback (model.train_range_fallbacks) and runs this and the following steps on the bf16 triples.  Other optimizers: the host
+    waits for the flag and redoes the step on the triples before the optimizer sees a gradient.
+    Under DDP the flag is all-reduced (MAX) over the ranks of the model's process group before anybody acts on it, and the
+    lagged read looks at the same step on every rank: all ranks skip, restore, redo and switch to the triples together."""
     dev = feats.device
+    group = _step_group(model)
 
     def fwd_bwd():
         optimizer.zero_grad(set_to_none=True)
@@ -120,17 +197,32 @@ def train_step(model, optimizer, coords4, feats, xyz_labels, scale_labels, class
         optimizer.step()
         return loss.detach(), {k: v.detach() for k, v in parts.items()}
 
+    bufs, saved = _bn_state(model)
     if _skips_on_device(optimizer):
-        if ME.training_range_flag_peek(dev):
-            # an earlier step left the fp16 range: its update (and that of every step queued since) was skipped on the device
+        ring = model.__dict__.get("_flag_ring")
+        if ring is None or ring.dev != dev:
+            ring = model.__dict__["_flag_ring"] = _FlagRing(dev)
+        if ring.noticed():
+            # the step FLAG_LAG calls ago left the fp16 range (on this rank or, under DDP, on any rank): its update and that
+            # of every step queued since was skipped on the device, and the BatchNorm snapshot still holds the statistics and
+            # counters of before it
             torch.cuda.current_stream(dev).synchronize()
+            with torch.no_grad():
+                torch._foreach_copy_(bufs, saved)
             ME.range_flag(dev).zero_()
             model.train_range_fallbacks = getattr(model, "train_range_fallbacks", 0) + 1
             model.__dict__["_pairs_off"] = True
+            model.__dict__.pop("_flag_ring", None)
             return train_step(model, optimizer, coords4, feats, xyz_labels, scale_labels, class_labels, **loss_kw)
+        # BatchNorm statistics of before this step, kept ON THE DEVICE only while no step has raised the flag
+        ME.copy_unless_flag(bufs, saved, dev, ME.range_flag(dev))
         with ME.pair_scale_hints(model):
             loss, parts = fwd_bwd()
-        optimizer.found_inf = ME.training_range_flag_device(dev)
+        found = ring.push(ME.training_range_flag_device(dev), group)
+        if found is not None and group is not None:
+            # the local flag follows the group's: every rank's later steps skip too, and every rank's snapshot guard closes
+            ME.range_flag(dev).copy_(found.reshape(1).to(torch.int32), non_blocking=True)
+        optimizer.found_inf = found
         try:
             optimizer.step()
         finally:
@@ -140,17 +232,11 @@ def train_step(model, optimizer, coords4, feats, xyz_labels, scale_labels, class
     # the step may have to be redone: keep the BatchNorm running statistics of before the step, so that the redo does not count
     # the batch twice (one momentum update and one num_batches_tracked increment per iteration, as train_joint.py:250-283 gives)
     # (one multi-tensor copy into buffers that live with the model: 186 one-element clones per step were 186 launches)
-    bufs = [b for m in model.modules() for b in (getattr(m, "running_mean", None), getattr(m, "running_var", None),
-                                                 getattr(m, "num_batches_tracked", None)) if b is not None]
-    saved = model.__dict__.get("_bn_snapshot")
-    if saved is None or len(saved) != len(bufs) or any(a.shape != b.shape or a.device != b.device or a.dtype != b.dtype
-                                                       for a, b in zip(saved, bufs)):
-        saved = model.__dict__["_bn_snapshot"] = [torch.empty_like(b) for b in bufs]
     with torch.no_grad():
         torch._foreach_copy_(saved, bufs)
     with ME.pair_scale_hints(model):
         loss, parts = fwd_bwd()
-    if ME.training_forward_left_fp16_range(dev):
+    if ME.training_forward_left_fp16_range(dev, group):
         with torch.no_grad():
             torch._foreach_copy_(bufs, saved)
         loss, parts = on_triples(fwd_bwd)

@@ -33,8 +33,9 @@ extern "C" {
 /* Version of this header.  cv_abi_version() returns the value the LIBRARY was built with: a binding compiled against
  * this header compares the two (csrc/hv_cuda_ext.cpp does at import) and refuses a stale pair.
  * 2 (round 5): neighbour windows (cv_sp_build_windows, cv_conv_desc.win, cv_scene_maps.win, win_levels arguments of the
- *    scene-plan calls, `wins` of cv_net_run_f32); the round 1-3 tile-plan symbols are gone. */
-#define CV_ABI_VERSION 2
+ *    scene-plan calls, `wins` of cv_net_run_f32); the round 1-3 tile-plan symbols are gone.
+ * 3 (round 6): launch sizing per call - cv_scene_desc.conv_split_target / vote_part_records, cv_hv_set_part_records_thread. */
+#define CV_ABI_VERSION 3
 int cv_abi_version(void);
 const char* cv_last_error(void);
 
@@ -84,6 +85,9 @@ int cv_hv_forward_f32(const float* d_points, const float* d_xyz, const float* d_
  * bound assumes it); records <= 0 restores the default.  Returns the previous value.  Process-wide, like
  * cv_sp_set_split_target. */
 int cv_hv_set_part_records(int records);
+/* The same for the CALLING THREAD's launches only (0 = follow the process-wide value); returns the previous thread value.
+ * cv_detect_scene_f32 sets it from cv_scene_desc.vote_part_records for the duration of the call. */
+int cv_hv_set_part_records_thread(int records);
 /* Measurement hook (no reference counterpart): the CALLING THREAD's following cv_hv_forward_f32 calls record the two
  * hipEvent_t handles directly before and after the accumulation kernel of the tile algorithm (hv_fwd_tiles), on the
  * stream of the call - bench.py times exactly the kernel its `roofline` prices, with other scenes in flight, instead
@@ -470,6 +474,16 @@ int cv_sp_bn_backward_hl_f32(const float* d_x, const float* d_dy, const float* d
                              float* d_dbeta, float* d_dx, float* d_dres, void* d_ws, size_t ws_bytes, float* d_dx_hl,
                              uint32_t* d_slot, int32_t* range_flag, const uint32_t* d_relu_bits, void* stream);
 
+/* Multi-tensor copy with a device-side guard: h_dst[i][0 .. h_bytes[i]) = h_src[i][...] for i < n (device pointers in host
+ * arrays, sizes multiples of 4 bytes; ceil(n / 96) launches) UNLESS *flag != 0 when the launch runs (flag: device-visible
+ * int32, NULL = always copy).  The training step snapshots the BatchNorm running statistics with it in front of every
+ * forward: once a forward has left the fp16 range (cv_conv_desc.range_flag, sticky until the host resets it) the snapshot stays
+ * the state before the FIRST flagged step, whatever was queued since - the host restores from it when it notices
+ * (canonicalvoting_amd/train.py; the reference's BatchNorm statistics, train_joint.py:250, see every batch exactly once).
+ * Asynchronous. */
+int cv_sp_copy_unless_flag(const void* const* h_src, void* const* h_dst, const long long* h_bytes, int n, const int32_t* flag,
+                           void* stream);
+
 /* y = relu?(x * scale + shift + residual): MinkowskiBatchNorm (eval) / MinkowskiReLU / the residual add of
  * BasicBlock on feature rows; scale, shift and residual may each be NULL. */
 int cv_sp_affine_f32(const float* d_x, long long n, int c, int x_ld, const float* d_scale,
@@ -545,6 +559,12 @@ typedef struct cv_scene_desc {
     /* optional measurement hook: hipEvent_t handles recorded on `stream` at the scene's start, behind the network, the head
      * split, the vote and the decode (NULL entries are skipped) */
     void* events[5];
+    /* launch sizing of THIS call (with masked_min_rows above: the three choices that depend on how many scenes the host keeps
+     * in flight - every integer output stays the same bits, the network output moves in fp32 summation order only).  0 = the
+     * calling thread's / process-wide value (cv_sp_set_split_target[_thread], cv_hv_set_part_records[_thread]).
+     * conv_split_target > 0 overrides adaptive_split. */
+    int conv_split_target;        /* workgroups a split coarse-level convolution aims at (library default 768; 256 from four scenes in flight) */
+    int vote_part_records;        /* records one workgroup of a hot (tile, plane) takes (library default 4096; 12288 from four in flight) */
 } cv_scene_desc;
 typedef struct cv_scene_result {
     int n_cand, n_boxes, n_det, truncated, range_flag, duplicates, out_of_window;

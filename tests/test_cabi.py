@@ -249,6 +249,50 @@ def test_in_flight_launch_sizing_policy(built_lib):
         pipeline.configure_for_scenes_in_flight(1)
 
 
+def test_launch_policy_travels_with_the_call_not_the_process(built_lib):
+    """pipeline.ScenePolicy / scene_policy: the three in-flight knobs as the CALLING THREAD's values for the duration of a
+    block (cv_sp_set_split_target_thread, cv_hv_set_part_records_thread, ME.masked_min_rows()), restored on exit, invisible
+    to other threads and to the process-wide values; cv_scene_desc carries the same three for the one-call path"""
+    import threading
+    from canonicalvoting_amd import me as ME, pipeline
+    from canonicalvoting_amd.minkunet import MinkUNet34C
+    L = _lib.lib()
+    lib_rows = ME.CoordinateManager.LIB_MASKED_MIN_ROWS
+    assert pipeline.policy_for_scenes_in_flight(3) == pipeline.ScenePolicy(0, 0, lib_rows)
+    pol = pipeline.policy_for_scenes_in_flight(4)
+    assert pol == pipeline.ScenePolicy(256, 12288, min(8192, lib_rows)) == pipeline.policy_for_scenes_in_flight(7)
+    assert {"conv_split_target", "vote_part_records", "masked_min_rows"} <= {f[0] for f in _lib.SceneDesc._fields_}
+    process_target = L.cv_sp_set_split_target(0)
+    L.cv_sp_set_split_target(process_target)
+    model = MinkUNet34C(3, 8)
+    seen = {}
+    with pipeline.scene_policy(pol):
+        assert ME.masked_min_rows() == model.masked_min_rows() == pol.masked_min_rows
+        assert L.cv_sp_set_split_target_thread(256) == 256 and L.cv_hv_set_part_records_thread(12288) == 12288
+        with pipeline.scene_policy(pipeline.ScenePolicy(512, 100, 4096)):               # nests; part records clamp up to 4096
+            assert ME.masked_min_rows() == 4096 and L.cv_sp_set_split_target_thread(512) == 512
+            assert L.cv_hv_set_part_records_thread(4096) == 4096
+        assert ME.masked_min_rows() == pol.masked_min_rows and L.cv_sp_set_split_target_thread(256) == 256
+
+        def other():
+            seen["rows"] = ME.masked_min_rows()
+            seen["target"] = L.cv_sp_set_split_target_thread(0)
+            seen["records"] = L.cv_hv_set_part_records_thread(0)
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert ME.CoordinateManager.MASKED_MIN_ROWS == lib_rows                          # nothing process-wide moved
+        assert L.cv_sp_set_split_target(process_target) == process_target
+    assert seen == {"rows": lib_rows, "target": 0, "records": 0}
+    assert ME.masked_min_rows() == lib_rows and L.cv_sp_set_split_target_thread(0) == 0 and L.cv_hv_set_part_records_thread(0) == 0
+    with pipeline.scene_policy(None):
+        assert ME.masked_min_rows() == lib_rows
+    model.MASKED_MIN_ROWS = 1234                                   # a pinned model value yields to a policy, not to the process
+    assert model.masked_min_rows() == 1234
+    with pipeline.scene_policy(pol):
+        assert model.masked_min_rows() == pol.masked_min_rows
+
+
 def test_a_changed_define_makes_the_object_stale(built_lib, monkeypatch):
     """csrc/build.py keeps the command line of every object beside it: another -D through CV_*_DEFS (or another HIPCC)
     is a rebuild of exactly that source, not a silent re-use (round 5 lost a table of ablations to that)."""

@@ -189,3 +189,50 @@ def test_late_wgrad_join_only_when_nothing_can_touch_the_gradient():
     mp.spawn(_late_join_worker, args=(2, port, q), nprocs=2, join=True)
     got = dict(q.get() for _ in range(2))
     assert got == {0: False, 1: False}
+
+
+def _flag_worker(rank, world_size, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world_size), RANK=str(rank), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from canonicalvoting_amd import train
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    ring = train._FlagRing(torch.device("cpu"))
+    log = []
+    for step in range(8):
+        if ring.noticed():
+            log.append(("noticed", step))
+            break
+        # rank 1's forward leaves the fp16 range at step 3 (and its flag is sticky); rank 0's never does
+        local = 1.0 if (rank == 1 and step >= 3) else 0.0
+        found = ring.push(torch.tensor(local), dist.group.WORLD)
+        log.append(("skip" if float(found) else "step", step))
+    q.put((rank, log))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_act_on_the_same_range_flag_at_the_same_step():
+    """train.train_step's range flag under DDP.  One rank's forward overflows at step 3: after the
+    all-reduce (MAX) BOTH ranks skip the update of steps 3 and 4 (found_inf), and both notice at step 3 + FLAG_LAG - the
+    same call - where each restores, redoes and switches to the triples; nobody is left in a collective alone."""
+    from canonicalvoting_amd import train
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flag_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [("step", 0), ("step", 1), ("step", 2)] + [("skip", 3 + i) for i in range(train.FLAG_LAG)] + [("noticed", 3 + train.FLAG_LAG)]
+    assert out[0] == out[1] == want, out
+    # one process, no group: the same lag on the local flag
+    ring = train._FlagRing(torch.device("cpu"))
+    seen = []
+    for step in range(6):
+        seen.append(ring.noticed())
+        ring.push(torch.tensor(1.0 if step >= 1 else 0.0))
+    assert seen == [False, False, False, True, True, True]
+    ring = train._FlagRing(torch.device("cpu"))
+    assert ring.push(None) is None and not ring.noticed() and not ring.noticed()       # a step without fp16 pairs stores nothing

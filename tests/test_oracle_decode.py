@@ -168,6 +168,33 @@ def test_joint_loss_matches_reference_lines_executed_on_cpu():
     np.testing.assert_allclose(out.grad.numpy(), z["grad"], rtol=1e-5, atol=1e-8)
 
 
+def test_joint_loss_never_touches_background_rows():
+    """train_joint.py:262-272 index the predictions with the object mask: a non-finite prediction in a background row reaches
+    neither the loss nor a gradient.  The host-wait-free form of train.joint_loss selects (torch.where) instead of indexing -
+    and must not multiply by zero (inf * 0 = NaN): ADVICE r5."""
+    import os
+    import torch
+    from canonicalvoting_amd import train
+    from tests.golden.make_loss_golden import make_inputs
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "loss_ref.npz"))
+    F, labels, xyz, scale = make_inputs(int(z["seed"]), int(z["n"]))
+    bg = np.nonzero((labels == 9) | (labels < 0))[0]
+    assert len(bg) >= 3
+    bad = F.copy()
+    bad[bg[0], :27] = np.inf              # xyz heads of a background row
+    bad[bg[1], 27:54] = -np.inf           # scale heads
+    bad[bg[2], :54] = np.nan
+    out = torch.from_numpy(bad).requires_grad_(True)
+    loss, parts = train.joint_loss(out, torch.from_numpy(xyz), torch.from_numpy(scale), torch.from_numpy(labels))
+    loss.backward()
+    for k in ("loss_xyz", "loss_scale", "loss_class"):
+        assert abs(float(parts[k]) - float(z[k])) < 1e-6 * max(1.0, abs(float(z[k]))), k
+    g = out.grad.numpy()
+    assert np.isfinite(g).all()
+    assert not g[bg[:3], :54].any()                      # no gradient into the regression heads of background rows
+    np.testing.assert_allclose(g, z["grad"], rtol=1e-5, atol=1e-8)
+
+
 def test_separate_loss_matches_reference_lines_executed_on_cpu():
     """train.separate_loss against train_separate.py:247-286 exec()'d on CPU torch over a two-scan batch of the mini
     dataset: objectness CE, log-scale MSE, minimum-over-symmetric-poses coordinate loss, sum, gradient.  The

@@ -28,8 +28,8 @@ def resident(seed, n, cuda, small):
     return sc, c4, feats, pts, (xyz, scale, prob, cls.int())
 
 
-def by_calls(model, hv, c4, feats, pts, res, teacher, thresh_high):
-    with torch.no_grad():
+def by_calls(model, hv, c4, feats, pts, res, teacher, thresh_high, policy=None):
+    with torch.no_grad(), pipeline.scene_policy(policy):
         x = ME.SparseTensor(feats, c4, device=feats.device)
         y = model(x).F
         pred = pipeline.head_joint(y)
@@ -53,18 +53,22 @@ def assert_same(a, keep, dets, raw, y, tag):
         assert c0 == c1 and s0 == s1 and np.array_equal(b0, b1), tag + ": detections"
 
 
+@pytest.mark.parametrize("in_flight", [None, 7])
 @pytest.mark.parametrize("n,small,thresh", [(3000, True, 20), (80000, False, 60)])
-def test_one_call_scene_equals_the_call_by_call_pipeline(cuda, built_lib, n, small, thresh):
+def test_one_call_scene_equals_the_call_by_call_pipeline(cuda, built_lib, n, small, thresh, in_flight):
+    """in_flight None: no policy (the thread's / process-wide launch sizing); 7: bench.py's timed region - the policy travels in
+    cv_scene_desc for the one call and in the thread's values for the call-by-call pipeline, and both give the same bits"""
     torch.manual_seed(0)
     model = MinkUNet34C(3, 64).to(cuda).eval()
     sc, c4, feats, pts, teacher = resident(1, n, cuda, small)
     hv = HoughVoting(sc.res, 120)
+    policy = None if in_flight is None else pipeline.policy_for_scenes_in_flight(in_flight)
     for pred, tag in ((teacher, "teacher predictions"), (None, "network predictions")):
-        want = by_calls(model, hv, c4, feats, pts, sc.res, pred, thresh)
+        want = by_calls(model, hv, c4, feats, pts, sc.res, pred, thresh, policy)
         for rep in range(2):            # the second call runs on the grown scratch
             keep = {}
             dets, raw, y = pipeline.detect_scene_c(model, hv, c4, feats, sc.res, scan_points=pts, predictions=pred,
-                                                   keep=keep, thresh_high=thresh)
+                                                   keep=keep, thresh_high=thresh, policy=policy)
             assert_same(want, keep, dets, raw, y, "%s (%d points, call %d)" % (tag, n, rep))
         if pred is not None:
             assert len(want["raw"]["boxes"]) >= 2          # the comparison saw accepted boxes and rejected candidates
@@ -78,6 +82,54 @@ def test_one_call_scene_equals_the_call_by_call_pipeline(cuda, built_lib, n, sma
     torch.cuda.synchronize()
     times = [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
     assert all(t > 0 for t in times) and times[0] > times[1], times          # the network is the longest stage, the head the shortest
+
+
+def test_two_hosts_with_different_policies_in_one_process(cuda, built_lib):
+    """the launch sizing is per call.  Two threads run the same 80k scene at the same time, one under the
+    one-scene policy and one under the seven-in-flight policy; each must get exactly what it gets when it runs alone (the
+    network output differs between the policies in fp32 summation order - a thread that picked up the other's sizing shows)."""
+    torch.manual_seed(0)
+    model = MinkUNet34C(3, 64).to(cuda).eval()
+    sc, c4, feats, pts, teacher = resident(1, 80000, cuda, False)
+    pols = [pipeline.policy_for_scenes_in_flight(1), pipeline.policy_for_scenes_in_flight(7)]
+    alone = []
+    for pol in pols:
+        keep = {}
+        pipeline.detect_scene_c(model, HoughVoting(sc.res, 120), c4, feats, sc.res, scan_points=pts, predictions=teacher, keep=keep, policy=pol)
+        alone.append(keep)
+    assert not torch.equal(alone[0]["y"], alone[1]["y"])                       # the policies ARE visible in the summation order
+    assert all(torch.equal(a, b) for a, b in zip(alone[0]["grids"], alone[1]["grids"]))     # ... and only there
+    errors, start = [], threading.Barrier(2)
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(cuda)
+            hv = HoughVoting(sc.res, 120)
+            with torch.cuda.stream(torch.cuda.Stream(cuda)):
+                start.wait()
+                for k in range(6):
+                    keep = {}
+                    if k % 2:                       # the call-by-call path under the thread's values
+                        with torch.no_grad(), pipeline.scene_policy(pols[i]):
+                            y = model(ME.SparseTensor(feats, c4, device=cuda)).F
+                    else:
+                        pipeline.detect_scene_c(model, hv, c4, feats, sc.res, scan_points=pts, predictions=teacher, keep=keep, policy=pols[i])
+                        y = keep["y"]
+                    assert torch.equal(y, alone[i]["y"]), "thread %d step %d ran under another launch policy" % (i, k)
+                torch.cuda.current_stream().synchronize()
+        except BaseException as e:      # noqa: BLE001
+            errors.append(repr(e))
+            start.abort()
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:2]
+    from canonicalvoting_amd import _lib
+    L = _lib.lib()
+    assert L.cv_sp_set_split_target_thread(0) == 0 and L.cv_hv_set_part_records_thread(0) == 0 and ME.masked_min_rows() == ME.CoordinateManager.MASKED_MIN_ROWS
 
 
 def test_one_call_scene_from_four_threads(cuda, built_lib):

@@ -319,9 +319,11 @@ def test_input_gradients_on_the_hl_kernels(cuda, built_lib, monkeypatch):
 def test_a_forward_beyond_the_fp16_range_skips_its_update_on_the_device(cuda, built_lib, monkeypatch):
     """train.train_step with the fused Adam: no host wait in the step.  A BatchNorm gain of 1e7 puts activations beyond 65000:
     the hl twin raises the range flag, the optimizer gets it as found_inf and leaves every parameter (and its step count)
-    alone; the NEXT call notices, counts the fallback, runs on the bf16 triples from then on and updates.  With an optimizer
-    that cannot skip on the device (SGD) the step is redone on the triples before the optimizer sees a gradient, and the
-    BatchNorm running statistics count the batch once."""
+    alone; the call FLAG_LAG steps later notices, restores the BatchNorm running statistics and counters of before the first
+    flagged step (the flagged forwards wrote inf / NaN statistics downstream of the overflow), counts the fallback,
+    runs on the bf16 triples from then on and updates: every flagged batch is dropped as a whole, the redone one counts once.
+    With an optimizer that cannot skip on the device (SGD) the step is redone on the triples before the optimizer sees a
+    gradient, and the BatchNorm running statistics count the batch once."""
     from canonicalvoting_amd import train
     batch = _small_batch(cuda, seed0=40)
     monkeypatch.setattr(ME, "TRAIN_FWD_HL", 1)
@@ -333,17 +335,30 @@ def test_a_forward_beyond_the_fp16_range_skips_its_update_on_the_device(cuda, bu
     with torch.no_grad():
         model.bn0.bn.weight.fill_(1e7)
     before = {k: p.detach().clone() for k, p in model.named_parameters()}
-    nbt = int(model.bn0.bn.num_batches_tracked)
-    loss, _ = train.train_step(model, opt, *batch)
     torch.cuda.synchronize()
-    assert all(torch.equal(before[k], p.detach()) for k, p in model.named_parameters())       # skipped on the device
-    assert getattr(model, "train_range_fallbacks", 0) == 0                                   # ... and nobody has looked yet
+    stats_before = {k: b.detach().clone() for k, b in model.named_buffers()}
+    nbt = int(model.bn0.bn.num_batches_tracked)
+    for _ in range(train.FLAG_LAG):
+        loss, _ = train.train_step(model, opt, *batch)
+        torch.cuda.synchronize()
+        assert all(torch.equal(before[k], p.detach()) for k, p in model.named_parameters())   # skipped on the device
+        assert getattr(model, "train_range_fallbacks", 0) == 0                               # ... and nobody has looked yet
+    # the flagged forwards DID poison the running statistics behind the overflow - what the snapshot is for
+    assert not all(bool(torch.isfinite(b).all()) for b in model.buffers() if b.is_floating_point())
+    # the snapshot guard: still the statistics of before the FIRST flagged step, although two flagged steps have run
+    bufs, saved = train._bn_state(model)
+    names = [k for k, _ in model.named_buffers()]
+    assert len(names) == len(saved) and all(torch.equal(stats_before[k], s) for k, s in zip(names, saved))
     loss, _ = train.train_step(model, opt, *batch)
     torch.cuda.synchronize()
     assert model.train_range_fallbacks == 1 and np.isfinite(float(loss))
     assert any(not torch.equal(before[k], p.detach()) for k, p in model.named_parameters())   # the triples step went through
-    assert int(model.bn0.bn.num_batches_tracked) == nbt + 2
+    assert int(model.bn0.bn.num_batches_tracked) == nbt + 1            # the flagged batches dropped, the redone one counted once
+    assert all(int(m.bn.num_batches_tracked) == nbt + 1 for m in model.modules() if isinstance(m, ME.MinkowskiBatchNorm))
+    assert all(bool(torch.isfinite(b).all()) for b in model.buffers())                        # no NaN statistics survive
     assert int(ME.range_flag(torch.device(cuda))[0]) == 0
+    loss, _ = train.train_step(model, opt, *batch)                     # and the next step is an ordinary (triples) step
+    assert model.train_range_fallbacks == 1 and np.isfinite(float(loss)) and int(model.bn0.bn.num_batches_tracked) == nbt + 2
     # an optimizer without found_inf: redone inside the step
     torch.manual_seed(0)
     model = MinkUNet34C(3, 64).cuda().train()
