@@ -115,6 +115,10 @@ def parse():
                          "hipStreamCreateWithPriority): the scenes that start last have the most work left when the ticket "
                          "counter runs out, so favouring them shortens the drain of a short region (longest remaining work "
                          "first); fill and drain stay inside the timed region, results are bit-identical.  0 = off")
+    ap.add_argument("--xcd-partition", type=int, default=0,
+                    help="experiment: the scene streams are created with CU masks (hipExtStreamCreateWithCUMask) of this many XCDs "
+                         "each (1, 2 or 4 of the 8; stream i takes group i mod (8 / N)): a scene's kernels stay on its XCDs' CUs and "
+                         "L2s.  0 (default): every stream may use the whole chip")
     ap.add_argument("--mode", default="eval", choices=["eval", "train", "separate"],
                     help="eval (default, the BASELINE metric): eval_joint.py path.  train: train_joint.py step "
                          "(fwd + bwd + Adam, fp32) on --train-batch scenes per GPU-step, DDP gradient all-reduce over "
@@ -166,6 +170,29 @@ def scene_threads(requested):
     except AttributeError:
         cores = os.cpu_count() or 1
     return max(1, min(max(1, requested), max(2, cores // max(1, local_world))))
+
+
+def xcd_streams(dev, count, xcds_per_stream):
+    """streams whose kernels run on a group of XCDs only: hipExtStreamCreateWithCUMask.  The CU mask of a multi-XCD device
+    is interleaved - bit k belongs to XCD k mod 8 - so a group of XCDs is one byte pattern repeated over the 256 bits."""
+    import ctypes
+    assert xcds_per_stream in (1, 2, 4)
+    hip = ctypes.CDLL("libamdhip64.so")
+    groups = 8 // xcds_per_stream
+    out = []
+    for i in range(count):
+        g = i % groups
+        byte = 0
+        for x in range(g * xcds_per_stream, (g + 1) * xcds_per_stream):
+            byte |= 1 << x
+        word = byte | (byte << 8) | (byte << 16) | (byte << 24)
+        mask = (ctypes.c_uint32 * 8)(*([word] * 8))
+        st = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, mask)
+        assert rc == 0 and st.value, "hipExtStreamCreateWithCUMask failed (%d)" % rc
+        out.append(torch.cuda.ExternalStream(st.value, device=dev))
+    return out
 
 
 def check_world(a):
@@ -733,7 +760,7 @@ def main():
     # from four on): the tail of a short run, where the scene threads run dry one by one, gets the one-scene sizing
     global ADAPTIVE_SPLIT
     ADAPTIVE_SPLIT = bool(a.adaptive_split) and a.split_target < 0 and a.scene_call == "c"
-    streams = [torch.cuda.Stream(dev) for _ in range(S)]
+    streams = [torch.cuda.Stream(dev) for _ in range(S)] if not a.xcd_partition else xcd_streams(dev, S, a.xcd_partition)
     # (N < 0: the last -N steps on LOW-priority streams instead - oldest scene first at the drain)
     hi_streams = [torch.cuda.Stream(dev, priority=-1 if a.tail_priority > 0 else 1) for _ in range(S)] if a.tail_priority != 0 else None
     hvs = [hv] + [HoughVoting(RES, NUM_ROTS) for _ in range(S - 1)]
@@ -909,13 +936,24 @@ def main():
         m = measure_vote_traffic(a)
         if m is not None:
             traffic, traffic_source = m
-    for rnd in (() if traffic is not None else ("r5", "r4", "r3", "r2", "r1")):
+    for rnd in (() if traffic is not None else ("r6", "r5", "r4", "r3", "r2", "r1")):
         tj = os.path.join(ROOT, "profiles", rnd, "vote_hbm_traffic.json")
         if os.path.exists(tj) and a.points == N_POINTS and not a.large and a.algo in (0, 2):
             traffic = json.load(open(tj))["hbm_bytes_per_launch"]
             traffic_source = "file: profiles/%s/vote_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, " \
                              "profiles/vote_pmc.sh; not measured by this run)" % rnd
             break
+    # counters of the regime that is timed (profiles/in_flight_counters.sh, collected offline: dispatch counters serialise the
+    # kernels, so they cannot be taken inside the timed region): CU time and matrix-pipe time a scene's kernels occupy with the
+    # chip to themselves, over the chip time a scene gets at the in-flight rate.  Reported as read from a file.
+    in_flight = None
+    ifj = os.path.join(ROOT, "profiles", "r6", "in_flight_counters.json")
+    if default_workload and full and S >= 4 and os.path.exists(ifj):
+        j = json.load(open(ifj))
+        in_flight = {k: j[k] for k in ("cu_busy_in_flight", "mfma_busy_in_flight", "mean_kernels_running",
+                                       "wall_share_with_at_least_1024_workgroups_running", "kernels_running_at_once",
+                                       "fetch_mb_per_scene_raw", "write_mb_per_scene", "scenes_per_s_under_tracer") if k in j}
+        in_flight["source"] = "file: profiles/r6/in_flight_counters.json - " + j.get("source", "")
     conv_peak = 2500.0 if a.dtype == "bf16" else 157.3       # dense bf16 / fp32 matrix peak, TFLOP/s
     pieces_n = 1 if a.dtype == "bf16" else 3 if (full and model.USE_PROGRAM and model.PIECES == 2) else 6
     net_ms = (iso_stage or stage_ms)["net"]
@@ -943,7 +981,7 @@ def main():
                                   if teacher else "network output (random init: no cell reaches thresh_high)",
                    "points": a.points, "num_rots": NUM_ROTS, "res": RES, "grid": s0.dims,
                    "vote_algo": {0: "auto(tiles)", 1: "direct", 2: "tiles"}.get(a.algo, "ablation-%d" % a.algo),
-                   "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": S, "tail_priority_steps": a.tail_priority,
+                   "parallelism": "scene-parallel x%d, no collective" % world, "scenes_in_flight_per_gpu": S, "tail_priority_steps": a.tail_priority, "xcd_partition": a.xcd_partition,
                    "conv_split_target": "adaptive: 768 below four scenes in flight, 256 from four on" if ADAPTIVE_SPLIT else (split_target or 768),
                    "vote_part_records": part_records or 4096, "masked_min_rows": masked_min_rows,
                    **({"ablate": a.ablate, "INVALID": "timing ablation: results are wrong, not a reportable number"} if a.ablate else {})},
@@ -975,6 +1013,7 @@ def main():
             "piece_flops_per_forward": pieces_n * net_flops[0] if ME.CONV_X6 else None,
             "frac_of_16bit_matrix_peak": (pieces_n * net_flops[0] / (net_ms * 1e-3) / 1e12 / 2500.0) if ME.CONV_X6 else None,
             "range_fallbacks": int(getattr(model, "range_fallbacks", 0)),
+            "mfma_busy_in_flight": in_flight["mfma_busy_in_flight"] if in_flight else None,
             "measured_in": "one scene in flight" if (S == 1 or iso_stage) else "timed region",
             "note": ("opt-in bf16 compute mode: operands rounded to bf16, one product on v_mfma_f32_32x32x16_bf16, fp32 "
                      "accumulation and storage; outside the 1e-4 parity bar; " if pieces_n == 1 else
@@ -989,6 +1028,8 @@ def main():
                      "fp32 matrix cores (v_mfma_f32_32x32x2_f32); ") +
                     "achieved counts only existing (input,output) pairs, sum 2*P*Cin*Cout over the 63 conv layers, "
                     "against the %s matrix peak" % ("bf16" if a.dtype == "bf16" else "fp32")},
+        "cu_busy_in_flight": in_flight["cu_busy_in_flight"] if in_flight else None,
+        "in_flight_counters": in_flight,
         "detections_per_scene": n_det / a.steps,
         "collective": coll,
         "stage_ms": stage_ms,

@@ -42,15 +42,14 @@ class ConvDesc(ctypes.Structure):
                 ("weight_packed", vp), ("weight_x6", vp), ("in2", vp), ("in2_ld", ctypes.c_int), ("cin2", ctypes.c_int),
                 ("weight2_x6", vp), ("perm_has_map", ctypes.c_int), ("weight_pieces", ctypes.c_int),
                 ("acc_scale", ctypes.c_float), ("range_flag", vp), ("in_hl", ctypes.c_int), ("out_hl", ctypes.c_int),
-                ("res_hl", ctypes.c_int), ("split_tickets", vp), ("win", vp), ("acc_scale_dev", vp)]
+                ("res_hl", ctypes.c_int), ("split_tickets", vp), ("acc_scale_dev", vp)]
 
 
 class SceneMaps(ctypes.Structure):
     """struct cv_scene_maps (include/cv_hip.h)"""
     _fields_ = [("stem", ctypes.c_longlong), ("out", ctypes.c_longlong), ("down", ctypes.c_longlong * 4),
                 ("k3", ctypes.c_longlong * 5), ("up", ctypes.c_longlong * 4), ("mask_perm", ctypes.c_longlong * 5),
-                ("up_perm", ctypes.c_longlong * 4), ("scratch", ctypes.c_longlong), ("bitmap", ctypes.c_longlong),
-                ("win", ctypes.c_longlong * 5)]
+                ("up_perm", ctypes.c_longlong * 4), ("scratch", ctypes.c_longlong), ("bitmap", ctypes.c_longlong)]
 
 
 class NetBuf(ctypes.Structure):
@@ -73,7 +72,7 @@ class SceneDesc(ctypes.Structure):
     _fields_ = [("d_coords4", vp), ("n", ctypes.c_longlong), ("d_feats", vp), ("feats_ld", ctypes.c_int), ("d_points", vp),
                 ("res", ctypes.c_float), ("num_rots", ctypes.c_int), ("ops", vp), ("n_ops", ctypes.c_int), ("bufs", vp),
                 ("n_bufs", ctypes.c_int), ("stem_k", ctypes.c_int), ("mask_groups", ctypes.c_int),
-                ("masked_min_rows", ctypes.c_longlong), ("win_levels", ctypes.c_int), ("max_channels", ctypes.c_int),
+                ("masked_min_rows", ctypes.c_longlong), ("max_channels", ctypes.c_int),
                 ("use_range_flag", ctypes.c_int),
                 ("d_out_feats", vp), ("out_ld", ctypes.c_int), ("out_channels", ctypes.c_int), ("nclasses", ctypes.c_int),
                 ("log_scale", ctypes.c_int), ("d_xyz_in", vp), ("d_scale_in", vp), ("d_prob_in", vp), ("d_class_in", vp),
@@ -83,6 +82,12 @@ class SceneDesc(ctypes.Structure):
                 ("h_cand_idx", vp), ("h_verdict", vp), ("h_boxes", vp), ("h_scores", vp), ("h_classes", vp), ("h_pick", vp),
                 ("adaptive_split", ctypes.c_int), ("events", vp * 5),
                 ("conv_split_target", ctypes.c_int), ("vote_part_records", ctypes.c_int)]
+
+
+class PackJob(ctypes.Structure):
+    """struct cv_pack_job (include/cv_hip.h)"""
+    _fields_ = [("w", vp), ("wp", vp), ("K", ctypes.c_int), ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("trans", ctypes.c_int),
+                ("scale_log2", ctypes.c_int), ("reserved", ctypes.c_int)]
 
 
 class SceneResult(ctypes.Structure):
@@ -136,6 +141,7 @@ SIGNATURES = {
     "cv_sp_set_split_target": (ctypes.c_int, [ctypes.c_int]),
     "cv_hv_set_part_records": (ctypes.c_int, [ctypes.c_int]),
     "cv_hv_set_part_records_thread": (ctypes.c_int, [ctypes.c_int]),
+    "cv_sp_pack_weights_h2_batch_f32": (ctypes.c_int, [ctypes.POINTER(PackJob), ctypes.c_int, vp, vp]),
     "cv_sp_copy_unless_flag": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_longlong), ctypes.c_int, vp, vp]),
     "cv_sp_pack_weights_t_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_set_split_target_thread": (ctypes.c_int, [ctypes.c_int]),
@@ -146,25 +152,20 @@ SIGNATURES = {
     "cv_sp_pack_weights_h2_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
     "cv_sp_pack_weights_bf16_f32": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     "cv_sp_scene_maps_words": (ctypes.c_size_t, [c_i64_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
-                                                 ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(SceneMaps)]),
+                                                 ctypes.c_longlong, ctypes.POINTER(SceneMaps)]),
     "cv_sp_scene_maps": (ctypes.c_int, [ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_longlong,
                                         c_i64_p, vp, ctypes.c_longlong, ctypes.c_int,
-                                        ctypes.c_int, ctypes.c_longlong, ctypes.c_int, vp, ctypes.c_size_t, vp]),
-    "cv_sp_scene_plan_words": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_longlong,
-                                                 ctypes.c_int]),
+                                        ctypes.c_int, ctypes.c_longlong, vp, ctypes.c_size_t, vp]),
+    "cv_sp_scene_plan_words": (ctypes.c_size_t, [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_longlong]),
     "cv_sp_scene_plan": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                         ctypes.POINTER(vp), ctypes.c_longlong, vp, c_i32_p, ctypes.c_int, ctypes.c_int,
-                                        ctypes.c_longlong, ctypes.c_int, vp, ctypes.c_size_t, ctypes.POINTER(SceneMaps), vp,
+                                        ctypes.c_longlong, vp, ctypes.c_size_t, ctypes.POINTER(SceneMaps), vp,
                                         ctypes.c_size_t, vp, ctypes.c_size_t, vp]),
-    "cv_sp_windows_supported": (ctypes.c_int, [ctypes.c_longlong]),
-    "cv_sp_windows_words": (ctypes.c_size_t, [ctypes.c_longlong]),
-    "cv_sp_build_windows": (ctypes.c_int, [vp, ctypes.c_longlong, vp, vp]),
-    "cv_net_win_levels": (ctypes.c_int, [ctypes.POINTER(NetOp), ctypes.c_int, ctypes.POINTER(NetBuf), ctypes.c_int]),
     "cv_net_arena_bytes": (ctypes.c_size_t, [ctypes.POINTER(NetBuf), ctypes.c_int, c_i64_p, ctypes.c_int]),
     "cv_net_run_f32": (ctypes.c_int, [ctypes.POINTER(NetOp), ctypes.c_int, ctypes.POINTER(NetBuf), ctypes.c_int,
                                       c_i64_p, ctypes.c_int, vp, ctypes.c_size_t, ctypes.POINTER(vp), c_int_p,
                                       ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(vp), ctypes.c_int,
-                                      ctypes.POINTER(vp), ctypes.c_int, vp, ctypes.c_size_t, vp, vp]),
+                                      vp, ctypes.c_size_t, vp, vp]),
     "cv_sp_mask_keys": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "cv_sp_mask_perms": (ctypes.c_int, [vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_size_t,
                                         ctypes.c_int, vp]),

@@ -39,7 +39,6 @@ def _sources():
         "hv_decode.hip": STRICT + env("CV_DEC_DEFS"),    # greedy-walk experiments (-DDEC_BLOCKED=0)
         "sparse_coords.hip": [],
         "sparse_conv.hip": env("CV_SC_DEFS"),            # kernel experiments (-DCV_WP_CLAMPED_GATHER=1)
-        "sparse_win.hip": env("CV_WIN_DEFS"),            # conv_win ablations (-DCV_WIN_ABL=2)
         "net_exec.cpp": [],
         "scene_exec.cpp": [],
     }

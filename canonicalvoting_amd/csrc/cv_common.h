@@ -96,17 +96,10 @@ int cv_sp_sort_rows_ex(const int32_t* d_coords, long long n, int32_t* d_sorted, 
                        size_t ws_bytes, bool single_batch, void* stream, bool bounds_prefilled = false);   // sparse_coords.hip
 int cv_sp_scene_plan_ex(const int32_t* d_input, long long n, int32_t* d_perm, int32_t* d_inv, int32_t* const* d_coords,
                         unsigned long long* const* d_keys, int32_t* const* d_vals, long long cap, int32_t* d_counts,
-                        int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int win_levels,
+                        int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows,
                         int32_t* d_arena, size_t arena_words, cv_scene_maps* offsets, void* d_sort_ws, size_t sort_ws_bytes,
                         void* d_levels_ws, size_t levels_ws_bytes, bool single_batch, void* stream,
                         bool bounds_prefilled = false);                                       // net_exec.cpp
 int cv_sp_mask_perms_batch(const CvPermJob* jobs, int n_jobs, void* d_ws, size_t ws_bytes, void* stream,
                            bool pre_zeroed = false);
 
-// ---- neighbour windows of the 3x3x3 kernel maps (sparse_win.hip): one launch for the levels of a scene
-#ifndef CV_WIN_CAP
-#define CV_WIN_CAP 512       // window rows a tile keeps in LDS (see conv_win's LDS budget)
-#endif
-struct CvWinJob { const int32_t* nbr; long long n; int32_t* win; };      // nbr[n][27] -> win[cv_sp_windows_words(n)]
-constexpr int CV_MAX_WIN_JOBS = 5;
-int cv_sp_windows_batch(const CvWinJob* jobs, int n_jobs, void* stream);

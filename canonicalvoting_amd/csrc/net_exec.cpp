@@ -22,13 +22,8 @@ extern "C" {
 
 // ---- every kernel map and processing order of the fused network in ONE call per scene ----------------------
 // (the Python coordinate manager issued ~25 calls for them: 0.65 ms of host time per scene on the critical path)
-// win_levels bit i: level i runs its 3x3x3 convolutions on neighbour windows (conv_win) when it has at least masked_min_rows
-// rows: the level then gets a window block instead of mask orders
-static bool level_has_windows(int win_levels, int level, long long rows, long long masked_min_rows) {
-    return ((win_levels >> level) & 1) && rows >= masked_min_rows && cv_sp_windows_supported(rows);
-}
 static void scene_maps_layout(const long long* rows, long long n_orig, int stem_k, int mask_groups,
-                              long long masked_min_rows, int win_levels, cv_scene_maps* o, size_t* total) {
+                              long long masked_min_rows, cv_scene_maps* o, size_t* total) {
     size_t off = 0;
     auto take = [&](size_t words) { const size_t at = off; off += cv_align_up(words, 64); return (long long)at; };
     const size_t K5 = (size_t)stem_k * stem_k * stem_k;
@@ -37,8 +32,7 @@ static void scene_maps_layout(const long long* rows, long long n_orig, int stem_
     // what depends on the caller's row count only comes first: cv_sp_scene_plan builds it before the coarse counts are known
     o->stem = take((size_t)rows[0] * K5);
     o->k3[0] = take((size_t)rows[0] * 27);
-    o->win[0] = level_has_windows(win_levels, 0, rows[0], masked_min_rows) ? take(cv_sp_windows_words(rows[0])) : -1;
-    o->mask_perm[0] = (o->win[0] < 0 && mask_groups > 1 && rows[0] >= masked_min_rows) ? take(mp_w * rows[0]) : -1;
+    o->mask_perm[0] = (mask_groups > 1 && rows[0] >= masked_min_rows) ? take(mp_w * rows[0]) : -1;
     // bin counts + running counts of the mask orders (cv_sp_mask_perms_batch: 2 x 1024 words per group): level 0, then <= 4
     // coarse levels and the 4 up-map orders
     o->scratch = take((size_t)(5 * std::max(mask_groups, 1) + 4) * 2048);
@@ -48,19 +42,16 @@ static void scene_maps_layout(const long long* rows, long long n_orig, int stem_
     for (int i = 0; i < 4; ++i) o->down[i] = take((size_t)rows[i + 1] * 8);
     for (int i = 1; i < 5; ++i) o->k3[i] = take((size_t)rows[i] * 27);
     for (int i = 0; i < 4; ++i) o->up[i] = take((size_t)rows[3 - i] * 8);            // up[i]: level 4-i -> 3-i
-    for (int i = 1; i < 5; ++i) {
-        o->win[i] = level_has_windows(win_levels, i, rows[i], masked_min_rows) ? take(cv_sp_windows_words(rows[i])) : -1;
-        o->mask_perm[i] = (o->win[i] < 0 && mask_groups > 1 && rows[i] >= masked_min_rows) ? take(mp_w * rows[i]) : -1;
-    }
+    for (int i = 1; i < 5; ++i) o->mask_perm[i] = (mask_groups > 1 && rows[i] >= masked_min_rows) ? take(mp_w * rows[i]) : -1;
     for (int i = 0; i < 4; ++i) o->up_perm[i] = take((size_t)rows[3 - i]);
     *total = off;
 }
 
 size_t cv_sp_scene_maps_words(const long long* level_rows, long long n_orig, int stem_k, int mask_groups,
-                              long long masked_min_rows, int win_levels, cv_scene_maps* offsets) {
+                              long long masked_min_rows, cv_scene_maps* offsets) {
     if (!level_rows || !offsets || n_orig <= 0 || stem_k < 1) return 0;
     size_t total = 0;
-    scene_maps_layout(level_rows, n_orig, stem_k, mask_groups, masked_min_rows, win_levels, offsets, &total);
+    scene_maps_layout(level_rows, n_orig, stem_k, mask_groups, masked_min_rows, offsets, &total);
     return total;
 }
 
@@ -86,11 +77,6 @@ static int scene_maps_level0(int32_t* const* d_coords, const unsigned long long*
     mj[1] = {d_coords[0], n, d_keys[0], d_vals[0], cap, 3, 1, d_arena + o.k3[0], nullptr, bits, d_bbox, 0};
     int rc = cv_sp_kernel_maps_batch(mj, 2, stream);
     if (rc != CV_OK) return rc;
-    if (o.win[0] >= 0) {
-        CvWinJob wj = {d_arena + o.k3[0], n, d_arena + o.win[0]};
-        rc = cv_sp_windows_batch(&wj, 1, stream);
-        if (rc != CV_OK) return rc;
-    }
     if (o.mask_perm[0] >= 0) {
         CvPermJob pj = {d_arena + o.k3[0], n, 27, mask_groups, d_arena + o.mask_perm[0], 1};
         rc = cv_sp_mask_perms_batch(&pj, 1, d_arena + o.scratch, sizeof(int) * (size_t)mask_groups * 2048, stream, pre_cleared);
@@ -117,16 +103,6 @@ static int scene_maps_coarse(int32_t* const* d_coords, const unsigned long long*
     }
     int rc = cv_sp_kernel_maps_batch(mj, nm, stream);
     if (rc != CV_OK) return rc;
-    {
-        CvWinJob wj[CV_MAX_WIN_JOBS];
-        int nw = 0;
-        for (int i = 1; i < 5; ++i)
-            if (o.win[i] >= 0) wj[nw++] = {d_arena + o.k3[i], level_rows[i], d_arena + o.win[i]};
-        if (nw > 0) {
-            rc = cv_sp_windows_batch(wj, nw, stream);
-            if (rc != CV_OK) return rc;
-        }
-    }
     CvPermJob pj[CV_MAX_PERM_JOBS];
     int np = 0, groups = 0;
     for (int i = 1; i < 5; ++i)
@@ -144,12 +120,12 @@ static int scene_maps_coarse(int32_t* const* d_coords, const unsigned long long*
 
 int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
                      long long cap, const long long* level_rows, const int32_t* d_perm, long long n_orig, int stem_k,
-                     int mask_groups, long long masked_min_rows, int win_levels, int32_t* d_arena, size_t arena_words, void* stream) {
+                     int mask_groups, long long masked_min_rows, int32_t* d_arena, size_t arena_words, void* stream) {
     CV_REQUIRE(d_coords && d_keys && d_vals && level_rows && d_perm && d_arena, CV_EINVAL, "null pointer argument");
     CV_REQUIRE(n_orig == level_rows[0], CV_EINVAL, "the sorted set must hold the caller's %lld rows", n_orig);
     cv_scene_maps o;
     size_t total = 0;
-    scene_maps_layout(level_rows, n_orig, stem_k, mask_groups, masked_min_rows, win_levels, &o, &total);
+    scene_maps_layout(level_rows, n_orig, stem_k, mask_groups, masked_min_rows, &o, &total);
     CV_REQUIRE(arena_words >= total, CV_ENOMEM, "scene map arena too small");
     int rc = scene_maps_level0(d_coords, d_keys, d_vals, cap, n_orig, d_perm, stem_k, mask_groups, o, d_arena, nullptr, stream);
     if (rc != CV_OK) return rc;
@@ -198,24 +174,22 @@ struct PlanSideLease {
 };
 }  // namespace
 
-size_t cv_sp_scene_plan_words(long long n, int stem_k, int mask_groups, long long masked_min_rows, int win_levels) {
+size_t cv_sp_scene_plan_words(long long n, int stem_k, int mask_groups, long long masked_min_rows) {
     if (n <= 0 || stem_k < 1) return 0;
     const long long rows[5] = {n, n, n, n, n};          // a coarser level never has more rows than a finer one
     cv_scene_maps o;
     size_t total = 0;
-    // (a level takes windows OR mask orders; with every level at n rows each takes what it would take with fewer rows, or
-    // more: windows are supported for fewer rows whenever they are for n, and cost fewer words than the mask orders)
-    scene_maps_layout(rows, n, stem_k, mask_groups, masked_min_rows, win_levels, &o, &total);
+    scene_maps_layout(rows, n, stem_k, mask_groups, masked_min_rows, &o, &total);
     return total;
 }
 
 int cv_sp_scene_plan(const int32_t* d_input, long long n, int32_t* d_perm, int32_t* d_inv, int32_t* const* d_coords,
                      unsigned long long* const* d_keys, int32_t* const* d_vals, long long cap, int32_t* d_counts,
-                     int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int win_levels, int32_t* d_arena,
+                     int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int32_t* d_arena,
                      size_t arena_words, cv_scene_maps* offsets, void* d_sort_ws, size_t sort_ws_bytes, void* d_levels_ws,
                      size_t levels_ws_bytes, void* stream) {
     return cv_sp_scene_plan_ex(d_input, n, d_perm, d_inv, d_coords, d_keys, d_vals, cap, d_counts, h_counts, stem_k, mask_groups,
-                               masked_min_rows, win_levels, d_arena, arena_words, offsets, d_sort_ws, sort_ws_bytes, d_levels_ws,
+                               masked_min_rows, d_arena, arena_words, offsets, d_sort_ws, sort_ws_bytes, d_levels_ws,
                                levels_ws_bytes, false, stream);
 }
 
@@ -224,12 +198,12 @@ int cv_sp_scene_plan(const int32_t* d_input, long long n, int32_t* d_perm, int32
 // (C++ linkage, cv_common.h) single_batch: the rows are one scene (cv_detect_scene_f32): the sort skips its batch digit
 int cv_sp_scene_plan_ex(const int32_t* d_input, long long n, int32_t* d_perm, int32_t* d_inv, int32_t* const* d_coords,
                         unsigned long long* const* d_keys, int32_t* const* d_vals, long long cap, int32_t* d_counts,
-                        int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int win_levels,
+                        int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows,
                         int32_t* d_arena, size_t arena_words, cv_scene_maps* offsets, void* d_sort_ws, size_t sort_ws_bytes,
                         void* d_levels_ws, size_t levels_ws_bytes, bool single_batch, void* stream, bool bounds_prefilled) {
     CV_REQUIRE(d_input && d_perm && d_inv && d_coords && d_keys && d_vals && d_counts && h_counts && d_arena && offsets &&
                    d_sort_ws && d_levels_ws, CV_EINVAL, "null pointer argument");
-    CV_REQUIRE(arena_words >= cv_sp_scene_plan_words(n, stem_k, mask_groups, masked_min_rows, win_levels), CV_ENOMEM,
+    CV_REQUIRE(arena_words >= cv_sp_scene_plan_words(n, stem_k, mask_groups, masked_min_rows), CV_ENOMEM,
                "scene map arena too small (cv_sp_scene_plan_words)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     int rc = cv_sp_sort_rows_ex(d_input, n, d_coords[0], d_perm, d_inv, d_sort_ws, sort_ws_bytes, single_batch, stream, bounds_prefilled);
@@ -239,7 +213,7 @@ int cv_sp_scene_plan_ex(const int32_t* d_input, long long n, int32_t* d_perm, in
     long long rows[5] = {n, 1, 1, 1, 1};
     cv_scene_maps o;
     size_t total = 0;
-    scene_maps_layout(rows, n, stem_k, mask_groups, masked_min_rows, win_levels, &o, &total);
+    scene_maps_layout(rows, n, stem_k, mask_groups, masked_min_rows, &o, &total);
     static const bool bitmap_on = !(getenv("CV_MAP_BITMAP") && atoi(getenv("CV_MAP_BITMAP")) == 0);
     const long long n_zero = o.bitmap + (bitmap_on ? CV_BITMAP_WORDS : 0) - o.scratch;
     // (the sort leaves its bounds - min, -max per axis, -max batch - in the first 8 ints of its workspace; [7] = 1 marks
@@ -264,7 +238,7 @@ int cv_sp_scene_plan_ex(const int32_t* d_input, long long n, int32_t* d_perm, in
     if (h_counts[5] != 0 || h_counts[6] != 0) return CV_OK;      // duplicates / out-of-window rows: the caller reports them
     for (int i = 0; i < 5; ++i) rows[i] = h_counts[i];
     CV_REQUIRE(rows[0] == n, CV_EINVAL, "level 0 lost rows (%lld of %lld)", rows[0], n);
-    scene_maps_layout(rows, n, stem_k, mask_groups, masked_min_rows, win_levels, &o, &total);
+    scene_maps_layout(rows, n, stem_k, mask_groups, masked_min_rows, &o, &total);
     CV_REQUIRE(arena_words >= total, CV_ENOMEM, "scene map arena too small");
     *offsets = o;
     return scene_maps_coarse(d_coords, d_keys, d_vals, cap, rows, mask_groups, o, d_arena, stream, true);
@@ -282,31 +256,10 @@ size_t cv_net_arena_bytes(const cv_net_buf* bufs, int n_bufs, const long long* l
     return total;
 }
 
-// Levels (bit i = the level whose mask orders sit in order slot i) whose mask-grouped 3x3x3 convolutions can all run on
-// neighbour windows: hl-format input, fp16-pair weights, Cout 32 / 64 / 96, channels % 32 == 0.
-int cv_net_win_levels(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int n_bufs) {
-    if (!ops || !bufs || n_ops <= 0) return 0;
-    long long on = 0;
-    cv_sp_get_option("win", &on);
-    if (!on) return 0;
-    int yes = 0, no = 0;
-    for (int k = 0; k < n_ops; ++k) {
-        const cv_net_op& o = ops[k];
-        if (o.K != 27 || o.perm < 0 || o.perm >= 5 || o.perm_groups <= 1) continue;
-        const bool ok = o.in_buf >= 0 && o.in_buf < n_bufs && bufs[o.in_buf].hl && o.weight_pieces == 2 && o.weight_x6 &&
-                        (o.cout == 32 || o.cout == 64 || o.cout == 96) && o.cin % 32 == 0 && o.cin >= 32 &&
-                        (o.in2_buf < 0 || (o.cin2 % 32 == 0 && o.weight2_x6));
-        (ok ? yes : no) |= 1 << o.perm;
-    }
-    long long lv = 31;
-    cv_sp_get_option("win_levels", &lv);
-    return yes & ~no & (int)lv;
-}
-
 int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int n_bufs, const long long* level_rows,
                    int n_levels, void* d_arena, size_t arena_bytes, const void* const* ext_ptr, const int* ext_ld,
                    const int32_t* const* maps, int n_maps, const int32_t* const* perms, int n_perms,
-                   const int32_t* const* wins, int n_wins, void* d_ws, size_t ws_bytes, int32_t* range_flag, void* stream) {
+                   void* d_ws, size_t ws_bytes, int32_t* range_flag, void* stream) {
     CV_REQUIRE(ops && bufs && level_rows && d_arena && n_ops > 0 && n_bufs > 0 && n_levels > 0, CV_EINVAL,
                "bad network program arguments");
     CV_REQUIRE(arena_bytes >= cv_net_arena_bytes(bufs, n_bufs, level_rows, n_levels), CV_ENOMEM, "arena too small");
@@ -385,7 +338,6 @@ int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int 
         d.out_ld = out.ld;
         d.ws = d_ws;
         d.ws_bytes = conv_ws_bytes;
-        if (wins && o.K == 27 && o.perm >= 0 && o.perm < n_wins && o.perm_groups > 1) d.win = wins[o.perm];
         const int32_t* perm = o.perm >= 0 ? perms[o.perm] : nullptr;
         d.split_tickets = d.in_hl ? tickets : nullptr;
         if (perm) {

@@ -93,8 +93,7 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
     void* mm_ws = cv.take<char>(cv_hv_minmax_workspace_bytes());
     // ---- coordinate plan buffers (the layout of CoordinateManager.fused_fast)
     const long long cap = cv_sp_table_capacity(n);
-    const int win_levels = d->win_levels;
-    const size_t words = cv_sp_scene_plan_words(n, d->stem_k, d->mask_groups, d->masked_min_rows, win_levels);
+    const size_t words = cv_sp_scene_plan_words(n, d->stem_k, d->mask_groups, d->masked_min_rows);
     const size_t o_perm = 0, o_inv = up64((size_t)n);
     size_t o_coords[NL], o_vals[NL];
     for (int i = 0; i < NL; ++i) o_coords[i] = o_inv + up64((size_t)n) + (size_t)i * up64(4 * (size_t)n);
@@ -133,7 +132,7 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
     int32_t counts_h[8] = {0};
     cv_scene_maps off;
     rc = cv_sp_scene_plan_ex(d->d_coords4, n, ibuf + o_perm, ibuf + o_inv, c_coords, c_keys, c_vals, cap, ibuf + o_counts, counts_h,
-                          d->stem_k, d->mask_groups, d->masked_min_rows, win_levels, ibuf + o_arena, words, &off, sort_ws, sws_b, lev_ws, lws_b, /* one scene: the sort skips its batch digit */ true,
+                          d->stem_k, d->mask_groups, d->masked_min_rows, ibuf + o_arena, words, &off, sort_ws, sws_b, lev_ws, lws_b, /* one scene: the sort skips its batch digit */ true,
                           stream, /* bound words filled above */ true);
     if (rc != CV_OK) return rc;
     r->duplicates = counts_h[5];
@@ -187,13 +186,11 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
     const int32_t* perms[9];
     for (int i = 0; i < 5; ++i) perms[i] = (off.mask_perm[i] >= 0 && rows[i] >= d->masked_min_rows) ? ap + off.mask_perm[i] : nullptr;
     for (int i = 0; i < 4; ++i) perms[5 + i] = ap + off.up_perm[i];
-    const int32_t* wins[5];
-    for (int i = 0; i < 5; ++i) wins[i] = off.win[i] >= 0 ? ap + off.win[i] : nullptr;
     std::unique_lock<std::mutex> enq(g_enqueue_mu, std::defer_lock);
     if (serialize_enqueue()) enq.lock();
     const void* ext_ptr[2] = {d->d_feats, d->d_out_feats};
     const int ext_ld[2] = {d->feats_ld, d->out_ld};
-    rc = cv_net_run_f32(d->ops, d->n_ops, d->bufs, d->n_bufs, rows, NL, arena, arena_b, ext_ptr, ext_ld, maps, 15, perms, 9, wins, 5, conv_ws,
+    rc = cv_net_run_f32(d->ops, d->n_ops, d->bufs, d->n_bufs, rows, NL, arena, arena_b, ext_ptr, ext_ld, maps, 15, perms, 9, conv_ws,
                         conv_ws_b, d->use_range_flag ? d_flag : nullptr, stream);
     if (rc != CV_OK) return rc;
     CV_HIP_CHECK(mark(1));

@@ -250,6 +250,31 @@ __global__ __launch_bounds__(256) void pack_weights_h2(const float* __restrict__
 }
 
 // wp6 layout (unsigned short): ((((j*nch + c)*3 + plane)*cout + col)*32 + k) for channel c*32 + k of offset j
+// pack_weights_h2 for a whole network in ONE launch (cv_sp_pack_weights_h2_batch_f32): blockIdx.y = job
+__global__ __launch_bounds__(256) void pack_weights_h2_batch(const cv_pack_job* __restrict__ jobs) {
+    const cv_pack_job jb = jobs[blockIdx.y];
+    const int K = jb.K, cin = jb.cin, cout = jb.cout, trans = jb.trans;
+    const float* __restrict__ w = jb.w;
+    unsigned short* __restrict__ wp = static_cast<unsigned short*>(jb.wp);
+    const float mult = __uint_as_float((unsigned)(127 + jb.scale_log2) << 23);        // 2^scale_log2, |scale_log2| <= 60
+    const long long total = (long long)K * cin * cout / 2;
+    const int nch = cin / 32;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long r = i;
+        const int k2 = (int)(r % 16); r /= 16;
+        const int col = (int)(r % cout); r /= cout;
+        const int c = (int)(r % nch); r /= nch;
+        const int j = (int)r;
+        const float* p = trans ? w + ((long long)j * cout + col) * cin + c * 32 + 2 * k2
+                               : w + ((long long)j * cin + c * 32 + 2 * k2) * cout + col;
+        unsigned h, l;
+        split2h(p[0] * mult, p[trans ? 1 : cout] * mult, h, l);
+        const long long base = ((long long)(j * nch + c) * 2 * cout + col) * 32 + 2 * k2;
+        *reinterpret_cast<unsigned*>(wp + base) = h;
+        *reinterpret_cast<unsigned*>(wp + base + (long long)cout * 32) = l;
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_weights_x6(const float* __restrict__ w, int K, int cin, int cout,
                                                        const float* __restrict__ col_scale,
                                                        unsigned short* __restrict__ wp, int trans = 0) {
@@ -1314,99 +1339,11 @@ __global__ __launch_bounds__(NW * 64, (hd_blocks(NB, NW, NSTG) * NW + 3) / 4) vo
 // launch (bit-identical; one scene in flight +0.5-1 %, 576 -> 544-566 scenes/s with seven: its prefetches take 246 VGPRs and the
 // polling workgroups hold their CU).  LABNOTES "Round 5".)
 
-// ------------------------------------------------------------------ stem (tiny Cin, 32 outputs)
-// conv0p1s1 (utils/minkunet.py:53: 5x5x5, 3 or 6 -> 32 channels) is a kernel-map walk, not a GEMM: 13 % of its
-// 125 offsets exist per row and each pair is a CIN x 32 product.  One lane owns one output row and all 32
-// outputs in registers; the tile's slice of the kernel map is staged in LDS with coalesced loads (row stride
-// K is odd: conflict-free column reads), the weights of the current offset are wave-uniform and come through
-// the scalar cache, so the loop body is the map lookup, CIN gathered floats and 32*CIN FMAs.
-// Measured 153 -> 107 us at 80k rows; a variant with the gathers software-pipelined two offsets ahead and no
-// divergence ran slower (130 us): the loop is bound by the scalar weight fetches, not by the gathers.
-constexpr int STEM_ROWS = 128;
-template <int CIN>
-__global__ __launch_bounds__(STEM_ROWS) void conv_stem(ConvArgs a, int JC) {
-    // The tile's map rows are staged JC offsets at a time ([STEM_ROWS][JC | 1] ints): with the whole 125-offset slice
-    // resident (64 KB) two workgroups = ONE wave per SIMD fitted on a CU and every per-offset gather latency was
-    // exposed (108 us for 1.3 M pairs); 32 offsets at a time need 17 KB and leave the occupancy to the registers.
-    extern __shared__ int stem_nbr[];
-    const int K = a.K, KLD = JC | 1;
-    const long long r0 = (long long)blockIdx.x * STEM_ROWS;
-    const int rows = (int)min((long long)STEM_ROWS, a.n_out - r0);
-    const int r = threadIdx.x;
-    float acc[32];
-#pragma unroll
-    for (int co = 0; co < 32; ++co) acc[co] = 0.f;
-    const float* __restrict__ w = a.w;
-    for (int jc = a.j_begin; jc < a.j_end; jc += JC) {
-        const int jw = min(JC, a.j_end - jc);
-        __syncthreads();                                   // the previous chunk's map entries are consumed
-        {   // copy of the tile's map entries for offsets [jc, jc + jw), 8 independent loads in flight per lane
-            const int total = rows * jw;
-            const int* src_p = a.nbr + r0 * K + jc;
-            for (int e0 = threadIdx.x; e0 < total; e0 += 8 * STEM_ROWS) {
-                int v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int e = e0 + q * STEM_ROWS;
-                    const int rr = e / jw;
-                    v[q] = e < total ? src_p[(long long)rr * K + (e - rr * jw)] : -1;
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int e = e0 + q * STEM_ROWS;
-                    if (e < total) { const int rr = e / jw; stem_nbr[rr * KLD + (e - rr * jw)] = v[q]; }
-                }
-            }
-        }
-        __syncthreads();
-        if (r < rows)
-            for (int jj = 0; jj < jw; ++jj) {
-                const int src = stem_nbr[r * KLD + jj];
-                if (src < 0) continue;
-                float x[CIN];
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) x[ci] = a.in[(long long)src * a.in_ld + ci];
-                const float* wj = w + (long long)(jc + jj) * CIN * 32;
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-                    for (int co = 0; co < 32; ++co) acc[co] = fmaf(x[ci], wj[ci * 32 + co], acc[co]);
-            }
-    }
-    if (r >= rows) return;
-    const long long row = r0 + r;
-#pragma unroll
-    for (int co = 0; co < 32; ++co) {
-        float v = acc[co];
-        if (a.acc_in) v += a.acc_in[row * a.acc_ld + co];
-        v = v * (a.scale ? a.scale[co] : 1.f) + (a.shift ? a.shift[co] : 0.f);
-        if (a.res) v += a.res[row * a.res_ld + co];
-        if (a.relu) v = fmaxf(v, 0.f);
-        acc[co] = v;
-    }
-    float* o = a.out + row * a.out_ld;
-    if (a.out_hl) {                        // one 128-byte chunk: 32 high pieces, 32 low pieces (host: aligned, out_ld % 32 == 0)
-        bool big = false;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-            big |= hl_out_of_range(v);
-            hl_store4(o, 4 * q, v);
-        }
-        if (big && a.range_flag) *a.range_flag = 1;
-    } else if ((a.out_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            reinterpret_cast<float4*>(o)[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-    } else {
-#pragma unroll
-        for (int co = 0; co < 32; ++co) o[co] = acc[co];
-    }
-}
-
 // ------------------------------------------------------------------ stem on the matrix cores (fp16 pairs)
-// The lane-per-row stem above executes 32*CIN FMAs for every offset ANY of a wave's 64 rows has (~90 % of the 125) while
-// 13 % of the (row, offset) pairs exist: 93 us for 0.25 GFLOP.  As a GEMM over the gathered operand
+// conv0p1s1 (utils/minkunet.py:53: 5x5x5, 3 or 6 -> 32 channels): 13 % of the 125 (row, offset) pairs exist.  Rounds 1-5 also
+// kept a lane-per-row stem on the vector ALUs (one lane = one output row and all 32 outputs in registers, weights through the
+// scalar cache; 93-107 us at 80k rows, removed in round 6: the training forward takes this kernel too, other fp32 callers the
+// generic conv_rows): it executed 32*CIN FMAs for every offset ANY of a wave's 64 rows had (~90 % of the 125).  As a GEMM over the gathered operand
 // [rows][CIN * 128] (offsets padded to 128, dead entries zero) it is 1.97 GFLOP dense - nothing for the matrix cores -
 // and what remains is what the stem really is: 125 map entries and ~16 gathers of CIN floats per row.
 // A wave owns 32 rows; per group of 16 offsets a lane (row = lane % 32, half = lane / 32) reads its row's 8 map
@@ -2710,10 +2647,9 @@ int pick_splits(long long n_out, int cout, int K, int cin, bool vec) {
 
 int cv_sp_set_option(const char* name, long long value, long long* previous) {
     CV_REQUIRE(name, CV_EINVAL, "null option name");
-    if (cvsc::win_option(name, value, previous)) return CV_OK;
     std::atomic<long long>* o = !strcmp(name, "hd_mask") ? &g_opt_hd_mask : !strcmp(name, "hd_min_rows") ? &g_opt_hd_min_rows :
                                 !strcmp(name, "hd_shape") ? &g_opt_hd_shape : !strcmp(name, "zskip") ? &g_opt_zskip : nullptr;
-    CV_REQUIRE(o, CV_EINVAL, "unknown option '%s' (hd_mask, hd_min_rows, hd_shape, zskip, win, win_xcd, win_levels)", name);
+    CV_REQUIRE(o, CV_EINVAL, "unknown option '%s' (hd_mask, hd_min_rows, hd_shape, zskip)", name);
     const long long before = o->exchange(value, std::memory_order_relaxed);
     if (previous) *previous = before;
     return CV_OK;
@@ -2721,7 +2657,6 @@ int cv_sp_set_option(const char* name, long long value, long long* previous) {
 
 int cv_sp_get_option(const char* name, long long* value) {
     CV_REQUIRE(name && value, CV_EINVAL, "null option name / value");
-    if (cvsc::win_option_get(name, value)) return CV_OK;
     const std::atomic<long long>* o = !strcmp(name, "hd_mask") ? &g_opt_hd_mask : !strcmp(name, "hd_min_rows") ? &g_opt_hd_min_rows :
                                       !strcmp(name, "hd_shape") ? &g_opt_hd_shape : !strcmp(name, "zskip") ? &g_opt_zskip : nullptr;
     CV_REQUIRE(o, CV_EINVAL, "unknown option '%s'", name);
@@ -2859,25 +2794,8 @@ int cv_sp_conv_f32(const cv_conv_desc* d, void* stream) {
             CV_LAUNCH_CHECK();
             return CV_OK;
         }
-        const unsigned grid = (unsigned)((d->n_out + STEM_ROWS - 1) / STEM_ROWS);
-        static const int jc_env = getenv("CV_STEM_JC") ? atoi(getenv("CV_STEM_JC")) : 32;
-        const int JC = std::max(1, std::min(jc_env, 160));
-        const size_t lds = (size_t)STEM_ROWS * (JC | 1) * sizeof(int);
-        if (d->cin == 3) {
-            CV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem<3>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            conv_stem<3><<<grid, STEM_ROWS, lds, st>>>(a, JC);
-        } else {
-            CV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem<6>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            conv_stem<6><<<grid, STEM_ROWS, lds, st>>>(a, JC);
-        }
-        CV_LAUNCH_CHECK();
-        return CV_OK;
     }
-    a.win = d->win;
     a.acc_scale_dev = d->acc_scale_dev;
-    if (a.win && cvsc::win_enabled() && cvsc::win_eligible(a)) return cvsc::launch_win(a, st);
     if (d->perm_groups > 1) {
         // offsets split into perm_groups contiguous groups, each processed in its own row order, all in
         // one launch (grid.z); partial tiles are reduced by conv_finish
@@ -3057,6 +2975,23 @@ int cv_sp_pack_weights_t_f32(const float* d_w, int K, int rows, int cols, int pi
     if (pieces == 3) pack_weights_x6<<<grid, 256, 0, st>>>(d_w, K, cin, cout, nullptr, wp, 1);
     else if (pieces == 2) pack_weights_h2<<<grid, 256, 0, st>>>(d_w, K, cin, cout, nullptr, ldexpf(1.f, scale_log2), wp, 1);
     else pack_weights_b1<<<grid, 256, 0, st>>>(d_w, K, cin, cout, nullptr, wp, 1);
+    CV_LAUNCH_CHECK();
+    return CV_OK;
+}
+
+int cv_sp_pack_weights_h2_batch_f32(const cv_pack_job* h_jobs, int n_jobs, void* d_jobs, void* stream) {
+    CV_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || (h_jobs && d_jobs)), CV_EINVAL, "bad pack batch");
+    if (n_jobs == 0) return CV_OK;
+    for (int i = 0; i < n_jobs; ++i) {
+        const cv_pack_job& j = h_jobs[i];
+        CV_REQUIRE(j.w && j.wp && j.K > 0 && j.cin > 0 && j.cout > 0 && j.cin % 32 == 0, CV_EINVAL,
+                   "pack job %d: null pointer or Cin %% 32 != 0 (K %d, Cin %d, Cout %d)", i, j.K, j.cin, j.cout);
+        CV_REQUIRE(j.scale_log2 >= -60 && j.scale_log2 <= 60 && (j.trans == 0 || j.trans == 1), CV_EINVAL, "pack job %d: scale_log2 / trans out of range", i);
+        CV_REQUIRE((reinterpret_cast<uintptr_t>(j.wp) & 15) == 0, CV_EINVAL, "pack job %d: wp must be 16-byte aligned", i);
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CV_HIP_CHECK(hipMemcpyAsync(d_jobs, h_jobs, sizeof(cv_pack_job) * (size_t)n_jobs, hipMemcpyHostToDevice, st));
+    pack_weights_h2_batch<<<dim3(64, (unsigned)n_jobs), 256, 0, st>>>(static_cast<const cv_pack_job*>(d_jobs));
     CV_LAUNCH_CHECK();
     return CV_OK;
 }

@@ -48,7 +48,6 @@ struct ConvArgs {
     int in_hl, out_hl, res_hl;   // 1: the operand is in the hl format (fp16 pairs in place, see below) instead of fp32
     int xcd_tiles;               // conv_rows_wp / conv_hl: XCD-aware tile numbering (xcd_tile)
     int* tickets;                // conv_hl split-K: arrival counters per output tile (zero; the last arriver reduces, see there)
-    const int* win;              // conv_win: the window block of the kernel map (cv_sp_build_windows), see sparse_win.hip
     const float* acc_scale_dev;  // optional device scalar multiplied into acc_scale (the input gradient's hl operand carries a
                                  // per-layer power of two chosen on the device)
     const unsigned char* gvalid; // mask groups: [splits][n_out] 1 = the row has a neighbour in the group; tiles without any write no
@@ -238,7 +237,7 @@ __device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigne
 __device__ __forceinline__ void hl_split2(float x0, float x1, unsigned& h, unsigned& l) { split2h(x0, x1, h, l); }
 
 
-// ---- shared by the LDS-DMA kernels (conv_hd in sparse_conv.hip, conv_win in sparse_win.hip) -----------------------------
+// ---- shared by the LDS-DMA kernels (conv_hd in sparse_conv.hip) ------------------------------------------------------------
 template <int... I, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -302,10 +301,4 @@ __device__ __forceinline__ void hd_read_frags(unsigned aa0, unsigned aa1, unsign
 // ---- across the two translation units
 int launch_finish(const ConvArgs& a, hipStream_t st);                  // sparse_conv.hip: reduce the partial tiles + epilogue
 int nb_full(int cout);                                                 // sparse_conv.hip
-bool win_eligible(const ConvArgs& a);                                  // sparse_win.hip: conv_win takes this launch
-int launch_win(const ConvArgs& a, hipStream_t st);                     // sparse_win.hip
-bool win_option(const char* name, long long value, long long* previous);
-bool win_option_get(const char* name, long long* value);                   // sparse_win.hip: the same knobs, read only   // sparse_win.hip: "win", "win_xcd" of cv_sp_set_option
-bool win_enabled();
-int win_level_mask();                                                  // option "win_levels": levels that may take windows
 }  // namespace cvsc

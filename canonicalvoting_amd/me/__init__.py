@@ -59,7 +59,7 @@ def _on(dev):
 
 class _FusedPlan:
     """what CoordinateManager.fused_fast() returns"""
-    __slots__ = ("keep", "counts", "cap", "stem_k", "groups", "off", "layout", "map_ptrs", "perm_ptrs", "win_ptrs", "views")
+    __slots__ = ("keep", "counts", "cap", "stem_k", "groups", "off", "layout", "map_ptrs", "perm_ptrs", "views")
 
 
 class CoordinateManager:
@@ -217,24 +217,7 @@ class CoordinateManager:
     MASKED_MIN_ROWS = int(os.environ.get("CV_MASKED_MIN_ROWS", "16384"))      # process-wide; a thread's own: masked_min_rows()
     LIB_MASKED_MIN_ROWS = MASKED_MIN_ROWS          # the one-scene-at-a-time default (pipeline.policy_for_scenes_in_flight)
 
-    def windows(self, ts=1):
-        """neighbour windows of the 3x3x3 map at tensor stride ts (cv_sp_build_windows; int32 block, cached): hand it to
-        conv_forward(win=...) - the rows of this manager must be in spatial order (a sorted twin from fused_plan)"""
-        key = ("win", ts)
-        m = self._maps.get(key)
-        if m is None:
-            L = _lib.lib()
-            nbr = self.kernel_map(3, ts)
-            n = nbr.shape[0]
-            if not L.cv_sp_windows_supported(n):
-                raise RuntimeError("coordinate set too large for the window plan (%d rows)" % n)
-            m = torch.empty(int(L.cv_sp_windows_words(n)), dtype=torch.int32, device=self.device)
-            with torch.cuda.device(self.device):
-                _lib.check(L.cv_sp_build_windows(_ptr(nbr), n, _ptr(m), _stream(self.device)), "cv_sp_build_windows")
-            self._maps[key] = m
-        return m
-
-    def fused_fast(self, stem_k=5, win_levels=0):
+    def fused_fast(self, stem_k=5):
         """The coordinate plan of the fused network as raw device pointers (what MinkUNet.program_forward hands to the
         C executor): .counts rows per level, .map_ptrs [stem, down 0-3, k3 0-4, up 0-3, out], .perm_ptrs [mask orders of
         levels 0-4 (None where a level is not mask-sorted), octant orders of the four transposed convs].
@@ -242,15 +225,15 @@ class CoordinateManager:
         three allocations; the tensor views of the plan (fused_plan) are only made when somebody asks for them."""
         cache = self.__dict__.setdefault("_fused_cache", {})
         mmr = masked_min_rows()                # (part of the key: a plan built under another launch policy has other orders)
-        if (stem_k, win_levels, mmr) in cache:
-            return cache[(stem_k, win_levels, mmr)]
+        if (stem_k, mmr) in cache:
+            return cache[(stem_k, mmr)]
         L = _lib.lib()
         dev = self.device
         n = self._input.shape[0]
         NL = CoordinateManager.NUM_LEVELS
         G = self.MASK_GROUPS if (27 + self.MASK_GROUPS - 1) // self.MASK_GROUPS <= 10 else 0   # wide groups: lazily
         cap = int(L.cv_sp_table_capacity(n))
-        words = int(L.cv_sp_scene_plan_words(n, stem_k, G, mmr, win_levels))
+        words = int(L.cv_sp_scene_plan_words(n, stem_k, G, mmr))
         up64 = lambda v: (v + 63) // 64 * 64
         # int32 buffer: perm | inv | coords of the 5 levels | table values of the 5 levels | counts | arena (sized for
         # the worst case, every coarse level bounded by n: the call does not come back between the levels and the maps)
@@ -273,7 +256,7 @@ class CoordinateManager:
         with _on(dev):
             _lib.check(L.cv_sp_scene_plan(_ptr(self._input), n, vp(ib + 4 * o_perm), vp(ib + 4 * o_inv), c_coords, c_keys,
                                           c_vals, cap, vp(ib + 4 * o_counts), counts_h, stem_k, G, mmr,
-                                          win_levels, vp(ib + 4 * o_arena), words, ctypes.byref(off), vp(wb), sws_b, vp(wb + up64(sws_b)),
+                                          vp(ib + 4 * o_arena), words, ctypes.byref(off), vp(wb), sws_b, vp(wb + up64(sws_b)),
                                           lws_b, _stream(dev)), "cv_sp_scene_plan")
         self._raise_on_dups(counts_h[5], counts_h[6])
         plan = _FusedPlan()
@@ -286,9 +269,8 @@ class CoordinateManager:
                         [ap(off.up[i]) for i in range(4)] + [ib + 4 * o_inv]
         plan.perm_ptrs = [ap(off.mask_perm[i]) if off.mask_perm[i] >= 0 else None for i in range(5)] + \
                          [ap(off.up_perm[i]) for i in range(4)]
-        plan.win_ptrs = [ap(off.win[i]) if off.win[i] >= 0 else None for i in range(5)]
         plan.views = None
-        cache[(stem_k, win_levels, mmr)] = plan
+        cache[(stem_k, mmr)] = plan
         self._fused = plan
         self._fused_k = stem_k
         return plan
@@ -467,7 +449,7 @@ def range_flag(dev):
 def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=None, relu=False,
                  out=None, flavour=0, row_perm=None, j_begin=0, j_end=0, acc_in=None, perm_groups=0,
                  cache_weights=True, pieces=None, in_hl=False, out_hl=False, res_hl=False, stem_mfma=False,
-                 split_tickets=None, weight_t=False, win=None, acc_scale_dev=None):
+                 split_tickets=None, weight_t=False, acc_scale_dev=None):
     """Low-level call into cv_sp_conv_f32 (fused epilogue).  weight [K,Cin,Cout] or [Cin,Cout].
     in_hl / out_hl / res_hl: the operand is in the hl format (to_hl / from_hl; cv_conv_desc.in_hl), pieces=2 only.
     pieces=2: fp16-pair products (weights packed per call; the caller reads range_flag(dev) after synchronising);
@@ -502,20 +484,31 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
     if CONV_X6 and flavour in (0, 1) and cin % 32 == 0 and cout % 4 == 0:
         if pieces == 2 and weight_t:
             # the input gradient on fp16 pairs: W^T packed straight from the forward layout with the layer's scale of this step
-            hints = _bwd_ctx.get("pair_scales")         # (the backward nodes run on the autograd engine's thread)
-            k = hints.get(weight.data_ptr()) if hints is not None else None
-            if k is None:
-                k = h2_scale_log2((w, None))
-            wp6 = torch.empty(2 * w.numel(), dtype=torch.int16, device=dev)
-            with _on(dev):
-                _lib.check(L.cv_sp_pack_weights_t_f32(_ptr(w), K, cout, cin, 2, int(k), _ptr(wp6), _stream(dev)),
-                           "cv_sp_pack_weights_t_f32")
+            pk = _bwd_ctx.get("packed")
+            pre = pk.get((w.data_ptr(), 1)) if pk else None
+            if pre is not None and pre[0].numel() == 2 * w.numel():
+                wp6, k = pre                              # packed at the start of the step (_prepack_pairs)
+                TRAIN_COUNTERS["prepacked"] += 1
+            else:
+                hints = _bwd_ctx.get("pair_scales")         # (the backward nodes run on the autograd engine's thread)
+                k = hints.get(weight.data_ptr()) if hints is not None else None
+                if k is None:
+                    k = h2_scale_log2((w, None))
+                wp6 = torch.empty(2 * w.numel(), dtype=torch.int16, device=dev)
+                with _on(dev):
+                    _lib.check(L.cv_sp_pack_weights_t_f32(_ptr(w), K, cout, cin, 2, int(k), _ptr(wp6), _stream(dev)),
+                               "cv_sp_pack_weights_t_f32")
             acc_scale, flag = 2.0 ** -k, range_flag(dev)
         elif pieces == 2:
             key = id(weight)
             ver = (weight.data_ptr(), weight._version, tuple(weight.shape))
             hit = _packed_h2.get(key) if cache_weights else None
-            if hit is None or hit[0] != ver:
+            pk = _bwd_ctx.get("packed") if not cache_weights else None
+            pre = pk.get((w.data_ptr(), 0)) if pk else None
+            if pre is not None and pre[0].numel() == 2 * w.numel():
+                hit = (ver, pre[0], pre[1])               # packed at the start of the step (_prepack_pairs)
+                TRAIN_COUNTERS["prepacked"] += 1
+            elif hit is None or hit[0] != ver:
                 hints = getattr(_train_state, "pair_scales", None)
                 k = hints.get(weight.data_ptr()) if hints is not None else None
                 if k is None:
@@ -537,7 +530,10 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
             wp6 = packed_weights_x6(weight, w, cache_weights)
     if stem_mfma and pieces == 2 and cin in (3, 6) and cout == 32 and K <= 128 and nbr is not None and flavour == 0:
         # the matrix-core stem (conv_stem_mfma): BatchNorm scale folded into the fp16-pair weights
-        k = h2_scale_log2((w, scale))
+        hints = getattr(_train_state, "pair_scales", None) if scale is None else None      # (a training step hands the scales over)
+        k = hints.get(weight.data_ptr()) if hints is not None else None
+        if k is None:
+            k = h2_scale_log2((w, scale))
         wp6, acc_scale, flag, scale = packed_weights_stem_h2(w, scale, k), 2.0 ** -k, range_flag(dev), None
     ws = None
     if perm_groups > 1:
@@ -553,7 +549,7 @@ def conv_forward(x_feats, weight, nbr, n_out, scale=None, shift=None, residual=N
                       None, None, None, p(wp6), None, 0, 0, None,
                       1 if (perm_groups > 1 and getattr(row_perm, "_cv_has_map", False)) else 0,
                       2 if flag is not None else (1 if (pieces == 1 and wp6 is not None) else 0), acc_scale, p(flag),
-                      1 if in_hl else 0, 1 if out_hl else 0, 1 if res_hl else 0, p(split_tickets), p(win), p(acc_scale_dev))
+                      1 if in_hl else 0, 1 if out_hl else 0, 1 if res_hl else 0, p(split_tickets), p(acc_scale_dev))
     with _on(dev):
         _lib.check(L.cv_sp_conv_f32(ctypes.byref(d), _stream(dev)), "cv_sp_conv_f32")
     return out
@@ -893,10 +889,52 @@ def train_forward_hl():
 TRAIN_BWD_HL = int(os.environ.get("CV_TRAIN_BWD_HL", "1"))
 
 
-TRAIN_COUNTERS = {"hl_dgrad": 0}           # (tests: how many input gradients took the hl path)
+# 1 (default): train.train_step packs the fp16-pair weights of all convolutions (both directions) by one launch per step
+TRAIN_PREPACK = int(os.environ.get("CV_TRAIN_PREPACK", "1"))
+TRAIN_COUNTERS = {"hl_dgrad": 0, "prepacked": 0}           # (tests: how many input gradients took the hl path)
 # what the backward nodes of the step in progress share.  Process-wide, not thread-local: the autograd engine runs the nodes on
 # its own thread.  One training step at a time per process (the one-process-per-GPU layout of train_joint.py).
-_bwd_ctx = {"slots": None, "twins": {}, "pair_scales": None}
+_bwd_ctx = {"slots": None, "twins": {}, "pair_scales": None, "packed": None}
+
+
+def _prepack_pairs(module, ks, scales, dev):
+    """fp16-pair weights of every convolution of a training step - forward layout and, for the input gradients, transposed -
+    packed by ONE launch in front of the step's forward (cv_sp_pack_weights_h2_batch_f32) into an arena that lives with the
+    module: {(kernel.data_ptr(), transposed): (packed words, scale_log2)} for conv_forward.  Per layer and direction this
+    was a launch of its own (117 per MinkUNet34C step) with the stream idle in front of most of them."""
+    L = _lib.lib()
+    sig = tuple((k.data_ptr(), tuple(k.shape), k.is_contiguous()) for k in ks) + (bool(TRAIN_BWD_HL),)
+    st = module.__dict__.get("_prepack_state")
+    if st is None or st["sig"] != sig or st["arena"].device != dev:
+        meta, off = [], 0
+        for k in ks:
+            if not k.is_contiguous():
+                continue
+            K, cin, cout = (k.shape if k.dim() == 3 else (1,) + tuple(k.shape))
+            words = 2 * K * cin * cout
+            if cin % 32 == 0 and cout % 4 == 0:
+                meta.append((k.data_ptr(), 0, K, cin, cout, off, words))
+                off += (words + 63) // 64 * 64
+            if TRAIN_BWD_HL and cout % 32 == 0 and cin % 4 == 0:      # the transposed convolution: Cin' = cout, Cout' = cin
+                meta.append((k.data_ptr(), 1, K, cout, cin, off, words))
+                off += (words + 63) // 64 * 64
+        arena = torch.empty(max(off, 64), dtype=torch.int16, device=dev)
+        jobs = (_lib.PackJob * max(len(meta), 1))()
+        for j, (ptr, trans, K, cin, cout, o, words) in zip(jobs, meta):
+            j.w, j.wp, j.K, j.cin, j.cout, j.trans = ptr, arena.data_ptr() + 2 * o, K, cin, cout, trans
+        st = module.__dict__["_prepack_state"] = {
+            "sig": sig, "meta": meta, "arena": arena, "jobs": jobs,
+            "d_jobs": torch.empty(max(len(meta), 1) * ctypes.sizeof(_lib.PackJob), dtype=torch.uint8, device=dev)}
+    meta, arena, jobs = st["meta"], st["arena"], st["jobs"]
+    packed = {}
+    for j, (ptr, trans, K, cin, cout, o, words) in zip(jobs, meta):
+        j.scale_log2 = int(scales.get(ptr, 0))
+        packed[(ptr, trans)] = (arena[o:o + words], j.scale_log2)
+    if meta:
+        with _on(dev):
+            _lib.check(L.cv_sp_pack_weights_h2_batch_f32(jobs, len(meta), ctypes.c_void_p(st["d_jobs"].data_ptr()), _stream(dev)),
+                       "cv_sp_pack_weights_h2_batch_f32")
+    return packed
 
 
 class _GradSlots:
@@ -961,6 +999,8 @@ class pair_scale_hints:
         _train_state.pair_scales = scales
         self.outer_slots = _bwd_ctx["slots"]
         _bwd_ctx["slots"], _bwd_ctx["twins"] = None, {}
+        self.outer_packed = _bwd_ctx["packed"]
+        _bwd_ctx["packed"] = _prepack_pairs(self.module, ks, scales, ks[0].device) if (ks and train_forward_hl() and TRAIN_PREPACK) else None
         if ks and train_forward_hl() and TRAIN_BWD_HL:
             slots = self.module.__dict__.get("_grad_slots")
             if slots is None or slots.buf.device != ks[0].device:
@@ -981,6 +1021,7 @@ class pair_scale_hints:
     def __exit__(self, *exc):
         _train_state.pair_scales = self.outer
         _bwd_ctx["slots"], _bwd_ctx["twins"], _bwd_ctx["pair_scales"] = self.outer_slots, {}, None
+        _bwd_ctx["packed"] = self.outer_packed
         return False
 
 
@@ -1054,6 +1095,11 @@ class _ConvFn(torch.autograd.Function):
             # the eval path's kernels on the hl twin (the fp32 rows stay saved for the weight gradient)
             _train_state.used_pairs = True
             return conv_forward(feats_hl, kernel, nbr, n_out, shift=shift, cache_weights=False, pieces=2, in_hl=True)
+        k3 = kernel if kernel.dim() == 3 else kernel[None]
+        if (train_forward_hl() and nbr is not None and feats.shape[1] in (3, 6) and k3.shape[2] == 32 and k3.shape[0] <= 128):
+            # the stem (conv0p1s1: 5x5x5, 3 or 6 -> 32 channels) on the matrix cores, like the eval program's (conv_stem_mfma)
+            _train_state.used_pairs = True
+            return conv_forward(feats, kernel, nbr, n_out, shift=shift, cache_weights=False, pieces=2, stem_mfma=True)
         pieces = None
         if TRAIN_FWD_PIECES == 2 and COMPUTE_DTYPE != "bf16" and feats.shape[1] % 32 == 0:
             pieces = 2

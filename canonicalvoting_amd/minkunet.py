@@ -420,12 +420,10 @@ class MinkUNetBase(ResNetBase):
         if pieces is None:
             pieces = 1 if ME.COMPUTE_DTYPE == "bf16" else self.PIECES
         c_ops, c_bufs, _ = self._program(dev, pieces)
-        # levels whose 3x3x3 convolutions run on neighbour windows (conv_win): the plan builds windows there, no mask orders
-        win_levels = int(L.cv_net_win_levels(c_ops, len(c_ops), c_bufs, len(c_bufs))) if ME.option("win") else 0
-        plan = x.coordinate_manager.fused_fast(self.conv0p1s1.kernel_size, win_levels)
+        plan = x.coordinate_manager.fused_fast(self.conv0p1s1.kernel_size)
         flag = ME.range_flag(dev) if pieces == 2 else None
         n = plan.counts
-        masked = [n[i] >= self.masked_min_rows() and plan.win_ptrs[i] is None for i in range(5)]
+        masked = [n[i] >= self.masked_min_rows() for i in range(5)]
         if any(m and plan.perm_ptrs[i] is None for i, m in enumerate(masked)):
             # mask groups too wide for the plan's counting sort: orders from the generic path
             cm = x.coordinate_manager.fused_plan(self.conv0p1s1.kernel_size)[0]
@@ -448,11 +446,10 @@ class MinkUNetBase(ResNetBase):
         ext_ld = (ctypes.c_int * 2)(feats.stride(0), y.stride(0))
         c_maps = (vp * len(map_ptrs))(*map_ptrs)
         c_perms = (vp * len(perm_ptrs))(*perm_ptrs)
-        c_wins = (vp * 5)(*plan.win_ptrs)
         with torch.cuda.device(dev):
             _lib.check(L.cv_net_run_f32(c_ops, len(c_ops), c_bufs, len(c_bufs), rows, 5, vp(arena.data_ptr()),
                                         arena.numel(), ext_ptr, ext_ld, c_maps, len(map_ptrs), c_perms, len(perm_ptrs),
-                                        c_wins, 5, vp(ws.data_ptr()), ws.numel(), vp(flag.data_ptr()) if flag is not None else None,
+                                        vp(ws.data_ptr()), ws.numel(), vp(flag.data_ptr()) if flag is not None else None,
                                         vp(torch.cuda.current_stream(dev).cuda_stream)), "cv_net_run_f32")
         out = x._like(y, 1)
         if flag is not None and not (self.defer_range_check if defer_check is None else defer_check):

@@ -208,7 +208,6 @@ def detect_scene_c(model, hv, coords4, feats, res, nclasses=9, log_scale=True, s
     d.masked_min_rows = policy.masked_min_rows if policy is not None else model.masked_min_rows()
     if policy is not None:
         d.conv_split_target, d.vote_part_records = int(policy.conv_split_target), int(policy.vote_part_records)
-    d.win_levels = int(L.cv_net_win_levels(c_ops, len(c_ops), c_bufs, len(c_bufs))) if ME.option("win") else 0
     d.max_channels, d.use_range_flag = max(model.PLANES), 1 if pieces == 2 else 0
     d.d_out_feats, d.out_ld, d.out_channels = vp(y.data_ptr()), y.stride(0), y.shape[1]
     d.nclasses, d.log_scale = nclasses, 1 if log_scale else 0

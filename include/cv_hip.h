@@ -34,7 +34,10 @@ extern "C" {
  * this header compares the two (csrc/hv_cuda_ext.cpp does at import) and refuses a stale pair.
  * 2 (round 5): neighbour windows (cv_sp_build_windows, cv_conv_desc.win, cv_scene_maps.win, win_levels arguments of the
  *    scene-plan calls, `wins` of cv_net_run_f32); the round 1-3 tile-plan symbols are gone.
- * 3 (round 6): launch sizing per call - cv_scene_desc.conv_split_target / vote_part_records, cv_hv_set_part_records_thread. */
+ * 3 (round 6): launch sizing per call - cv_scene_desc.conv_split_target / vote_part_records, cv_hv_set_part_records_thread;
+ *    cv_sp_copy_unless_flag, cv_sp_pack_weights_h2_batch_f32; the neighbour windows of round 5 (conv_win: exact, measured slower
+ *    than the mask-sorted kernels at every level, LABNOTES round 5) are gone - cv_sp_build_windows, cv_conv_desc.win,
+ *    cv_scene_maps.win, the win_levels arguments and cv_net_win_levels. */
 #define CV_ABI_VERSION 3
 int cv_abi_version(void);
 const char* cv_last_error(void);
@@ -252,11 +255,6 @@ typedef struct cv_conv_desc {
                                stream.  A split launch then reduces its partial tiles in the last-arriving workgroup of every
                                output tile (same summation order as the finish launch: bit-identical) instead of a second
                                launch; the library leaves the counters at zero.  NULL: two launches. */
-    const int32_t* win;     /* optional: neighbour windows of `nbr` (cv_sp_build_windows; K == 27, n_in == n_out rows in spatial
-                               order).  With hl-format input, fp16-pair weights and Cout 32 / 64 / 96 the convolution then runs as
-                               conv_win: every 256-row tile lands its window of input rows in LDS once and multiplies all 27
-                               offsets out of it - no mask groups, no partial tiles, no finish launch (row_perm / perm_groups
-                               are ignored).  Other shapes ignore it. */
     const float* acc_scale_dev; /* optional, hl-format input only: a device scalar multiplied into acc_scale when the kernel
                                runs (the training backward scales a layer's gradient rows by a power of two chosen on the
                                device, cv_sp_bn_backward_hl_f32, and hands the inverse over here: no host wait). */
@@ -279,6 +277,22 @@ int cv_sp_pack_weights_x6_f32(const float* d_w, int K, int cin, int cout, const 
  * sets of a two-source convolution share it) and passes acc_scale = 2^-scale_log2 in the descriptor. */
 int cv_sp_pack_weights_h2_f32(const float* d_w, int K, int cin, int cout, const float* d_col_scale, int scale_log2,
                               void* d_wp, void* stream);
+/* cv_sp_pack_weights_h2_f32 / cv_sp_pack_weights_t_f32 (pieces 2) for MANY weight tensors in ONE launch: a training step packs
+ * the fp16 pairs of all 63 convolutions - forward and transposed - in front of its forward instead of one launch per layer
+ * and direction (117 launches and the stream's idle time in front of them, profiles/r5/train_gaps.txt).  Job i packs
+ * w[K][cin][cout] (trans = 0) or, trans = 1, the transposed convolution of a FORWARD kernel w[K][cout][cin] (what
+ * cv_sp_pack_weights_t_f32(w, K, rows = cout, cols = cin, 2, ...) makes) into wp: 2*K*cin*cout 16-bit words, 16-byte
+ * aligned, no column scale.  h_jobs: host array (read before the call returns; pinned memory makes the table copy asynchronous);
+ * d_jobs: n_jobs * sizeof(cv_pack_job) bytes of device scratch that must stay untouched until the launch has run. */
+typedef struct cv_pack_job {
+    const float* w;
+    void* wp;
+    int K, cin, cout;
+    int trans;
+    int scale_log2;
+    int reserved;
+} cv_pack_job;
+int cv_sp_pack_weights_h2_batch_f32(const cv_pack_job* h_jobs, int n_jobs, void* d_jobs, void* stream);
 /* Weights of the opt-in bf16 compute mode (cv_conv_desc.weight_pieces = 1): w * d_col_scale rounded to bf16 (RNE),
  * one plane of the same layout: K*cin*cout 16-bit words.  Not an fp32-parity path (operands carry 8 significant
  * bits); the reference trains and evaluates in fp32 (train_joint.py:218), BASELINE config 3 asks for bf16. */
@@ -298,15 +312,6 @@ int cv_sp_pack_weights_stem_h2_f32(const float* d_w, int K, int cin, const float
 size_t cv_sp_conv_workspace_bytes(long long n_out, int cout, int K);
 int cv_sp_conv_f32(const cv_conv_desc* desc, void* stream);
 
-/* Neighbour windows of a 3x3x3 kernel map d_nbr[n][27] whose rows are in spatial order (cv_sp_sort_rows): for every tile of
- * 256 consecutive rows the ascending list of distinct input rows it touches (the first 512 of them: the window) and the
- * map rewritten to 16-bit window slots.  d_win: cv_sp_windows_words(n) int32 words, 256-byte aligned.  Built once per
- * coordinate level, shared by every convolution on that map (cv_conv_desc.win).  cv_sp_windows_supported: the plan kernel
- * ranks a tile's rows with a bitmap over the level's rows in LDS - levels beyond ~800k rows keep the mask-sorted path.
- * (No reference counterpart: MinkowskiEngine's kernel maps are internal.)  Asynchronous. */
-int cv_sp_windows_supported(long long n);
-size_t cv_sp_windows_words(long long n);
-int cv_sp_build_windows(const int32_t* d_nbr, long long n, int32_t* d_win, void* stream);
 /* Launch sizing of the convolutions whose output tiles alone do not fill the chip (the coarse levels): the number of
  * workgroups a launch is split up to (over the kernel offsets; partial tiles, then a finish pass).  Default 768
  * (or CV_SPLIT_TARGET) - best for ONE scene in flight; a host that keeps several scenes in flight on separate streams
@@ -345,16 +350,12 @@ typedef struct cv_scene_maps {
     long long stem, out, down[4], k3[5], up[4], mask_perm[5], up_perm[4], scratch;
     long long bitmap;       /* 2^20 words: occupancy bits of the level-0 set over its bounding box (cv_sp_scene_plan puts
                                them in front of the hash probes of the level-0 maps: 87 % of the lookups are misses) */
-    long long win[5];       /* neighbour windows of k3[i] (cv_sp_build_windows) for the levels of `win_levels` with at least
-                               masked_min_rows rows; such a level has no mask_perm */
 } cv_scene_maps;
-/* win_levels: bit i set = level i runs its 3x3x3 convolutions on neighbour windows (cv_net_win_levels of the program) */
 size_t cv_sp_scene_maps_words(const long long* level_rows, long long n_orig, int stem_k, int mask_groups,
-                              long long masked_min_rows, int win_levels, cv_scene_maps* offsets);
+                              long long masked_min_rows, cv_scene_maps* offsets);
 int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* d_keys, const int32_t* const* d_vals,
                      long long cap, const long long* level_rows, const int32_t* d_perm, long long n_orig, int stem_k,
-                     int mask_groups, long long masked_min_rows, int win_levels, int32_t* d_arena, size_t arena_words,
-                     void* stream);
+                     int mask_groups, long long masked_min_rows, int32_t* d_arena, size_t arena_words, void* stream);
 
 /* The whole coordinate plan of a scene in ONE call (replaces cv_sp_sort_rows + cv_sp_build_levels + cv_sp_scene_maps
  * issued by the caller): spatial row sort of d_input[n][4] into d_coords[0], the five levels with their tables, every
@@ -363,10 +364,10 @@ int cv_sp_scene_maps(int32_t* const* d_coords, const unsigned long long* const* 
  * filled on return.  The level counts are copied to pinned host memory behind the levels and the call waits for that copy
  * only (an event), while `stream` goes on with the level-0 maps queued behind it.  When h_counts[5] (duplicates) or h_counts[6] (rows
  * outside the key window) is non-zero nothing beyond the level-0 maps is built and the caller must reject the input. */
-size_t cv_sp_scene_plan_words(long long n, int stem_k, int mask_groups, long long masked_min_rows, int win_levels);
+size_t cv_sp_scene_plan_words(long long n, int stem_k, int mask_groups, long long masked_min_rows);
 int cv_sp_scene_plan(const int32_t* d_input, long long n, int32_t* d_perm, int32_t* d_inv, int32_t* const* d_coords,
                      unsigned long long* const* d_keys, int32_t* const* d_vals, long long cap, int32_t* d_counts,
-                     int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int win_levels, int32_t* d_arena,
+                     int32_t* h_counts, int stem_k, int mask_groups, long long masked_min_rows, int32_t* d_arena,
                      size_t arena_words, cv_scene_maps* offsets, void* d_sort_ws, size_t sort_ws_bytes, void* d_levels_ws,
                      size_t levels_ws_bytes, void* stream);
 
@@ -401,15 +402,10 @@ typedef struct cv_net_op {
     float acc_scale;
 } cv_net_op;
 size_t cv_net_arena_bytes(const cv_net_buf* bufs, int n_bufs, const long long* level_rows, int n_levels);
-/* wins[n_wins] (may be NULL): window blocks indexed like the first entries of perms (the level of a mask-grouped 3x3x3
- * op's order slot): a non-NULL entry hands the op cv_conv_desc.win.  cv_net_win_levels: the levels of a program whose
- * mask-grouped ops can ALL take windows (what the scene plan is then asked to build instead of mask orders). */
-int cv_net_win_levels(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int n_bufs);
 int cv_net_run_f32(const cv_net_op* ops, int n_ops, const cv_net_buf* bufs, int n_bufs, const long long* level_rows,
                    int n_levels, void* d_arena, size_t arena_bytes, const void* const* ext_ptr, const int* ext_ld,
                    const int32_t* const* maps, int n_maps, const int32_t* const* perms, int n_perms,
-                   const int32_t* const* wins, int n_wins, void* d_ws, size_t ws_bytes, int32_t* range_flag,
-                   void* stream);   /* range_flag: cv_conv_desc.range_flag of every fp16-pair op, or NULL */
+                   void* d_ws, size_t ws_bytes, int32_t* range_flag, void* stream);   /* range_flag: cv_conv_desc.range_flag of every fp16-pair op, or NULL */
 
 /* d_keys[n] (int64) = bit mask of the valid neighbours among offsets [j_begin, j_end) of every row of a
  * kernel map; argsort of it is a row_perm for cv_conv_desc.  Asynchronous. */
@@ -533,7 +529,6 @@ typedef struct cv_scene_desc {
     const cv_net_buf* bufs; int n_bufs;
     int stem_k, mask_groups;
     long long masked_min_rows;
-    int win_levels;               /* cv_net_win_levels(ops, ...): levels whose 3x3x3 convolutions run on neighbour windows (0: none) */
     int max_channels;             /* widest convolution output (workspace sizing) */
     int use_range_flag;           /* 1: the program runs on fp16 pairs; result.range_flag reports an input beyond the fp16 range */
     float* d_out_feats;           /* [n][out_ld] network output, caller's buffer, caller's row order */

@@ -14,5 +14,5 @@ PCMD="python $R/bench.py --steps 56 --warmup 14 --min-warm-seconds 0 --cpu-scene
 timeout 1500 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d /tmp/ifA --output-format csv -- $PCMD > /tmp/ifA.log 2>&1
 timeout 1500 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/ifB --output-format csv -- $PCMD > /tmp/ifB.log 2>&1
 timeout 1500 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/ifC --output-format csv -- $PCMD > /tmp/ifC.log 2>&1
-python $R/profiles/in_flight_summary.py /tmp/ifT /tmp/ifA /tmp/ifB /tmp/ifC $O/if_trace_bench.json > $O/in_flight_counters.txt 2> $O/in_flight_counters.err
+IN_FLIGHT_JSON=$O/in_flight_counters.json python $R/profiles/in_flight_summary.py /tmp/ifT /tmp/ifA /tmp/ifB /tmp/ifC $O/if_trace_bench.json > $O/in_flight_counters.txt 2> $O/in_flight_counters.err
 tail -40 $O/in_flight_counters.txt

@@ -19,10 +19,10 @@ import sys
 def family(name):
     n = name.replace("(anonymous namespace)::", "").replace("void ", "")
     for key, fam in (("conv_hl", "conv_hl"), ("conv_hd", "conv_hd"), ("conv_finish", "conv_finish"), ("conv_stem", "conv_stem"),
-                     ("conv_win", "conv_win"), ("conv_rows", "conv_rows"), ("hv_fwd_tiles", "hv_fwd_tiles"), ("hv_", "hv_prep"),
+                     ("conv_rows", "conv_rows"), ("hv_fwd_tiles", "hv_fwd_tiles"), ("hv_", "hv_prep"),
                      ("minmax", "hv_prep"), ("dec_", "decode"), ("head_", "head"), ("build_kernel_maps", "plan"), ("mp_", "plan"),
                      ("sort_", "plan"), ("insert_all", "plan"), ("flag_levels", "plan"), ("emit_levels", "plan"), ("table_clear", "plan"),
-                     ("up_map", "plan"), ("build_windows", "plan"), ("__amd_rocclr", "runtime copy/fill")):
+                     ("up_map", "plan"), ("__amd_rocclr", "runtime copy/fill")):
         if n.startswith(key) or (key in n and key.startswith("__")):
             return fam
     return "other (" + re.split(r"[<(]", n)[0][:24] + ")"
@@ -44,7 +44,9 @@ def main():
           % (rate, steps, ms_per_scene, bench["config"]["scenes_in_flight_per_gpu"],
              {k: bench["config"][k] for k in ("conv_split_target", "vote_part_records", "masked_min_rows")}))
     # ---- part 1: the trace
-    rows = list(csv.DictReader(open(find(tdir, "kernel_trace.csv"))))
+    import gzip
+    tfile = tdir if tdir.endswith(".gz") else find(tdir, "kernel_trace.csv")
+    rows = list(csv.DictReader(gzip.open(tfile, "rt") if tfile.endswith(".gz") else open(tfile)))
     def wgs(r):
         try:
             g = [int(r[k]) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z")]
@@ -54,6 +56,7 @@ def main():
             return int(r.get("Grid_Size", 0)) // max(1, int(r.get("Workgroup_Size", 1)))
     ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], wgs(r)) for r in rows]
     ev.sort()
+    heads = [e for e in ev if family(e[2]) == "head"]
     # the steady state of the timed region: bench.py ends with its one-scene-in-flight side pass (2 x resident scenes to warm the
     # main thread's stream + max(min(steps, 48), 24) measured scenes), the timed region's `steps` scenes come before it; a scene
     # has exactly one head_joint launch.  20 scenes are cut off at either end (fill and drain of the seven scene threads).
@@ -119,10 +122,14 @@ def main():
         rows = list(csv.DictReader(open(find(d, "counter_collection.csv"))))
         rows.sort(key=lambda r: int(r["Dispatch_Id"]))
         ids = sorted({int(r["Dispatch_Id"]) for r in rows if family(r["Kernel_Name"]) == "head"})
-        # whole scenes only: between the first and the last head launch every scene thread is in steady state; the scenes are
-        # counted by their head launches
-        lo, hi = ids[len(ids) // 4], ids[-1]
+        # whole scenes of the timed region only (its launch policy): the run ends with the one-in-flight side pass of
+        # 2 x 4 + max(min(steps, 48), 24) scenes under the library's policy; the scenes are counted by their head launches
+        p_steps = int(__import__("os").environ.get("PMC_STEPS", "56"))
+        p_iso = 2 * 4 + max(min(p_steps, 48), 24)
+        assert len(ids) >= p_steps + p_iso, (len(ids), p_steps, p_iso)
+        lo, hi = ids[-(p_steps + p_iso) - 1], ids[-p_iso - 1]
         k = len([i for i in ids if lo < i <= hi])
+        assert k == p_steps, (k, p_steps)
         for r in rows:
             if lo < int(r["Dispatch_Id"]) <= hi:
                 per[family(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"]) / k
@@ -168,6 +175,18 @@ def main():
     for clk in (2.4e6, 1.95e6):
         print("  mfma_busy_in_flight = %.4f ms of all-SIMD matrix time per scene / %.3f = %.3f  (clock %.2f GHz)"
               % (mf_all / clk, ms_per_scene, mf_all / clk / ms_per_scene, clk / 1e6))
+    out = {"source": "profiles/in_flight_counters.sh (rocprofv3 --pmc dispatch counters of bench.py's timed-region scenes under the "
+                     "seven-in-flight launch policy, kernels serialised by the profiler; rate from the kernel-trace run)",
+           "scenes_per_s_under_tracer": rate, "ms_per_scene": ms_per_scene,
+           "cu_busy_in_flight": cu_need / 8.0 / 2.4e6 / ms_per_scene, "mfma_busy_in_flight": mf_all / 2.4e6 / ms_per_scene,
+           "clock_ghz_assumed": 2.4, "kernels_running_at_once": {str(k): round(v / wall, 4) for k, v in sorted(by_depth.items())},
+           "mean_kernels_running": sum(k * v for k, v in by_depth.items()) / wall,
+           "wall_share_with_at_least_1024_workgroups_running": by_wgs.get(">= 1024", 0.0) / wall,
+           "fetch_mb_per_scene_raw": tot["FETCH_SIZE"] / 1024, "write_mb_per_scene": tot["WRITE_SIZE"] / 1024,
+           "per_family": {f: {c: d.get(c, 0.0) for c in names} for f, d in per.items()}}
+    jpath = __import__("os").environ.get("IN_FLIGHT_JSON")
+    if jpath:
+        json.dump(out, open(jpath, "w"), indent=1)
     print("  HBM-side traffic per scene: FETCH %.1f MB raw (<= %.1f with the gfx950 wide-read correction) + WRITE %.1f MB -> %.2f-%.2f TB/s at the in-flight rate"
           % (tot["FETCH_SIZE"] / 1024, 2 * tot["FETCH_SIZE"] / 1024, tot["WRITE_SIZE"] / 1024,
              (tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) / 1024 / 1e6 / (ms_per_scene * 1e-3),

@@ -112,29 +112,22 @@ def test_host_side_layout_functions(built_lib):
     L = _lib.lib()
     rows = (ctypes.c_int64 * 5)(80000, 36822, 9929, 2349, 494)
     off = _lib.SceneMaps()
-    for win_levels in (0, 3, 31):
-        words = L.cv_sp_scene_maps_words(rows, 80000, 5, 4, 16384, win_levels, ctypes.byref(off))
-        assert off.out == -1          # the caller's rows <- sorted rows map is cv_sp_sort_rows' inverse permutation
-        spans = [(off.stem, 80000 * 125)] + [(off.down[i], rows[i + 1] * 8) for i in range(4)] + \
-                [(off.k3[i], rows[i] * 27) for i in range(5)] + [(off.up[i], rows[3 - i] * 8) for i in range(4)] + \
-                [(off.up_perm[i], rows[3 - i]) for i in range(4)] + [(off.scratch, (5 * 4 + 4) * 2048), (off.bitmap, 1 << 20)]
-        for i in range(5):
-            windows = rows[i] >= 16384 and (win_levels >> i) & 1          # a level has windows OR mask orders
-            if windows:
-                assert off.win[i] >= 0 and off.mask_perm[i] == -1
-                spans.append((off.win[i], L.cv_sp_windows_words(rows[i])))
-                assert L.cv_sp_windows_words(rows[i]) >= -(-rows[i] // 256) * (512 + 27 * 128)
-            elif rows[i] >= 16384:
-                assert off.mask_perm[i] >= 0 and off.win[i] == -1
-                spans.append((off.mask_perm[i], 4 * rows[i] * (1 + 7)))      # orders + map rows in processing order
-            else:
-                assert off.mask_perm[i] == -1 and off.win[i] == -1
-        spans.sort()
-        for (a, la), (b, _) in zip(spans[:-1], spans[1:]):
-            assert a % 64 == 0 and a + la <= b                               # aligned, non-overlapping
-        assert spans[-1][0] + spans[-1][1] <= words
-        assert words <= L.cv_sp_scene_plan_words(80000, 5, 4, 16384, win_levels)      # the pre-count sizing covers it
-    assert L.cv_sp_windows_supported(80000) == 1 and L.cv_sp_windows_supported(5_000_000) == 0
+    words = L.cv_sp_scene_maps_words(rows, 80000, 5, 4, 16384, ctypes.byref(off))
+    assert off.out == -1          # the caller's rows <- sorted rows map is cv_sp_sort_rows' inverse permutation
+    spans = [(off.stem, 80000 * 125)] + [(off.down[i], rows[i + 1] * 8) for i in range(4)] + \
+            [(off.k3[i], rows[i] * 27) for i in range(5)] + [(off.up[i], rows[3 - i] * 8) for i in range(4)] + \
+            [(off.up_perm[i], rows[3 - i]) for i in range(4)] + [(off.scratch, (5 * 4 + 4) * 2048), (off.bitmap, 1 << 20)]
+    for i in range(5):
+        if rows[i] >= 16384:
+            assert off.mask_perm[i] >= 0
+            spans.append((off.mask_perm[i], 4 * rows[i] * (1 + 7)))      # orders + map rows in processing order
+        else:
+            assert off.mask_perm[i] == -1
+    spans.sort()
+    for (a, la), (b, _) in zip(spans[:-1], spans[1:]):
+        assert a % 64 == 0 and a + la <= b                               # aligned, non-overlapping
+    assert spans[-1][0] + spans[-1][1] <= words
+    assert words <= L.cv_sp_scene_plan_words(80000, 5, 4, 16384)      # the pre-count sizing covers it
     # arena of a two-buffer program: one external, one level-1 buffer of 96 channels
     bufs = (_lib.NetBuf * 2)(_lib.NetBuf(-1, 3, 0), _lib.NetBuf(1, 96, 1))
     assert L.cv_net_arena_bytes(bufs, 2, rows, 5) >= 36822 * 96 * 4
@@ -193,41 +186,17 @@ def test_compiled_hv_cuda_extension_loads_and_checks_its_inputs(built_lib):
     del sys.modules["hv_cuda"]
 
 
-def test_window_levels_of_a_program(built_lib):
-    """cv_net_win_levels (host only): a level takes neighbour windows when ALL its mask-grouped 3x3x3 ops are hl-format,
-    fp16-pair, Cout 32 / 64 / 96 - and only while the option "win" is on (off by default: DESIGN.md 4.3)."""
+def test_kernel_selection_knobs(built_lib):
+    """cv_sp_set_option / cv_sp_get_option (host only)"""
     import ctypes
     L = _lib.lib()
-    hl, fp32 = _lib.NetBuf(0, 96, 0, 1), _lib.NetBuf(0, 96, 0, 0)
-
-    def op(cin, cout, perm, in_buf=0, K=27, groups=3, pieces=2, in2=-1, cin2=0):
-        return _lib.NetOp(in_buf=in_buf, in_col=0, cin=cin, out_buf=0, out_col=0, cout=cout, res_buf=-1, res_col=0, map=5, K=K,
-                          perm=perm, perm_groups=groups, relu=1, weight=None, scale=None, shift=None, weight_x6=1,
-                          in2_buf=in2, in2_col=0, cin2=cin2, weight2_x6=1 if in2 >= 0 else None, weight_pieces=pieces, acc_scale=1.0)
-
-    bufs = (_lib.NetBuf * 2)(hl, fp32)
-    ops = [op(96, 96, 0), op(128, 96, 0, in2=0, cin2=128), op(32, 32, 1), op(64, 64, 2), op(128, 128, 2),     # level 2: one op too wide
-           op(96, 96, 3, in_buf=1), op(96, 96, 4, pieces=3), op(32, 32, 1, K=8, groups=1)]                      # fp32 input; bf16 triples; a k2s2 op does not count
-    c_ops = (_lib.NetOp * len(ops))(*ops)
-    prev = ctypes.c_longlong(0)
-    assert L.cv_sp_set_option(b"win", 0, ctypes.byref(prev)) == 0
-    try:
-        assert L.cv_net_win_levels(c_ops, len(ops), bufs, 2) == 0                  # the switch is off
-        L.cv_sp_set_option(b"win", 1, None)
-        assert L.cv_net_win_levels(c_ops, len(ops), bufs, 2) == 0b00011
-        lv = ctypes.c_longlong(0)
-        L.cv_sp_set_option(b"win_levels", 2, ctypes.byref(lv))
-        assert L.cv_net_win_levels(c_ops, len(ops), bufs, 2) == 0b00010
-        L.cv_sp_set_option(b"win_levels", lv.value, None)
-    finally:
-        L.cv_sp_set_option(b"win", prev.value, None)
     assert L.cv_sp_set_option(b"no_such_knob", 1, None) != 0
     # cv_sp_get_option reads a knob without touching it (what the executor uses while other threads launch)
-    for name in (b"hd_mask", b"hd_min_rows", b"hd_shape", b"zskip", b"win", b"win_xcd", b"win_levels"):
+    for name in (b"hd_mask", b"hd_min_rows", b"hd_shape", b"zskip"):
         v, old = ctypes.c_longlong(-7), ctypes.c_longlong(-9)
         assert L.cv_sp_get_option(name, ctypes.byref(v)) == 0
         assert L.cv_sp_set_option(name, v.value, ctypes.byref(old)) == 0 and old.value == v.value
-    assert L.cv_sp_get_option(b"no_such_knob", ctypes.byref(v)) != 0 and L.cv_sp_get_option(b"win", None) != 0
+    assert L.cv_sp_get_option(b"no_such_knob", ctypes.byref(v)) != 0 and L.cv_sp_get_option(b"zskip", None) != 0
 
 
 def test_in_flight_launch_sizing_policy(built_lib):
@@ -297,7 +266,7 @@ def test_a_changed_define_makes_the_object_stale(built_lib, monkeypatch):
     """csrc/build.py keeps the command line of every object beside it: another -D through CV_*_DEFS (or another HIPCC)
     is a rebuild of exactly that source, not a silent re-use (round 5 lost a table of ablations to that)."""
     from canonicalvoting_amd.csrc import build as b
-    for k in ("CV_HV_DEFS", "CV_DEC_DEFS", "CV_SC_DEFS", "CV_WIN_DEFS"):
+    for k in ("CV_HV_DEFS", "CV_DEC_DEFS", "CV_SC_DEFS"):
         monkeypatch.delenv(k, raising=False)
     assert b.plan() == []
     monkeypatch.setenv("CV_SC_DEFS", "-DX=1")

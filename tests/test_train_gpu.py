@@ -316,6 +316,33 @@ def test_input_gradients_on_the_hl_kernels(cuda, built_lib, monkeypatch):
     assert any(not torch.equal(a2[k], b2[k]) for k in a2)             # it IS another kernel
 
 
+def test_weights_packed_once_per_step_are_the_same_bits(cuda, built_lib, monkeypatch):
+    """ME.TRAIN_PREPACK (default): train.train_step packs the fp16-pair weights of all convolutions - forward layout and, for
+    the input gradients, transposed - by ONE launch in front of the forward (cv_sp_pack_weights_h2_batch_f32) instead of one
+    launch per layer and direction.  Same scales, same split: losses and every parameter gradient of two steps are bit-identical
+    to the per-layer packing, and the second step takes > 100 packed tensors from the batch."""
+    from canonicalvoting_amd import train
+    batch = _small_batch(cuda, seed0=60, n=1500)
+    runs = []
+    for pre in (1, 0):
+        monkeypatch.setattr(ME, "TRAIN_PREPACK", pre)
+        torch.manual_seed(0)
+        model = MinkUNet34C(3, 64).cuda().train()
+        opt = train.make_optimizer(model, lr=1e-3)
+        ME.TRAIN_COUNTERS["prepacked"] = 0
+        out = []
+        for _ in range(2):
+            loss, _ = train.train_step(model, opt, *batch)
+            out.append((float(loss), {k: p.grad.clone() for k, p in model.named_parameters()}))
+        runs.append((out, ME.TRAIN_COUNTERS["prepacked"]))
+    (a, n_a), (b, n_b) = runs
+    assert n_b == 0 and n_a > 100, (n_a, n_b)
+    for (la, ga), (lb, gb) in zip(a, b):
+        assert la == lb
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+
+
 def test_a_forward_beyond_the_fp16_range_skips_its_update_on_the_device(cuda, built_lib, monkeypatch):
     """train.train_step with the fused Adam: no host wait in the step.  A BatchNorm gain of 1e7 puts activations beyond 65000:
     the hl twin raises the range flag, the optimizer gets it as found_inf and leaves every parameter (and its step count)
