@@ -24,9 +24,17 @@ The JSON line also carries
                 INSIDE the timed region, priced with the algorithmic bytes of SURVEY.md 8d:
                 B_vote = 40 N + 192 V_in + 68 G.  With S > 1 the events include the stretch from co-running scenes;
                 `isolated_*` give the same op from a one-scene-in-flight pass after the timed region.
-  stage_ms      per-stage event times inside the timed region (and `stage_ms_isolated` from that second pass)
-  parity        match flags of the SAME run against the CPU oracle on one scene: grid shape, in-bounds vote count,
-                candidate cells, box count, classes exact; network max abs error
+  stage_ms      per-stage event times inside the timed region (and `stage_ms_isolated` from that second pass): DEVICE times -
+                every boundary event sits behind the stage's last launch (the decode's in front of its host wait)
+  parity        match flags of the SAME run against the CPU oracle on one scene, UNDER THE LAUNCH SIZING OF THE TIMED REGION
+                (`parity.config`): grid shape, in-bounds vote count, candidate cells, box count, classes exact; network max
+                abs error.  `parity_one_in_flight`: the same under the library's one-scene sizing, plus whether the two runs
+                agree bit for bit on the grids and every integer output.
+  launch sizing the three choices that depend on the scenes in flight (`config.conv_split_target`, `vote_part_records`,
+                `masked_min_rows`) travel with every call (pipeline.ScenePolicy -> cv_scene_desc): nothing process-wide
+  cu_busy_in_flight, roofline_conv.mfma_busy_in_flight, in_flight_counters
+                counters of the regime that is timed, collected offline (dispatch counters serialise the kernels) by
+                profiles/in_flight_counters.sh and read from profiles/r6/in_flight_counters.json (labelled as such)
   cpu_baseline  the CPU oracle (oracle/, a port - the reference has no CPU path) on a bounded sample of the same
                 scenes, rank 0 only: best of --cpu-reps after one warm-up on all host threads, plus one 1-thread run.
 """

@@ -1,6 +1,6 @@
 # HBM traffic of the vote kernel from the PMC counters: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (with --kernel-trace
 # only), per launch of hv_fwd_tiles; gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE (KB) counts half of a wide
-# coalesced read stream -> doubled; WRITE_SIZE taken as is.  Writes gpurun_out/vote_pmc/vote_hbm_traffic.json (copied to profiles/r5/) (bench.py reads it).
+# coalesced read stream -> doubled; WRITE_SIZE taken as is.  Writes gpurun_out/vote_pmc/vote_hbm_traffic.json (copied to profiles/r6/) (bench.py reads it).
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 CMD="python $R/bench.py --streams 1 --stage vote_decode --steps 10 --warmup 2 --cpu-scenes 0 --measure-traffic 0"
 rm -rf /tmp/vp_f /tmp/vp_w
@@ -20,8 +20,8 @@ out = {"kernel": "hv_fwd_tiles<0>", "workload": "80k-point scene, bench.py --str
        "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w, "launches": [nf, nw],
        "correction": "gfx950: FETCH_SIZE reads 1/2 of a wide coalesced stream (MI355X_MICROARCH.md HBM section) -> doubled; WRITE_SIZE uncalibrated, taken as is",
        "hbm_bytes_per_launch": (2 * f + w) * 1024.0,
-       "source": ["profiles/r5/vote_pmc_fetch_size.csv", "profiles/r5/vote_pmc_write_size.csv"],
-       "note": "the CSVs under profiles/r5 keep the hv_fwd_tiles rows only", "collected": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/vote_pmc.sh)"}
+       "source": ["profiles/r6/vote_pmc_fetch_size.csv", "profiles/r6/vote_pmc_write_size.csv"],
+       "note": "the CSVs under profiles/r6 keep the hv_fwd_tiles rows only", "collected": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/vote_pmc.sh)"}
 json.dump(out, open("gpurun_out/vote_pmc/vote_hbm_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
