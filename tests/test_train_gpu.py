@@ -697,3 +697,66 @@ def test_sorted_training_forward_equals_the_caller_order_forward(cuda, built_lib
     gb = torch.cat([b[2][k].flatten().double() for k in a[2]])
     assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > 0.9999
     assert all(float((a[3][k] - b[3][k]).abs().max()) < 1e-5 for k in a[3])
+
+
+def test_batched_weight_pack_equals_the_per_layer_packs(cuda, built_lib):
+    """cv_sp_pack_weights_h2_batch_f32 against cv_sp_pack_weights_h2_f32 / cv_sp_pack_weights_t_f32, job by job: same fp16-pair
+    words for a set of shapes of the network (1x1, k2s2, 3x3x3; forward and transposed; different scales), in one launch."""
+    import ctypes
+    from canonicalvoting_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    shapes = [(27, 96, 96, 0, 3), (27, 96, 96, 1, 3), (8, 64, 128, 0, -2), (8, 64, 128, 1, -2), (1, 128, 96, 0, 0), (27, 32, 64, 1, 7),
+              (27, 256, 256, 0, 5)]
+    ws = [torch.randn((K, cin, cout), generator=g).mul_(0.05).to(cuda) for K, cin, cout, _, _ in shapes]
+    jobs = (_lib.PackJob * len(shapes))()
+    outs, want = [], []
+    st = torch.cuda.current_stream().cuda_stream
+    for j, w, (K, cin, cout, trans, k) in zip(jobs, ws, shapes):
+        o = torch.zeros(2 * w.numel(), dtype=torch.int16, device=cuda)
+        outs.append(o)
+        # trans: the packed tensor of the TRANSPOSED convolution of the forward kernel w[K][cin][cout] (Cin' = cout, Cout' = cin)
+        j.w, j.wp, j.K, j.trans, j.scale_log2 = w.data_ptr(), o.data_ptr(), K, trans, k
+        j.cin, j.cout = (cout, cin) if trans else (cin, cout)
+        ref = torch.zeros_like(o)
+        if trans:
+            _lib.check(L.cv_sp_pack_weights_t_f32(w.data_ptr(), K, cin, cout, 2, k, ref.data_ptr(), st), "pack_t")
+        else:
+            _lib.check(L.cv_sp_pack_weights_h2_f32(w.data_ptr(), K, cin, cout, None, k, ref.data_ptr(), st), "pack_h2")
+        want.append(ref)
+    d_jobs = torch.empty(len(shapes) * ctypes.sizeof(_lib.PackJob), dtype=torch.uint8, device=cuda)
+    _lib.check(L.cv_sp_pack_weights_h2_batch_f32(jobs, len(shapes), d_jobs.data_ptr(), st), "batch")
+    torch.cuda.synchronize()
+    for o, r, s in zip(outs, want, shapes):
+        assert torch.equal(o, r), s
+    jobs[0].cin = 48                                                     # Cin % 32 != 0 is refused, with a message
+    assert L.cv_sp_pack_weights_h2_batch_f32(jobs, len(shapes), d_jobs.data_ptr(), st) == -22 and b"pack job 0" in L.cv_last_error()
+    assert L.cv_sp_pack_weights_h2_batch_f32(None, 0, None, st) == 0
+
+
+def test_guarded_multi_tensor_copy(cuda, built_lib):
+    """cv_sp_copy_unless_flag (ME.copy_unless_flag): many small tensors of mixed dtypes in ceil(n / 96) launches; nothing is
+    copied while the device-visible flag is non-zero (what keeps train.train_step's BatchNorm snapshot at the state before the
+    first flagged step)."""
+    g = torch.Generator().manual_seed(4)
+    srcs = [torch.randn(int(n), generator=g).to(cuda) for n in torch.randint(1, 700, (150,), generator=g)]
+    srcs += [torch.arange(5, dtype=torch.int64, device=cuda), torch.tensor(7, dtype=torch.int64, device=cuda)]
+    dsts = [torch.zeros_like(s) for s in srcs]
+    flag = ME.range_flag(torch.device(cuda))
+    flag.zero_()
+    ME.copy_unless_flag(srcs, dsts, torch.device(cuda), flag)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(srcs, dsts))
+    for s in srcs:
+        s.add_(1)
+    flag.fill_(1)
+    try:
+        ME.copy_unless_flag(srcs, dsts, torch.device(cuda), flag)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a - 1, b) for a, b in zip(srcs, dsts))          # guarded: the old values stay
+    finally:
+        flag.zero_()
+    ME.copy_unless_flag(srcs, dsts, torch.device(cuda))                        # no flag: always
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(srcs, dsts))
+    ME.copy_unless_flag([], [], torch.device(cuda), flag)
