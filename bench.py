@@ -785,6 +785,7 @@ def main():
     events = [step_events() if k % every == 0 else None for k in range(a.steps)]
     counts = [0] * S
     step_log = [None] * a.steps         # (thread, host time at start, at end) of every timed step
+    host_us = [None] * a.steps          # cv_scene_result.host_us of every timed step
     warm_steps = [0] * S
     errors = []
     # the K steps are handed out from one counter: a thread whose scene was cheap takes the next step at once
@@ -837,6 +838,8 @@ def main():
                     else:
                         dets, _ = run_step(model, hvs[i], scenes[k % len(scenes)], events[k], teacher)
                     step_log[k] = (i, ts, time.perf_counter())
+                    if SCENE_CALL == "c" and model is not None:
+                        host_us[k] = pipeline.last_scene_host_us(dev)
                     counts[i] += len(dets)
                 streams[i].synchronize()
                 if hi_streams is not None:
@@ -1048,6 +1051,11 @@ def main():
         "device_allocs_in_timed_region": device_allocs,
         "step_host_ms": {"median": float(np.median([(e - b) * 1e3 for _, b, e in step_log])),
                          "max": float(max((e - b) * 1e3 for _, b, e in step_log))},
+        # where a scene call's host time goes in the timed region (cv_scene_result.host_us, medians): the coordinate plan with its
+        # wait for the level counts, ENQUEUEING the network program (~100 launches, no wait), head + vote enqueue, decode + its wait
+        "scene_call_host_ms": (lambda h: None if not h else dict(zip(
+            ("plan_and_wait", "net_enqueue", "head_vote_enqueue", "decode_and_wait"),
+            [float(np.median([x[i] for x in h])) * 1e-3 for i in range(4)])))([x for x in host_us if x is not None]),
     }
     out["cpu_baseline"] = out["parity"] = out["parity_one_in_flight"] = out["train_step_ms"] = None
     if rank == 0 and full and a.train_steps > 0 and not a.large:

@@ -97,7 +97,7 @@ class SceneResult(ctypes.Structure):
                 ("scenes_in_flight", ctypes.c_int), ("dims", ctypes.c_int * 3), ("corner", ctypes.c_float * 3), ("level_rows", ctypes.c_longlong * 5),
                 ("needed_ws_bytes", ctypes.c_size_t), ("needed_grid_floats", ctypes.c_size_t),
                 ("d_grid_obj", vp), ("d_grid_rot", vp), ("d_grid_scale", vp), ("d_xyz", vp), ("d_scale", vp),
-                ("d_prob", vp), ("d_class", vp)]
+                ("d_prob", vp), ("d_class", vp), ("host_us", ctypes.c_float * 4)]
 
 
 # symbol -> (restype, argtypes); tests check every symbol of include/cv_hip.h is here and exported

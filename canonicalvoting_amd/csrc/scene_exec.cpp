@@ -12,6 +12,7 @@
 // to the call-by-call path (tests/test_scene_call_gpu.py).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -85,6 +86,12 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
     r->scenes_in_flight = in_flight.before + 1;
     Carver cv(d->d_ws, d->ws_bytes);
     auto mark = [&](int i) { return d->events[i] ? hipEventRecord(static_cast<hipEvent_t>(d->events[i]), st) : hipSuccess; };
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](int i) {
+        const auto t = std::chrono::steady_clock::now();
+        r->host_us[i] += std::chrono::duration<float, std::micro>(t - t_prev).count();
+        t_prev = t;
+    };
     CV_HIP_CHECK(mark(0));
 
     // ---- bounds of the points (the vote grid's origin and shape): reduced first, read after the plan's own host wait
@@ -139,6 +146,7 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
     r->out_of_window = counts_h[6];
     CV_REQUIRE(counts_h[5] == 0 && counts_h[6] == 0, CV_EINVAL,
                "duplicate coordinates (%d) or coordinates outside the 16-bit key window (%d)", counts_h[5], counts_h[6]);
+    lap(0);
     long long rows[NL];
     for (int i = 0; i < NL; ++i) { rows[i] = counts_h[i]; r->level_rows[i] = counts_h[i]; }
     // (the plan waited for an event recorded behind the bounds reduction: the pinned bounds are valid)
@@ -193,6 +201,7 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
     rc = cv_net_run_f32(d->ops, d->n_ops, d->bufs, d->n_bufs, rows, NL, arena, arena_b, ext_ptr, ext_ld, maps, 15, perms, 9, conv_ws,
                         conv_ws_b, d->use_range_flag ? d_flag : nullptr, stream);
     if (rc != CV_OK) return rc;
+    lap(1);
     CV_HIP_CHECK(mark(1));
     rc = cv_head_joint_f32(d->d_out_feats, n, d->out_ld, d->nclasses, d->log_scale, xyz, scale, prob, cls, stream);
     if (rc != CV_OK) return rc;
@@ -209,6 +218,7 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
                            std::max<size_t>(vote_ws_b, 256), d->vote_algo, stream);
     if (rc != CV_OK) return rc;
     CV_HIP_CHECK(mark(3));
+    lap(2);
     if (enq.owns_lock()) enq.unlock();
     cv_decode_params prm = d->decode;
     prm.max_iters = d->max_candidates;
@@ -242,6 +252,7 @@ int cv_detect_scene_f32(const cv_scene_desc* d, cv_scene_result* r, void* stream
         for (int j = 0; j < k; ++j) d->h_pick[n_det++] = idx[(size_t)pick[j]];
     }
     r->n_det = n_det;
+    lap(3);
     return CV_OK;
 }
 

@@ -165,6 +165,7 @@ class _SceneHost:
         self.pick = np.zeros(max_candidates, np.int32)
         self.ws_hint = 0
         self.grid_hint = 0
+        self.last_host_us = (0.0, 0.0, 0.0, 0.0)
 
 
 _scene_hosts = {}
@@ -254,6 +255,7 @@ def detect_scene_c(model, hv, coords4, feats, res, nclasses=9, log_scale=True, s
     else:
         _lib.check(rc, "cv_detect_scene_f32")          # still CV_ENOMEM after four growing attempts: not an empty scene
     host.ws_hint = max(host.ws_hint, int(r.needed_ws_bytes))
+    host.last_host_us = tuple(r.host_us)            # where the call's host time went (plan + wait, network enqueue, head + vote, decode + wait)
     host.grid_hint = max(host.grid_hint, int(r.needed_grid_floats) * 9 // 8)
     if r.range_flag or r.truncated:
         # rare: a convolution input beyond the fp16 range, or more candidate cells than the result arrays hold
@@ -279,6 +281,14 @@ def detect_scene_c(model, hv, coords4, feats, res, nclasses=9, log_scale=True, s
                     net_pred=(view(r.d_xyz, (n, 3)), view(r.d_scale, (n, 3)), view(r.d_prob, (n,)),
                               view(r.d_class, (n,), torch.int32)), raw=raw)
     return dets, raw, y
+
+
+def last_scene_host_us(dev=None):
+    """(plan + wait, network enqueue, head + vote enqueue, decode + wait) host microseconds of the calling thread's last
+    detect_scene_c call on its current stream"""
+    dev = torch.device("cuda", torch.cuda.current_device()) if dev is None else dev
+    host = _scene_hosts.get((dev.index, torch.cuda.current_stream(dev).cuda_stream))
+    return host.last_host_us if host is not None else None
 
 
 def _device_view(ptr, shape, dtype, dev, owner):

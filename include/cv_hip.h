@@ -571,6 +571,9 @@ typedef struct cv_scene_result {
     /* device views into d_ws / d_grids, valid until the next call that uses the same scratch */
     float* d_grid_obj; float* d_grid_rot; float* d_grid_scale;
     float* d_xyz; float* d_scale; float* d_prob; int32_t* d_class;      /* the network's own head outputs */
+    /* host time the call spent (microseconds): [0] coordinate plan incl. its wait for the level counts, [1] enqueueing the network
+     * program (~100 launches, no wait), [2] head + vote enqueue, [3] decode incl. its wait for the results + NMS */
+    float host_us[4];
 } cv_scene_result;
 int cv_detect_scene_f32(const cv_scene_desc* desc, cv_scene_result* result, void* stream);
 
