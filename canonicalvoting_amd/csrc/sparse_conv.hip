@@ -3039,15 +3039,21 @@ static long long wgrad_plan(long long n_out, int cin, int cout, int K, WgradPlan
             const int h = ks / 2;
             d1 = std::abs(j % ks - h) + std::abs(j / ks % ks - h) + std::abs(j / (ks * ks) - h);
         }
-        mult[j] = cubic && d1 <= 1 ? 2 : 1;
+        // splits per offset class (centre / face / edge+corner of an odd cubic kernel); CV_WGRAD_MULT="c,f,o" overrides (experiment)
+        static int m_c = 2, m_f = 2, m_o = 1;
+        static const bool m_env = [] { const char* e = getenv("CV_WGRAD_MULT"); if (e) sscanf(e, "%d,%d,%d", &m_c, &m_f, &m_o); return true; }();
+        (void)m_env;
+        mult[j] = !cubic ? 1 : d1 == 0 ? m_c : d1 == 1 ? m_f : m_o;
         cls[j] = !cubic ? 2 : d1 == 0 ? 0 : d1 == 1 ? 1 : 2;
         msum += mult[j];
     }
-    const long long want = (WGRAD_TARGET_TASKS + (long long)msum * tiles - 1) / ((long long)msum * tiles);
+    static const long long target_tasks = getenv("CV_WGRAD_TASKS") ? atoll(getenv("CV_WGRAD_TASKS")) : WGRAD_TARGET_TASKS;
+    static const long long cap_env = getenv("CV_WGRAD_CAP") ? atoll(getenv("CV_WGRAD_CAP")) : 64;
+    const long long want = (target_tasks + (long long)msum * tiles - 1) / ((long long)msum * tiles);
     // partial tiles <= 96 MB (they are written once and read once by wgrad_reduce); few-offset kernels (1x1, 2x2x2)
     // have few (offset, block) tasks and get their parallelism from the rows instead: up to 1024 row splits
     const long long ws_cap = (96ll << 20) / ((long long)msum * cin * cout * 4);
-    const long long cap = K <= 8 ? 1024 : 64;
+    const long long cap = K <= 8 ? 1024 : cap_env;
     const long long base = std::max<long long>(1, std::min({cap, want, n_out / (K <= 8 ? 128 : 256), ws_cap}));
     long long slots = 0;
     int rank = 0, tasks = 0;
