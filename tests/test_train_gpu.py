@@ -747,13 +747,15 @@ def test_guarded_multi_tensor_copy(cuda, built_lib):
     ME.copy_unless_flag(srcs, dsts, torch.device(cuda), flag)
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(srcs, dsts))
+    old = [d.clone() for d in dsts]
     for s in srcs:
         s.add_(1)
     flag.fill_(1)
     try:
         ME.copy_unless_flag(srcs, dsts, torch.device(cuda), flag)
         torch.cuda.synchronize()
-        assert all(torch.equal(a - 1, b) for a, b in zip(srcs, dsts))          # guarded: the old values stay
+        assert all(torch.equal(a, b) for a, b in zip(old, dsts))               # guarded: the old values stay
+        assert not any(torch.equal(a, b) for a, b in zip(srcs, dsts))
     finally:
         flag.zero_()
     ME.copy_unless_flag(srcs, dsts, torch.device(cuda))                        # no flag: always
