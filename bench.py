@@ -32,6 +32,9 @@ The JSON line also carries
                 agree bit for bit on the grids and every integer output.
   launch sizing the three choices that depend on the scenes in flight (`config.conv_split_target`, `vote_part_records`,
                 `masked_min_rows`) travel with every call (pipeline.ScenePolicy -> cv_scene_desc): nothing process-wide
+  steady_state  side field (one rank, --steps below --steady-steps): the same scene threads, streams and launch policy over 160
+                more steps right after the timed region - the driver's 20-step region spends ~9 % of its 37 ms filling and
+                draining a seven-deep pipeline; never `value`
   cu_busy_in_flight, roofline_conv.mfma_busy_in_flight, in_flight_counters
                 counters of the regime that is timed, collected offline (dispatch counters serialise the kernels) by
                 profiles/in_flight_counters.sh and read from profiles/r6/in_flight_counters.json (labelled as such)
@@ -123,6 +126,9 @@ def parse():
                          "hipStreamCreateWithPriority): the scenes that start last have the most work left when the ticket "
                          "counter runs out, so favouring them shortens the drain of a short region (longest remaining work "
                          "first); fill and drain stay inside the timed region, results are bit-identical.  0 = off")
+    ap.add_argument("--steady-steps", type=int, default=160,
+                    help="side field `steady_state`: when --steps is smaller than this, the scene threads run this many more steps "
+                         "after the timed region (one rank only); 0 = off")
     ap.add_argument("--xcd-partition", type=int, default=0,
                     help="experiment: the scene streams are created with CU masks (hipExtStreamCreateWithCUMask) of this many XCDs "
                          "each (1, 2 or 4 of the 8; stream i takes group i mod (8 / N)): a scene's kernels stay on its XCDs' CUs and "
@@ -916,6 +922,52 @@ def main():
     kernel_timed = vote_ms is not op_ms
     achieved = float((vb / (vote_ms * 1e-3)).mean() / 1e9)
     op_achieved = float((vb / (op_ms * 1e-3)).mean() / 1e9)
+    # Side field: the same scene threads and streams once more over a LONGER region (no events, same launch policy).  The
+    # driver's 20-step region is 37 ms of a seven-deep pipeline whose scenes take 11 ms each under load - fill and drain cost
+    # it ~9 % against the steady state; this region shows the steady state from inside the same process.  Never `value`.
+    steady = None
+    if S > 1 and world == 1 and a.steady_steps > a.steps and not ABLATE:
+        n_side = int(a.steady_steps)
+        ticket2, lock2, gate2, errors2 = itertools.count(), threading.Lock(), threading.Barrier(S + 1), []
+
+        def side_worker(i):
+            try:
+                torch.cuda.set_device(local)
+                with torch.cuda.stream(streams[i]):
+                    gate2.wait()
+                    if a.stagger_us > 0 and i > 0:
+                        time.sleep(i * a.stagger_us * 1e-6)
+                    while True:
+                        with lock2:
+                            k = next(ticket2)
+                        if k >= n_side:
+                            break
+                        run_step(model, hvs[i], scenes[k % len(scenes)], None, teacher)
+                    streams[i].synchronize()
+            except BaseException as e:      # noqa: BLE001
+                errors2.append(e)
+                gate2.abort()
+                raise
+
+        side_threads = [threading.Thread(target=side_worker, args=(i,)) for i in range(S)]
+        for t in side_threads:
+            t.start()
+        while gate2.n_waiting < S and not errors2:
+            time.sleep(0.0005)
+        torch.cuda.synchronize()
+        gc.disable()
+        t0s = time.perf_counter()
+        if not errors2:
+            gate2.wait()
+        for t in side_threads:
+            t.join()
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0s
+        gc.enable()
+        if not errors2:
+            steady = {"value": n_side / dts, "unit": "scenes/s", "steps": n_side, "ms_per_step": dts / n_side * 1e3,
+                      "note": "side field, not `value`: the same threads, streams and launch policy over a longer region right after "
+                              "the timed one (fill and drain of the seven-deep pipeline amortised)"}
     iso_stage = iso_achieved = iso_vote = iso_op = None
     if S > 1:
         # kernels of concurrent scenes stretch each other's event-to-event times: the same steps once more with ONE
@@ -1041,6 +1093,7 @@ def main():
                     "against the %s matrix peak" % ("bf16" if a.dtype == "bf16" else "fp32")},
         "cu_busy_in_flight": in_flight["cu_busy_in_flight"] if in_flight else None,
         "in_flight_counters": in_flight,
+        "steady_state": steady,
         "detections_per_scene": n_det / a.steps,
         "collective": coll,
         "stage_ms": stage_ms,
