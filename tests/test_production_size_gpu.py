@@ -227,6 +227,13 @@ def test_config5_300k_separate_heads_on_one_sparse_tensor(cuda, built_lib, scene
     ref = so.minkunet34c_forward(sds[0], coords4, feats)
     err = float((ys[0].cpu() - ref).abs().max())
     assert err < 1e-4 * max(1.0, float(ref.abs().max())), err
+    # the same network under the launch sizing of a host with seven scenes in flight (bench.py --large): within the same bar of
+    # the oracle, and another summation order than the library's policy (the policy did arrive)
+    with torch.no_grad(), pipeline.scene_policy(pipeline.policy_for_scenes_in_flight(7)):
+        y7 = models[0](ME.SparseTensor(dev(feats, cuda), dev(coords4, cuda).int(), device=cuda)).F
+    err7 = float((y7.cpu() - ref).abs().max())
+    assert err7 < 1e-4 * max(1.0, float(ref.abs().max())), err7
+    assert not torch.equal(y7, ys[0])
     xyz, scale, prob = pipeline.head_separate(ys[0])
     rx, rs, rp = so.head_separate_eval(ys[0].cpu())
     np.testing.assert_allclose(xyz.cpu().numpy(), rx.numpy(), rtol=0, atol=0)
