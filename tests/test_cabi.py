@@ -279,3 +279,24 @@ def test_a_changed_define_makes_the_object_stale(built_lib, monkeypatch):
     obj = os.path.join(b.OBJ_DIR, "cv_host.cpp.o")
     assert open(obj + ".cmd").read().split("\n")[0] == b.HIPCC and not b._stale(obj, [])
     assert b._stale(obj, [], ["another", "command"])
+
+
+def test_scene_call_refuses_bad_descriptors_before_touching_the_gpu(built_lib):
+    """cv_detect_scene_f32: null pointers and negative launch sizing come back as CV_EINVAL with a message (host-side checks only:
+    no GPU needed); cv_scene_result is zeroed first, host_us included"""
+    import ctypes
+    L = _lib.lib()
+    d, r = _lib.SceneDesc(), _lib.SceneResult()
+    assert L.cv_detect_scene_f32(ctypes.byref(d), ctypes.byref(r), None) == -22 and b"scene descriptor" in L.cv_last_error()
+    fake = ctypes.c_void_p(4096)          # never dereferenced: the sizing check comes before the first launch
+    for f in ("d_coords4", "d_feats", "d_points", "ops", "bufs", "d_out_feats", "h_pinned", "d_ws", "h_boxes", "h_scores", "h_classes",
+              "h_cand_idx", "h_verdict", "h_pick"):
+        setattr(d, f, fake)
+    d.n, d.n_ops, d.n_bufs, d.out_ld, d.out_channels, d.pinned_bytes, d.max_candidates = 100, 1, 1, 64, 64, 256, 8
+    r.host_us[0] = 7.0
+    for field in ("conv_split_target", "vote_part_records"):
+        setattr(d, field, -1)
+        assert L.cv_detect_scene_f32(ctypes.byref(d), ctypes.byref(r), None) == -22 and b"negative launch sizing" in L.cv_last_error()
+        assert r.host_us[0] == 0.0 and r.n_cand == 0
+        setattr(d, field, 0)
+    assert L.cv_sp_set_split_target_thread(0) == 0 and L.cv_hv_set_part_records_thread(0) == 0      # nothing left behind
