@@ -282,8 +282,10 @@ int cv_sp_pack_weights_h2_f32(const float* d_w, int K, int cin, int cout, const 
  * and direction (117 launches and the stream's idle time in front of them, profiles/r5/train_gaps.txt).  Job i packs
  * w[K][cin][cout] (trans = 0) or, trans = 1, the transposed convolution of a FORWARD kernel w[K][cout][cin] (what
  * cv_sp_pack_weights_t_f32(w, K, rows = cout, cols = cin, 2, ...) makes) into wp: 2*K*cin*cout 16-bit words, 16-byte
- * aligned, no column scale.  h_jobs: host array (read before the call returns; pinned memory makes the table copy asynchronous);
- * d_jobs: n_jobs * sizeof(cv_pack_job) bytes of device scratch that must stay untouched until the launch has run. */
+ * aligned, no column scale.  h_jobs: host array, copied to d_jobs by hipMemcpyAsync on `stream`: ordinary (pageable) memory is
+ * staged before the call returns and may be reused at once; a PINNED array is read when the copy runs on the stream and must stay
+ * unchanged until then.  d_jobs: n_jobs * sizeof(cv_pack_job) bytes of device scratch that must stay untouched until the launch
+ * has run. */
 typedef struct cv_pack_job {
     const float* w;
     void* wp;
