@@ -575,16 +575,7 @@ def train_side_field(a, scenes, dev):
             loss, _ = train.train_step(model, opt, *batch)
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
-        # the same steps queued back to back with ONE wait at the end (what `--mode train` times: a loop that reads its losses one
-        # step late never waits for the step it has just queued)
-        t0 = time.perf_counter()
-        for _ in range(a.train_steps):
-            loss, _ = train.train_step(model, opt, *batch)
-        torch.cuda.synchronize()
-        free_ms = (time.perf_counter() - t0) / a.train_steps * 1e3
-        return {"value": float(np.median(times) * 1e3), "unit": "ms per step (median of %d, the host waits for every step as "
-                                                                "train_joint.py's loss.item() does)" % a.train_steps,
-                "free_running_ms": float(free_ms),
+        return {"value": float(np.median(times) * 1e3), "unit": "ms per step (median of %d)" % a.train_steps,
                 "scenes_per_step": B, "points_per_scene": a.points, "dtype": "f32",
                 "what": "train_joint.py:244-288 step: MinkUNet34C(3, 64) forward + backward + Adam on one GPU, "
                         "batch-statistics BatchNorm", "final_loss": float(loss)}
